@@ -1,0 +1,137 @@
+/* moldiff_hip.h -- C ABI of libmoldiff_hip.so: the MI355X (gfx950) implementation of MolDiff's
+ * denoising hot path.  Plain C: opaque handles, raw pointers, sizes; no C++/torch types.
+ *
+ * The reference (pengxingang/MolDiff @ 2024_08_07) has no FFI layer of its own -- its boundary is
+ * the Python model API plus one third-party op -- so each entry point below names the reference
+ * function (file:line) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns MDX_OK (0) or an error code; mdx_last_error() gives the message
+ *     (thread-local).  No C++ exception crosses this boundary.
+ *   - pointers named h_* / *_host are HOST pointers; everything else is a DEVICE pointer valid on
+ *     the current HIP device.  `stream` is a hipStream_t passed as void*.
+ *   - no hidden per-call device allocation: forward-type calls take a caller-owned workspace of
+ *     at least mdx_workspace_bytes() bytes (256-byte aligned).  Handles own only their packed
+ *     weights / graph index arrays.
+ *   - edge-indexed tensors crossing this boundary use the REFERENCE edge order
+ *     (edge_index = cat[halfedge_index, flip(halfedge_index)], models/model.py:269); the library
+ *     re-orders internally.  float = IEEE fp32, indices = int64 like the reference's LongTensors.
+ */
+#ifndef MOLDIFF_HIP_H
+#define MOLDIFF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_OK 0
+#define MDX_ERR_ARG 1         /* bad argument / shape */
+#define MDX_ERR_HIP 2         /* HIP runtime error (no device, launch failure, OOM) */
+#define MDX_ERR_STATE 3       /* missing parameters, workspace too small, call order */
+#define MDX_ERR_UNSUPPORTED 4 /* configuration outside what the kernels are built for */
+
+#define MDX_KIND_MOLDIFF 0  /* models/model.py:13-46         (embedders + denoiser + 2 decoders) */
+#define MDX_KIND_BONDPRED 1 /* models/bond_predictor.py:12-37 (embedders + encoder + edge decoder) */
+#define MDX_KIND_NET 2      /* a bare NodeEdgeNet, models/graph.py:298-346 */
+
+typedef struct mdx_model_s* mdx_model_t;
+typedef struct mdx_graph_s* mdx_graph_t;
+
+typedef struct mdx_config {
+  int32_t kind;           /* MDX_KIND_* */
+  int32_t node_dim;       /* 256 */
+  int32_t edge_dim;       /* 64  */
+  int32_t num_blocks;     /* 6 (denoiser) / 8 (bond predictor encoder) */
+  float cutoff;           /* distance smearing stop: 15 / 20 */
+  int32_t num_gaussians;  /* 16 */
+  int32_t update_pos;     /* 1 / 0 */
+  int32_t time_dim;       /* 10 / 20 (ignored for MDX_KIND_NET) */
+  int32_t num_timesteps;  /* 1000 */
+  int32_t num_node_types; /* 8 */
+  int32_t num_edge_types; /* 6 (MolDiff) / 5 (bond predictor) */
+} mdx_config;
+
+const char* mdx_last_error(void);
+int mdx_version(void);
+int mdx_device_count(int* count); /* 0 devices is MDX_OK with *count = 0 */
+
+/* ---- model handle: parameters enter by state_dict key (Appendix B of SURVEY.md; the strict
+ * load_state_dict contract of scripts/sample_drug3d.py:79) ---------------------------------- */
+int mdx_model_create(const mdx_config* cfg, mdx_model_t* out);
+int mdx_model_destroy(mdx_model_t m);
+/* h_data: host fp32, row-major, `ndim` dims in `shape`.  Key prefix for MDX_KIND_NET is "" (keys as
+ * inside NodeEdgeNet, e.g. "edge_embs.0.weight"), otherwise the full model key ("denoiser.edge_embs.0.weight"). */
+int mdx_model_set_param(mdx_model_t m, const char* key, const float* h_data, const int64_t* shape, int32_t ndim);
+/* Packs all weights into MFMA fragment order and uploads them.  Fails with MDX_ERR_STATE listing the
+ * first missing key.  Must be called after the last set_param and before any forward. */
+int mdx_model_finalize(mdx_model_t m);
+
+/* ---- graph handle: CSR plan of one packed batch (utils/transforms.py:125-156 produces the inputs) */
+/* h_edge_index: (2,E) int64 row-major, row 0 = left/row, row 1 = right/col; h_batch_node: (N) int64,
+ * non-decreasing.  h_mol_ids: (n_graphs) int64 global molecule ids for noise keying, or NULL = 0..n_graphs-1. */
+int mdx_graph_create(int64_t n_nodes, int64_t n_edges, const int64_t* h_edge_index, const int64_t* h_batch_node,
+                     int64_t n_graphs, const int64_t* h_mol_ids, mdx_graph_t* out);
+int mdx_graph_destroy(mdx_graph_t g);
+/* Host-only plan (no GPU needed; used by the CPU tests).  All outputs int32, caller-allocated:
+ * left/right/int2ref/col_eids: E, row_ptr/col_ptr: N+1. */
+int mdx_graph_plan_host(int64_t n_nodes, int64_t n_edges, const int64_t* h_edge_index, int32_t* left, int32_t* right,
+                        int32_t* int2ref, int32_t* row_ptr, int32_t* col_ptr, int32_t* col_eids);
+
+size_t mdx_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+
+/* ---- network (models/graph.py) ---------------------------------------------------------------- */
+/* NodeEdgeNet.forward, graph.py:348-367.  node_time (N), edge_time (E, reference order) are t/T floats. */
+int mdx_net_forward(mdx_model_t m, mdx_graph_t g, const float* h_node, const float* pos, const float* h_edge,
+                    const float* node_time, const float* edge_time, float* h_node_out, float* pos_out,
+                    float* h_edge_out, void* ws, size_t ws_bytes, void* stream);
+/* NodeBlock.forward, graph.py:29-55: out (N,256) = block `i`'s node update (no residual). */
+int mdx_node_block(mdx_model_t m, mdx_graph_t g, int32_t i, const float* x, const float* edge_attr,
+                   const float* node_time, float* out, void* ws, size_t ws_bytes, void* stream);
+/* EdgeBlock.forward, graph.py:268-295: out (E,64) reference order (no residual). */
+int mdx_edge_block(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_bond, const float* h_node,
+                   const float* bond_time, float* out, void* ws, size_t ws_bytes, void* stream);
+/* PosUpdate.forward, graph.py:384-396: rel (E,3), dist (E) reference order; out (N,3) = delta_pos. */
+int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_node, const float* h_edge,
+                   const float* rel, const float* dist, const float* edge_time, float* out, void* ws,
+                   size_t ws_bytes, void* stream);
+/* torch_scatter.scatter_sum(src, index, dim=0, dim_size=N) for index = left (by_right = 0) or right
+ * (by_right = 1) of the graph; src (E,C) reference order, C in {3, 64, 256}; call sites graph.py:50,279,283,394. */
+int mdx_segment_sum(mdx_graph_t g, const float* src, int32_t C, int32_t by_right, float* out, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ---- model forward ------------------------------------------------------------------------------ */
+/* MolDiff.forward, model.py:204-234.  h_node_pert (N,Kn), h_edge_pert (E,Ke) reference order (may be NULL
+ * when h_halfedge_pert (Eh,Ke) is given: then both directions use it, model.py:273), t (n_graphs) int64. */
+int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_node_pert, const float* pos_pert,
+                        const float* h_edge_pert, const float* h_halfedge_pert, const int64_t* t, float* pred_node,
+                        float* pred_pos, float* pred_halfedge, void* ws, size_t ws_bytes, void* stream);
+/* BondPredictor.forward, bond_predictor.py:128-162: logits (Eh, num_edge_types). */
+int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h_node, const float* pos, const int64_t* t,
+                         float* logits, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- transitions (models/transition.py, models/diffusion.py) -------------------------------------- */
+/* ContigousTransition.get_prev_from_recon, transition.py:44-63 (eps passed in). x (n,3). */
+int mdx_pos_posterior(const float* coef_x0, const float* coef_xt, const float* std, const float* x_t,
+                      const float* x_recon, const float* eps, const int64_t* t, const int64_t* batch, int64_t n,
+                      float* out, void* stream);
+/* GeneralCategoricalTransition.q_v_posterior(v0_prob=True), transition.py:285-315.  in0 = log_v0, or raw
+ * logits when is_logits != 0 (fuses F.log_softmax of model.py:291,297).  (n,K), K <= 8. */
+int mdx_cat_posterior(const float* q_mats, const float* qT_onestep, int32_t K, int32_t T, const float* in0,
+                      int32_t is_logits, const float* log_vt, const int64_t* t, const int64_t* batch, int64_t n,
+                      float* out, void* stream);
+/* log_sample_categorical, diffusion.py:79-85 (u passed in) + onehot_encode, transition.py:255. */
+int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n, int64_t* cls, float* onehot,
+                      void* stream);
+/* Philox4x32-10 noise for draw index `draw` (0 = prior, i+1 = loop iteration i): eps_pos (N,3) ~ N(0,1),
+ * u_node (N,Kn), u_halfedge (Eh,Ke) ~ U[0,1).  Any output may be NULL.  Replaces torch.randn_like /
+ * rand_like at transition.py:60, diffusion.py:80. */
+int mdx_noise(mdx_graph_t g, uint64_t seed, int32_t draw, int32_t Kn, int32_t Ke, float* eps_pos, float* u_node,
+              float* u_halfedge, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLDIFF_HIP_H */

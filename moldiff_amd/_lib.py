@@ -1,0 +1,205 @@
+"""ctypes binding of libmoldiff_hip.so (declared in include/moldiff_hip.h) + thin torch-tensor wrappers.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised.  Tensors are only used for device memory / streams; every computation happens in the HIP kernels.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmoldiff_hip.so')
+
+MDX_KIND_MOLDIFF, MDX_KIND_BONDPRED, MDX_KIND_NET = 0, 1, 2
+
+EXPORTS = [
+    'mdx_last_error', 'mdx_version', 'mdx_device_count',
+    'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
+    'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
+    'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
+    'mdx_moldiff_forward', 'mdx_bondpred_forward',
+    'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
+]
+
+
+class MdxConfig(ctypes.Structure):
+    _fields_ = [('kind', c_int32), ('node_dim', c_int32), ('edge_dim', c_int32), ('num_blocks', c_int32),
+                ('cutoff', c_float), ('num_gaussians', c_int32), ('update_pos', c_int32), ('time_dim', c_int32),
+                ('num_timesteps', c_int32), ('num_node_types', c_int32), ('num_edge_types', c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                               f'(or `make -C moldiff_amd/csrc`). moldiff_amd has no CPU/PyTorch fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        L.mdx_last_error.restype = c_char_p
+        L.mdx_workspace_bytes.restype = c_size_t
+        L.mdx_workspace_bytes.argtypes = [c_int64, c_int64]
+        L.mdx_model_create.argtypes = [POINTER(MdxConfig), POINTER(c_void_p)]
+        L.mdx_model_destroy.argtypes = [c_void_p]
+        L.mdx_model_set_param.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
+        L.mdx_model_finalize.argtypes = [c_void_p]
+        L.mdx_graph_create.argtypes = [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_void_p)]
+        L.mdx_graph_destroy.argtypes = [c_void_p]
+        L.mdx_graph_plan_host.argtypes = [c_int64, c_int64] + [c_void_p] * 7
+        L.mdx_net_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_node_block.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 4 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_edge_block.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 4 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_pos_update.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_segment_sum.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]
+        L.mdx_moldiff_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_bondpred_forward.argtypes = [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_pos_posterior.argtypes = [c_void_p] * 8 + [c_int64, c_void_p, c_void_p]
+        L.mdx_cat_posterior.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_void_p, c_void_p]
+        L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_noise.argtypes = [c_void_p, c_uint64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.mdx_device_count.argtypes = [POINTER(c_int)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f'libmoldiff_hip error {rc}: {lib().mdx_last_error().decode()}')
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('moldiff_amd runs on a ROCm device only (got a CPU tensor); there is no CPU fallback. '
+                               'The CPU oracle lives in oracle/ and is test infrastructure.')
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def i64c(t):
+    return t.detach().to(torch.int64).contiguous()
+
+
+class Graph:
+    """Device CSR plan of one packed batch (edge list stably sorted by (left, right))."""
+
+    def __init__(self, edge_index, batch_node, n_graphs, mol_ids=None):
+        ei = edge_index.detach().to('cpu', torch.int64).contiguous()
+        bn = batch_node.detach().to('cpu', torch.int64).contiguous()
+        self.N, self.E, self.B = int(bn.numel()), int(ei.shape[1]), int(n_graphs)
+        self.Eh = self.E // 2
+        mids = None
+        if mol_ids is not None:
+            mids = torch.as_tensor(mol_ids, dtype=torch.int64).contiguous()
+        h = c_void_p()
+        check(lib().mdx_graph_create(self.N, self.E, ptr(ei), ptr(bn), self.B, ptr(mids), ctypes.byref(h)))
+        self.h = h
+        self._ws = None
+
+    def workspace(self, device):
+        if self._ws is None or self._ws.device != device:
+            nbytes = lib().mdx_workspace_bytes(self.N, self.E)
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        off = (-self._ws.data_ptr()) % 256
+        return c_void_p(self._ws.data_ptr() + off), c_size_t(self._ws.numel() - off)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                lib().mdx_graph_destroy(self.h)
+        except Exception:
+            pass
+
+
+_graph_cache = {}
+
+
+def graph_for(edge_index, batch_node, n_graphs=None, mol_ids=None):
+    """Small identity-keyed cache so repeated forward() calls on the same index tensors reuse the plan."""
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, batch_node.data_ptr(),
+           batch_node._version, int(batch_node.numel()), n_graphs)
+    g = _graph_cache.get(key)
+    if g is None:
+        if n_graphs is None:
+            n_graphs = int(batch_node.max().item()) + 1 if batch_node.numel() else 0
+        g = Graph(edge_index, batch_node, n_graphs, mol_ids)
+        g._keepalive = (edge_index, batch_node)
+        if len(_graph_cache) > 8:
+            _graph_cache.clear()
+        _graph_cache[key] = g
+    return g
+
+
+class Model:
+    """Packed weights of one MolDiff / BondPredictor / bare NodeEdgeNet on the device."""
+
+    def __init__(self, kind, *, num_blocks, cutoff, update_pos, time_dim=0, num_timesteps=1, num_node_types=1,
+                 num_edge_types=1, node_dim=256, edge_dim=64, num_gaussians=16):
+        cfg = MdxConfig(kind, node_dim, edge_dim, num_blocks, float(cutoff), num_gaussians, int(bool(update_pos)),
+                        time_dim, num_timesteps, num_node_types, num_edge_types)
+        h = c_void_p()
+        check(lib().mdx_model_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self.cfg = cfg
+
+    def upload(self, state_dict, prefix=''):
+        for k, v in state_dict.items():
+            if not k.startswith(prefix) or v.dtype not in (torch.float32, torch.float64, torch.float16, torch.bfloat16):
+                continue
+            t = v.detach().to('cpu', torch.float32).contiguous()
+            shape = (c_int64 * max(t.dim(), 1))(*t.shape)
+            check(lib().mdx_model_set_param(self.h, k[len(prefix):].encode(), ptr(t), shape, t.dim()))
+        check(lib().mdx_model_finalize(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                lib().mdx_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ---- transition wrappers (used by moldiff_amd.transition) ------------------------------------------
+
+def pos_posterior(c0, ct, sd, x_t, x_recon, eps, t, batch):
+    _need_gpu(x_t, x_recon, eps, t, batch, c0)
+    x_t, x_recon, eps = f32c(x_t), f32c(x_recon), f32c(eps)
+    out = torch.empty_like(x_t)
+    check(lib().mdx_pos_posterior(ptr(c0), ptr(ct), ptr(sd), ptr(x_t), ptr(x_recon), ptr(eps), ptr(i64c(t)),
+                                  ptr(i64c(batch)), x_t.shape[0], ptr(out), stream()))
+    return out
+
+
+def cat_posterior(q_mats, qT, in0, log_vt, t, batch, is_logits=False):
+    _need_gpu(in0, log_vt, t, batch, q_mats)
+    in0, log_vt = f32c(in0), f32c(log_vt)
+    out = torch.empty_like(in0)
+    check(lib().mdx_cat_posterior(ptr(q_mats), ptr(qT), in0.shape[1], q_mats.shape[0], ptr(in0), int(is_logits),
+                                  ptr(log_vt), ptr(i64c(t)), ptr(i64c(batch)), in0.shape[0], ptr(out), stream()))
+    return out
+
+
+def gumbel_argmax(logits, u, want_onehot=False):
+    _need_gpu(logits, u)
+    logits, u = f32c(logits), f32c(u)
+    n, K = logits.shape
+    cls = torch.empty(n, dtype=torch.int64, device=logits.device)
+    oh = torch.empty(n, K, dtype=torch.float32, device=logits.device) if want_onehot else None
+    check(lib().mdx_gumbel_argmax(ptr(logits), ptr(u), K, n, ptr(cls), ptr(oh), stream()))
+    return (cls, oh) if want_onehot else cls

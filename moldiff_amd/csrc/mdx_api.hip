@@ -1,0 +1,786 @@
+// Host side of libmoldiff_hip.so: handles, weight packing, CSR planning, launch orchestration, C ABI.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/moldiff_hip.h"
+#include "mdx_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(x)                                                                           \
+  do {                                                                                      \
+    hipError_t e_ = (x);                                                                    \
+    if (e_ != hipSuccess) return fail(MDX_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));   \
+  } while (0)
+
+extern "C" const char* mdx_last_error(void) { return g_err; }
+extern "C" int mdx_version(void) { return 100; }
+extern "C" int mdx_device_count(int* count) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  if (count) *count = n;
+  return MDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+struct BlockW {
+  EdgeAW ea;
+  EdgeBW eb;
+  NodeW nd;  // mid fields = tail of this block, pre fields = pre-stage of this block
+};
+
+struct mdx_model_s {
+  mdx_config cfg;
+  std::map<std::string, HostTensor> params;
+  bool finalized = false;
+  float* arena = nullptr;  // device
+  size_t arena_floats = 0;
+  std::vector<BlockW> blocks;
+  const float *soff = nullptr, *scoef = nullptr;  // distance smearing
+  // heads
+  const float *Wn = nullptr, *We = nullptr, *toff = nullptr, *tcoef = nullptr;
+  MlpW nodedec{}, edgedec{};
+  // bond predictor decoder (3 layers)
+  const float *bd_W1e = nullptr, *bd_W1n = nullptr, *bd_b1 = nullptr, *bd_g1 = nullptr, *bd_be1 = nullptr;
+  const float *bd_W2 = nullptr, *bd_b2 = nullptr, *bd_g2 = nullptr, *bd_be2 = nullptr, *bd_W3 = nullptr, *bd_b3 = nullptr;
+};
+
+namespace {
+
+struct Packer {
+  std::vector<float> host;
+  std::vector<std::pair<const float**, size_t>> fix;  // pointer slot <- arena offset
+  size_t reserve(size_t n) {
+    size_t off = (host.size() + 63) & ~size_t(63);
+    host.resize(off + n, 0.f);
+    return off;
+  }
+  void bind(const float** slot, size_t off) { fix.emplace_back(slot, off); }
+};
+
+struct PackCtx {
+  mdx_model_s* m;
+  Packer pk;
+  std::string missing;
+  const HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
+    auto it = m->params.find(key);
+    if (it == m->params.end()) {
+      if (missing.empty()) missing = key;
+      return nullptr;
+    }
+    std::vector<int64_t> s(shape);
+    if (it->second.shape != s) {
+      if (missing.empty()) missing = key + " (shape mismatch)";
+      return nullptr;
+    }
+    return &it->second;
+  }
+  // dense row-major (F x ldw) -> fragment order for gemm_tile: float index ((g*FT + ft)*64 + lane)*4 + s
+  void pack_dense(const float** slot, const std::vector<float>& W, int F, int ldw, int col0, int K) {
+    const int FT = (F + 15) / 16, G = K / 16;
+    size_t off = pk.reserve((size_t)G * FT * 256);
+    float* o = pk.host.data() + off;
+    for (int g = 0; g < G; ++g)
+      for (int ft = 0; ft < FT; ++ft)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int f = 16 * ft + (lane & 15), k = 16 * g + 4 * (lane >> 4) + s;
+            o[(((size_t)g * FT + ft) * 64 + lane) * 4 + s] = f < F ? W[(size_t)f * ldw + col0 + k] : 0.f;
+          }
+    pk.bind(slot, off);
+  }
+  void packA(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    pack_dense(slot, t->data, F, ldw, col0, K);
+  }
+  void vec(const float** slot, const std::string& key, int n, int pad_to = 0) {
+    const HostTensor* t = get(key, {n});
+    if (!t) return;
+    size_t off = pk.reserve(std::max(n, pad_to));
+    std::copy(t->data.begin(), t->data.end(), pk.host.begin() + off);
+    pk.bind(slot, off);
+  }
+  void raw(const float** slot, const std::vector<float>& v) {
+    size_t off = pk.reserve(v.size());
+    std::copy(v.begin(), v.end(), pk.host.begin() + off);
+    pk.bind(slot, off);
+  }
+  void column(const float** slot, const std::string& key, int F, int ldw, int col) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    std::vector<float> v(F);
+    for (int f = 0; f < F; ++f) v[f] = t->data[(size_t)f * ldw + col];
+    raw(slot, v);
+  }
+  void mlp(MlpW* w, const std::string& pre, int in, int hid, int out, int out_pad = 0) {
+    packA(&w->W1, pre + ".net.0.weight", hid, in, 0, in);
+    vec(&w->b1, pre + ".net.0.bias", hid);
+    vec(&w->g, pre + ".net.1.weight", hid);
+    vec(&w->be, pre + ".net.1.bias", hid);
+    packA(&w->W2, pre + ".net.3.weight", out, hid, 0, hid);
+    vec(&w->b2, pre + ".net.3.bias", out, out_pad);
+  }
+};
+
+int pack_model(mdx_model_s* m) {
+  PackCtx c{m};
+  const mdx_config& cf = m->cfg;
+  const int ND = MDX_ND, ED = MDX_ED, GIN = ED + ND + 1;  // 321
+  const std::string net = cf.kind == MDX_KIND_MOLDIFF ? "denoiser." : cf.kind == MDX_KIND_BONDPRED ? "encoder." : "";
+  m->blocks.assign(cf.num_blocks, BlockW{});
+  c.vec(&m->soff, net + "distance_expansion.offset", MDX_NG);
+  c.vec(&m->scoef, net + "distance_expansion.coeff", MDX_NG);
+  std::vector<float> scalars_bi2(cf.num_blocks, 0.f), scalars_bg2(cf.num_blocks, 0.f);
+  for (int i = 0; i < cf.num_blocks; ++i) {
+    BlockW& b = m->blocks[i];
+    const std::string si = std::to_string(i);
+    const std::string nb = net + "node_blocks_with_edge." + si, eb = net + "edge_blocks." + si, pb = net + "pos_blocks." + si;
+    // ---- edge kernel A
+    c.packA(&b.ea.Wemb, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, 0, ED + MDX_NG);
+    c.vec(&b.ea.bemb, net + "edge_embs." + si + ".bias", ED);
+    c.packA(&b.ea.Wg1e, nb + ".gate.net.0.weight", ND, GIN, 0, ED);
+    c.vec(&b.ea.bg1, nb + ".gate.net.0.bias", ND);
+    c.column(&b.ea.wtg1, nb + ".gate.net.0.weight", ND, GIN, GIN - 1);
+    c.vec(&b.ea.gg, nb + ".gate.net.1.weight", ND);
+    c.vec(&b.ea.gb, nb + ".gate.net.1.bias", ND);
+    c.packA(&b.ea.Wg2, nb + ".gate.net.3.weight", ND, ND, 0, ND);
+    c.vec(&b.ea.bg2, nb + ".gate.net.3.bias", ND);
+    c.mlp(&b.ea.en, nb + ".edge_net", ED, ND, ND);
+    c.packA(&b.ea.Wm, nb + ".msg_net.weight", ND, ND, 0, ND);
+    c.vec(&b.ea.bm, nb + ".msg_net.bias", ND);
+    for (int s = 0; s < 2; ++s) {
+      FfnW& f = b.ea.ffn[s];
+      const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
+      c.packA(&f.Wbl, fp + ".bond_linear.weight", 2 * ED, ED, 0, ED);
+      c.mlp(&f.inter, fp + ".inter_module", 2 * ED, 2 * ED, ED);
+      c.packA(&f.Wg1e, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
+      c.vec(&f.bg1, fp + ".gate.net.0.bias", 32);
+      c.column(&f.wtg1, fp + ".gate.net.0.weight", 32, GIN, GIN - 1);
+      c.vec(&f.gg, fp + ".gate.net.1.weight", 32);
+      c.vec(&f.gb, fp + ".gate.net.1.bias", 32);
+      c.packA(&f.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
+      c.vec(&f.bg2, fp + ".gate.net.3.bias", ED);
+    }
+    // ---- edge kernel B
+    c.packA(&b.eb.Wself, eb + ".self_ffn.weight", ED, ED, 0, ED);
+    c.vec(&b.eb.bself, eb + ".self_ffn.bias", ED);
+    c.vec(&b.eb.lng, eb + ".layer_norm.weight", ED);
+    c.vec(&b.eb.lnb, eb + ".layer_norm.bias", ED);
+    c.packA(&b.eb.Wout, eb + ".out_transform.weight", ED, ED, 0, ED);
+    c.vec(&b.eb.bout, eb + ".out_transform.bias", ED);
+    // ---- node kernel
+    c.vec(&b.nd.lng, nb + ".layer_norm.weight", ND);
+    c.vec(&b.nd.lnb, nb + ".layer_norm.bias", ND);
+    c.packA(&b.nd.Wout, nb + ".out_transform.weight", ND, ND, 0, ND);
+    c.vec(&b.nd.bout, nb + ".out_transform.bias", ND);
+    c.mlp(&b.nd.nn, nb + ".node_net", ND, ND, ND);
+    {  // concatenated per-node table weights (960 x 256) + bias
+      std::vector<float> W((size_t)MDX_NTW * ND, 0.f), bias(MDX_NTW, 0.f);
+      auto put = [&](const std::string& key, int rows, int ldw, int col0, int dst_row, const std::string& bkey) {
+        const HostTensor* t = c.get(key, {rows, ldw});
+        if (!t) return;
+        for (int r = 0; r < rows; ++r)
+          for (int k = 0; k < ND; ++k) W[(size_t)(dst_row + r) * ND + k] = t->data[(size_t)r * ldw + col0 + k];
+        if (!bkey.empty()) {
+          const HostTensor* bt = c.get(bkey, {rows});
+          if (bt) std::copy(bt->data.begin(), bt->data.end(), bias.begin() + dst_row);
+        }
+      };
+      put(nb + ".centroid_lin.weight", ND, ND, 0, MDX_NT_C, nb + ".centroid_lin.bias");
+      put(nb + ".gate.net.0.weight", ND, GIN, ED, MDX_NT_GX, "");
+      put(eb + ".bond_ffn_left.node_linear.weight", 2 * ED, ND, 0, MDX_NT_NLL, "");
+      put(eb + ".bond_ffn_right.node_linear.weight", 2 * ED, ND, 0, MDX_NT_NLR, "");
+      put(eb + ".node_ffn_left.weight", ED, ND, 0, MDX_NT_NFL, eb + ".node_ffn_left.bias");
+      put(eb + ".node_ffn_right.weight", ED, ND, 0, MDX_NT_NFR, eb + ".node_ffn_right.bias");
+      put(eb + ".bond_ffn_left.gate.net.0.weight", 32, GIN, ED, MDX_NT_GXL, "");
+      put(eb + ".bond_ffn_right.gate.net.0.weight", 32, GIN, ED, MDX_NT_GXR, "");
+      c.pack_dense(&b.nd.Wcat, W, MDX_NTW, ND, 0, ND);
+      c.raw(&b.nd.bcat, bias);
+    }
+    if (cf.update_pos) {
+      c.mlp(&b.nd.left, pb + ".left_lin_edge", ND, ED, ED);
+      c.mlp(&b.nd.right, pb + ".right_lin_edge", ND, ED, ED);
+      const std::string el = pb + ".edge_lin";
+      c.packA(&b.eb.Wbl, el + ".bond_linear.weight", ND, ED, 0, ED);
+      c.packA(&b.eb.Wnl, el + ".node_linear.weight", ND, ED, 0, ED);
+      c.packA(&b.eb.Wi1, el + ".inter_module.net.0.weight", ND, ND, 0, ND);
+      c.vec(&b.eb.bi1, el + ".inter_module.net.0.bias", ND);
+      c.vec(&b.eb.ig, el + ".inter_module.net.1.weight", ND);
+      c.vec(&b.eb.ib, el + ".inter_module.net.1.bias", ND);
+      if (const HostTensor* t = c.get(el + ".inter_module.net.3.weight", {1, ND})) c.raw(&b.eb.wi2, t->data);
+      if (const HostTensor* t = c.get(el + ".inter_module.net.3.bias", {1})) b.eb.bi2 = t->data[0];
+      c.packA(&b.eb.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
+      c.packA(&b.eb.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
+      c.vec(&b.eb.bg1, el + ".gate.net.0.bias", 32);
+      c.column(&b.eb.wtg1, el + ".gate.net.0.weight", 32, 2 * ED + 1, 2 * ED);
+      c.vec(&b.eb.gg, el + ".gate.net.1.weight", 32);
+      c.vec(&b.eb.gb, el + ".gate.net.1.bias", 32);
+      if (const HostTensor* t = c.get(el + ".gate.net.3.weight", {1, 32})) c.raw(&b.eb.wg2, t->data);
+      if (const HostTensor* t = c.get(el + ".gate.net.3.bias", {1})) b.eb.bg2 = t->data[0];
+    }
+  }
+  if (cf.kind == MDX_KIND_MOLDIFF || cf.kind == MDX_KIND_BONDPRED) {
+    const int nd_emb = ND - cf.time_dim, ed_emb = ED - cf.time_dim;
+    const int ein = cf.kind == MDX_KIND_MOLDIFF ? cf.num_edge_types : 2 * cf.num_node_types;
+    if (const HostTensor* t = c.get("node_embedder.weight", {nd_emb, cf.num_node_types})) c.raw(&m->Wn, t->data);
+    if (const HostTensor* t = c.get("edge_embedder.weight", {ed_emb, ein})) c.raw(&m->We, t->data);
+    const std::string te = cf.kind == MDX_KIND_MOLDIFF ? "time_emb.0." : "time_emb.";
+    c.vec(&m->toff, te + "offset", cf.time_dim);
+    c.vec(&m->tcoef, te + "coeff", cf.time_dim);
+  }
+  if (cf.kind == MDX_KIND_MOLDIFF) {
+    c.mlp(&m->nodedec, "node_decoder", ND, ND, cf.num_node_types, 16);
+    c.mlp(&m->edgedec, "edge_decoder", ED, ED, cf.num_edge_types, 16);
+  }
+  if (cf.kind == MDX_KIND_BONDPRED) {
+    const std::string d = "edge_decoder.net.";
+    c.packA(&m->bd_W1e, d + "0.weight", ED, ED + ND, 0, ED);
+    c.packA(&m->bd_W1n, d + "0.weight", ED, ED + ND, ED, ND);
+    c.vec(&m->bd_b1, d + "0.bias", ED);
+    c.vec(&m->bd_g1, d + "1.weight", ED);
+    c.vec(&m->bd_be1, d + "1.bias", ED);
+    c.packA(&m->bd_W2, d + "3.weight", ED, ED, 0, ED);
+    c.vec(&m->bd_b2, d + "3.bias", ED);
+    c.vec(&m->bd_g2, d + "4.weight", ED);
+    c.vec(&m->bd_be2, d + "4.bias", ED);
+    c.packA(&m->bd_W3, d + "6.weight", cf.num_edge_types, ED, 0, ED);
+    c.vec(&m->bd_b3, d + "6.bias", cf.num_edge_types, 16);
+  }
+  if (!c.missing.empty()) return fail(MDX_ERR_STATE, "missing or mis-shaped parameter: %s", c.missing.c_str());
+  if (m->arena) hipFree(m->arena);
+  m->arena = nullptr;
+  m->arena_floats = c.pk.host.size();
+  HIPCHK(hipMalloc((void**)&m->arena, m->arena_floats * sizeof(float)));
+  HIPCHK(hipMemcpy(m->arena, c.pk.host.data(), m->arena_floats * sizeof(float), hipMemcpyHostToDevice));
+  for (auto& f : c.pk.fix) *f.first = m->arena + f.second;
+  m->finalized = true;
+  return MDX_OK;
+}
+
+}  // namespace
+
+extern "C" int mdx_model_create(const mdx_config* cfg, mdx_model_t* out) {
+  if (!cfg || !out) return fail(MDX_ERR_ARG, "null argument");
+  if (cfg->node_dim != MDX_ND || cfg->edge_dim != MDX_ED || cfg->num_gaussians != MDX_NG)
+    return fail(MDX_ERR_UNSUPPORTED, "kernels are built for node_dim=%d edge_dim=%d num_gaussians=%d (got %d/%d/%d)", MDX_ND,
+                MDX_ED, MDX_NG, cfg->node_dim, cfg->edge_dim, cfg->num_gaussians);
+  if (cfg->num_blocks < 1 || cfg->num_blocks > 64) return fail(MDX_ERR_ARG, "num_blocks out of range");
+  if (cfg->kind != MDX_KIND_NET) {
+    if (cfg->num_node_types < 1 || cfg->num_node_types > 8 || cfg->num_edge_types < 1 || cfg->num_edge_types > 8)
+      return fail(MDX_ERR_UNSUPPORTED, "class counts must be in 1..8");
+    if (cfg->time_dim < 0 || cfg->time_dim >= MDX_ED) return fail(MDX_ERR_ARG, "time_dim out of range");
+  }
+  mdx_model_s* m = new mdx_model_s();
+  m->cfg = *cfg;
+  *out = m;
+  return MDX_OK;
+}
+
+extern "C" int mdx_model_destroy(mdx_model_t m) {
+  if (!m) return MDX_OK;
+  if (m->arena) hipFree(m->arena);
+  delete m;
+  return MDX_OK;
+}
+
+extern "C" int mdx_model_set_param(mdx_model_t m, const char* key, const float* h_data, const int64_t* shape,
+                                   int32_t ndim) {
+  if (!m || !key || !h_data || (ndim > 0 && !shape) || ndim < 0 || ndim > 4) return fail(MDX_ERR_ARG, "bad argument");
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] < 0) return fail(MDX_ERR_ARG, "negative dim");
+    t.shape.push_back(shape[i]);
+    n *= (size_t)shape[i];
+  }
+  t.data.assign(h_data, h_data + n);
+  m->params[key] = std::move(t);
+  m->finalized = false;
+  return MDX_OK;
+}
+
+extern "C" int mdx_model_finalize(mdx_model_t m) {
+  if (!m) return fail(MDX_ERR_ARG, "null model");
+  return pack_model(m);
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph
+// ------------------------------------------------------------------------------------------------
+struct mdx_graph_s {
+  int64_t N = 0, E = 0, Eh = 0, B = 0;
+  int32_t* dev = nullptr;   // one int32 slab
+  int64_t* mol_ids = nullptr;
+  const int32_t *left, *right, *int2ref, *ref2int, *row_ptr, *col_ptr, *col_eids, *node_graph, *node_local, *he_graph,
+      *he_local;
+};
+
+namespace {
+struct HostPlan {
+  std::vector<int32_t> left, right, int2ref, ref2int, row_ptr, col_ptr, col_eids;
+};
+
+int plan_graph(int64_t N, int64_t E, const int64_t* ei, HostPlan& p) {
+  if (N < 0 || E < 0 || N > INT32_MAX / 4 || E > INT32_MAX / 4) return fail(MDX_ERR_ARG, "graph too large");
+  const int64_t* L = ei;
+  const int64_t* R = ei + E;
+  for (int64_t e = 0; e < E; ++e)
+    if (L[e] < 0 || L[e] >= N || R[e] < 0 || R[e] >= N) return fail(MDX_ERR_ARG, "edge_index out of range at %lld", (long long)e);
+  p.int2ref.resize(E);
+  std::iota(p.int2ref.begin(), p.int2ref.end(), 0);
+  std::stable_sort(p.int2ref.begin(), p.int2ref.end(), [&](int32_t a, int32_t b) {
+    if (L[a] != L[b]) return L[a] < L[b];
+    return R[a] < R[b];
+  });
+  p.left.resize(E);
+  p.right.resize(E);
+  p.ref2int.resize(E);
+  p.row_ptr.assign(N + 1, 0);
+  p.col_ptr.assign(N + 1, 0);
+  for (int64_t i = 0; i < E; ++i) {
+    const int32_t e = p.int2ref[i];
+    p.left[i] = (int32_t)L[e];
+    p.right[i] = (int32_t)R[e];
+    p.ref2int[e] = (int32_t)i;
+    p.row_ptr[L[e] + 1]++;
+    p.col_ptr[R[e] + 1]++;
+  }
+  for (int64_t v = 0; v < N; ++v) {
+    p.row_ptr[v + 1] += p.row_ptr[v];
+    p.col_ptr[v + 1] += p.col_ptr[v];
+  }
+  p.col_eids.resize(E);
+  std::vector<int32_t> cur(p.col_ptr.begin(), p.col_ptr.end() - 1);
+  for (int64_t i = 0; i < E; ++i) p.col_eids[cur[p.right[i]]++] = (int32_t)i;
+  return MDX_OK;
+}
+}  // namespace
+
+extern "C" int mdx_graph_plan_host(int64_t N, int64_t E, const int64_t* ei, int32_t* left, int32_t* right,
+                                   int32_t* int2ref, int32_t* row_ptr, int32_t* col_ptr, int32_t* col_eids) {
+  if ((E > 0 && !ei) || !left || !right || !int2ref || !row_ptr || !col_ptr || !col_eids) return fail(MDX_ERR_ARG, "null argument");
+  HostPlan p;
+  int rc = plan_graph(N, E, ei, p);
+  if (rc) return rc;
+  std::copy(p.left.begin(), p.left.end(), left);
+  std::copy(p.right.begin(), p.right.end(), right);
+  std::copy(p.int2ref.begin(), p.int2ref.end(), int2ref);
+  std::copy(p.row_ptr.begin(), p.row_ptr.end(), row_ptr);
+  std::copy(p.col_ptr.begin(), p.col_ptr.end(), col_ptr);
+  std::copy(p.col_eids.begin(), p.col_eids.end(), col_eids);
+  return MDX_OK;
+}
+
+extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const int64_t* bn, int64_t B,
+                                const int64_t* mol_ids, mdx_graph_t* out) {
+  if (!out || (E > 0 && !ei) || (N > 0 && !bn) || B < 0) return fail(MDX_ERR_ARG, "null argument");
+  HostPlan p;
+  int rc = plan_graph(N, E, ei, p);
+  if (rc) return rc;
+  std::vector<int32_t> node_graph(N), node_local(N);
+  {
+    int64_t prev = -1, cnt = 0;
+    for (int64_t v = 0; v < N; ++v) {
+      if (bn[v] < 0 || bn[v] >= B) return fail(MDX_ERR_ARG, "batch_node[%lld] out of range", (long long)v);
+      if (bn[v] < prev) return fail(MDX_ERR_ARG, "batch_node must be non-decreasing");
+      if (bn[v] != prev) cnt = 0;
+      node_graph[v] = (int32_t)bn[v];
+      node_local[v] = (int32_t)cnt++;
+      prev = bn[v];
+    }
+  }
+  // half-edge bookkeeping (reference order: first E/2 columns are the i<j pairs, model.py:269)
+  const int64_t Eh = E / 2;
+  std::vector<int32_t> he_graph(Eh), he_local(Eh);
+  {
+    int64_t prev = -1, cnt = 0;
+    for (int64_t h = 0; h < Eh; ++h) {
+      const int64_t gph = bn[ei[h]];
+      if (gph != prev) cnt = 0;
+      he_graph[h] = (int32_t)gph;
+      he_local[h] = (int32_t)cnt++;
+      prev = gph;
+    }
+  }
+  mdx_graph_s* g = new mdx_graph_s();
+  g->N = N; g->E = E; g->Eh = Eh; g->B = B;
+  std::vector<int32_t> slab;
+  auto add = [&](const std::vector<int32_t>& v) {
+    size_t off = (slab.size() + 63) & ~size_t(63);
+    slab.resize(off + v.size() + 1, 0);
+    std::copy(v.begin(), v.end(), slab.begin() + off);
+    return off;
+  };
+  const size_t o_l = add(p.left), o_r = add(p.right), o_i2r = add(p.int2ref), o_r2i = add(p.ref2int), o_rp = add(p.row_ptr),
+               o_cp = add(p.col_ptr), o_ce = add(p.col_eids), o_ng = add(node_graph), o_nl = add(node_local),
+               o_hg = add(he_graph), o_hl = add(he_local);
+  if (hipMalloc((void**)&g->dev, slab.size() * 4) != hipSuccess ||
+      hipMemcpy(g->dev, slab.data(), slab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    delete g;
+    return fail(MDX_ERR_HIP, "graph upload failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  std::vector<int64_t> ids(B);
+  for (int64_t i = 0; i < B; ++i) ids[i] = mol_ids ? mol_ids[i] : i;
+  if (hipMalloc((void**)&g->mol_ids, std::max<int64_t>(B, 1) * 8) != hipSuccess ||
+      (B > 0 && hipMemcpy(g->mol_ids, ids.data(), B * 8, hipMemcpyHostToDevice) != hipSuccess)) {
+    hipFree(g->dev);
+    delete g;
+    return fail(MDX_ERR_HIP, "graph upload failed");
+  }
+  g->left = g->dev + o_l; g->right = g->dev + o_r; g->int2ref = g->dev + o_i2r; g->ref2int = g->dev + o_r2i;
+  g->row_ptr = g->dev + o_rp; g->col_ptr = g->dev + o_cp; g->col_eids = g->dev + o_ce; g->node_graph = g->dev + o_ng;
+  g->node_local = g->dev + o_nl; g->he_graph = g->dev + o_hg; g->he_local = g->dev + o_hl;
+  *out = g;
+  return MDX_OK;
+}
+
+extern "C" int mdx_graph_destroy(mdx_graph_t g) {
+  if (!g) return MDX_OK;
+  if (g->dev) hipFree(g->dev);
+  if (g->mol_ids) hipFree(g->mol_ids);
+  delete g;
+  return MDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Ws {
+  float *Hn, *H, *NT, *aggr, *SL, *SR, *Lf, *Rf, *tn, *posA, *posB;
+  float *HeA, *HeB, *M, *FL, *FR, *Fe, *te, *tmpE;  // tmpE: (E,64) scratch for boundary permutes
+  int64_t* tzero;  // (B) zeros? (unused)
+  size_t bytes;
+};
+
+size_t ws_layout(int64_t N, int64_t E, char* base, Ws* w) {
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += ((nfloat * 4 + 255) / 256) * 256;
+    return p;
+  };
+  const size_t n = (size_t)std::max<int64_t>(N, 1), e = (size_t)std::max<int64_t>(E, 1);
+  Ws t{};
+  t.Hn = take(n * MDX_ND); t.H = take(n * MDX_ND); t.NT = take(n * MDX_NTW); t.aggr = take(n * MDX_ND);
+  t.SL = take(n * 64); t.SR = take(n * 64); t.Lf = take(n * 64); t.Rf = take(n * 64); t.tn = take(n);
+  t.posA = take(n * 3); t.posB = take(n * 3);
+  t.HeA = take(e * 64); t.HeB = take(e * 64); t.M = take(e * MDX_ND); t.FL = take(e * 64); t.FR = take(e * 64);
+  t.Fe = take(e * 3); t.te = take(e); t.tmpE = take(e * 64);
+  t.bytes = off;
+  if (w) *w = t;
+  return off;
+}
+}  // namespace
+
+extern "C" size_t mdx_workspace_bytes(int64_t N, int64_t E) { return ws_layout(N, E, nullptr, nullptr); }
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels (permutes at the ABI boundary)
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
+                                   int n, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * C) return;
+  const int r = i / C, c = i - (size_t)r * C;
+  dst[i] = src[(size_t)idx[r] * C + c];
+}
+static void gather_rows(const float* src, const int* idx, float* dst, int64_t n, int C, hipStream_t s) {
+  if (n <= 0) return;
+  const size_t tot = (size_t)n * C;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, src, idx, dst, (int)n, C);
+}
+
+__global__ void expand_halfedge_kernel(const float* __restrict__ xh, const int* __restrict__ int2ref, float* __restrict__ dst,
+                                       int E, int Eh, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)E * K) return;
+  const int e = i / K, k = i - (size_t)e * K;
+  int r = int2ref[e];
+  if (r >= Eh) r -= Eh;
+  dst[i] = xh[(size_t)r * K + k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// block driver
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+#define CHECK_READY(m, g, ws, ws_bytes)                                                                    \
+  if (!(m) || !(g)) return fail(MDX_ERR_ARG, "null handle");                                               \
+  if (!(m)->finalized) return fail(MDX_ERR_STATE, "model not finalized (call mdx_model_finalize)");        \
+  if (!(ws) || (ws_bytes) < mdx_workspace_bytes((g)->N, (g)->E))                                           \
+    return fail(MDX_ERR_STATE, "workspace too small: need %zu bytes", mdx_workspace_bytes((g)->N, (g)->E)); \
+  if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(MDX_ERR_ARG, "workspace must be 256-byte aligned");
+
+EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i, const float* pos, const float* He_in,
+                  float* He_out, int flags) {
+  EdgeAArgs a{};
+  a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.pos = pos; a.dist_in = nullptr;
+  a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = w.NT;
+  a.M = w.M; a.F[0] = w.FL; a.F[1] = w.FR; a.w = m->blocks[i].ea;
+  return a;
+}
+
+EdgeBArgs make_eb(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i, const float* pos, const float* Hep,
+                  float* He_out, int flags) {
+  EdgeBArgs a{};
+  a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.pos = pos; a.rel_in = nullptr;
+  a.dist_in = nullptr; a.Hep = Hep; a.SL = w.SL; a.SR = w.SR; a.NT = w.NT; a.He_out = He_out; a.Lf = w.Lf; a.Rf = w.Rf;
+  a.Fe = w.Fe; a.w = m->blocks[i].eb;
+  return a;
+}
+
+NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int imid, int ipre, int flags) {
+  NodeArgs a{};
+  a.N = (int)g->N; a.flags = flags; a.Hn = w.Hn; a.aggr = w.aggr; a.NTin = w.NT; a.dHn = nullptr; a.Lf = w.Lf; a.Rf = w.Rf;
+  a.H = w.H; a.NT = w.NT;
+  if (imid >= 0) a.wmid = m->blocks[imid].nd;
+  if (ipre >= 0) a.wpre = m->blocks[ipre].nd;
+  return a;
+}
+
+// Runs all blocks.  In: w.Hn, w.HeA (internal order), pos_in, w.tn / w.te.  Out: w.Hn, He (returned pointer), pos (returned).
+void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
+                const float** pos_final, hipStream_t s) {
+  const int nb = m->cfg.num_blocks;
+  const bool upos = m->cfg.update_pos != 0;
+  const float* pos = pos_in;
+  float* pos_next = w.posA;
+  launch_node(make_nd(m, g, w, -1, 0, ND_PRE), s);
+  for (int i = 0; i < nb; ++i) {
+    launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN), s);
+    launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s);
+    launch_seg_reduce(w.FL, g->col_ptr, g->col_eids, w.SL, nullptr, (int)g->N, 64, s);
+    launch_seg_reduce(w.FR, g->row_ptr, nullptr, w.SR, nullptr, (int)g->N, 64, s);
+    int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (i + 1 < nb ? ND_PRE : 0);
+    launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags), s);
+    launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0)), s);
+    if (upos) {
+      launch_seg_reduce(w.Fe, g->row_ptr, nullptr, pos_next, pos, (int)g->N, 3, s);
+      pos = pos_next;
+      pos_next = (pos_next == w.posA) ? w.posB : w.posA;
+    }
+  }
+  *He_final = w.HeA;
+  *pos_final = pos;
+}
+
+}  // namespace
+
+extern "C" int mdx_net_forward(mdx_model_t m, mdx_graph_t g, const float* h_node, const float* pos, const float* h_edge,
+                               const float* node_time, const float* edge_time, float* h_node_out, float* pos_out,
+                               float* h_edge_out, void* ws, size_t ws_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (!h_node || !pos || !h_edge || !node_time || !edge_time) return fail(MDX_ERR_ARG, "null input");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  HIPCHK(hipMemcpyAsync(w.Hn, h_node, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(w.tn, node_time, (size_t)g->N * 4, hipMemcpyDeviceToDevice, s));
+  gather_rows(h_edge, g->int2ref, w.HeA, g->E, 64, s);
+  gather_rows(edge_time, g->int2ref, w.te, g->E, 1, s);
+  const float *He, *pf;
+  run_blocks(m, g, w, pos, &He, &pf, s);
+  if (h_node_out) HIPCHK(hipMemcpyAsync(h_node_out, w.Hn, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
+  if (pos_out) HIPCHK(hipMemcpyAsync(pos_out, pf, (size_t)g->N * 12, hipMemcpyDeviceToDevice, s));
+  if (h_edge_out) gather_rows(He, g->ref2int, h_edge_out, g->E, 64, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_node_block(mdx_model_t m, mdx_graph_t g, int32_t i, const float* x, const float* edge_attr,
+                              const float* node_time, float* out, void* ws, size_t ws_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (i < 0 || i >= m->cfg.num_blocks || !x || !edge_attr || !node_time || !out) return fail(MDX_ERR_ARG, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  HIPCHK(hipMemcpyAsync(w.Hn, x, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
+  gather_rows(edge_attr, g->int2ref, w.HeA, g->E, 64, s);
+  // NodeBlock's gate sees node_time[col]: per-edge time = node_time[right]
+  gather_rows(node_time, g->right, w.te, g->E, 1, s);
+  launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
+  launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_NODE), s);
+  launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s);
+  NodeArgs na = make_nd(m, g, w, i, -1, ND_MID | ND_DELTA);
+  na.dHn = out;
+  launch_node(na, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_edge_block(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_bond, const float* h_node,
+                              const float* bond_time, float* out, void* ws, size_t ws_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (i < 0 || i >= m->cfg.num_blocks || !h_bond || !h_node || !bond_time || !out) return fail(MDX_ERR_ARG, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  HIPCHK(hipMemcpyAsync(w.Hn, h_node, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
+  gather_rows(h_bond, g->int2ref, w.HeA, g->E, 64, s);
+  gather_rows(bond_time, g->int2ref, w.te, g->E, 1, s);
+  launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
+  launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s);
+  launch_seg_reduce(w.FL, g->col_ptr, g->col_eids, w.SL, nullptr, (int)g->N, 64, s);
+  launch_seg_reduce(w.FR, g->row_ptr, nullptr, w.SR, nullptr, (int)g->N, 64, s);
+  launch_edge_b(make_eb(m, g, w, i, nullptr, w.HeA, w.HeB, EB_EDGE | EB_DELTA), s);
+  gather_rows(w.HeB, g->ref2int, out, g->E, 64, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_node, const float* h_edge,
+                              const float* rel, const float* dist, const float* edge_time, float* out, void* ws,
+                              size_t ws_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (!m->cfg.update_pos) return fail(MDX_ERR_STATE, "model has no pos blocks");
+  if (i < 0 || i >= m->cfg.num_blocks || !h_node || !h_edge || !rel || !dist || !edge_time || !out)
+    return fail(MDX_ERR_ARG, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  HIPCHK(hipMemcpyAsync(w.Hn, h_node, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
+  gather_rows(h_edge, g->int2ref, w.HeA, g->E, 64, s);
+  gather_rows(edge_time, g->int2ref, w.te, g->E, 1, s);
+  gather_rows(rel, g->int2ref, w.M, g->E, 3, s);        // M reused as scratch for rel (E,3)
+  gather_rows(dist, g->int2ref, w.FL, g->E, 1, s);      // FL reused as scratch for dist (E)
+  launch_node(make_nd(m, g, w, i, -1, ND_POSMLP), s);
+  EdgeBArgs eb = make_eb(m, g, w, i, nullptr, w.HeA, nullptr, EB_POS);
+  eb.rel_in = w.M;
+  eb.dist_in = w.FL;
+  launch_edge_b(eb, s);
+  launch_seg_reduce(w.Fe, g->row_ptr, nullptr, out, nullptr, (int)g->N, 3, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_segment_sum(mdx_graph_t g, const float* src, int32_t C, int32_t by_right, float* out, void* ws,
+                               size_t ws_bytes, void* stream) {
+  if (!g || !src || !out) return fail(MDX_ERR_ARG, "null argument");
+  if (C != 3 && C != 64 && C != 256) return fail(MDX_ERR_UNSUPPORTED, "C must be 3, 64 or 256");
+  if (!ws || ws_bytes < mdx_workspace_bytes(g->N, g->E)) return fail(MDX_ERR_STATE, "workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  gather_rows(src, g->int2ref, w.M, g->E, C, s);
+  if (by_right)
+    launch_seg_reduce(w.M, g->col_ptr, g->col_eids, out, nullptr, (int)g->N, C, s);
+  else
+    launch_seg_reduce(w.M, g->row_ptr, nullptr, out, nullptr, (int)g->N, C, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_node_pert, const float* pos_pert,
+                                   const float* h_edge_pert, const float* h_halfedge_pert, const int64_t* t,
+                                   float* pred_node, float* pred_pos, float* pred_halfedge, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (m->cfg.kind != MDX_KIND_MOLDIFF) return fail(MDX_ERR_STATE, "not a MolDiff model handle");
+  if (!h_node_pert || !pos_pert || (!h_edge_pert && !h_halfedge_pert) || !t) return fail(MDX_ERR_ARG, "null input");
+  if (g->E % 2) return fail(MDX_ERR_ARG, "MolDiff.forward needs E = 2*Eh directed edges");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  const mdx_config& cf = m->cfg;
+  EmbedArgs ea{};
+  ea.N = (int)g->N; ea.E = (int)g->E; ea.Kn = cf.num_node_types; ea.Ke = cf.num_edge_types; ea.time_dim = cf.time_dim;
+  ea.T = cf.num_timesteps; ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node_pert;
+  ea.int2ref = g->int2ref; ea.l = g->left; ea.r = g->right; ea.node_graph = g->node_graph; ea.t = t; ea.Wn = m->Wn;
+  ea.We = m->We; ea.toff = m->toff; ea.tcoef = m->tcoef; ea.Hn = w.Hn; ea.He = w.HeA; ea.tn = w.tn; ea.te = w.te;
+  if (h_edge_pert) {
+    ea.xe = h_edge_pert;
+  } else {  // both directions share the half-edge one-hot (model.py:273); expand into reference order
+    const size_t tot = (size_t)g->E * cf.num_edge_types;
+    if (tot) {
+      // write directly in *internal* order into tmpE, then read with identity mapping
+      hipLaunchKernelGGL(expand_halfedge_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, h_halfedge_pert, g->int2ref,
+                         w.tmpE, (int)g->E, (int)g->Eh, cf.num_edge_types);
+    }
+    ea.xe = w.tmpE;
+    ea.int2ref = nullptr;
+  }
+  launch_embed(ea, s);
+  const float *He, *pf;
+  run_blocks(m, g, w, pos_pert, &He, &pf, s);
+  DecodeArgs da{};
+  da.N = (int)g->N; da.Eh = (int)g->Eh; da.Kn = cf.num_node_types; da.Ke = cf.num_edge_types; da.Hn = w.Hn; da.He = He;
+  da.ref2int = g->ref2int; da.nodedec = m->nodedec; da.edgedec = m->edgedec; da.pred_node = pred_node;
+  da.pred_halfedge = pred_halfedge;
+  launch_decode(da, s);
+  if (pred_pos) HIPCHK(hipMemcpyAsync(pred_pos, pf, (size_t)g->N * 12, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h_node, const float* pos, const int64_t* t,
+                                    float* logits, void* ws, size_t ws_bytes, void* stream) {
+  (void)m; (void)g; (void)h_node; (void)pos; (void)t; (void)logits; (void)ws; (void)ws_bytes; (void)stream;
+  return fail(MDX_ERR_UNSUPPORTED, "mdx_bondpred_forward: not built yet (SURVEY section 8 row a15, next)");
+}
+
+// ------------------------------------------------------------------------------------------------
+// transitions
+// ------------------------------------------------------------------------------------------------
+extern "C" int mdx_pos_posterior(const float* c0, const float* ct, const float* sd, const float* x_t, const float* x_recon,
+                                 const float* eps, const int64_t* t, const int64_t* batch, int64_t n, float* out,
+                                 void* stream) {
+  if (n < 0 || (n > 0 && (!c0 || !ct || !sd || !x_t || !x_recon || !eps || !t || !batch || !out)))
+    return fail(MDX_ERR_ARG, "bad argument");
+  launch_pos_posterior(c0, ct, sd, x_t, x_recon, eps, t, batch, (int)n, out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_cat_posterior(const float* q_mats, const float* qT, int32_t K, int32_t T, const float* in0,
+                                 int32_t is_logits, const float* log_vt, const int64_t* t, const int64_t* batch, int64_t n,
+                                 float* out, void* stream) {
+  if (K < 2 || K > 8) return fail(MDX_ERR_UNSUPPORTED, "K must be in 2..8");
+  if (n < 0 || (n > 0 && (!q_mats || !qT || !in0 || !log_vt || !t || !batch || !out))) return fail(MDX_ERR_ARG, "bad argument");
+  launch_cat_posterior(q_mats, qT, K, T, in0, is_logits, log_vt, t, batch, (int)n, out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n, int64_t* cls, float* onehot,
+                                 void* stream) {
+  if (K < 1 || n < 0 || (n > 0 && (!logits || !u))) return fail(MDX_ERR_ARG, "bad argument");
+  launch_gumbel_argmax(logits, u, K, (int)n, cls, onehot, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_noise(mdx_graph_t g, uint64_t seed, int32_t draw, int32_t Kn, int32_t Ke, float* eps_pos, float* u_node,
+                         float* u_halfedge, void* stream) {
+  if (!g) return fail(MDX_ERR_ARG, "null graph");
+  if (Kn < 1 || Kn > 8 || Ke < 1 || Ke > 8) return fail(MDX_ERR_ARG, "class counts must be in 1..8");
+  launch_philox_noise(seed, draw, g->node_graph, g->node_local, g->he_graph, g->he_local, g->mol_ids, (int)g->N,
+                      (int)g->Eh, Kn, Ke, eps_pos, u_node, u_halfedge, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}

@@ -1,0 +1,163 @@
+// Kernel parameter blocks + launch prototypes shared by the host API (mdx_api.cpp) and the device
+// code (*.hip).  All pointers are device pointers.  "internal edge order" = directed edges stably
+// sorted by (left, right); see mdx_graph.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define MDX_ND 256  // node feature width (shipped configs; other widths are rejected at create)
+#define MDX_ED 64   // edge feature width
+#define MDX_NG 16   // distance gaussians
+#define MDX_ET 3    // edge tile = 16*MDX_ET rows per workgroup
+#define MDX_NT 2    // node tile = 16*MDX_NT rows per workgroup
+
+// Column layout of the per-node table NT (N, MDX_NTW) written by the node kernel (PRE stage) and
+// gathered by the edge kernels:  everything that is Linear(h_node)[idx] in the reference is hoisted
+// to one per-node GEMM (exact for a plain Linear; for the first layer of the gate MLPs it splits the
+// 321-wide contraction into edge + node + time parts, see DESIGN.md "hoisting").
+#define MDX_NT_C 0       // centroid_lin(x) + bias                         (256)
+#define MDX_NT_GX 256    // gate.net.0.weight[:, 64:320] x   (no bias)      (256)
+#define MDX_NT_NLL 512   // bond_ffn_left.node_linear x                     (128)
+#define MDX_NT_NLR 640   // bond_ffn_right.node_linear x                    (128)
+#define MDX_NT_NFL 768   // node_ffn_left(x) + bias                         (64)
+#define MDX_NT_NFR 832   // node_ffn_right(x) + bias                        (64)
+#define MDX_NT_GXL 896   // bond_ffn_left.gate.net.0.weight[:, 64:320] x    (32)
+#define MDX_NT_GXR 928   // bond_ffn_right.gate.net.0.weight[:, 64:320] x   (32)
+#define MDX_NTW 960
+
+struct MlpW {  // Linear -> LN -> ReLU -> Linear, all packed for gemm_tile
+  const float *W1, *b1, *g, *be, *W2, *b2;
+};
+
+struct FfnW {  // BondFFN of the EdgeBlock (bond 64, node 256 hoisted, inter 128, gate hidden 32, out 64)
+  const float* Wbl;            // bond_linear (128 x 64), no bias
+  MlpW inter;                  // 128 -> 128 -> 64
+  const float *Wg1e, *bg1, *wtg1, *gg, *gb;  // gate first layer: edge part (32 x 64), bias, time column, LN
+  const float *Wg2, *bg2;      // gate second layer (64 x 32)
+};
+
+struct EdgeAW {  // weights of edge kernel A for one block
+  const float *Wemb, *bemb;                        // edge_embs (64 x 80)
+  const float *Wg1e, *bg1, *wtg1, *gg, *gb, *Wg2, *bg2;  // NodeBlock gate: edge part (256x64), bias, time col, LN, 256x256
+  MlpW en;                                         // edge_net 64 -> 256 -> 256
+  const float *Wm, *bm;                            // msg_net 256 x 256
+  FfnW ffn[2];                                     // left, right
+};
+
+struct EdgeBW {  // weights of edge kernel B for one block
+  const float *Wself, *bself, *lng, *lnb, *Wout, *bout;  // EdgeBlock tail
+  // PosUpdate.edge_lin (BondFFN bond 64, node 64, inter 256, out 1)
+  const float *Wbl, *Wnl;          // 256 x 64 each, no bias
+  const float *Wi1, *bi1, *ig, *ib;  // inter_module first layer 256x256 + LN
+  const float *wi2;                // (256) second layer row
+  float bi2;
+  const float *Wg1h, *Wg1a, *bg1, *wtg1, *gg, *gb;  // gate first layer split: He part (32x64), a part (32x64), bias, time col, LN
+  const float *wg2;                // (32)
+  float bg2;
+};
+
+struct NodeW {  // weights of the node kernel
+  // MID stage (block i): NodeBlock tail + PosUpdate per-node MLPs
+  const float *lng, *lnb, *Wout, *bout;
+  MlpW left, right;  // 256 -> 64 -> 64
+  // PRE stage (block i or i+1)
+  MlpW nn;                     // node_net 256 -> 256 -> 256
+  const float *Wcat, *bcat;    // concatenated (960 x 256) + bias (960, zeros where the reference has none)
+};
+
+struct EdgeAArgs {
+  int E, flags;
+  const int *l, *r;       // internal order
+  const float* te;        // per-edge time t/T (internal order)
+  const float* pos;       // (N,3)
+  const float* dist_in;   // optional (E) internal order: use instead of |pos[l]-pos[r]| (unused in product path)
+  const float *soff, *scoef;  // distance smearing tables (16)
+  float cutoff;
+  const float* He_in;     // (E,64)
+  float* He_out;          // (E,64) = edge_embs([He|D])   (== He_in when !EA_EMB)
+  const float* H;         // (N,256) node_net(x)
+  const float* NT;        // (N,960)
+  float* M;               // (E,256) gated messages
+  float* F[2];            // (E,64) bond_ffn_left / right outputs
+  EdgeAW w;
+};
+#define EA_EMB 1
+#define EA_NODE 2
+#define EA_FFN 4
+
+struct EdgeBArgs {
+  int E, flags;
+  const int *l, *r;
+  const float* te;
+  const float* pos;        // (N,3) positions at block start (rel/dist source)
+  const float *rel_in, *dist_in;  // optional explicit (E,3)/(E) internal order (per-function API)
+  const float* Hep;        // (E,64) He' (edge_embs output)
+  const float *SL, *SR;    // (N,64) reduced FFN messages
+  const float* NT;         // (N,960) (nfl, nfr columns)
+  float* He_out;           // (E,64): He' + EdgeBlock(...)  (or just EdgeBlock(...) when EB_DELTA)
+  const float *Lf, *Rf;    // (N,64) PosUpdate per-node MLP outputs
+  float* Fe;               // (E,3) per-edge force
+  EdgeBW w;
+};
+#define EB_EDGE 1   // run the EdgeBlock tail
+#define EB_POS 2    // run PosUpdate
+#define EB_DELTA 4  // He_out = delta only (per-function EdgeBlock API)
+
+struct NodeArgs {
+  int N, flags;
+  float* Hn;             // (N,256) in/out (updated in place by MID)
+  const float* aggr;     // (N,256) segment-summed messages
+  const float* NTin;     // (N,960) table of the block being finished (centroid column)
+  float* dHn;            // optional (N,256): write out_transform(...) here instead of updating Hn (ND_DELTA)
+  float *Lf, *Rf;        // (N,64)
+  float* H;              // (N,256) out: node_net(x) for the next block
+  float* NT;             // (N,960) out
+  NodeW wmid, wpre;
+};
+#define ND_MID 1
+#define ND_PRE 2
+#define ND_DELTA 4
+#define ND_POSMLP 8
+
+void launch_edge_a(const EdgeAArgs& a, hipStream_t s);
+void launch_edge_b(const EdgeBArgs& a, hipStream_t s);
+void launch_node(const NodeArgs& a, hipStream_t s);
+
+// out[v][0..C) (+)= sum_{j in ptr[v]..ptr[v+1]} src[(eids ? eids[j] : j)][0..C)
+void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float* out, const float* addend, int N, int C,
+                       hipStream_t s);
+
+struct EmbedArgs {
+  int N, E, Kn, Ke, time_dim, T, nd_emb, ed_emb;  // nd_emb = 256 - time_dim, ed_emb = 64 - time_dim
+  const float* xn;        // (N,Kn)
+  const float* xe;        // (E_ref,Ke) reference edge order (MolDiff)   | nullptr for the bond predictor
+  const int* int2ref;     // (E)
+  const int *l, *r;       // internal
+  const int* node_graph;  // (N)
+  const int64_t* t;       // (B) device
+  const float *Wn, *We;   // node_embedder (nd_emb x Kn), edge_embedder (ed_emb x Ke or 2*Kn)
+  const float *toff, *tcoef;  // time smearing tables
+  float *Hn, *He, *tn, *te;   // outputs: (N,256) (E,64) (N) (E)
+};
+void launch_embed(const EmbedArgs& a, hipStream_t s);
+
+struct DecodeArgs {
+  int N, Eh, Kn, Ke;
+  const float* Hn;  // (N,256)
+  const float* He;  // (E,64) internal order
+  const int* ref2int;  // (E): reference index -> internal index
+  MlpW nodedec, edgedec;  // second layers padded to 16 outputs
+  float *pred_node, *pred_halfedge;
+};
+void launch_decode(const DecodeArgs& a, hipStream_t s);
+
+// transitions / noise (mdx_transition.hip)
+void launch_pos_posterior(const float* c0, const float* ct, const float* sd, const float* xt, const float* x0,
+                          const float* eps, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
+void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, const float* logits_or_log_v0, int is_logits,
+                          const float* log_vt, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
+void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s);
+void launch_philox_noise(uint64_t seed, int step, const int* node_graph, const int* node_local, const int* he_graph,
+                         const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,
+                         float* u_node, float* u_half, hipStream_t s);

@@ -1,0 +1,358 @@
+// Per-node kernels + graph reductions + embed/decode (gfx950).
+//
+//   node kernel  : MID  = NodeBlock tail   x += out_transform(relu(LN(centroid_lin(x) + sum_row m)))   (graph.py:50-54,363)
+//                  POSMLP = PosUpdate.left/right_lin_edge(x_new)                                      (graph.py:387-388)
+//                  PRE  = everything the next block computes per node: node_net(x) and the hoisted
+//                         Linear(x) terms of the gates / BondFFNs / node_ffn (table NT, see mdx_kernels.h)
+//   seg_reduce   : deterministic segmented sum over a CSR (the replacement for torch_scatter.scatter_sum,
+//                  call sites graph.py:50,279,283,394): one wave-slice per node, sequential in CSR order.
+//   embed/decode : MolDiff.forward / BondPredictor.forward ends (model.py:210-213,225-228; bond_predictor.py:135-140)
+#include "mdx_kernels.h"
+#include "mdx_tile.h"
+
+namespace {
+
+constexpr int NT_ = MDX_NT;
+constexpr int TN = 16 * NT_;
+constexpr int LD64 = mdx_ld(64);
+constexpr int LD256 = mdx_ld(256);
+constexpr int OFF_HN = 0;
+constexpr int OFF_X = OFF_HN + TN * LD256;
+constexpr int OFF_S = OFF_X + TN * LD256;
+constexpr int OFF_RED = OFF_S + TN * LD64;
+constexpr int OFF_RED2 = OFF_RED + 4 * TN;
+constexpr int NODE_LDS_FLOATS = OFF_RED2 + 4 * TN;
+
+__device__ __forceinline__ void mlp_small(const MlpW& w, const float* Hn, float* S, float* red, float* red2, float* out,
+                                          int v0, int N, int wave, int lane) {
+  // 256 -> 64 (LN, ReLU) -> 64 ; each wave owns one 16-feature tile
+  const int c = lane & 15, q = lane >> 4;
+  f32x4 t[1][NT_];
+  acc_bias<1, NT_>(t, w.b1, wave, lane);
+  gemm_tile<1, NT_, 256>(t, w.W1, 4, wave, Hn, LD256, lane);
+  layernorm_relu<1, NT_, 4>(t, w.g, w.be, wave, red, red2, wave, lane, true);
+  acc_to_lds<1, NT_>(t, S, LD64, 0, wave, lane);
+  __syncthreads();
+  acc_bias<1, NT_>(t, w.b2, wave, lane);
+  gemm_tile<1, NT_, 64>(t, w.W2, 4, wave, S, LD64, lane);
+#pragma unroll
+  for (int et = 0; et < NT_; ++et) {
+    const int v = v0 + 16 * et + c;
+    if (v < N) stg4(out + (size_t)v * 64 + 16 * wave + 4 * q, t[0][et]);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hn = smem + OFF_HN;
+  float* X = smem + OFF_X;
+  float* S = smem + OFF_S;
+  float* red = smem + OFF_RED;
+  float* red2 = smem + OFF_RED2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int v0 = blockIdx.x * TN;
+  const int N = a.N;
+  const int ft0 = 4 * wave;
+  bool valid[NT_];
+  int vi[NT_];
+#pragma unroll
+  for (int et = 0; et < NT_; ++et) {
+    vi[et] = v0 + 16 * et + c;
+    valid[et] = vi[et] < N;
+    if (!valid[et]) vi[et] = N - 1;
+  }
+
+  if (a.flags & ND_MID) {
+    f32x4 z[4][NT_];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int et = 0; et < NT_; ++et) {
+        const int f = 16 * (ft0 + ft) + 4 * q;
+        z[ft][et] = ldg4(a.NTin + (size_t)vi[et] * MDX_NTW + MDX_NT_C + f) + ldg4(a.aggr + (size_t)vi[et] * MDX_ND + f);
+      }
+    layernorm_relu<4, NT_, 4>(z, a.wmid.lng, a.wmid.lnb, ft0, red, red2, wave, lane, true);
+    acc_to_lds<4, NT_>(z, X, LD256, 0, ft0, lane);
+    __syncthreads();
+    acc_bias<4, NT_>(z, a.wmid.bout, ft0, lane);
+    gemm_tile<4, NT_, 256>(z, a.wmid.Wout, 16, ft0, X, LD256, lane);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int et = 0; et < NT_; ++et) {
+        const int f = 16 * (ft0 + ft) + 4 * q;
+        if (a.flags & ND_DELTA) {
+          if (valid[et]) stg4(a.dHn + (size_t)vi[et] * MDX_ND + f, z[ft][et]);
+        } else {
+          z[ft][et] = z[ft][et] + ldg4(a.Hn + (size_t)vi[et] * MDX_ND + f);
+          if (valid[et]) stg4(a.Hn + (size_t)vi[et] * MDX_ND + f, z[ft][et]);
+        }
+      }
+    acc_to_lds<4, NT_>(z, Hn, LD256, 0, ft0, lane);
+  } else {
+    for (int i = tid; i < TN * 64; i += MDX_WG) {
+      const int row = i >> 6, c4 = i & 63;
+      const int v = v0 + row;
+      sts4(Hn + row * LD256 + 4 * c4, v < N ? ldg4(a.Hn + (size_t)v * MDX_ND + 4 * c4) : splat4(0.f));
+    }
+  }
+  __syncthreads();
+
+  if (a.flags & ND_POSMLP) {
+    mlp_small(a.wmid.left, Hn, S, red, red2, a.Lf, v0, N, wave, lane);
+    mlp_small(a.wmid.right, Hn, S, red, red2, a.Rf, v0, N, wave, lane);
+  }
+
+  if (a.flags & ND_PRE) {
+    {
+      f32x4 t[4][NT_];
+      acc_bias<4, NT_>(t, a.wpre.nn.b1, ft0, lane);
+      gemm_tile<4, NT_, 256>(t, a.wpre.nn.W1, 16, ft0, Hn, LD256, lane);
+      layernorm_relu<4, NT_, 4>(t, a.wpre.nn.g, a.wpre.nn.be, ft0, red, red2, wave, lane, true);
+      acc_to_lds<4, NT_>(t, X, LD256, 0, ft0, lane);
+      __syncthreads();
+      acc_bias<4, NT_>(t, a.wpre.nn.b2, ft0, lane);
+      gemm_tile<4, NT_, 256>(t, a.wpre.nn.W2, 16, ft0, X, LD256, lane);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int et = 0; et < NT_; ++et)
+          if (valid[et]) stg4(a.H + (size_t)vi[et] * MDX_ND + 16 * (ft0 + ft) + 4 * q, t[ft][et]);
+    }
+    // concatenated per-node table: 60 feature tiles, 15 per wave in 3 chunks of 5
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+      const int f0 = 15 * wave + 5 * j;
+      f32x4 t[5][NT_];
+      acc_bias<5, NT_>(t, a.wpre.bcat, f0, lane);
+      gemm_tile<5, NT_, 256>(t, a.wpre.Wcat, MDX_NTW / 16, f0, Hn, LD256, lane);
+#pragma unroll
+      for (int ft = 0; ft < 5; ++ft)
+#pragma unroll
+        for (int et = 0; et < NT_; ++et)
+          if (valid[et]) stg4(a.NT + (size_t)vi[et] * MDX_NTW + 16 * (f0 + ft) + 4 * q, t[ft][et]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented sum.  C = 256: one wave per node (64 lanes x float4);  C = 64: 16 lanes per node;
+// C = 3: one lane per (node, component).  Sequential in CSR order => bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(MDX_WG) void seg_reduce_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
+                                                            const int* __restrict__ eids, float* __restrict__ out,
+                                                            const float* __restrict__ addend, int N) {
+  constexpr int LPN = C / 4;              // lanes per node
+  constexpr int NPB = MDX_WG / LPN;       // nodes per block
+  const int v = blockIdx.x * NPB + threadIdx.x / LPN;
+  const int c4 = threadIdx.x % LPN;
+  if (v >= N) return;
+  const int j0 = ptr[v], j1 = ptr[v + 1];
+  f32x4 s0 = splat4(0.f);
+  int j = j0;
+  // 4 independent loads in flight, summed in order
+  for (; j + 4 <= j1; j += 4) {
+    const int i0 = eids ? eids[j] : j, i1 = eids ? eids[j + 1] : j + 1, i2 = eids ? eids[j + 2] : j + 2,
+              i3 = eids ? eids[j + 3] : j + 3;
+    const f32x4 a0 = ldg4(src + (size_t)i0 * C + 4 * c4), a1 = ldg4(src + (size_t)i1 * C + 4 * c4),
+                a2 = ldg4(src + (size_t)i2 * C + 4 * c4), a3 = ldg4(src + (size_t)i3 * C + 4 * c4);
+    s0 = (((s0 + a0) + a1) + a2) + a3;
+  }
+  for (; j < j1; ++j) {
+    const int i0 = eids ? eids[j] : j;
+    s0 = s0 + ldg4(src + (size_t)i0 * C + 4 * c4);
+  }
+  if (addend) s0 = ldg4(addend + (size_t)v * C + 4 * c4) + s0;
+  stg4(out + (size_t)v * C + 4 * c4, s0);
+}
+
+__global__ __launch_bounds__(MDX_WG) void seg_reduce3_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
+                                                             const int* __restrict__ eids, float* __restrict__ out,
+                                                             const float* __restrict__ addend, int N) {
+  const int i = blockIdx.x * MDX_WG + threadIdx.x;
+  if (i >= 3 * N) return;
+  const int v = i / 3, k = i - 3 * v;
+  float s = 0.f;
+  for (int j = ptr[v]; j < ptr[v + 1]; ++j) s += src[3 * (size_t)(eids ? eids[j] : j) + k];
+  out[i] = addend ? addend[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding: h_node = [x_n W_n^T | smear(t)],  h_edge = [x_e W_e^T | smear(t)]  (internal edge order),
+// plus the per-row time arrays t/T used by the gates.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MDX_WG) void embed_node_kernel(const EmbedArgs a) {
+  const int i = blockIdx.x * MDX_WG + threadIdx.x;
+  if (i >= a.N * MDX_ND) return;
+  const int v = i / MDX_ND, f = i - v * MDX_ND;
+  const int64_t t = a.t[a.node_graph[v]];
+  float out;
+  if (f < a.nd_emb) {
+    float s = 0.f;
+    for (int k = 0; k < a.Kn; ++k) s = fmaf(a.xn[(size_t)v * a.Kn + k], a.Wn[f * a.Kn + k], s);
+    out = s;
+  } else {
+    const int k = f - a.nd_emb;
+    const float x = fminf(fmaxf((float)t, 0.f), (float)a.T) - a.toff[k];
+    out = expf(a.tcoef[k] * (x * x));
+  }
+  a.Hn[i] = out;
+  if (f == 0) a.tn[v] = (float)t / (float)a.T;
+}
+
+__global__ __launch_bounds__(MDX_WG) void embed_edge_kernel(const EmbedArgs a) {
+  const int i = blockIdx.x * MDX_WG + threadIdx.x;
+  if (i >= a.E * MDX_ED) return;
+  const int e = i / MDX_ED, f = i - e * MDX_ED;
+  const int nl = a.l[e], nr = a.r[e];
+  const int64_t t = a.t[a.node_graph[nl]];
+  float out;
+  if (f < a.ed_emb) {
+    float s = 0.f;
+    if (a.xe) {
+      const float* x = a.xe + (size_t)(a.int2ref ? a.int2ref[e] : e) * a.Ke;
+      for (int k = 0; k < a.Ke; ++k) s = fmaf(x[k], a.We[f * a.Ke + k], s);
+    } else {  // bond predictor: cat[x_n[left], x_n[right]]
+      const int K2 = 2 * a.Kn;
+      for (int k = 0; k < a.Kn; ++k) s = fmaf(a.xn[(size_t)nl * a.Kn + k], a.We[f * K2 + k], s);
+      for (int k = 0; k < a.Kn; ++k) s = fmaf(a.xn[(size_t)nr * a.Kn + k], a.We[f * K2 + a.Kn + k], s);
+    }
+    out = s;
+  } else {
+    const int k = f - a.ed_emb;
+    const float x = fminf(fmaxf((float)t, 0.f), (float)a.T) - a.toff[k];
+    out = expf(a.tcoef[k] * (x * x));
+  }
+  a.He[i] = out;
+  if (f == 0) a.te[e] = (float)t / (float)a.T;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoders: node_decoder MLP(256 -> 256 -> Kn), edge_decoder MLP(64 -> 64 -> Ke) on He[h] + He[Eh + h].
+// Second layers are zero-padded to 16 outputs on the host.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MDX_WG, 2) void decode_node_kernel(const DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hn = smem + OFF_HN;
+  float* X = smem + OFF_X;
+  float* red = smem + OFF_RED;
+  float* red2 = smem + OFF_RED2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int v0 = blockIdx.x * TN, N = a.N, ft0 = 4 * wave;
+  for (int i = tid; i < TN * 64; i += MDX_WG) {
+    const int row = i >> 6, c4 = i & 63;
+    const int v = v0 + row;
+    sts4(Hn + row * LD256 + 4 * c4, v < N ? ldg4(a.Hn + (size_t)v * MDX_ND + 4 * c4) : splat4(0.f));
+  }
+  __syncthreads();
+  f32x4 t[4][NT_];
+  acc_bias<4, NT_>(t, a.nodedec.b1, ft0, lane);
+  gemm_tile<4, NT_, 256>(t, a.nodedec.W1, 16, ft0, Hn, LD256, lane);
+  layernorm_relu<4, NT_, 4>(t, a.nodedec.g, a.nodedec.be, ft0, red, red2, wave, lane, true);
+  acc_to_lds<4, NT_>(t, X, LD256, 0, ft0, lane);
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 o[1][NT_];
+    acc_bias<1, NT_>(o, a.nodedec.b2, 0, lane);
+    gemm_tile<1, NT_, 256>(o, a.nodedec.W2, 1, 0, X, LD256, lane);
+#pragma unroll
+    for (int et = 0; et < NT_; ++et) {
+      const int v = v0 + 16 * et + c;
+      if (v < N)
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < a.Kn) a.pred_node[(size_t)v * a.Kn + 4 * q + r] = o[0][et][r];
+    }
+  }
+}
+
+constexpr int DET = MDX_ET;
+constexpr int DTE = 16 * DET;
+constexpr int DOFF_A = 0;
+constexpr int DOFF_B = DOFF_A + DTE * LD64;
+constexpr int DOFF_RED = DOFF_B + DTE * LD64;
+constexpr int DEC_EDGE_LDS_FLOATS = DOFF_RED + 8 * DTE;
+
+__global__ __launch_bounds__(MDX_WG, 2) void decode_edge_kernel(const DecodeArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[DEC_EDGE_LDS_FLOATS];
+  float* A = smem + DOFF_A;
+  float* B = smem + DOFF_B;
+  float* red = smem + DOFF_RED;
+  float* red2 = red + 4 * DTE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int h0 = blockIdx.x * DTE, Eh = a.Eh;
+  for (int i = tid; i < DTE * 16; i += MDX_WG) {
+    const int row = i >> 4, c4 = i & 15;
+    const int h = h0 + row;
+    f32x4 v = splat4(0.f);
+    if (h < Eh)
+      v = ldg4(a.He + (size_t)a.ref2int[h] * 64 + 4 * c4) + ldg4(a.He + (size_t)a.ref2int[Eh + h] * 64 + 4 * c4);
+    sts4(A + row * LD64 + 4 * c4, v);
+  }
+  __syncthreads();
+  f32x4 t[1][DET];
+  acc_bias<1, DET>(t, a.edgedec.b1, wave, lane);
+  gemm_tile<1, DET, 64>(t, a.edgedec.W1, 4, wave, A, LD64, lane);
+  layernorm_relu<1, DET, 4>(t, a.edgedec.g, a.edgedec.be, wave, red, red2, wave, lane, true);
+  acc_to_lds<1, DET>(t, B, LD64, 0, wave, lane);
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 o[1][DET];
+    acc_bias<1, DET>(o, a.edgedec.b2, 0, lane);
+    gemm_tile<1, DET, 64>(o, a.edgedec.W2, 1, 0, B, LD64, lane);
+#pragma unroll
+    for (int et = 0; et < DET; ++et) {
+      const int h = h0 + 16 * et + c;
+      if (h < Eh)
+        for (int r = 0; r < 4; ++r)
+          if (4 * q + r < a.Ke) a.pred_halfedge[(size_t)h * a.Ke + 4 * q + r] = o[0][et][r];
+    }
+  }
+}
+
+}  // namespace
+
+void launch_node(const NodeArgs& a, hipStream_t s) {
+  if (a.N <= 0) return;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_FLOATS * 4);
+    attr = true;
+  }
+  hipLaunchKernelGGL(node_kernel, dim3((a.N + TN - 1) / TN), dim3(MDX_WG), NODE_LDS_FLOATS * 4, s, a);
+}
+
+void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float* out, const float* addend, int N, int C,
+                       hipStream_t s) {
+  if (N <= 0) return;
+  if (C == 256)
+    hipLaunchKernelGGL(seg_reduce_kernel<256>, dim3((N + 3) / 4), dim3(MDX_WG), 0, s, src, ptr, eids, out, addend, N);
+  else if (C == 64)
+    hipLaunchKernelGGL(seg_reduce_kernel<64>, dim3((N + 15) / 16), dim3(MDX_WG), 0, s, src, ptr, eids, out, addend, N);
+  else
+    hipLaunchKernelGGL(seg_reduce3_kernel, dim3((3 * N + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, src, ptr, eids, out,
+                       addend, N);
+}
+
+void launch_embed(const EmbedArgs& a, hipStream_t s) {
+  if (a.N > 0)
+    hipLaunchKernelGGL(embed_node_kernel, dim3(((size_t)a.N * MDX_ND + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, a);
+  if (a.E > 0)
+    hipLaunchKernelGGL(embed_edge_kernel, dim3(((size_t)a.E * MDX_ED + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, a);
+}
+
+void launch_decode(const DecodeArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)decode_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_FLOATS * 4);
+    attr = true;
+  }
+  if (a.N > 0 && a.pred_node)
+    hipLaunchKernelGGL(decode_node_kernel, dim3((a.N + TN - 1) / TN), dim3(MDX_WG), NODE_LDS_FLOATS * 4, s, a);
+  if (a.Eh > 0 && a.pred_halfedge)
+    hipLaunchKernelGGL(decode_edge_kernel, dim3((a.Eh + DTE - 1) / DTE), dim3(MDX_WG), 0, s, a);
+}

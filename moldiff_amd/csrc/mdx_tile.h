@@ -1,0 +1,220 @@
+// Device-side building blocks for the fused row-tile MLP kernels (gfx950 / CDNA4 only).
+//
+// Convention used by every fused kernel in this directory:
+//   * a workgroup = 256 threads = 4 wave64s, owns a tile of TE = 16*ET rows (edges or nodes);
+//   * activations of the tile live in LDS as X[row][feature] with a padded leading dimension
+//     (ldx = K + 8 floats: conflict-free ds_read_b128 / ds_write_b128);
+//   * a Linear layer  Y[row][f] = sum_k W[f][k] X[row][k]  is computed TRANSPOSED on the matrix
+//     cores with v_mfma_f32_16x16x4_f32 (exact fp32, == an fmaf chain):  A operand = weights
+//     (features x k, pre-packed on the host in fragment order so each wave-load is 1 KiB
+//     contiguous), B operand = activations (k x rows, one ds_read_b128 per 16 k-values);
+//   * each wave owns a slice of FTW feature tiles (16 features each) for ALL rows of the tile, so
+//     the weight stream is wave-private (global -> VGPR, no LDS staging, no barrier) and the
+//     accumulator layout is: lane (c = lane&15, q = lane>>4), acc[ft][et][r] =
+//     Y[row = 16*et + c][feature = 16*(ft0+ft) + 4*q + r]  -- i.e. 4 consecutive features of one
+//     row per accumulator, so every epilogue gather/store is a 16-byte vector access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MDX_WG 256
+#define MDX_LN_EPS 1e-5f
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void sts4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+  f32x4 r = {sigmoidf_(v[0]), sigmoidf_(v[1]), sigmoidf_(v[2]), sigmoidf_(v[3])};
+  return r;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  f32x4 r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  return r;
+}
+
+// Padded leading dimension for a K-wide activation tile in LDS.
+__host__ __device__ constexpr int mdx_ld(int K) { return K + 8; }
+
+// ----------------------------------------------------------------------------------------------
+// acc[ft][et] += W[16*(ft0+ft) .. +16][0..K) * X[16*et .. +16][0..K)^T
+//   Wp : packed weights, float4 index ((g*FT + ft)*64 + lane), g = k/16   (host: mdx_pack.cpp)
+//   X  : LDS tile, row-major, leading dimension ldx (floats, multiple of 4)
+// ----------------------------------------------------------------------------------------------
+template <int FTW, int ET, int K>
+__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __restrict__ Wp, int FT, int ft0,
+                                          const float* X, int ldx, int lane) {
+  static_assert(K % 16 == 0, "K must be a multiple of 16");
+  const int c = lane & 15, q = lane >> 4;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)ft0 * 64 + lane;
+  const float* xb = X + c * ldx + 4 * q;
+  constexpr int G = K / 16;
+  f32x4 a_cur[FTW], a_nxt[FTW];
+#pragma unroll
+  for (int ft = 0; ft < FTW; ++ft) a_cur[ft] = wp[(size_t)ft * 64];
+#pragma unroll 2
+  for (int g = 0; g < G; ++g) {
+    const int gn = (g + 1 < G) ? g + 1 : g;
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft) a_nxt[ft] = wp[((size_t)gn * FT + ft) * 64];
+    f32x4 b[ET];
+#pragma unroll
+    for (int et = 0; et < ET; ++et) b[et] = lds4(xb + et * 16 * ldx + g * 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+          acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft][s], b[et][s], acc[ft][et], 0, 0, 0);
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft) a_cur[ft] = a_nxt[ft];
+  }
+}
+
+template <int FTW, int ET>
+__device__ __forceinline__ void acc_zero(f32x4 (&acc)[FTW][ET]) {
+#pragma unroll
+  for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+    for (int et = 0; et < ET; ++et) acc[ft][et] = splat4(0.f);
+}
+
+// acc[ft][et] = bias[16*(ft0+ft) + 4q .. +4]   (bias may be nullptr -> zeros)
+template <int FTW, int ET>
+__device__ __forceinline__ void acc_bias(f32x4 (&acc)[FTW][ET], const float* __restrict__ bias, int ft0, int lane) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int ft = 0; ft < FTW; ++ft) {
+    f32x4 b = bias ? ldg4(bias + 16 * (ft0 + ft) + 4 * q) : splat4(0.f);
+#pragma unroll
+    for (int et = 0; et < ET; ++et) acc[ft][et] = b;
+  }
+}
+
+// Store the accumulator tile to LDS X[row][colbase + 16*(ft0+ft) + 4q].
+template <int FTW, int ET>
+__device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[FTW][ET], float* X, int ldx, int colbase, int ft0, int lane) {
+  const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+    for (int et = 0; et < ET; ++et) sts4(X + (16 * et + c) * ldx + colbase + 16 * (ft0 + ft) + 4 * q, acc[ft][et]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm (biased variance, eps 1e-5, affine) + ReLU over NOUT = NW * FTW * 16 features that are
+// spread over the first NW waves of the workgroup.  Two-pass (mean, then centred second moment).
+// ALL 256 threads must call this (it contains two __syncthreads); waves >= NW pass active=false.
+//   red, red2 : LDS scratch, 4*TE floats each.
+// ----------------------------------------------------------------------------------------------
+template <int FTW, int ET, int NW>
+__device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, int ft0, float* red, float* red2,
+                                               int wave, int lane, bool active, bool relu = true) {
+  constexpr int TE = 16 * ET;
+  constexpr float inv_n = 1.0f / (float)(NW * FTW * 16);
+  const int c = lane & 15, q = lane >> 4;
+  if (active) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft) s += (z[ft][et][0] + z[ft][et][1]) + (z[ft][et][2] + z[ft][et][3]);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (q == 0) red[wave * TE + 16 * et + c] = s;
+    }
+  }
+  __syncthreads();
+  float mean[ET];
+  if (active) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * TE + 16 * et + c];
+      mean[et] = s * inv_n;
+      float d2 = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float d = z[ft][et][r] - mean[et];
+          d2 = fmaf(d, d, d2);
+        }
+      d2 += __shfl_xor(d2, 16);
+      d2 += __shfl_xor(d2, 32);
+      if (q == 0) red2[wave * TE + 16 * et + c] = d2;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    f32x4 gm[FTW], bt[FTW];
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft) {
+      gm[ft] = ldg4(gamma + 16 * (ft0 + ft) + 4 * q);
+      bt[ft] = ldg4(beta + 16 * (ft0 + ft) + 4 * q);
+    }
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red2[w * TE + 16 * et + c];
+      const float rstd = 1.0f / sqrtf(v * inv_n + MDX_LN_EPS);
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft) {
+        f32x4 y = (z[ft][et] - splat4(mean[et])) * splat4(rstd) * gm[ft] + bt[ft];
+        z[ft][et] = relu ? relu4(y) : y;
+      }
+    }
+  }
+}
+
+// Sum over NOUT = NW*FTW*16 features of  w2[f] * z[row][f]  ->  one scalar per row, result broadcast
+// to every lane that holds row 16*et + c (used for the 256->1 and 32->1 heads of PosUpdate).
+// ALL threads call (one __syncthreads).  red: LDS scratch 4*TE floats.
+template <int FTW, int ET, int NW>
+__device__ __forceinline__ void dot_rows(const f32x4 (&z)[FTW][ET], const float* __restrict__ w2, int ft0, float* red,
+                                         int wave, int lane, bool active, float (&out)[ET]) {
+  constexpr int TE = 16 * ET;
+  const int c = lane & 15, q = lane >> 4;
+  if (active) {
+    f32x4 w[FTW];
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft) w[ft] = ldg4(w2 + 16 * (ft0 + ft) + 4 * q);
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s = fmaf(w[ft][r], z[ft][et][r], s);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (q == 0) red[wave * TE + 16 * et + c] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int et = 0; et < ET; ++et) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * TE + 16 * et + c];
+    out[et] = s;
+  }
+}
+
+// XCD-aware tile remap (MI355X: 8 XCDs, block b is dispatched to XCD b % 8): give every XCD a
+// contiguous range of tiles so neighbouring tiles (same molecule -> same node rows) share an L2.
+// Bijective for any ntiles.
+__device__ __forceinline__ int xcd_remap(int bid, int ntiles) {
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}

@@ -1,0 +1,199 @@
+// Per-step transition math + counter-based noise (gfx950).  One thread per row (K <= 8).
+//   pos_posterior      models/transition.py:44-63   (ContigousTransition.get_prev_from_recon)
+//   cat_posterior      models/transition.py:285-315 (GeneralCategoricalTransition.q_v_posterior, v0_prob=True)
+//                      optionally fused with the log_softmax of models/model.py:291,297
+//   gumbel_argmax      models/diffusion.py:79-85    (log_sample_categorical) + one-hot (transition.py:255)
+//   philox_noise       replaces torch.rand_like / randn_like (diffusion.py:80, transition.py:60): Philox4x32-10
+//                      keyed by (seed; global molecule id, local element, draw index, stream) so that a
+//                      molecule's noise does not depend on how the batch is sharded over GPUs.
+// Compiled with -ffp-contract=off: the reference evaluates these formulas with separate mul/add.
+#include "mdx_kernels.h"
+
+#define MDX_MAXK 8
+
+namespace {
+
+__global__ void pos_posterior_kernel(const float* __restrict__ c0, const float* __restrict__ ct,
+                                     const float* __restrict__ sd, const float* __restrict__ xt,
+                                     const float* __restrict__ x0, const float* __restrict__ eps,
+                                     const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
+                                     float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n) return;
+  const int v = i / 3;
+  const int64_t tv = t[batch[v]];
+  const float mu = c0[tv] * x0[i] + ct[tv] * xt[i];
+  const float x = mu + sd[tv] * eps[i];
+  out[i] = (tv == 0) ? mu : x;
+}
+
+template <int K>
+__global__ void cat_posterior_kernel(const float* __restrict__ qmats, const float* __restrict__ qT1, int T,
+                                     const float* __restrict__ in0, int is_logits, const float* __restrict__ log_vt,
+                                     const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
+                                     float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t tv = t[batch[i]];
+  const int64_t tm1 = tv > 0 ? tv - 1 : 0;
+  float l0[K], lt[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    l0[k] = in0[(size_t)i * K + k];
+    lt[k] = log_vt[(size_t)i * K + k];
+  }
+  if (is_logits) {  // log_softmax
+    float m = l0[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) m = fmaxf(m, l0[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s += expf(l0[k] - m);
+    const float ls = logf(s);
+#pragma unroll
+    for (int k = 0; k < K; ++k) l0[k] = (l0[k] - m) - ls;
+  }
+  const float* Q1 = qT1 + (size_t)tv * K * K;
+  const float* Q0 = qmats + (size_t)tm1 * K * K;
+  float e0[K], et[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    e0[k] = expf(l0[k]);
+    et[k] = expf(lt[k]);
+  }
+  float o[K];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      f1 += et[j] * Q1[j * K + k];
+      f2 += e0[j] * Q0[j * K + k];
+    }
+    o[k] = fmaxf(logf(f1 + 1e-30f), -32.f) + fmaxf(logf(f2 + 1e-30f), -32.f);
+    m = fmaxf(m, o[k]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) s += expf(o[k] - m);
+  const float lse = m + logf(s);
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[(size_t)i * K + k] = (tv == 0) ? l0[k] : (o[k] - lse);
+}
+
+__global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const float* __restrict__ u, int K, int n,
+                                     int64_t* __restrict__ cls, float* __restrict__ onehot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = 0;
+  float bv = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const float g = -logf(-logf(u[(size_t)i * K + k] + 1e-30f) + 1e-30f);
+    const float z = g + logits[(size_t)i * K + k];
+    if (k == 0 || z > bv) {  // first maximum wins, like torch.argmax
+      bv = z;
+      best = k;
+    }
+  }
+  if (cls) cls[i] = best;
+  if (onehot)
+    for (int k = 0; k < K; ++k) onehot[(size_t)i * K + k] = (k == best) ? 1.f : 0.f;
+}
+
+struct u4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    u4 n = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }  // [0,1)
+
+__global__ void philox_noise_kernel(uint64_t seed, int draw, const int* __restrict__ node_graph,
+                                    const int* __restrict__ node_local, const int* __restrict__ he_graph,
+                                    const int* __restrict__ he_local, const int64_t* __restrict__ mol_ids, int N, int Eh,
+                                    int Kn, int Ke, float* __restrict__ eps_pos, float* __restrict__ u_node,
+                                    float* __restrict__ u_half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  if (i < N) {
+    const uint64_t mol = (uint64_t)mol_ids[node_graph[i]];
+    const uint32_t loc = (uint32_t)node_local[i];
+    if (eps_pos) {
+      u4 c = {loc, (uint32_t)draw, (uint32_t)mol, (uint32_t)(mol >> 32) << 4 | 0u};
+      const u4 r = philox4x32_10(c, k0, k1);
+      const float u1 = ((float)(r.x >> 8) + 1.0f) * 5.9604644775390625e-08f;  // (0,1]
+      const float u3 = ((float)(r.z >> 8) + 1.0f) * 5.9604644775390625e-08f;
+      const float r1 = sqrtf(-2.0f * logf(u1)), r2 = sqrtf(-2.0f * logf(u3));
+      const float a1 = 6.283185307179586f * u01(r.y), a2 = 6.283185307179586f * u01(r.w);
+      eps_pos[3 * (size_t)i + 0] = r1 * cosf(a1);
+      eps_pos[3 * (size_t)i + 1] = r1 * sinf(a1);
+      eps_pos[3 * (size_t)i + 2] = r2 * cosf(a2);
+    }
+    if (u_node) {
+      for (int b = 0; 4 * b < Kn; ++b) {
+        u4 c = {loc * 2u + (uint32_t)b, (uint32_t)draw, (uint32_t)mol, (uint32_t)(mol >> 32) << 4 | 1u};
+        const u4 r = philox4x32_10(c, k0, k1);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+        for (int j = 0; j < 4 && 4 * b + j < Kn; ++j) u_node[(size_t)i * Kn + 4 * b + j] = u01(rr[j]);
+      }
+    }
+  }
+  if (i < Eh && u_half) {
+    const uint64_t mol = (uint64_t)mol_ids[he_graph[i]];
+    const uint32_t loc = (uint32_t)he_local[i];
+    for (int b = 0; 4 * b < Ke; ++b) {
+      u4 c = {loc * 2u + (uint32_t)b, (uint32_t)draw, (uint32_t)mol, (uint32_t)(mol >> 32) << 4 | 2u};
+      const u4 r = philox4x32_10(c, k0, k1);
+      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+      for (int j = 0; j < 4 && 4 * b + j < Ke; ++j) u_half[(size_t)i * Ke + 4 * b + j] = u01(rr[j]);
+    }
+  }
+}
+
+}  // namespace
+
+void launch_pos_posterior(const float* c0, const float* ct, const float* sd, const float* xt, const float* x0,
+                          const float* eps, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(pos_posterior_kernel, dim3((3 * n + 255) / 256), dim3(256), 0, s, c0, ct, sd, xt, x0, eps, t, batch,
+                     n, out);
+}
+
+void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, const float* in0, int is_logits,
+                          const float* log_vt, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  dim3 g((n + 255) / 256), b(256);
+#define MDX_CP(KK)                                                                                                     \
+  case KK:                                                                                                             \
+    hipLaunchKernelGGL(cat_posterior_kernel<KK>, g, b, 0, s, qmats, qT1, T, in0, is_logits, log_vt, t, batch, n, out); \
+    break;
+  switch (K) {
+    MDX_CP(2) MDX_CP(3) MDX_CP(4) MDX_CP(5) MDX_CP(6) MDX_CP(7) MDX_CP(8)
+    default: break;
+  }
+#undef MDX_CP
+}
+
+void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gumbel_argmax_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, u, K, n, cls, onehot);
+}
+
+void launch_philox_noise(uint64_t seed, int draw, const int* node_graph, const int* node_local, const int* he_graph,
+                         const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,
+                         float* u_node, float* u_half, hipStream_t s) {
+  const int n = N > Eh ? N : Eh;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(philox_noise_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, draw, node_graph, node_local,
+                     he_graph, he_local, mol_ids, N, Eh, Kn, Ke, eps_pos, u_node, u_half);
+}

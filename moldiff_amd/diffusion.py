@@ -1,0 +1,96 @@
+"""Noise schedules and log-space helpers of the denoising path (host side, float64 numpy).
+
+Mirrors the names the reference exposes in ``models/diffusion.py`` so call sites read the same:
+``get_beta_schedule`` (:153-192), ``advance_schedule`` (:110-131), ``segment_schedule`` (:133-148),
+``to_torch_const`` (:41-44), ``extract`` (:60-72), ``index_to_log_onehot`` (:53-57),
+``log_sample_categorical`` (:79-85).  The schedules run once at model construction; nothing here is
+on the per-step device path (the per-step math lives in ``csrc/transition.hip``).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def advance_schedule(timesteps, scale_start, scale_end, width, return_alphas_bar=False):
+    """alphas_bar follows a rescaled sigmoid from `scale_start` down to `scale_end`."""
+    amp = (scale_end - scale_start) / (sigmoid(-width) - sigmoid(width))
+    shift = 0.5 * (scale_end + scale_start - amp)
+    alphas_bar = amp * sigmoid(-width * np.linspace(-1, 1, timesteps)) + shift
+    betas = _betas_of(alphas_bar)
+    return (betas, alphas_bar) if return_alphas_bar else betas
+
+
+def _betas_of(alphas_bar):
+    ratio = np.concatenate([alphas_bar[:1], alphas_bar[1:] / alphas_bar[:-1]])
+    return np.clip(1.0 - ratio, 0, 1)
+
+
+def segment_schedule(timesteps, time_segment, segment_diff):
+    """Piecewise 'advance' curve; each piece is drawn on n+1 points and its first point dropped."""
+    assert np.sum(time_segment) == timesteps
+    chunks = [advance_schedule(int(n) + 1, return_alphas_bar=True, **dict(p))[1][1:]
+              for n, p in zip(time_segment, segment_diff)]
+    return _betas_of(np.concatenate(chunks))
+
+
+def get_beta_schedule(beta_schedule, num_timesteps, **kwargs):
+    """Same selector strings and keyword names as the reference."""
+    T = num_timesteps
+    if beta_schedule == 'quad':
+        betas = np.linspace(kwargs['beta_start'] ** 0.5, kwargs['beta_end'] ** 0.5, T, dtype=np.float64) ** 2
+    elif beta_schedule == 'linear':
+        betas = np.linspace(kwargs['beta_start'], kwargs['beta_end'], T, dtype=np.float64)
+    elif beta_schedule == 'const':
+        betas = kwargs['beta_end'] * np.ones(T, dtype=np.float64)
+    elif beta_schedule == 'jsd':
+        betas = 1.0 / np.linspace(T, 1, T, dtype=np.float64)
+    elif beta_schedule == 'sigmoid':
+        s = kwargs.get('s', 6)
+        betas = sigmoid(np.linspace(-s, s, T)) * (kwargs['beta_end'] - kwargs['beta_start']) + kwargs['beta_start']
+    elif beta_schedule == 'cosine':
+        s = kwargs.get('s', 0.008)
+        x = np.linspace(0, T + 1, T + 1)
+        ab = np.cos(((x / (T + 1)) + s) / (1 + s) * np.pi * 0.5) ** 2
+        ab = ab / ab[0]
+        betas = np.clip(1 - ab[1:] / ab[:-1], 0, 0.999)
+    elif beta_schedule == 'advance':
+        betas = advance_schedule(T, kwargs.get('scale_start', 0.999), kwargs.get('scale_end', 0.001),
+                                 kwargs.get('width', 2))
+    elif beta_schedule == 'segment':
+        betas = segment_schedule(T, kwargs['time_segment'], kwargs['segment_diff'])
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (T,)
+    return betas
+
+
+def to_torch_const(x):
+    """Frozen float32 parameter: ends up in state_dict (checkpoint contract) but never trains."""
+    return nn.Parameter(torch.from_numpy(np.asarray(x)).float(), requires_grad=False)
+
+
+def extract(coef, t, batch, ndim=2):
+    out = coef[t][batch]
+    if ndim == 1:
+        return out
+    if ndim == 2:
+        return out.unsqueeze(-1)
+    if ndim == 3:
+        return out.unsqueeze(-1).unsqueeze(-1)
+    raise NotImplementedError('ndim > 3')
+
+
+def index_to_log_onehot(x, num_classes):
+    assert x.max().item() < num_classes, f'Error: {x.max().item()} >= {num_classes}'
+    return torch.log(F.one_hot(x, num_classes).float().clamp(min=1e-30))
+
+
+def log_sample_categorical(logits):
+    """Gumbel-max draw using torch's generator (host/compat helper; the device path draws Philox noise)."""
+    u = torch.rand_like(logits)
+    return (logits - torch.log(-torch.log(u + 1e-30) + 1e-30)).argmax(dim=-1)

@@ -1,0 +1,386 @@
+"""CPU oracle for the MolDiff denoising hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain torch-CPU fp32 (functional style, no nn.Module), the
+algorithm of the reference's sampling path so that the HIP kernels in
+``moldiff_amd/csrc`` can be parity-checked without the reference being present
+(``/root/reference`` does not exist on the GPU box).  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it;
+the product path (``moldiff_amd``) never does.
+
+Pinning: every function below is checked against the *real* reference (imported with
+third-party shims by ``oracle/make_goldens.py`` in the build container) and against the
+golden vectors committed under ``tests/golden/`` (``tests/test_oracle_golden.py``).
+Parity on *trained* weights is unpinned: no checkpoint is available offline, all goldens
+use recipe weights (``recipe_state_dict`` below).
+
+Reference citations are relative to the upstream tree (tag 2024_08_07):
+  models/common.py:181-201   MLP                      -> mlp()
+  models/common.py:216-237   GaussianSmearing         -> smearing_table() / smear()
+  models/graph.py:29-55      NodeBlock.forward        -> node_block()
+  models/graph.py:133-141    BondFFN.forward          -> bond_ffn()
+  models/graph.py:268-295    EdgeBlock.forward        -> edge_block()
+  models/graph.py:348-374    NodeEdgeNet.forward      -> node_edge_net()
+  models/graph.py:384-396    PosUpdate.forward        -> pos_update()
+  models/model.py:204-234    MolDiff.forward          -> moldiff_forward()
+  models/model.py:271-372    one sampling iteration   -> sample_step()
+  models/model.py:236-378    MolDiff.sample           -> sample()
+  models/bond_predictor.py:128-162 BondPredictor.forward -> bondpred_forward()
+  models/model.py:309-325    'uncertainty' guidance   -> guidance_delta()
+  models/transition.py:9-69  ContigousTransition      -> pos_tables() / pos_posterior()
+  models/transition.py:178-339 GeneralCategoricalTransition -> cat_tables() / cat_posterior()
+  models/diffusion.py:79-85  log_sample_categorical   -> gumbel_argmax()
+  models/diffusion.py:110-192 schedules               -> beta_schedule()
+  utils/transforms.py:125-156 make_data_placeholder   -> placeholder()
+  torch_scatter.scatter_sum (un-vendored third party; call sites models/graph.py:50,279,
+  283,394; semantics = zero-initialised index-add)    -> seg_sum()
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# schedules (host, float64)  -- models/diffusion.py:110-192
+# --------------------------------------------------------------------------------------
+
+
+def _sig(x):
+    return 1.0 / (np.exp(-x) + 1.0)
+
+
+def _advance(T, scale_start, scale_end, width):
+    """alpha_bar = a*sigmoid(-k x)+b on linspace(-1,1,T)  (diffusion.py:110-131)."""
+    k, a0, a1 = width, scale_end, scale_start
+    a = (a0 - a1) / (_sig(-k) - _sig(k))
+    b = 0.5 * (a0 + a1 - a)
+    abar = a * _sig(-k * np.linspace(-1, 1, T)) + b
+    return abar
+
+
+def _betas_from_abar(abar):
+    alphas = np.empty_like(abar)
+    alphas[0] = abar[0]
+    alphas[1:] = abar[1:] / abar[:-1]
+    return np.clip(1.0 - alphas, 0, 1)
+
+
+def beta_schedule(cfg, T):
+    """cfg: mapping with 'beta_schedule' in {'advance','segment'} (the two the shipped
+    configs use; diffusion.py:153-192)."""
+    kind = cfg['beta_schedule']
+    if kind == 'advance':
+        abar = _advance(T, cfg.get('scale_start', 0.999), cfg.get('scale_end', 0.001), cfg.get('width', 2))
+        return _betas_from_abar(abar)
+    if kind == 'segment':
+        seg, diffs = cfg['time_segment'], cfg['segment_diff']
+        assert sum(seg) == T
+        pieces = []
+        for n, d in zip(seg, diffs):
+            pieces.append(_advance(n + 1, d['scale_start'], d['scale_end'], d['width'])[1:])
+        return _betas_from_abar(np.concatenate(pieces))
+    raise NotImplementedError(kind)
+
+
+def pos_tables(betas):
+    """coef_x0, coef_xt, std as float32 tensors (transition.py:13-26)."""
+    alphas = 1.0 - betas
+    abar = np.cumprod(alphas)
+    abar_prev = np.concatenate([[1.0], abar[:-1]])
+    c0 = np.sqrt(abar_prev) * betas / (1 - abar)
+    ct = np.sqrt(alphas) * (1 - abar_prev) / (1 - abar)
+    sd = np.sqrt((1 - abar_prev) * betas / (1 - abar))
+    f = lambda a: torch.from_numpy(a).float()
+    return {'betas': f(betas), 'alphas': f(alphas), 'alphas_bar': f(abar), 'alphas_bar_prev': f(abar_prev),
+            'coef_x0': f(c0), 'coef_xt': f(ct), 'std': f(sd)}
+
+
+def init_prob(kind, K):
+    if kind == 'absorb':
+        p = 0.01 * np.ones(K); p[0] = 1.0
+    elif kind == 'tomask':
+        p = 0.001 * np.ones(K); p[-1] = 1.0
+    elif kind == 'uniform' or kind is None:
+        p = np.ones(K)
+    else:
+        p = np.asarray(kind, dtype=np.float64)
+    return p / p.sum()
+
+
+def cat_tables(betas, K, init_kind):
+    """q_mats (cumulative) and transposed one-step mats (transition.py:179-242)."""
+    p0 = init_prob(init_kind, K)
+    T = len(betas)
+    one = np.stack([b * np.repeat(p0[None], K, 0) + (1 - b) * np.eye(K) for b in betas])
+    cum = [one[0]]
+    for t in range(1, T):
+        cum.append(cum[-1] @ one[t])
+    cum = np.stack(cum)
+    return {'q_mats': torch.from_numpy(cum).float(),
+            'transpopse_q_onestep_mats': torch.from_numpy(one.transpose(0, 2, 1).copy()).float(),
+            'init_prob': p0}
+
+
+# --------------------------------------------------------------------------------------
+# small building blocks
+# --------------------------------------------------------------------------------------
+
+
+def smearing_table(start, stop, G, kind):
+    """offset / coeff buffers of GaussianSmearing (common.py:217-231)."""
+    if kind == 'exp':
+        off = torch.exp(torch.linspace(math.log(start + 1), math.log(stop + 1), G)) - 1
+    else:
+        off = torch.linspace(start, stop, G)
+    d = torch.diff(off)
+    d = torch.cat([d[:1], d])
+    return off, -0.5 / d ** 2
+
+
+def smear(x, off, coeff, start, stop):
+    x = x.clamp_min(start).clamp_max(stop)
+    return torch.exp(coeff * (x.view(-1, 1) - off.view(1, -1)) ** 2)
+
+
+def lin(P, pre, x, bias=True):
+    return F.linear(x, P[pre + '.weight'], P[pre + '.bias'] if bias else None)
+
+
+def mlp(P, pre, x, layers=2):
+    """Linear -> LN -> ReLU -> ... -> Linear   (common.py:184-198). Sequential indices 0,1,(2),3[,4,(5),6]."""
+    idx = 0
+    for i in range(layers - 1):
+        x = lin(P, f'{pre}.net.{idx}', x)
+        w = P[f'{pre}.net.{idx + 1}.weight']
+        x = F.layer_norm(x, (w.shape[0],), w, P[f'{pre}.net.{idx + 1}.bias'], 1e-5)
+        x = torch.relu(x)
+        idx += 3
+    return lin(P, f'{pre}.net.{idx}', x)
+
+
+def seg_sum(src, index, n):
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
+# --------------------------------------------------------------------------------------
+# network
+# --------------------------------------------------------------------------------------
+
+
+def node_block(P, pre, x, edge_index, edge_attr, node_time):
+    row, col = edge_index
+    h = mlp(P, pre + '.node_net', x)
+    he = mlp(P, pre + '.edge_net', edge_attr)
+    m = lin(P, pre + '.msg_net', he * h[col])
+    g = mlp(P, pre + '.gate', torch.cat([edge_attr, x[col], node_time[col]], -1))
+    m = m * torch.sigmoid(g)
+    z = lin(P, pre + '.centroid_lin', x) + seg_sum(m, row, x.shape[0])
+    w = P[pre + '.layer_norm.weight']
+    z = F.layer_norm(z, (w.shape[0],), w, P[pre + '.layer_norm.bias'], 1e-5)
+    return lin(P, pre + '.out_transform', torch.relu(z))
+
+
+def bond_ffn(P, pre, b, n, t):
+    inter = lin(P, pre + '.bond_linear', b, bias=False) * lin(P, pre + '.node_linear', n, bias=False)
+    inter = mlp(P, pre + '.inter_module', inter)
+    return inter * torch.sigmoid(mlp(P, pre + '.gate', torch.cat([b, n, t], -1)))
+
+
+def edge_block(P, pre, h_bond, bond_index, h_node, bond_time):
+    left, right = bond_index
+    n = h_node.shape[0]
+    ml = seg_sum(bond_ffn(P, pre + '.bond_ffn_left', h_bond, h_node[left], bond_time), right, n)[left]
+    mr = seg_sum(bond_ffn(P, pre + '.bond_ffn_right', h_bond, h_node[right], bond_time), left, n)[right]
+    u = (ml + mr + lin(P, pre + '.node_ffn_left', h_node[left]) + lin(P, pre + '.node_ffn_right', h_node[right])
+         + lin(P, pre + '.self_ffn', h_bond))
+    w = P[pre + '.layer_norm.weight']
+    u = F.layer_norm(u, (w.shape[0],), w, P[pre + '.layer_norm.bias'], 1e-5)
+    return lin(P, pre + '.out_transform', torch.relu(u))
+
+
+def pos_update(P, pre, h_node, h_edge, edge_index, rel, dist, edge_time):
+    left, right = edge_index
+    a = mlp(P, pre + '.left_lin_edge', h_node[left]) * mlp(P, pre + '.right_lin_edge', h_node[right])
+    w = bond_ffn(P, pre + '.edge_lin', h_edge, a, edge_time)
+    force = w * rel / dist.unsqueeze(-1) / (dist.unsqueeze(-1) + 1.0)
+    return seg_sum(force, left, h_node.shape[0])
+
+
+def node_edge_net(P, pre, h_node, pos, h_edge, edge_index, node_time, edge_time, *,
+                  num_blocks, cutoff, update_pos=True, num_gaussians=16):
+    """graph.py:348-374 (update_edge=True only, the two shipped configs)."""
+    off, coeff = P[pre + '.distance_expansion.offset'], P[pre + '.distance_expansion.coeff']
+    for i in range(num_blocks):
+        if update_pos or i == 0:
+            rel = pos[edge_index[0]] - pos[edge_index[1]]
+            dist = torch.norm(rel, dim=-1, p=2)
+            dfeat = smear(dist, off, coeff, 0.0, cutoff)
+        h_edge = lin(P, f'{pre}.edge_embs.{i}', torch.cat([h_edge, dfeat], -1))
+        dn = node_block(P, f'{pre}.node_blocks_with_edge.{i}', h_node, edge_index, h_edge, node_time)
+        h_edge = h_edge + edge_block(P, f'{pre}.edge_blocks.{i}', h_edge, edge_index, h_node, edge_time)
+        h_node = h_node + dn
+        if update_pos:
+            pos = pos + pos_update(P, f'{pre}.pos_blocks.{i}', h_node, h_edge, edge_index, rel, dist, edge_time)
+    return h_node, pos, h_edge
+
+
+def moldiff_forward(P, cfg, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_index, batch_edge, t):
+    """cfg: dict(num_timesteps, num_blocks, cutoff).  model.py:204-234."""
+    T = cfg['num_timesteps']
+    toff, tco = P['time_emb.0.offset'], P['time_emb.0.coeff']
+    tn = t.index_select(0, batch_node)
+    te = t.index_select(0, batch_edge)
+    hn = torch.cat([F.linear(h_node_pert, P['node_embedder.weight']), smear(tn, toff, tco, 0.0, T)], -1)
+    he = torch.cat([F.linear(h_edge_pert, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
+    hn, pos, he = node_edge_net(P, 'denoiser', hn, pos_pert, he, edge_index,
+                                tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
+                                num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'])
+    nh = he.shape[0] // 2
+    return {'pred_node': mlp(P, 'node_decoder', hn),
+            'pred_pos': pos,
+            'pred_halfedge': mlp(P, 'edge_decoder', he[:nh] + he[nh:])}
+
+
+def bondpred_forward(P, cfg, h_node, pos, batch_node, edge_index, batch_edge, t):
+    """bond_predictor.py:128-162 (num_timesteps != 0 branch)."""
+    T = cfg['num_timesteps']
+    toff, tco = P['time_emb.offset'], P['time_emb.coeff']
+    he = torch.cat([h_node[edge_index[0]], h_node[edge_index[1]]], -1)
+    tn = t.index_select(0, batch_node)
+    te = t.index_select(0, batch_edge)
+    hn = torch.cat([F.linear(h_node, P['node_embedder.weight']), smear(tn, toff, tco, 0.0, T)], -1)
+    he = torch.cat([F.linear(he, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
+    hn, _, he = node_edge_net(P, 'encoder', hn, pos, he, edge_index, tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
+                              num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], update_pos=False)
+    nh = he.shape[0] // 2
+    ext = torch.cat([he[:nh] + he[nh:], hn[edge_index[0, :nh]] + hn[edge_index[1, :nh]]], -1)
+    return mlp(P, 'edge_decoder', ext, layers=3)
+
+
+def guidance_delta(Pb, cfgb, h_node, pos, batch_node, edge_index, batch_edge, t, scale):
+    """'uncertainty' guidance (model.py:312-325): -scale * d/dpos sum log sigmoid(-LSE(logits))."""
+    with torch.enable_grad():
+        p = pos.detach().clone().requires_grad_(True)
+        logits = bondpred_forward(Pb, cfgb, h_node.detach(), p, batch_node, edge_index, batch_edge, t)
+        u = torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum()
+        g, = torch.autograd.grad(u, p)
+    return -g * scale, logits.detach()
+
+
+# --------------------------------------------------------------------------------------
+# transitions
+# --------------------------------------------------------------------------------------
+
+
+def pos_posterior(tab, x_t, x_recon, t, batch, eps):
+    """transition.py:44-63 with the N(0,1) draw passed in explicitly."""
+    tb = t[batch]
+    mu = tab['coef_x0'][tb].unsqueeze(-1) * x_recon + tab['coef_xt'][tb].unsqueeze(-1) * x_t
+    x = mu + tab['std'][tb].unsqueeze(-1) * eps
+    return torch.where((tb == 0).unsqueeze(-1), mu, x)
+
+
+def cat_posterior(tab, log_v0, log_vt, t, batch):
+    """q(v_{t-1} | v_t, v_0) with v0_prob=True  (transition.py:285-315)."""
+    tb = t[batch]
+    tm1 = torch.clamp(t - 1, min=0)[batch]
+    f1 = torch.einsum('bj,bjk->bk', log_vt.exp(), tab['transpopse_q_onestep_mats'][tb])
+    f2 = torch.einsum('bj,bjk->bk', log_v0.exp(), tab['q_mats'][tm1])
+    out = torch.log(f1 + 1e-30).clamp_min(-32.) + torch.log(f2 + 1e-30).clamp_min(-32.)
+    out = out - torch.logsumexp(out, -1, keepdim=True)
+    return torch.where((tb == 0).unsqueeze(-1), log_v0, out)
+
+
+def gumbel_argmax(logits, u):
+    """diffusion.py:79-85 with the U[0,1) draw passed in explicitly."""
+    g = -torch.log(-torch.log(u + 1e-30) + 1e-30)
+    return (g + logits).argmax(-1)
+
+
+def cat_init(tab, n, u):
+    """transition.py:331-339; logits are float64 (from_numpy of float64 init_prob)."""
+    K = tab['q_mats'].shape[-1]
+    logits = torch.log(torch.from_numpy(tab['init_prob']) + 1e-30).clamp_min(-32.).unsqueeze(0).repeat(n, 1)
+    c = gumbel_argmax(logits, u)
+    oh = F.one_hot(c, K).float()
+    return c, oh, torch.log(oh.clamp(min=1e-30))
+
+
+def sample_step(P, cfg, tabs, state, graph, step, noise, Pb=None, cfgb=None, guidance=None):
+    """One iteration of model.py:272-372.  state: dict(h_node, pos, h_halfedge, log_node, log_halfedge);
+    noise: dict(eps_pos (N,3), u_node (N,K), u_halfedge (Eh,K)).  Returns (new_state, preds)."""
+    bn, hei, bh = graph['batch_node'], graph['halfedge_index'], graph['batch_halfedge']
+    B = int(bn.max()) + 1 if bn.numel() else 0
+    B = graph.get('n_graphs', B)
+    edge_index = torch.cat([hei, hei.flip(0)], 1)
+    batch_edge = torch.cat([bh, bh], 0)
+    t = torch.full((B,), step, dtype=torch.long)
+    preds = moldiff_forward(P, cfg, state['h_node'], state['pos'], bn,
+                            torch.cat([state['h_halfedge']] * 2, 0), edge_index, batch_edge, t)
+    pos_prev = pos_posterior(tabs['pos'], state['pos'], preds['pred_pos'], t, bn, noise['eps_pos'])
+    ln = cat_posterior(tabs['node'], F.log_softmax(preds['pred_node'], -1), state['log_node'], t, bn)
+    cn = gumbel_argmax(ln, noise['u_node'])
+    lh = cat_posterior(tabs['edge'], F.log_softmax(preds['pred_halfedge'], -1), state['log_halfedge'], t, bh)
+    ch = gumbel_argmax(lh, noise['u_halfedge'])
+    delta = None
+    if guidance is not None and guidance[1] > 0:
+        assert guidance[0] == 'uncertainty'
+        delta, _ = guidance_delta(Pb, cfgb, state['h_node'], state['pos'], bn, edge_index, batch_edge, t, guidance[1])
+        pos_prev = pos_prev + delta
+    new = {'h_node': F.one_hot(cn, ln.shape[-1]).float(), 'pos': pos_prev,
+           'h_halfedge': F.one_hot(ch, lh.shape[-1]).float(), 'log_node': ln, 'log_halfedge': lh,
+           'node_type': cn, 'halfedge_type': ch}
+    return new, preds
+
+
+# --------------------------------------------------------------------------------------
+# harness pieces
+# --------------------------------------------------------------------------------------
+
+
+def placeholder(n_graphs, max_size=None):
+    """utils/transforms.py:125-156 — consumes numpy's legacy global RNG exactly like the reference."""
+    if max_size is None:
+        sizes = np.random.normal(24.923464980477522, 5.516291901819105, size=n_graphs)
+    else:
+        sizes = np.array([max_size] * n_graphs)
+    sizes = sizes.astype('int64')
+    bn, hei, bh, off = [], [], [], 0
+    for i, n in enumerate(sizes):
+        n = int(n)
+        bn.append(np.full(max(n, 0), i, dtype=np.int64))
+        tri = torch.triu_indices(n, n, offset=1) if n > 0 else torch.zeros((2, 0), dtype=torch.long)
+        hei.append(tri + off)
+        bh.append(np.full(tri.shape[1], i, dtype=np.int64))
+        off += max(n, 0)
+    return {'n_nodes_list': sizes,
+            'batch_node': torch.from_numpy(np.concatenate(bn)) if bn else torch.zeros(0, dtype=torch.long),
+            'halfedge_index': torch.cat(hei, 1) if hei else torch.zeros((2, 0), dtype=torch.long),
+            'batch_halfedge': torch.from_numpy(np.concatenate(bh)) if bh else torch.zeros(0, dtype=torch.long)}
+
+
+FROZEN_MARKERS = ('_transition.', '.coeff', '.offset', 'ce_loss.weight')
+
+
+def is_frozen_key(k):
+    return any(m in k for m in FROZEN_MARKERS)
+
+
+def recipe_state_dict(shapes, seed):
+    """Recipe weights (DESIGN.md 'recipe weights'): iterate learnable keys in SORTED order with one
+    PCG64 generator; 2-D W ~ N(0,1)/sqrt(fan_in); 1-D '.weight' (LayerNorm gain) = 1+0.1z; 1-D '.bias' = 0.1z.
+    `shapes`: {key: shape} for learnable tensors only."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        z = g.standard_normal(shp, dtype=np.float32)
+        if len(shp) == 2:
+            w = z * np.float32(1.0 / math.sqrt(shp[1]))
+        elif k.endswith('.weight'):
+            w = np.float32(1.0) + np.float32(0.1) * z
+        else:
+            w = np.float32(0.1) * z
+        out[k] = torch.from_numpy(w.astype(np.float32))
+    return out
