@@ -131,6 +131,12 @@ int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n,
 int mdx_noise(mdx_graph_t g, uint64_t seed, int32_t draw, int32_t Kn, int32_t Ke, float* eps_pos, float* u_node,
               float* u_halfedge, void* stream);
 
+/* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
+ * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
+ * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass).  read() drains pending events. */
+int mdx_profile_enable(int32_t on);
+int mdx_profile_read(int32_t kernel, int64_t* count, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ EXPORTS = [
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_bondpred_forward',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
+    'mdx_profile_enable', 'mdx_profile_read',
 ]
 
 
@@ -64,6 +65,8 @@ def lib():
         L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_noise.argtypes = [c_void_p, c_uint64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.mdx_device_count.argtypes = [POINTER(c_int)]
+        L.mdx_profile_enable.argtypes = [c_int32]
+        L.mdx_profile_read.argtypes = [c_int32, POINTER(c_int64), POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 

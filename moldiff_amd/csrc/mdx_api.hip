@@ -471,7 +471,7 @@ extern "C" int mdx_graph_destroy(mdx_graph_t g) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct Ws {
-  float *Hn, *H, *NT, *aggr, *SL, *SR, *Lf, *Rf, *tn, *posA, *posB;
+  float *Hn, *H, *NT, *NT2, *aggr, *SL, *SR, *Lf, *Rf, *tn, *posA, *posB;
   float *HeA, *HeB, *M, *FL, *FR, *Fe, *te, *tmpE;  // tmpE: (E,64) scratch for boundary permutes
   int64_t* tzero;  // (B) zeros? (unused)
   size_t bytes;
@@ -486,7 +486,7 @@ size_t ws_layout(int64_t N, int64_t E, char* base, Ws* w) {
   };
   const size_t n = (size_t)std::max<int64_t>(N, 1), e = (size_t)std::max<int64_t>(E, 1);
   Ws t{};
-  t.Hn = take(n * MDX_ND); t.H = take(n * MDX_ND); t.NT = take(n * MDX_NTW); t.aggr = take(n * MDX_ND);
+  t.Hn = take(n * MDX_ND); t.H = take(n * MDX_ND); t.NT = take(n * MDX_NTW); t.NT2 = take(n * MDX_NTW); t.aggr = take(n * MDX_ND);
   t.SL = take(n * 64); t.SR = take(n * 64); t.Lf = take(n * 64); t.Rf = take(n * 64); t.tn = take(n);
   t.posA = take(n * 3); t.posB = take(n * 3);
   t.HeA = take(e * 64); t.HeB = take(e * 64); t.M = take(e * MDX_ND); t.FL = take(e * 64); t.FR = take(e * 64);
@@ -525,6 +525,75 @@ __global__ void expand_halfedge_kernel(const float* __restrict__ xh, const int* 
   dst[i] = xh[(size_t)r * K + k];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// live kernel timing (hipEvents on the launch stream) -- used by bench.py for the roofline numbers
+// ------------------------------------------------------------------------------------------------
+namespace {
+enum { PK_EDGE_A = 0, PK_EDGE_B = 1, PK_NODE = 2, PK_AGGR = 3, PK_COUNT = 4 };
+constexpr int PROF_RING = 1024;
+struct ProfSlot {
+  hipEvent_t a[PROF_RING], b[PROF_RING];
+  bool made = false;
+  int head = 0, pending = 0;
+  double total_ms = 0.0;
+  long long count = 0;
+};
+bool g_prof_on = false;
+ProfSlot g_prof[PK_COUNT];
+
+void prof_drain(ProfSlot& p, int n) {
+  for (; n > 0 && p.pending > 0; --n, --p.pending) {
+    const int i = (p.head - p.pending + PROF_RING * 4) % PROF_RING;
+    hipEventSynchronize(p.b[i]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a[i], p.b[i]) == hipSuccess) {
+      p.total_ms += ms;
+      p.count++;
+    }
+  }
+}
+struct ProfScope {
+  ProfSlot* p = nullptr;
+  hipStream_t s;
+  int i = 0;
+  ProfScope(int k, hipStream_t st) : s(st) {
+    if (!g_prof_on) return;
+    p = &g_prof[k];
+    if (!p->made) {
+      for (int j = 0; j < PROF_RING; ++j) {
+        hipEventCreate(&p->a[j]);
+        hipEventCreate(&p->b[j]);
+      }
+      p->made = true;
+    }
+    if (p->pending == PROF_RING) prof_drain(*p, PROF_RING / 2);
+    i = p->head;
+    hipEventRecord(p->a[i], s);
+  }
+  ~ProfScope() {
+    if (!p) return;
+    hipEventRecord(p->b[i], s);
+    p->head = (p->head + 1) % PROF_RING;
+    p->pending++;
+  }
+};
+}  // namespace
+
+extern "C" int mdx_profile_enable(int32_t on) {
+  g_prof_on = on != 0;
+  if (on)
+    for (auto& p : g_prof) { prof_drain(p, PROF_RING); p.total_ms = 0.0; p.count = 0; }
+  return MDX_OK;
+}
+extern "C" int mdx_profile_read(int32_t kernel, int64_t* count, double* total_ms) {
+  if (kernel < 0 || kernel >= PK_COUNT || !count || !total_ms) return fail(MDX_ERR_ARG, "bad argument");
+  prof_drain(g_prof[kernel], PROF_RING);
+  *count = g_prof[kernel].count;
+  *total_ms = g_prof[kernel].total_ms;
+  return MDX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // block driver
 // ------------------------------------------------------------------------------------------------
@@ -538,27 +607,28 @@ namespace {
   if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(MDX_ERR_ARG, "workspace must be 256-byte aligned");
 
 EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i, const float* pos, const float* He_in,
-                  float* He_out, int flags) {
+                  float* He_out, int flags, const float* NT = nullptr) {
   EdgeAArgs a{};
   a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.pos = pos; a.dist_in = nullptr;
-  a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = w.NT;
+  a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = NT ? NT : w.NT;
   a.M = w.M; a.F[0] = w.FL; a.F[1] = w.FR; a.w = m->blocks[i].ea;
   return a;
 }
 
 EdgeBArgs make_eb(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i, const float* pos, const float* Hep,
-                  float* He_out, int flags) {
+                  float* He_out, int flags, const float* NT = nullptr) {
   EdgeBArgs a{};
   a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.pos = pos; a.rel_in = nullptr;
-  a.dist_in = nullptr; a.Hep = Hep; a.SL = w.SL; a.SR = w.SR; a.NT = w.NT; a.He_out = He_out; a.Lf = w.Lf; a.Rf = w.Rf;
+  a.dist_in = nullptr; a.Hep = Hep; a.SL = w.SL; a.SR = w.SR; a.NT = NT ? NT : w.NT; a.He_out = He_out; a.Lf = w.Lf; a.Rf = w.Rf;
   a.Fe = w.Fe; a.w = m->blocks[i].eb;
   return a;
 }
 
-NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int imid, int ipre, int flags) {
+NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int imid, int ipre, int flags,
+                 const float* NTin = nullptr, float* NTout = nullptr) {
   NodeArgs a{};
-  a.N = (int)g->N; a.flags = flags; a.Hn = w.Hn; a.aggr = w.aggr; a.NTin = w.NT; a.dHn = nullptr; a.Lf = w.Lf; a.Rf = w.Rf;
-  a.H = w.H; a.NT = w.NT;
+  a.N = (int)g->N; a.flags = flags; a.Hn = w.Hn; a.aggr = w.aggr; a.NTin = NTin ? NTin : w.NT; a.dHn = nullptr; a.Lf = w.Lf;
+  a.Rf = w.Rf; a.H = w.H; a.NT = NTout ? NTout : w.NT;
   if (imid >= 0) a.wmid = m->blocks[imid].nd;
   if (ipre >= 0) a.wpre = m->blocks[ipre].nd;
   return a;
@@ -571,20 +641,25 @@ void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const f
   const bool upos = m->cfg.update_pos != 0;
   const float* pos = pos_in;
   float* pos_next = w.posA;
-  launch_node(make_nd(m, g, w, -1, 0, ND_PRE), s);
+  // The per-node table is double-buffered: edge kernel B of block i still reads block i's table (node_ffn columns)
+  // after the node kernel has already produced block i+1's table.
+  float* NTcur = w.NT;
+  float* NTnxt = w.NT2;
+  launch_node(make_nd(m, g, w, -1, 0, ND_PRE, nullptr, NTcur), s);
   for (int i = 0; i < nb; ++i) {
-    launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN), s);
-    launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s);
+    { ProfScope ps(PK_EDGE_A, s); launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN, NTcur), s); }
+    { ProfScope ps(PK_AGGR, s); launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s); }
     launch_seg_reduce(w.FL, g->col_ptr, g->col_eids, w.SL, nullptr, (int)g->N, 64, s);
     launch_seg_reduce(w.FR, g->row_ptr, nullptr, w.SR, nullptr, (int)g->N, 64, s);
     int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (i + 1 < nb ? ND_PRE : 0);
-    launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags), s);
-    launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0)), s);
+    { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
+    { ProfScope ps(PK_EDGE_B, s); launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s); }
     if (upos) {
       launch_seg_reduce(w.Fe, g->row_ptr, nullptr, pos_next, pos, (int)g->N, 3, s);
       pos = pos_next;
       pos_next = (pos_next == w.posA) ? w.posB : w.posA;
     }
+    std::swap(NTcur, NTnxt);
   }
   *He_final = w.HeA;
   *pos_final = pos;

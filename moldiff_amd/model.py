@@ -99,6 +99,12 @@ class MolDiff(Module):
                                        _lib.i64c(t))
         return {'pred_node': pn, 'pred_pos': pp, 'pred_halfedge': ph}
 
+    def sampler(self, n_graphs, batch_node, halfedge_index, batch_halfedge, *, seed=None, mol_ids=None, noise=None,
+                return_traj=True, bond_predictor=None, guidance=None):
+        """Stateful driver of the reverse chain (``init()`` then ``step(i)`` for i = 0..T-1); ``sample`` wraps it."""
+        return _Sampler(self, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
+                        bond_predictor, guidance)
+
     @torch.no_grad()
     def sample(self, n_graphs, batch_node, halfedge_index, batch_halfedge, bond_predictor=None, guidance=None, *,
                seed=None, mol_ids=None, noise=None, return_traj=True):
@@ -111,78 +117,115 @@ class MolDiff(Module):
         noise: optional callable draw -> (eps_pos, u_node, u_halfedge) to inject explicit noise (tests);
         return_traj=False skips the (large) trajectory buffers.
         """
+        sm = self.sampler(n_graphs, batch_node, halfedge_index, batch_halfedge, seed=seed, mol_ids=mol_ids, noise=noise,
+                          return_traj=return_traj, bond_predictor=bond_predictor, guidance=guidance)
+        sm.init()
+        for i in range(self.num_timesteps):
+            sm.step(i)
+        return sm.result()
+
+
+class _Sampler:
+    """One packed batch moving through models/model.py:244-378.  All buffers are allocated once in __init__;
+    a step is: noise draw -> denoiser forward -> 3 posteriors -> 2 Gumbel-max draws, every piece a HIP kernel."""
+
+    def __init__(self, model, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
+                 bond_predictor, guidance):
         _lib._need_gpu(batch_node, halfedge_index, batch_halfedge)
         if guidance is not None and guidance[1] > 0:
             raise NotImplementedError('bond-predictor guidance is not built yet (SURVEY.md section 8 rows a14/a15)')
-        dev = batch_node.device
-        T, Kn, Ke = self.num_timesteps, self.num_node_types, self.num_edge_types
-        N, Eh = int(batch_node.numel()), int(batch_halfedge.numel())
-        eng = self._engine()
+        self.m = m = model
+        self.dev = dev = batch_node.device
+        self.T, self.Kn, self.Ke = m.num_timesteps, m.num_node_types, m.num_edge_types
+        self.N, self.Eh = int(batch_node.numel()), int(batch_halfedge.numel())
+        self.n_graphs = n_graphs
+        self.eng = m._engine()
         edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
-        g = _lib.Graph(edge_index, batch_node, n_graphs, mol_ids)
-        if seed is None:
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        L = _lib.lib()
+        self.g = _lib.Graph(edge_index, batch_node, n_graphs, mol_ids)
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        self.noise = noise
+        self.return_traj = return_traj
         f32 = dict(dtype=torch.float32, device=dev)
-        eps, u_n, u_h = torch.empty(N, 3, **f32), torch.empty(N, Kn, **f32), torch.empty(Eh, Ke, **f32)
+        N, Eh, Kn, Ke, T = self.N, self.Eh, self.Kn, self.Ke, self.T
+        self.eps, self.u_n, self.u_h = torch.empty(N, 3, **f32), torch.empty(N, Kn, **f32), torch.empty(Eh, Ke, **f32)
+        nT = T + 1 if return_traj else 2
+        self.node_traj = torch.zeros(nT, N, Kn, **f32)
+        self.pos_traj = torch.zeros(nT, N, 3, **f32)
+        self.halfedge_traj = torch.zeros(nT, Eh, Ke, **f32)
+        self.t = torch.empty(n_graphs, dtype=torch.int64, device=dev)
+        self.bn, self.bh = _lib.i64c(batch_node), _lib.i64c(batch_halfedge)
+        self.preds = (torch.empty(N, Kn, **f32), torch.empty(N, 3, **f32), torch.empty(Eh, Ke, **f32))
+        self.log_node = [torch.empty(N, Kn, **f32), torch.empty(N, Kn, **f32)]
+        self.log_half = [torch.empty(Eh, Ke, **f32), torch.empty(Eh, Ke, **f32)]
+        self.cur = 0  # frame holding the current state
 
-        def draw(i):
-            if noise is not None:
-                e, a, b = noise(i)
-                eps.copy_(e); u_n.copy_(a); u_h.copy_(b)
-            else:
-                _lib.check(L.mdx_noise(g.h, ctypes.c_uint64(seed), i, Kn, Ke, _lib.ptr(eps), _lib.ptr(u_n), _lib.ptr(u_h),
-                                       _lib.stream()))
+    def _frame(self, j):
+        return j if self.return_traj else j % 2
 
-        nT = T + 1 if return_traj else 1
-        node_traj = torch.zeros(nT, N, Kn, **f32)
-        pos_traj = torch.zeros(nT, N, 3, **f32)
-        halfedge_traj = torch.zeros(nT, Eh, Ke, **f32)
+    def _draw(self, i):
+        if self.noise is not None:
+            e, a, b = self.noise(i)
+            self.eps.copy_(e); self.u_n.copy_(a); self.u_h.copy_(b)
+        else:
+            _lib.check(_lib.lib().mdx_noise(self.g.h, ctypes.c_uint64(self.seed), i, self.Kn, self.Ke, _lib.ptr(self.eps),
+                                            _lib.ptr(self.u_n), _lib.ptr(self.u_h), _lib.stream()))
 
-        # prior
-        draw(0)
-        tn, te = self.node_transition, self.edge_transition
-        ln0 = torch.log(torch.from_numpy(tn.init_prob).float() + 1e-30).clamp_min(-32.).to(dev).unsqueeze(0).repeat(N, 1)
-        lh0 = torch.log(torch.from_numpy(te.init_prob).float() + 1e-30).clamp_min(-32.).to(dev).unsqueeze(0).repeat(Eh, 1)
-        h_node = node_traj[0]
-        h_half = halfedge_traj[0]
-        _lib.check(L.mdx_gumbel_argmax(_lib.ptr(ln0), _lib.ptr(u_n), Kn, N, None, _lib.ptr(h_node), _lib.stream()))
-        _lib.check(L.mdx_gumbel_argmax(_lib.ptr(lh0), _lib.ptr(u_h), Ke, Eh, None, _lib.ptr(h_half), _lib.stream()))
-        log_node = torch.log(h_node.clamp(min=1e-30))
-        log_half = torch.log(h_half.clamp(min=1e-30))
-        pos_traj[0].copy_(eps)
-        pos = pos_traj[0]
+    @torch.no_grad()
+    def init(self):
+        """Prior draw (models/model.py:244-263): classes ~ init_prob by Gumbel-max, positions ~ N(0, I)."""
+        m, L, dev = self.m, _lib.lib(), self.dev
+        self._draw(0)
+        for tr, n, K, u, traj, logs in ((m.node_transition, self.N, self.Kn, self.u_n, self.node_traj, self.log_node),
+                                        (m.edge_transition, self.Eh, self.Ke, self.u_h, self.halfedge_traj, self.log_half)):
+            logit = torch.log(torch.from_numpy(tr.init_prob).float() + 1e-30).clamp_min(-32.).to(dev)
+            logit = logit.unsqueeze(0).repeat(n, 1).contiguous()
+            _lib.check(L.mdx_gumbel_argmax(_lib.ptr(logit), _lib.ptr(u), K, n, None, _lib.ptr(traj[0]), _lib.stream()))
+            torch.log(traj[0].clamp(min=1e-30), out=logs[0])
+        self.pos_traj[0].copy_(self.eps)
+        self.cur, self.lcur = 0, 0
 
-        t = torch.empty(n_graphs, dtype=torch.int64, device=dev)
-        bn, bh = _lib.i64c(batch_node), _lib.i64c(batch_halfedge)
-        preds = (torch.empty(N, Kn, **f32), torch.empty(N, 3, **f32), torch.empty(Eh, Ke, **f32))
-        log_node_new, log_half_new = torch.empty_like(log_node), torch.empty_like(log_half)
-        pt, ntr, etr = self.pos_transition, self.node_transition, self.edge_transition
-        for i, step in enumerate(range(T)[::-1]):
-            t.fill_(step)
-            draw(i + 1)
-            self._forward_raw(eng, g, h_node, pos, None, h_half, t, out=preds)
-            j = i + 1 if return_traj else 0
-            pos_new, h_node_new, h_half_new = pos_traj[j], node_traj[j], halfedge_traj[j]
-            if not return_traj:  # single frame: ping-pong through temporaries
-                pos_new, h_node_new, h_half_new = torch.empty_like(pos), torch.empty_like(h_node), torch.empty_like(h_half)
-            _lib.check(L.mdx_pos_posterior(_lib.ptr(pt.coef_x0), _lib.ptr(pt.coef_xt), _lib.ptr(pt.std), _lib.ptr(pos),
-                                           _lib.ptr(preds[1]), _lib.ptr(eps), _lib.ptr(t), _lib.ptr(bn), N,
-                                           _lib.ptr(pos_new), _lib.stream()))
-            _lib.check(L.mdx_cat_posterior(_lib.ptr(ntr.q_mats), _lib.ptr(ntr.transpopse_q_onestep_mats), Kn, T,
-                                           _lib.ptr(preds[0]), 1, _lib.ptr(log_node), _lib.ptr(t), _lib.ptr(bn), N,
-                                           _lib.ptr(log_node_new), _lib.stream()))
-            _lib.check(L.mdx_gumbel_argmax(_lib.ptr(log_node_new), _lib.ptr(u_n), Kn, N, None, _lib.ptr(h_node_new),
-                                           _lib.stream()))
-            _lib.check(L.mdx_cat_posterior(_lib.ptr(etr.q_mats), _lib.ptr(etr.transpopse_q_onestep_mats), Ke, T,
-                                           _lib.ptr(preds[2]), 1, _lib.ptr(log_half), _lib.ptr(t), _lib.ptr(bh), Eh,
-                                           _lib.ptr(log_half_new), _lib.stream()))
-            _lib.check(L.mdx_gumbel_argmax(_lib.ptr(log_half_new), _lib.ptr(u_h), Ke, Eh, None, _lib.ptr(h_half_new),
-                                           _lib.stream()))
-            pos, h_node, h_half = pos_new, h_node_new, h_half_new
-            log_node, log_node_new = log_node_new, log_node
-            log_half, log_half_new = log_half_new, log_half
-        if not return_traj:
-            node_traj, pos_traj, halfedge_traj = h_node[None], pos[None], h_half[None]
-        return {'pred': [preds[0], preds[1], preds[2]],
-                'traj': [node_traj, pos_traj, halfedge_traj]}
+    @torch.no_grad()
+    def step(self, i):
+        """Loop iteration i (diffusion step T-1-i), models/model.py:272-372."""
+        m, L, T, N, Eh, Kn, Ke = self.m, _lib.lib(), self.T, self.N, self.Eh, self.Kn, self.Ke
+        step = T - 1 - i
+        self.t.fill_(step)
+        self._draw(i + 1)
+        c, n = self._frame(i), self._frame(i + 1)
+        h_node, pos, h_half = self.node_traj[c], self.pos_traj[c], self.halfedge_traj[c]
+        m._forward_raw(self.eng, self.g, h_node, pos, None, h_half, self.t, out=self.preds)
+        lc, ln = self.lcur, 1 - self.lcur
+        pt, ntr, etr, st = m.pos_transition, m.node_transition, m.edge_transition, _lib.stream()
+        _lib.check(L.mdx_pos_posterior(_lib.ptr(pt.coef_x0), _lib.ptr(pt.coef_xt), _lib.ptr(pt.std), _lib.ptr(pos),
+                                       _lib.ptr(self.preds[1]), _lib.ptr(self.eps), _lib.ptr(self.t), _lib.ptr(self.bn), N,
+                                       _lib.ptr(self.pos_traj[n]), st))
+        _lib.check(L.mdx_cat_posterior(_lib.ptr(ntr.q_mats), _lib.ptr(ntr.transpopse_q_onestep_mats), Kn, T,
+                                       _lib.ptr(self.preds[0]), 1, _lib.ptr(self.log_node[lc]), _lib.ptr(self.t),
+                                       _lib.ptr(self.bn), N, _lib.ptr(self.log_node[ln]), st))
+        _lib.check(L.mdx_gumbel_argmax(_lib.ptr(self.log_node[ln]), _lib.ptr(self.u_n), Kn, N, None,
+                                       _lib.ptr(self.node_traj[n]), st))
+        _lib.check(L.mdx_cat_posterior(_lib.ptr(etr.q_mats), _lib.ptr(etr.transpopse_q_onestep_mats), Ke, T,
+                                       _lib.ptr(self.preds[2]), 1, _lib.ptr(self.log_half[lc]), _lib.ptr(self.t),
+                                       _lib.ptr(self.bh), Eh, _lib.ptr(self.log_half[ln]), st))
+        _lib.check(L.mdx_gumbel_argmax(_lib.ptr(self.log_half[ln]), _lib.ptr(self.u_h), Ke, Eh, None,
+                                       _lib.ptr(self.halfedge_traj[n]), st))
+        self.cur, self.lcur = n, ln
+
+    def state(self):
+        c = self.cur
+        return {'h_node': self.node_traj[c], 'pos': self.pos_traj[c], 'h_halfedge': self.halfedge_traj[c],
+                'log_node': self.log_node[self.lcur], 'log_halfedge': self.log_half[self.lcur]}
+
+    def set_state(self, h_node, pos, h_halfedge, log_node, log_halfedge, frame=0):
+        """Teacher-forcing hook for the parity tests."""
+        self.node_traj[frame].copy_(h_node); self.pos_traj[frame].copy_(pos); self.halfedge_traj[frame].copy_(h_halfedge)
+        self.log_node[0].copy_(log_node); self.log_half[0].copy_(log_halfedge)
+        self.cur, self.lcur = frame, 0
+
+    def result(self):
+        if self.return_traj:
+            traj = [self.node_traj, self.pos_traj, self.halfedge_traj]
+        else:
+            c = self.cur
+            traj = [self.node_traj[c:c + 1], self.pos_traj[c:c + 1], self.halfedge_traj[c:c + 1]]
+        return {'pred': [self.preds[0], self.preds[1], self.preds[2]], 'traj': traj}
