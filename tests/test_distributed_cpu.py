@@ -1,0 +1,80 @@
+"""CPU: the N>1 path (shard function + end-of-run gather) with world_size-2 gloo processes."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from moldiff_amd import distributed as DD
+from moldiff_amd.harness import placeholder_from_sizes
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 256, 2049):
+        for w in (1, 2, 3, 8):
+            spans = [DD.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_balanced_order_is_a_permutation_and_balances_cost():
+    np.random.seed(2920)
+    sizes = np.random.normal(24.92, 5.52, 2048).astype('int64')
+    order = DD.balanced_order(sizes, 8)
+    assert sorted(order.tolist()) == list(range(2048))
+    cost = [(sizes[order][slice(*DD.shard_bounds(2048, 8, r))] ** 2).sum() for r in range(8)]
+    naive = [(sizes[slice(*DD.shard_bounds(2048, 8, r))] ** 2).sum() for r in range(8)]
+    assert max(cost) / min(cost) < 1.01 <= max(naive) / min(naive) + 1.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sizes, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    my_sizes, ids = DD.shard_molecules(sizes, world, rank)
+    ph = placeholder_from_sizes(my_sizes)
+    N, Eh = len(ph['batch_node']), len(ph['batch_halfedge'])
+    # stand-in for the per-rank sampler output: values that encode the GLOBAL molecule id, so the test can check
+    # that the gathered tensors are in global molecule order
+    gid = torch.from_numpy(ids)[ph['batch_node']].float()
+    ghe = torch.from_numpy(ids)[ph['batch_halfedge']].float()
+    pred = [gid[:, None].repeat(1, 8), gid[:, None].repeat(1, 3) + 0.5, ghe[:, None].repeat(1, 6)]
+    out = DD.gather_pred(pred, dst=0)
+    if rank == 0:
+        q.put([o.numpy() for o in out])
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_reassembles_global_order():
+    sizes = [5, 9, 3, 0, 12, 7, 4]
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    full = placeholder_from_sizes(sizes)
+    ids = np.arange(len(sizes))
+    assert out[0].shape == (len(full['batch_node']), 8)
+    assert np.array_equal(out[0][:, 0], ids[full['batch_node'].numpy()].astype(np.float32))
+    assert np.array_equal(out[1][:, 0], ids[full['batch_node'].numpy()].astype(np.float32) + 0.5)
+    assert out[2].shape == (len(full['batch_halfedge']), 6)
+    assert np.array_equal(out[2][:, 0], ids[full['batch_halfedge'].numpy()].astype(np.float32))

@@ -1,0 +1,210 @@
+"""CPU: host-side logic of the product package (no GPU compute calls) and the C-ABI surface."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import moldiff_amd as M
+from moldiff_amd import _lib
+from moldiff_amd import diffusion as D
+from moldiff_amd.harness import default_config, placeholder_from_sizes
+from tests import util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- state_dict contract ---------------------------------------------------------------------------
+
+def test_state_dict_keys_match_reference_contract():
+    for kind, which, kn, ke in (('MolDiff', 'MolDiff', 8, 6), ('MolDiff_simple', 'MolDiff', 8, 6)):
+        sd = M.MolDiff(default_config(kind), kn, ke).state_dict()
+        ref = U.KEYS[which]
+        assert set(sd) == set(ref)
+        assert all(list(sd[k].shape) == ref[k] for k in ref)
+    sd = M.BondPredictor(default_config('bondpred'), 8, 5).state_dict()
+    ref = U.KEYS['BondPredictor']
+    assert set(sd) == set(ref) and all(list(sd[k].shape) == ref[k] for k in ref)
+
+
+def test_recipe_weights_hash():
+    m = U.moldiff('MolDiff')
+    h = hashlib.sha256()
+    sd = m.state_dict()
+    for k in sorted(sd):
+        if not M.is_frozen_key(k):
+            h.update(sd[k].numpy().tobytes())
+    assert h.hexdigest() == U.KEYS['recipe_sha256_MolDiff']
+
+
+def test_strict_load_rejects_missing_key():
+    m = M.MolDiff(default_config('MolDiff'), 8, 6)
+    sd = m.state_dict()
+    sd.pop('denoiser.edge_embs.0.weight')
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd, strict=True)
+
+
+def test_schedule_tables_match_reference_golden():
+    g = U.gold('schedules.npz')
+    for nm, kind in (('full', 'MolDiff'), ('simple', 'MolDiff_simple')):
+        cfg = default_config(kind).diff
+        for part, key in (('pos', 'diff_pos'), ('node', 'diff_atom'), ('edge', 'diff_bond')):
+            kw = {k: v for k, v in cfg[key].items() if k != 'init_prob'}
+            assert np.array_equal(D.get_beta_schedule(num_timesteps=1000, **kw), g[f'{nm}_{part}_betas'])
+        m = M.MolDiff(default_config(kind), 8, 6)
+        for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar'):
+            assert np.array_equal(getattr(m.pos_transition, k).numpy(), g[f'{nm}_pos_{k}'])
+        for part, tr in (('node', m.node_transition), ('edge', m.edge_transition)):
+            for k in ('q_mats', 'transpopse_q_onestep_mats'):
+                assert np.array_equal(getattr(tr, k)[g['probe_t']].numpy(), g[f'{nm}_{part}_{k}_probe'])
+            assert np.array_equal(tr.init_prob, g[f'{nm}_{part}_init_prob'])
+
+
+def test_smearing_buffers_match_reference_golden():
+    g = U.gold('smearing.npz')
+    m = M.MolDiff(default_config('MolDiff'), 8, 6)
+    assert np.array_equal(m.denoiser.distance_expansion.offset.numpy(), g['d15_offset'])
+    assert np.array_equal(m.denoiser.distance_expansion.coeff.numpy(), g['d15_coeff'])
+    assert np.array_equal(m.time_emb[0].offset.numpy(), g['t10_offset'])
+    b = M.BondPredictor(default_config('bondpred'), 8, 5)
+    assert np.array_equal(b.encoder.distance_expansion.coeff.numpy(), g['d20_coeff'])
+    assert np.array_equal(b.time_emb.coeff.numpy(), g['t20_coeff'])
+
+
+def test_unknown_schedule_and_backbone_raise_like_reference():
+    with pytest.raises(NotImplementedError):
+        D.get_beta_schedule('nope', 10)
+    cfg = default_config('MolDiff')
+    cfg.denoiser.backbone = 'Other'
+    with pytest.raises(NotImplementedError):
+        M.MolDiff(cfg, 8, 6)
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/configs'), reason='reference tree not present (GPU box)')
+def test_default_configs_equal_shipped_yaml():
+    for name, path in (('MolDiff', 'train_MolDiff.yml'), ('MolDiff_simple', 'train_MolDiff_simple.yml'),
+                       ('bondpred', 'train_bondpred.yml')):
+        ref = M.load_config(f'/root/reference/configs/train/{path}').model
+        assert dict(default_config(name)) == dict(ref)
+
+
+# ---- placeholder -----------------------------------------------------------------------------------
+
+def test_make_data_placeholder_matches_reference_golden():
+    p = U.gold('placeholder.npz')
+    for B in (8, 256, 2048):
+        np.random.seed(2920)
+        ph = M.make_data_placeholder(B)
+        assert len(ph['batch_node']) == int(p[f'B{B}_N']) and len(ph['batch_halfedge']) == int(p[f'B{B}_Eh'])
+        assert np.array_equal(ph['halfedge_index'][:, :16].numpy(), p[f'B{B}_he_first16'])
+        assert np.array_equal(ph['halfedge_index'][:, -16:].numpy(), p[f'B{B}_he_last16'])
+        assert np.array_equal(torch.bincount(ph['batch_node'], minlength=B).numpy(), np.maximum(p[f'B{B}_sizes'], 0))
+    ph = M.make_data_placeholder(3, max_size=4)
+    assert ph['halfedge_index'].shape == (2, 18) and ph['batch_halfedge'].tolist() == [0] * 6 + [1] * 6 + [2] * 6
+
+
+def test_placeholder_edge_cases():
+    ph = placeholder_from_sizes([0, 1, 2, -3])
+    assert ph['batch_node'].tolist() == [1, 2, 2] and ph['halfedge_index'].tolist() == [[1], [2]]
+    ph = placeholder_from_sizes([])
+    assert ph['batch_node'].numel() == 0 and ph['halfedge_index'].shape == (2, 0)
+
+
+# ---- C ABI surface ---------------------------------------------------------------------------------
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'moldiff_hip.h')).read()
+    declared = set(re.findall(r'\b(mdx_[a-z_0-9]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    L = _lib.lib()
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS)
+    assert L.mdx_version() >= 100
+
+
+def test_model_create_rejects_unsupported_dims():
+    cfg = _lib.MdxConfig(_lib.MDX_KIND_NET, 128, 64, 6, 15.0, 16, 1, 0, 1, 1, 1)
+    h = ctypes.c_void_p()
+    rc = _lib.lib().mdx_model_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == 4 and b'node_dim' in _lib.lib().mdx_last_error()
+
+
+def test_finalize_reports_missing_parameter():
+    cfg = _lib.MdxConfig(_lib.MDX_KIND_NET, 256, 64, 1, 15.0, 16, 1, 0, 1, 1, 1)
+    h = ctypes.c_void_p()
+    assert _lib.lib().mdx_model_create(ctypes.byref(cfg), ctypes.byref(h)) == 0
+    rc = _lib.lib().mdx_model_finalize(h)
+    assert rc == 3 and b'distance_expansion.offset' in _lib.lib().mdx_last_error()
+    _lib.lib().mdx_model_destroy(h)
+
+
+def _plan(ei, N):
+    E = ei.shape[1]
+    i32 = lambda n: np.zeros(n, dtype=np.int32)
+    left, right, i2r, rp, cp, ce = i32(E), i32(E), i32(E), i32(N + 1), i32(N + 1), i32(E)
+    ei = np.ascontiguousarray(ei, dtype=np.int64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = _lib.lib().mdx_graph_plan_host(N, E, P(ei), P(left), P(right), P(i2r), P(rp), P(cp), P(ce))
+    return rc, left, right, i2r, rp, cp, ce
+
+
+def test_graph_plan_host_invariants():
+    bn, hei, bh, ei, be = U.graph_from_sizes([5, 0, 1, 7, 3])
+    N, E = len(bn), ei.shape[1]
+    rc, left, right, i2r, rp, cp, ce = _plan(ei.numpy(), N)
+    assert rc == 0
+    ein = ei.numpy()
+    # permutation, sorted by (left, right), index arrays consistent with the reference order
+    assert sorted(i2r.tolist()) == list(range(E))
+    assert np.array_equal(left, ein[0][i2r]) and np.array_equal(right, ein[1][i2r])
+    key = left.astype(np.int64) * N + right
+    assert np.all(np.diff(key) > 0)
+    assert np.array_equal(np.diff(rp), np.bincount(ein[0], minlength=N))
+    assert np.array_equal(np.diff(cp), np.bincount(ein[1], minlength=N))
+    for v in range(N):
+        assert np.all(left[rp[v]:rp[v + 1]] == v)
+        ids = ce[cp[v]:cp[v + 1]]
+        assert np.all(right[ids] == v) and np.all(np.diff(ids) > 0)
+
+
+def test_graph_plan_rejects_out_of_range_and_handles_empty():
+    rc, *_ = _plan(np.array([[0, 5], [1, 0]]), 3)
+    assert rc == 1 and b'out of range' in _lib.lib().mdx_last_error()
+    rc, left, right, i2r, rp, cp, ce = _plan(np.zeros((2, 0), dtype=np.int64), 4)
+    assert rc == 0 and rp.tolist() == [0] * 5
+
+
+def test_analytic_halfedge_index_formula():
+    """pair (i<j) of a molecule of n atoms sits at i*n - i(i+1)/2 + (j-i-1)."""
+    n = 9
+    hei = placeholder_from_sizes([n])['halfedge_index'].numpy()
+    for h, (i, j) in enumerate(hei.T):
+        assert h == i * n - i * (i + 1) // 2 + (j - i - 1)
+
+
+def test_cpu_tensor_calls_fail_loudly_without_gpu_compute():
+    m = U.moldiff('MolDiff_simple')
+    bn, hei, bh, ei, be = U.graph_from_sizes([4, 6])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.sample(2, bn, hei, bh)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.denoiser(torch.zeros(10, 256), torch.zeros(10, 3), torch.zeros(ei.shape[1], 64), ei, torch.zeros(10, 1),
+                   torch.zeros(ei.shape[1], 1))
+
+
+def test_product_package_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import moldiff_amd, moldiff_amd.distributed; "
+            "bad = [m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]; "
+            "assert not bad, bad" % ROOT)
+    subprocess.run([sys.executable, '-c', code], check=True)
+    for fn in os.listdir(os.path.join(ROOT, 'moldiff_amd')):
+        if fn.endswith('.py'):
+            src = open(os.path.join(ROOT, 'moldiff_amd', fn)).read()
+            assert 'import oracle' not in src and 'from oracle' not in src, fn
