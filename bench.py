@@ -42,7 +42,15 @@ PEAK_FP32_MFMA = 157.3      # TFLOP/s (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0           # GB/s
 
 
-def build_workload(batch, rank, device):
+def build_bond_predictor():
+    import moldiff_amd as M
+    from moldiff_amd.harness import default_config
+    bp = M.BondPredictor(default_config('bondpred'), 8, 5).eval()
+    bp.load_state_dict(M.recipe_state_dict(bp, 20230808), strict=True)
+    return bp
+
+
+def build_workload(batch, rank, device, kind='MolDiff_simple'):
     import moldiff_amd as M
     from moldiff_amd.harness import default_config, placeholder_from_sizes, GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
     # the reference's size recipe (utils/transforms.py:128-131) with seed 2920 (= 2023 + sum(ord('./outputs')));
@@ -51,15 +59,19 @@ def build_workload(batch, rank, device):
     sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=batch * (rank + 1)).astype('int64')
     sizes = sizes[batch * rank: batch * (rank + 1)]
     ph = placeholder_from_sizes(sizes, device)
-    model = M.MolDiff(default_config('MolDiff_simple'), 8, 6).eval()
+    model = M.MolDiff(default_config(kind), 8, 6).eval()
     model.load_state_dict(M.recipe_state_dict(model, 20230807), strict=True)
     return model, ph, sizes
 
 
-def cpu_baseline(model, ph_cpu, batch, budget_s=20.0):
+def cpu_baseline(model, ph_cpu, batch, budget_s=20.0, bond_predictor=None):
     """Time the CPU oracle on the same workload (bounded sample)."""
     from oracle import moldiff_oracle as O
     import torch.nn.functional as F
+    gkw = {}
+    if bond_predictor is not None:
+        gkw = dict(Pb={k: v.detach().cpu() for k, v in bond_predictor.state_dict().items()},
+                   cfgb=dict(num_timesteps=1000, num_blocks=8, cutoff=20), guidance=['uncertainty', 1e-4])
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -84,7 +96,7 @@ def cpu_baseline(model, ph_cpu, batch, budget_s=20.0):
         noise = {'eps_pos': torch.randn(N, 3, generator=g), 'u_node': torch.rand(N, 8, generator=g),
                  'u_halfedge': torch.rand(Eh, 6, generator=g)}
         with torch.no_grad():
-            new, _ = O.sample_step(P, cfg, tabs, st, graph, step, noise)
+            new, _ = O.sample_step(P, cfg, tabs, st, graph, step, noise, **gkw)
         return {k: new[k] for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')}
 
     # thread-count calibration on a 64-molecule slice (many-core hosts are far slower with one thread per logical
@@ -102,9 +114,9 @@ def cpu_baseline(model, ph_cpu, batch, budget_s=20.0):
     for th in sorted({c for c in (8, 16, 32, 64, 128) if c <= cores} | {min(cores, 8)}):
         torch.set_num_threads(th)
         with torch.no_grad():
-            O.sample_step(P, cfg, tabs, sst, sgraph, 500, snoise)
+            O.sample_step(P, cfg, tabs, sst, sgraph, 500, snoise, **gkw)
             t0 = time.perf_counter()
-            O.sample_step(P, cfg, tabs, sst, sgraph, 500, snoise)
+            O.sample_step(P, cfg, tabs, sst, sgraph, 500, snoise, **gkw)
             dt = time.perf_counter() - t0
         if dt < best[0]:
             best = (dt, th)
@@ -135,6 +147,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='molecules per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--guided', action='store_true',
+                    help="BASELINE config #3: full model + bond-predictor 'uncertainty' guidance (default: config #2, simple)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -157,14 +171,17 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from moldiff_amd import _lib
-    model, ph_cpu, sizes = build_workload(args.batch, rank, None)
+    model, ph_cpu, sizes = build_workload(args.batch, rank, None, 'MolDiff' if args.guided else 'MolDiff_simple')
     model = model.to(dev)
+    gkw = {}
+    if args.guided:
+        gkw = dict(bond_predictor=build_bond_predictor().to(dev), guidance=['uncertainty', 1e-4])
     ph = {k: v.to(dev) for k, v in ph_cpu.items()}
     N, Eh = int(ph['batch_node'].numel()), int(ph['batch_halfedge'].numel())
     E = 2 * Eh
     mol_ids = np.arange(args.batch * rank, args.batch * (rank + 1), dtype=np.int64)
     sm = model.sampler(args.batch, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023,
-                       mol_ids=mol_ids, return_traj=False)
+                       mol_ids=mol_ids, return_traj=False, **gkw)
     sm.init()
     L = _lib.lib()
     i = 0
@@ -214,9 +231,10 @@ def main():
             'metric': 'molecules/sec (1000-step GEOM-Drugs sampling)', 'value': value, 'unit': 'molecules/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'sample_MolDiff_simple.yml: batch_size=%d molecules/GPU, T=1000 steps, no bond guidance; '
-                                   'sizes ~ reference recipe seed 2920 (rank 0: N=%d atoms, E=%d directed edges); recipe weights'
-                                   % (args.batch, N, E),
+            'config': {'workload': ('sample_MolDiff.yml: full model + bond_predictor guidance [uncertainty, 1e-4], '
+                                    if args.guided else 'sample_MolDiff_simple.yml: no bond guidance, ') +
+                                   'batch_size=%d molecules/GPU, T=1000 steps; sizes ~ reference recipe seed 2920 '
+                                   '(rank 0: N=%d atoms, E=%d directed edges); recipe weights' % (args.batch, N, E),
                        'molecules_per_gpu': args.batch, 'num_timesteps': T_STEPS, 'parallelism': f'independent streams x{world}',
                        'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
             'roofline': {'bound': 'mfma', 'kernel': 'edge_a_kernel (fused per-edge MLP chain, v_mfma_f32_16x16x4_f32)',
@@ -229,7 +247,8 @@ def main():
                                    'aggregate': mg / args.steps},
         }
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model.cpu(), ph_cpu, args.batch, args.cpu_budget)
+            out['cpu_baseline'] = cpu_baseline(model.cpu(), ph_cpu, args.batch, args.cpu_budget,
+                                               gkw['bond_predictor'].cpu() if args.guided else None)
             out['speedup_vs_cpu_baseline'] = value / world / out['cpu_baseline']['value'] if world == 1 else None
     if dist is not None:
         dist.barrier()

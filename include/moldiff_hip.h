@@ -108,9 +108,16 @@ int mdx_segment_sum(mdx_graph_t g, const float* src, int32_t C, int32_t by_right
 int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_node_pert, const float* pos_pert,
                         const float* h_edge_pert, const float* h_halfedge_pert, const int64_t* t, float* pred_node,
                         float* pred_pos, float* pred_halfedge, void* ws, size_t ws_bytes, void* stream);
-/* BondPredictor.forward, bond_predictor.py:128-162: logits (Eh, num_edge_types). */
+/* BondPredictor.forward, bond_predictor.py:128-162: logits (Eh, num_edge_types).  `tape` (caller-owned,
+ * mdx_bondpred_tape_bytes(), 256-byte aligned) records the per-block state the backward needs; NULL = inference only. */
+size_t mdx_bondpred_tape_bytes(int64_t n_nodes, int64_t n_edges, int32_t num_blocks);
 int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h_node, const float* pos, const int64_t* t,
-                         float* logits, void* ws, size_t ws_bytes, void* stream);
+                         float* logits, void* ws, size_t ws_bytes, void* tape, size_t tape_bytes, void* stream);
+/* The autograd call of the guidance block, model.py:312-325 (torch.autograd.grad(scalar(logits), pos_in)):
+ * gpos (N,3) = scale * dL/dpos given glogits = dL/dlogits (Eh, num_edge_types) and the tape of the matching
+ * forward (same model, graph, pos).  Hand-written data-gradient backward through all encoder blocks. */
+int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* pos, const float* glogits, float scale,
+                          float* gpos, void* ws, size_t ws_bytes, void* tape, size_t tape_bytes, void* stream);
 
 /* ---- transitions (models/transition.py, models/diffusion.py) -------------------------------------- */
 /* ContigousTransition.get_prev_from_recon, transition.py:44-63 (eps passed in). x (n,3). */
@@ -125,6 +132,11 @@ int mdx_cat_posterior(const float* q_mats, const float* qT_onestep, int32_t K, i
 /* log_sample_categorical, diffusion.py:79-85 (u passed in) + onehot_encode, transition.py:255. */
 int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n, int64_t* cls, float* onehot,
                       void* stream);
+/* dU/dlogits of the default 'uncertainty' guidance objective U = sum_h log sigmoid(-logsumexp_k logits[h,k])
+ * (model.py:322-324); glogits (n,K).  Feed to mdx_bondpred_backward with scale = -guidance_scale to get delta. */
+int mdx_guidance_uncertainty_grad(const float* logits, int32_t K, int64_t n, float* glogits, void* stream);
+/* dst[i] += src[i]  (pos_prev = pos_prev + delta, model.py:362). */
+int mdx_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 /* Philox4x32-10 noise for draw index `draw` (0 = prior, i+1 = loop iteration i): eps_pos (N,3) ~ N(0,1),
  * u_node (N,Kn), u_halfedge (Eh,Ke) ~ U[0,1).  Any output may be NULL.  Replaces torch.randn_like /
  * rand_like at transition.py:60, diffusion.py:80. */

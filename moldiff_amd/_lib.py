@@ -19,8 +19,9 @@ EXPORTS = [
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
-    'mdx_moldiff_forward', 'mdx_bondpred_forward',
+    'mdx_moldiff_forward', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
+    'mdx_guidance_uncertainty_grad', 'mdx_add_inplace',
     'mdx_profile_enable', 'mdx_profile_read',
 ]
 
@@ -58,12 +59,18 @@ def lib():
         L.mdx_pos_update.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
         L.mdx_segment_sum.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]
         L.mdx_moldiff_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]
-        L.mdx_bondpred_forward.argtypes = [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_bondpred_forward.argtypes = [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
+        L.mdx_bondpred_backward.argtypes = [c_void_p] * 4 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                                            c_void_p]
+        L.mdx_bondpred_tape_bytes.restype = c_size_t
+        L.mdx_bondpred_tape_bytes.argtypes = [c_int64, c_int64, c_int32]
         L.mdx_pos_posterior.argtypes = [c_void_p] * 8 + [c_int64, c_void_p, c_void_p]
         L.mdx_cat_posterior.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_noise.argtypes = [c_void_p, c_uint64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.mdx_guidance_uncertainty_grad.argtypes = [c_void_p, c_int32, c_int64, c_void_p, c_void_p]
+        L.mdx_add_inplace.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
         L.mdx_device_count.argtypes = [POINTER(c_int)]
         L.mdx_profile_enable.argtypes = [c_int32]
         L.mdx_profile_read.argtypes = [c_int32, POINTER(c_int64), POINTER(ctypes.c_double)]
@@ -121,6 +128,16 @@ class Graph:
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         off = (-self._ws.data_ptr()) % 256
         return c_void_p(self._ws.data_ptr() + off), c_size_t(self._ws.numel() - off)
+
+    def tape(self, device, num_blocks):
+        """Caller-owned tape + backward scratch of the bond predictor (allocated on first guided call)."""
+        key = (str(device), num_blocks)
+        if getattr(self, '_tape_key', None) != key:
+            nbytes = lib().mdx_bondpred_tape_bytes(self.N, self.E, num_blocks)
+            self._tape = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+            self._tape_key = key
+        off = (-self._tape.data_ptr()) % 256
+        return self._tape, c_void_p(self._tape.data_ptr() + off), c_size_t(self._tape.numel() - off)
 
     def __del__(self):
         try:

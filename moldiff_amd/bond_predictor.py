@@ -1,8 +1,15 @@
-"""BondPredictor: noisy (atom types, positions) -> bond-type logits; differentiated w.r.t. positions for
-guidance.  Constructor, state_dict keys and forward signature follow the reference's
-models/bond_predictor.py (:12-37, :128-162).  The HIP forward/backward
-is the next row to be built; until then forward raises instead of silently falling back.
+"""BondPredictor: noisy (atom types, positions) -> bond-type logits, differentiable w.r.t. positions.
+
+Constructor, ``state_dict`` keys and ``forward`` signature follow the reference's
+``models/bond_predictor.py`` (:12-37, :128-162).  ``forward`` runs the HIP encoder (8 NodeEdgeNet blocks,
+``update_pos=False``) + 3-layer decoder; when ``pos_node.requires_grad`` it records a per-block tape and the
+returned logits carry a ``grad_fn`` whose backward is the hand-written data-gradient pass of
+``csrc/mdx_bondpred.hip`` -- so the reference's guidance code
+``torch.autograd.grad(f(logits), pos_in)`` (models/model.py:312-325) works unchanged for every guidance type
+that is a function of the logits.  Only d/d pos is provided (what guidance needs); there is no weight gradient.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 from torch.nn import Module
@@ -10,8 +17,40 @@ from torch.nn import Module
 from . import _lib
 from .common import MLP, GaussianSmearing
 from .diffusion import get_beta_schedule
-from .graph import NodeEdgeNet
+from .graph import NodeEdgeNet, _sig
 from .transition import ContigousTransition, GeneralCategoricalTransition
+
+
+class _BondLogits(torch.autograd.Function):
+    """logits = BondPredictor(h_node, pos, t); backward returns dL/dpos only."""
+
+    @staticmethod
+    def forward(ctx, pos, h_node, t, eng, g, num_blocks, num_edge_types):
+        dev = pos.device
+        pos_c, h_c, t_c = _lib.f32c(pos), _lib.f32c(h_node), _lib.i64c(t)
+        logits = torch.empty(g.Eh, num_edge_types, dtype=torch.float32, device=dev)
+        ws, nb = g.workspace(dev)
+        tape, tptr, tbytes = None, ctypes.c_void_p(0), ctypes.c_size_t(0)
+        need_grad = pos.requires_grad
+        if need_grad:
+            tape, tptr, tbytes = g.tape(dev, num_blocks)
+        _lib.check(_lib.lib().mdx_bondpred_forward(eng.h, g.h, _lib.ptr(h_c), _lib.ptr(pos_c), _lib.ptr(t_c), _lib.ptr(logits),
+                                                   ws, nb, tptr, tbytes, _lib.stream()))
+        ctx.eng, ctx.g, ctx.num_blocks = eng, g, num_blocks
+        ctx.save_for_backward(pos_c)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        (pos_c,) = ctx.saved_tensors
+        g, eng = ctx.g, ctx.eng
+        dev = pos_c.device
+        gpos = torch.empty_like(pos_c)
+        ws, nb = g.workspace(dev)
+        _, tptr, tbytes = g.tape(dev, ctx.num_blocks)
+        _lib.check(_lib.lib().mdx_bondpred_backward(eng.h, g.h, _lib.ptr(pos_c), _lib.ptr(_lib.f32c(glogits)), 1.0,
+                                                    _lib.ptr(gpos), ws, nb, tptr, tbytes, _lib.stream()))
+        return gpos, None, None, None, None, None, None
 
 
 class BondPredictor(Module):
@@ -21,16 +60,21 @@ class BondPredictor(Module):
         self.num_node_types = num_node_types
         self.num_edge_types = num_edge_types
         self.define_betas_alphas(config.diff)
+        if self.num_timesteps == 0:
+            raise NotImplementedError('num_timesteps == 0 (time-free predictor) is not built')
         node_dim, edge_dim = config.node_dim, config.edge_dim
-        time_dim = config.diff.time_dim if self.num_timesteps > 0 else 0
+        time_dim = config.diff.time_dim
         self.node_embedder = nn.Linear(num_node_types, node_dim - time_dim, bias=False)
         self.edge_embedder = nn.Linear(num_node_types * 2, edge_dim - time_dim, bias=False)
-        if self.num_timesteps != 0:
-            self.time_emb = GaussianSmearing(stop=self.num_timesteps, num_gaussians=time_dim, type_='linear')
+        self.time_emb = GaussianSmearing(stop=self.num_timesteps, num_gaussians=time_dim, type_='linear')
         self.encoder = NodeEdgeNet(node_dim, edge_dim, **config.encoder)
+        if self.encoder.update_pos:
+            raise NotImplementedError('the bond predictor kernels assume update_pos=False (the shipped config)')
         self.edge_decoder = MLP(edge_dim + node_dim, num_edge_types, edge_dim, num_layer=3)
         self.edge_weight = torch.tensor([0.1] + [1.] * (self.num_edge_types - 1), dtype=torch.float32)
         self.ce_loss = torch.nn.CrossEntropyLoss(self.edge_weight)
+        self._eng = None
+        self._eng_sig = None
 
     def define_betas_alphas(self, config):
         self.num_timesteps = T = config.num_timesteps
@@ -45,9 +89,24 @@ class BondPredictor(Module):
             get_beta_schedule(num_timesteps=T, **config.diff_atom), self.num_node_types,
             init_prob=config.diff_atom.init_prob)
 
+    def _engine(self):
+        sig = _sig(self)
+        if self._eng is None or sig != self._eng_sig:
+            e = self.encoder
+            eng = _lib.Model(_lib.MDX_KIND_BONDPRED, num_blocks=e.num_blocks, cutoff=e.cutoff, update_pos=False,
+                             time_dim=self.config.diff.time_dim, num_timesteps=self.num_timesteps,
+                             num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
+                             node_dim=e.node_dim, edge_dim=e.edge_dim, num_gaussians=e.distance_expansion.offset.numel())
+            eng.upload(self.state_dict())
+            self._eng, self._eng_sig = eng, sig
+        return self._eng
+
     def get_loss(self, *args, **kwargs):
         raise NotImplementedError('training loss is outside the sampling hot path (SURVEY.md section 8(f))')
 
-    def forward(self, h_node, pos_node, batch_node, edge_index, batch_edge, t):
+    def forward(self, h_node, pos_node, batch_node, edge_index, batch_edge, t, _graph=None):
+        """Predict the bond type of every half-edge (first half of `edge_index`) -> (Eh, num_edge_types)."""
         _lib._need_gpu(h_node, pos_node, batch_node, edge_index, t)
-        raise NotImplementedError('BondPredictor HIP forward/backward is the next scope row (SURVEY.md 8 a14/a15)')
+        eng = self._engine()
+        g = _graph if _graph is not None else _lib.graph_for(edge_index, batch_node, int(t.numel()))
+        return _BondLogits.apply(pos_node, h_node, t, eng, g, self.encoder.num_blocks, self.num_edge_types)

@@ -63,9 +63,10 @@ struct mdx_model_s {
   // heads
   const float *Wn = nullptr, *We = nullptr, *toff = nullptr, *tcoef = nullptr;
   MlpW nodedec{}, edgedec{};
-  // bond predictor decoder (3 layers)
-  const float *bd_W1e = nullptr, *bd_W1n = nullptr, *bd_b1 = nullptr, *bd_g1 = nullptr, *bd_be1 = nullptr;
-  const float *bd_W2 = nullptr, *bd_b2 = nullptr, *bd_g2 = nullptr, *bd_be2 = nullptr, *bd_W3 = nullptr, *bd_b3 = nullptr;
+  // bond predictor: decoder + transposed packs for the guidance backward
+  BondDecW dec{};
+  std::vector<EdgeBwdW> ebw;
+  std::vector<NodeBwdW> nbw;
 };
 
 namespace {
@@ -117,6 +118,17 @@ struct PackCtx {
     if (!t) return;
     pack_dense(slot, t->data, F, ldw, col0, K);
   }
+  // transpose pack: out[k][f] = W[f][col0 + k]  (contraction over the forward's output features, zero padded to 16)
+  void packT(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    const int Fp = (F + 15) / 16 * 16;
+    std::vector<float> Wt((size_t)K * Fp, 0.f);
+    for (int k = 0; k < K; ++k)
+      for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
+    pack_dense(slot, Wt, K, Fp, 0, Fp);
+  }
+  std::map<int, std::vector<float>> wcat_dense;  // block -> dense (960 x 256) concatenated node-table weights
   void vec(const float** slot, const std::string& key, int n, int pad_to = 0) {
     const HostTensor* t = get(key, {n});
     if (!t) return;
@@ -219,6 +231,7 @@ int pack_model(mdx_model_s* m) {
       put(eb + ".bond_ffn_left.gate.net.0.weight", 32, GIN, ED, MDX_NT_GXL, "");
       put(eb + ".bond_ffn_right.gate.net.0.weight", 32, GIN, ED, MDX_NT_GXR, "");
       c.pack_dense(&b.nd.Wcat, W, MDX_NTW, ND, 0, ND);
+      c.wcat_dense[i] = W;
       c.raw(&b.nd.bcat, bias);
     }
     if (cf.update_pos) {
@@ -258,17 +271,61 @@ int pack_model(mdx_model_s* m) {
   }
   if (cf.kind == MDX_KIND_BONDPRED) {
     const std::string d = "edge_decoder.net.";
-    c.packA(&m->bd_W1e, d + "0.weight", ED, ED + ND, 0, ED);
-    c.packA(&m->bd_W1n, d + "0.weight", ED, ED + ND, ED, ND);
-    c.vec(&m->bd_b1, d + "0.bias", ED);
-    c.vec(&m->bd_g1, d + "1.weight", ED);
-    c.vec(&m->bd_be1, d + "1.bias", ED);
-    c.packA(&m->bd_W2, d + "3.weight", ED, ED, 0, ED);
-    c.vec(&m->bd_b2, d + "3.bias", ED);
-    c.vec(&m->bd_g2, d + "4.weight", ED);
-    c.vec(&m->bd_be2, d + "4.bias", ED);
-    c.packA(&m->bd_W3, d + "6.weight", cf.num_edge_types, ED, 0, ED);
-    c.vec(&m->bd_b3, d + "6.bias", cf.num_edge_types, 16);
+    BondDecW& w = m->dec;
+    c.packA(&w.W1e, d + "0.weight", ED, ED + ND, 0, ED);
+    c.packA(&w.W1n, d + "0.weight", ED, ED + ND, ED, ND);
+    c.vec(&w.b1, d + "0.bias", ED);
+    c.vec(&w.g1, d + "1.weight", ED);
+    c.vec(&w.be1, d + "1.bias", ED);
+    c.packA(&w.W2, d + "3.weight", ED, ED, 0, ED);
+    c.vec(&w.b2, d + "3.bias", ED);
+    c.vec(&w.g2, d + "4.weight", ED);
+    c.vec(&w.be2, d + "4.bias", ED);
+    c.packA(&w.W3, d + "6.weight", cf.num_edge_types, ED, 0, ED);
+    c.vec(&w.b3, d + "6.bias", cf.num_edge_types, 16);
+    c.packT(&w.W1eT, d + "0.weight", ED, ED + ND, 0, ED);
+    c.packT(&w.W1nT, d + "0.weight", ED, ED + ND, ED, ND);
+    c.packT(&w.W2T, d + "3.weight", ED, ED, 0, ED);
+    c.packT(&w.W3T, d + "6.weight", cf.num_edge_types, ED, 0, ED);
+    // transposed packs for the data-gradient backward (guidance)
+    m->ebw.assign(cf.num_blocks, EdgeBwdW{});
+    m->nbw.assign(cf.num_blocks, NodeBwdW{});
+    for (int i = 0; i < cf.num_blocks; ++i) {
+      const std::string si = std::to_string(i);
+      const std::string nb = net + "node_blocks_with_edge." + si, eb = net + "edge_blocks." + si;
+      EdgeBwdW& e = m->ebw[i];
+      c.packT(&e.WembHT, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, 0, ED);
+      c.packT(&e.WembDT, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, ED, MDX_NG);
+      c.packT(&e.Wg1eT, nb + ".gate.net.0.weight", ND, GIN, 0, ED);
+      c.packT(&e.Wg2T, nb + ".gate.net.3.weight", ND, ND, 0, ND);
+      c.packT(&e.W1T, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
+      c.packT(&e.W2T, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
+      c.packT(&e.WmT, nb + ".msg_net.weight", ND, ND, 0, ND);
+      for (int s = 0; s < 2; ++s) {
+        const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
+        FfnWT& f = e.ffn[s];
+        c.packT(&f.WblT, fp + ".bond_linear.weight", 2 * ED, ED, 0, ED);
+        c.packT(&f.Wi1T, fp + ".inter_module.net.0.weight", 2 * ED, 2 * ED, 0, 2 * ED);
+        c.packT(&f.Wi2T, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
+        c.packT(&f.Wg1eT, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
+        c.packT(&f.Wg2T, fp + ".gate.net.3.weight", ED, 32, 0, 32);
+      }
+      c.packT(&e.WselfT, eb + ".self_ffn.weight", ED, ED, 0, ED);
+      c.packT(&e.WoutT, eb + ".out_transform.weight", ED, ED, 0, ED);
+      NodeBwdW& n = m->nbw[i];
+      c.packT(&n.WoutT, nb + ".out_transform.weight", ND, ND, 0, ND);
+      c.packT(&n.W1T, nb + ".node_net.net.0.weight", ND, ND, 0, ND);
+      c.packT(&n.W2T, nb + ".node_net.net.3.weight", ND, ND, 0, ND);
+      const std::vector<float>& Wcat = c.wcat_dense[i];
+      if (!Wcat.empty())
+        for (int ch = 0; ch < 4; ++ch) {
+          const int kc = ch < 3 ? 256 : 192;
+          std::vector<float> Mt((size_t)ND * kc);
+          for (int f = 0; f < ND; ++f)
+            for (int k = 0; k < kc; ++k) Mt[(size_t)f * kc + k] = Wcat[(size_t)(256 * ch + k) * ND + f];
+          c.pack_dense(&n.WcatT[ch], Mt, ND, kc, 0, kc);
+        }
+    }
   }
   if (!c.missing.empty()) return fail(MDX_ERR_STATE, "missing or mis-shaped parameter: %s", c.missing.c_str());
   if (m->arena) hipFree(m->arena);
@@ -336,7 +393,7 @@ struct mdx_graph_s {
   int32_t* dev = nullptr;   // one int32 slab
   int64_t* mol_ids = nullptr;
   const int32_t *left, *right, *int2ref, *ref2int, *row_ptr, *col_ptr, *col_eids, *node_graph, *node_local, *he_graph,
-      *he_local;
+      *he_local, *half_of_int;
 };
 
 namespace {
@@ -438,6 +495,9 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   const size_t o_l = add(p.left), o_r = add(p.right), o_i2r = add(p.int2ref), o_r2i = add(p.ref2int), o_rp = add(p.row_ptr),
                o_cp = add(p.col_ptr), o_ce = add(p.col_eids), o_ng = add(node_graph), o_nl = add(node_local),
                o_hg = add(he_graph), o_hl = add(he_local);
+  std::vector<int32_t> half_of_int(E);
+  for (int64_t i = 0; i < E; ++i) half_of_int[i] = Eh > 0 ? (int32_t)(p.int2ref[i] % Eh) : 0;
+  const size_t o_hoi = add(half_of_int);
   if (hipMalloc((void**)&g->dev, slab.size() * 4) != hipSuccess ||
       hipMemcpy(g->dev, slab.data(), slab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
     delete g;
@@ -454,6 +514,7 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   g->left = g->dev + o_l; g->right = g->dev + o_r; g->int2ref = g->dev + o_i2r; g->ref2int = g->dev + o_r2i;
   g->row_ptr = g->dev + o_rp; g->col_ptr = g->dev + o_cp; g->col_eids = g->dev + o_ce; g->node_graph = g->dev + o_ng;
   g->node_local = g->dev + o_nl; g->he_graph = g->dev + o_hg; g->he_local = g->dev + o_hl;
+  g->half_of_int = g->dev + o_hoi;
   *out = g;
   return MDX_OK;
 }
@@ -813,10 +874,166 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
   return MDX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bond predictor: forward with a per-block tape, and the data-gradient backward w.r.t. positions
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct TapeBlock {
+  float *Hep, *Hn, *H, *NT, *aggr, *SL, *SR;
+};
+struct Tape {
+  std::vector<TapeBlock> b;
+  float *HeF, *HnF, *te;                       // final states + per-edge time
+  float *GGX, *GNL0, *GNL1, *GGXS0, *GGXS1, *GBN, *gdist, *tmpE3;  // backward scratch
+  size_t bytes;
+};
+size_t tape_layout(int64_t N, int64_t E, int nb, char* base, Tape* t) {
+  size_t off = 0;
+  auto take = [&](size_t nfloat) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += ((nfloat * 4 + 255) / 256) * 256;
+    return p;
+  };
+  const size_t n = (size_t)std::max<int64_t>(N, 1), e = (size_t)std::max<int64_t>(E, 1);
+  Tape tp;
+  tp.b.resize(nb);
+  for (int i = 0; i < nb; ++i) {
+    TapeBlock& k = tp.b[i];
+    k.Hep = take(e * 64); k.Hn = take(n * MDX_ND); k.H = take(n * MDX_ND); k.NT = take(n * MDX_NTW);
+    k.aggr = take(n * MDX_ND); k.SL = take(n * 64); k.SR = take(n * 64);
+  }
+  tp.HeF = take(e * 64); tp.HnF = take(n * MDX_ND); tp.te = take(e);
+  tp.GGX = take(e * MDX_ND); tp.GNL0 = take(e * 128); tp.GNL1 = take(e * 128); tp.GGXS0 = take(e * 32);
+  tp.GGXS1 = take(e * 32); tp.GBN = take(e * 128); tp.gdist = take(e); tp.tmpE3 = take(e * 3);
+  tp.bytes = off;
+  if (t) *t = std::move(tp);
+  return off;
+}
+}  // namespace
+
+extern "C" size_t mdx_bondpred_tape_bytes(int64_t N, int64_t E, int32_t num_blocks) {
+  return tape_layout(N, E, num_blocks, nullptr, nullptr);
+}
+
 extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h_node, const float* pos, const int64_t* t,
-                                    float* logits, void* ws, size_t ws_bytes, void* stream) {
-  (void)m; (void)g; (void)h_node; (void)pos; (void)t; (void)logits; (void)ws; (void)ws_bytes; (void)stream;
-  return fail(MDX_ERR_UNSUPPORTED, "mdx_bondpred_forward: not built yet (SURVEY section 8 row a15, next)");
+                                    float* logits, void* ws, size_t ws_bytes, void* tape, size_t tape_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (m->cfg.kind != MDX_KIND_BONDPRED) return fail(MDX_ERR_STATE, "not a BondPredictor model handle");
+  if (!h_node || !pos || !t || !logits) return fail(MDX_ERR_ARG, "null input");
+  if (g->E % 2) return fail(MDX_ERR_ARG, "BondPredictor.forward needs E = 2*Eh directed edges");
+  const int nb = m->cfg.num_blocks;
+  if (tape && (tape_bytes < mdx_bondpred_tape_bytes(g->N, g->E, nb) || (reinterpret_cast<uintptr_t>(tape) & 255)))
+    return fail(MDX_ERR_STATE, "tape too small or misaligned: need %zu bytes", mdx_bondpred_tape_bytes(g->N, g->E, nb));
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  Tape tp;
+  if (tape) tape_layout(g->N, g->E, nb, (char*)tape, &tp);
+  const mdx_config& cf = m->cfg;
+  EmbedArgs ea{};
+  ea.N = (int)g->N; ea.E = (int)g->E; ea.Kn = cf.num_node_types; ea.Ke = cf.num_edge_types; ea.time_dim = cf.time_dim;
+  ea.T = cf.num_timesteps; ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node; ea.xe = nullptr;
+  ea.int2ref = g->int2ref; ea.l = g->left; ea.r = g->right; ea.node_graph = g->node_graph; ea.t = t; ea.Wn = m->Wn;
+  ea.We = m->We; ea.toff = m->toff; ea.tcoef = m->tcoef; ea.Hn = w.Hn; ea.He = w.HeA; ea.tn = w.tn;
+  ea.te = tape ? tp.te : w.te;
+  launch_embed(ea, s);
+  Ws wr = w;
+  wr.te = ea.te;
+  const size_t nHn = (size_t)g->N * MDX_ND * 4;
+  for (int i = 0; i < nb; ++i) {
+    // same sequence as run_blocks (update_pos = false), with the per-block outputs redirected into the tape
+    Ws wi = wr;
+    float* Hep = wr.HeB;
+    if (tape) {
+      const TapeBlock& k = tp.b[i];
+      wi.H = k.H; wi.NT = k.NT; wi.aggr = k.aggr; wi.SL = k.SL; wi.SR = k.SR;
+      Hep = k.Hep;
+      HIPCHK(hipMemcpyAsync(k.Hn, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
+    }
+    if (i == 0 || tape) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
+    launch_edge_a(make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN, wi.NT), s);
+    launch_seg_reduce(wi.M, g->row_ptr, nullptr, wi.aggr, nullptr, (int)g->N, 256, s);
+    launch_seg_reduce(wi.FL, g->col_ptr, g->col_eids, wi.SL, nullptr, (int)g->N, 64, s);
+    launch_seg_reduce(wi.FR, g->row_ptr, nullptr, wi.SR, nullptr, (int)g->N, 64, s);
+    if (tape) {
+      launch_node(make_nd(m, g, wi, i, -1, ND_MID, wi.NT, nullptr), s);
+    } else {  // no tape: fuse the next block's PRE into this node launch (tables double-buffered like run_blocks)
+      float* NTn = (wr.NT == w.NT) ? w.NT2 : w.NT;
+      launch_node(make_nd(m, g, wi, i, i + 1 < nb ? i + 1 : -1, ND_MID | (i + 1 < nb ? ND_PRE : 0), wi.NT, NTn), s);
+      launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s);
+      wr.NT = NTn;
+      continue;
+    }
+    launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s);
+  }
+  if (tape) {
+    HIPCHK(hipMemcpyAsync(tp.HnF, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(tp.HeF, wr.HeA, (size_t)g->E * 64 * 4, hipMemcpyDeviceToDevice, s));
+  }
+  BondDecArgs da{};
+  da.Eh = (int)g->Eh; da.Ke = cf.num_edge_types; da.He = wr.HeA; da.Hn = wr.Hn; da.ref2int = g->ref2int; da.left = g->left;
+  da.right = g->right; da.logits = logits; da.w = m->dec;
+  launch_bond_decode(da, false, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+// gpos (N,3) = scale * dL/dpos given glogits = dL/dlogits (Eh,Ke); needs the tape of the matching forward.
+extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* pos, const float* glogits, float scale,
+                                     float* gpos, void* ws, size_t ws_bytes, void* tape, size_t tape_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (m->cfg.kind != MDX_KIND_BONDPRED) return fail(MDX_ERR_STATE, "not a BondPredictor model handle");
+  if (!pos || !glogits || !gpos || !tape) return fail(MDX_ERR_ARG, "null argument");
+  const int nb = m->cfg.num_blocks;
+  if (tape_bytes < mdx_bondpred_tape_bytes(g->N, g->E, nb) || (reinterpret_cast<uintptr_t>(tape) & 255))
+    return fail(MDX_ERR_STATE, "tape too small or misaligned");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  Tape tp;
+  tape_layout(g->N, g->E, nb, (char*)tape, &tp);
+  const mdx_config& cf = m->cfg;
+  const int N = (int)g->N, E = (int)g->E;
+  // scratch mapping onto the (now dead) forward workspace
+  float *gHn = w.Hn, *GNT = w.NT, *gH = w.H, *gHe = w.HeA, *gHe2 = w.HeB, *GU = w.FL, *GHEP = w.FR, *GH = w.M;
+  HIPCHK(hipMemsetAsync(tp.gdist, 0, (size_t)std::max(E, 1) * 4, s));
+  BondDecArgs da{};
+  da.Eh = (int)g->Eh; da.Ke = cf.num_edge_types; da.He = tp.HeF; da.Hn = tp.HnF; da.ref2int = g->ref2int; da.left = g->left;
+  da.right = g->right; da.glogits = glogits; da.gHe = gHe; da.GBN = tp.GBN; da.w = m->dec;
+  launch_bond_decode(da, true, s);
+  launch_seg_reduce_ld(tp.GBN, g->row_ptr, g->half_of_int, gHn, MDX_ND, N, 256, s);
+  for (int i = nb - 1; i >= 0; --i) {
+    const TapeBlock& k = tp.b[i];
+    NodeBwdArgs nt{};
+    nt.N = N; nt.flags = NB_TAIL; nt.gHn = gHn; nt.Hn = k.Hn; nt.NTin = k.NT; nt.aggr = k.aggr; nt.GNT = GNT; nt.gH = gH;
+    nt.w = m->blocks[i].nd; nt.wt = m->nbw[i];
+    launch_node_bwd(nt, s);
+    EdgeTailBwdArgs et{};
+    et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
+    et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
+    launch_edge_tail_bwd(et, s);
+    launch_seg_reduce_ld(GU, g->row_ptr, nullptr, GNT + MDX_NT_NFL, MDX_NTW, N, 64, s);
+    launch_seg_reduce_ld(GU, g->col_ptr, g->col_eids, GNT + MDX_NT_NFR, MDX_NTW, N, 64, s);
+    EdgeBwdArgs eb{};
+    eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
+    eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
+    eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
+    eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i];
+    launch_edge_bwd(eb, s);
+    launch_seg_reduce_ld(GH, g->col_ptr, g->col_eids, gH, MDX_ND, N, 256, s);
+    launch_seg_reduce_ld(tp.GGX, g->col_ptr, g->col_eids, GNT + MDX_NT_GX, MDX_NTW, N, 256, s);
+    launch_seg_reduce_ld(tp.GNL0, g->row_ptr, nullptr, GNT + MDX_NT_NLL, MDX_NTW, N, 128, s);
+    launch_seg_reduce_ld(tp.GNL1, g->col_ptr, g->col_eids, GNT + MDX_NT_NLR, MDX_NTW, N, 128, s);
+    launch_seg_reduce_ld(tp.GGXS0, g->row_ptr, nullptr, GNT + MDX_NT_GXL, MDX_NTW, N, 32, s);
+    launch_seg_reduce_ld(tp.GGXS1, g->col_ptr, g->col_eids, GNT + MDX_NT_GXR, MDX_NTW, N, 32, s);
+    nt.flags = NB_PRE;
+    launch_node_bwd(nt, s);
+    std::swap(gHe, gHe2);
+  }
+  launch_dist_to_pos(tp.gdist, pos, g->left, g->right, g->row_ptr, g->col_ptr, g->col_eids, tp.tmpE3, nullptr, gpos, scale, N,
+                     E, cf.cutoff, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,6 +1063,20 @@ extern "C" int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K,
                                  void* stream) {
   if (K < 1 || n < 0 || (n > 0 && (!logits || !u))) return fail(MDX_ERR_ARG, "bad argument");
   launch_gumbel_argmax(logits, u, K, (int)n, cls, onehot, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_guidance_uncertainty_grad(const float* logits, int32_t K, int64_t n, float* glogits, void* stream) {
+  if (K < 1 || n < 0 || (n > 0 && (!logits || !glogits))) return fail(MDX_ERR_ARG, "bad argument");
+  launch_uncertainty_grad(logits, K, (int)n, glogits, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_add_inplace(float* dst, const float* src, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!dst || !src))) return fail(MDX_ERR_ARG, "bad argument");
+  launch_add_inplace(dst, src, (int)n, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return MDX_OK;
 }

@@ -120,6 +120,91 @@ struct NodeArgs {
 #define ND_DELTA 4
 #define ND_POSMLP 8
 
+// ---- backward (bond-predictor guidance gradient; dgrad only, no weight gradients) ---------------------
+struct FfnWT {
+  const float *WblT, *Wi1T, *Wi2T, *Wg1eT, *Wg2T;
+};
+struct EdgeBwdW {  // transposed packs (contraction over the forward's output features)
+  const float *WembHT, *WembDT;                 // edge_embs^T: -> 64 (He part), -> 16 (distance part)
+  const float *Wg1eT, *Wg2T, *W1T, *W2T, *WmT;  // NodeBlock gate / edge_net / msg_net
+  FfnWT ffn[2];
+  const float *WselfT, *WoutT;                  // EdgeBlock tail
+};
+struct NodeBwdW {
+  const float* WoutT;      // NodeBlock out_transform^T
+  const float *W1T, *W2T;  // node_net^T
+  const float* WcatT[4];   // (960 x 256)^T in 4 K-chunks: 256, 256, 256, 192
+};
+
+struct EdgeTailBwdArgs {
+  int E;
+  const int *l, *r;
+  const float* te;
+  const float *Hep, *gHe;      // (E,64): He'_i (tape), dL/dHe_{i+1}
+  const float *SL, *SR, *NT;   // tape
+  float *GU, *GHEP;            // (E,64): dL/du ; gHe + self_ffn^T dL/du
+  EdgeBW w;
+  const float *WselfT, *WoutT;
+};
+
+struct EdgeBwdArgs {
+  int E;
+  const int *l, *r;
+  const float* te;
+  const float* pos;
+  const float *soff, *scoef;
+  float cutoff;
+  const float *Hep, *GHEP;     // (E,64)
+  const float *H, *NT;         // tape node tables of this block
+  const float* GNT;            // (N,960) gradient table: C cols = dL/d(aggr), NFL cols = A_l, NFR cols = A_r
+  float* gHe_out;              // (E,64) dL/dHe_i
+  float* gdist;                // (E) accumulated over blocks
+  float *GH, *GGX;             // (E,256) per-edge gradient payloads reduced by right endpoint
+  float* GNL[2];               // (E,128): left -> reduced by left, right -> by right
+  float* GGXS[2];              // (E,32)
+  EdgeAW w;
+  EdgeBwdW wt;
+};
+
+struct NodeBwdArgs {
+  int N, flags;
+  float* gHn;                  // (N,256) in/out
+  const float* Hn;             // tape Hn_i
+  const float *NTin, *aggr;    // tape NT_i, aggr_i
+  float* GNT;                  // (N,960)
+  const float* gH;             // (N,256) dL/d node_net(x)
+  NodeW w;
+  NodeBwdW wt;
+};
+#define NB_TAIL 1
+#define NB_PRE 2
+
+struct BondDecW {
+  const float *W1e, *W1n, *b1, *g1, *be1, *W2, *b2, *g2, *be2, *W3, *b3;
+  const float *W1eT, *W1nT, *W2T, *W3T;
+};
+struct BondDecArgs {
+  int Eh, Ke;
+  const float *He, *Hn;        // (E,64) internal order, (N,256)
+  const int *ref2int, *left, *right;
+  float* logits;               // fwd out (Eh,Ke)
+  const float* glogits;        // bwd in
+  float *gHe, *GBN;            // bwd out: (E,64) internal order, (Eh,256)
+  BondDecW w;
+};
+
+void launch_edge_tail_bwd(const EdgeTailBwdArgs& a, hipStream_t s);
+void launch_edge_bwd(const EdgeBwdArgs& a, hipStream_t s);
+void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
+void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s);
+// generalized segment sum: C in {32,64,128,256}; out row stride out_ld (floats), column offset already applied to `out`
+void launch_seg_reduce_ld(const float* src, const int* ptr, const int* eids, float* out, int out_ld, int N, int C,
+                          hipStream_t s);
+// dpos[v] = sum_{l=v} gd_e rel_e/d_e - sum_{r=v} gd_e rel_e/d_e   (two-pass, deterministic)
+void launch_dist_to_pos(const float* gdist, const float* pos, const int* l, const int* r, const int* row_ptr,
+                        const int* col_ptr, const int* col_eids, float* tmpE3, float* tmpN3, float* gpos, float scale, int N,
+                        int E, float cutoff, hipStream_t s);
+
 void launch_edge_a(const EdgeAArgs& a, hipStream_t s);
 void launch_edge_b(const EdgeBArgs& a, hipStream_t s);
 void launch_node(const NodeArgs& a, hipStream_t s);
@@ -157,6 +242,8 @@ void launch_pos_posterior(const float* c0, const float* ct, const float* sd, con
                           const float* eps, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
 void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, const float* logits_or_log_v0, int is_logits,
                           const float* log_vt, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
+void launch_uncertainty_grad(const float* logits, int K, int n, float* glogits, hipStream_t s);
+void launch_add_inplace(float* dst, const float* src, int n, hipStream_t s);
 void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s);
 void launch_philox_noise(uint64_t seed, int step, const int* node_graph, const int* node_local, const int* he_graph,
                          const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,

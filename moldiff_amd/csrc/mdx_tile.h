@@ -175,6 +175,136 @@ __device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float*
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Backward building blocks (bond-predictor guidance gradient).
+//   ln_xhat      : x (pre-LN, registers) -> x_hat in place, rstd per row out.   2 barriers.
+//   ln_relu_bwd  : g = dL/d relu(LN(x)) -> dL/dx in place, given x_hat/rstd.     1 barrier.
+//                  y = x_hat*gamma + beta ; mask = y > 0 ; gh = g*mask*gamma ;
+//                  dx = rstd * (gh - mean(gh) - x_hat * mean(gh * x_hat))
+// ALL threads call; waves >= NW pass active=false.  red..red4: 4*TE floats each.
+// ----------------------------------------------------------------------------------------------
+template <int FTW, int ET, int NW>
+__device__ __forceinline__ void ln_xhat(f32x4 (&x)[FTW][ET], float (&rstd)[ET], float* red, float* red2, int wave,
+                                        int lane, bool active) {
+  constexpr int TE = 16 * ET;
+  constexpr float inv_n = 1.0f / (float)(NW * FTW * 16);
+  const int c = lane & 15, q = lane >> 4;
+  if (active) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft) s += (x[ft][et][0] + x[ft][et][1]) + (x[ft][et][2] + x[ft][et][3]);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (q == 0) red[wave * TE + 16 * et + c] = s;
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[w * TE + 16 * et + c];
+      const float mean = s * inv_n;
+      float d2 = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft) {
+        x[ft][et] = x[ft][et] - splat4(mean);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2 = fmaf(x[ft][et][r], x[ft][et][r], d2);
+      }
+      d2 += __shfl_xor(d2, 16);
+      d2 += __shfl_xor(d2, 32);
+      if (q == 0) red2[wave * TE + 16 * et + c] = d2;
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red2[w * TE + 16 * et + c];
+      rstd[et] = 1.0f / sqrtf(v * inv_n + MDX_LN_EPS);
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft) x[ft][et] = x[ft][et] * splat4(rstd[et]);
+    }
+  }
+}
+
+// y = relu(x_hat * gamma + beta)
+template <int FTW, int ET>
+__device__ __forceinline__ void ln_apply_relu(f32x4 (&y)[FTW][ET], const f32x4 (&xhat)[FTW][ET],
+                                              const float* __restrict__ gamma, const float* __restrict__ beta, int ft0,
+                                              int lane) {
+  const int q = lane >> 4;
+#pragma unroll
+  for (int ft = 0; ft < FTW; ++ft) {
+    const f32x4 gm = ldg4(gamma + 16 * (ft0 + ft) + 4 * q), bt = ldg4(beta + 16 * (ft0 + ft) + 4 * q);
+#pragma unroll
+    for (int et = 0; et < ET; ++et) y[ft][et] = relu4(xhat[ft][et] * gm + bt);
+  }
+}
+
+template <int FTW, int ET, int NW>
+__device__ __forceinline__ void ln_relu_bwd(f32x4 (&g)[FTW][ET], const f32x4 (&xhat)[FTW][ET], const float (&rstd)[ET],
+                                            const float* __restrict__ gamma, const float* __restrict__ beta, int ft0,
+                                            float* red3, float* red4, int wave, int lane, bool active) {
+  constexpr int TE = 16 * ET;
+  constexpr float inv_n = 1.0f / (float)(NW * FTW * 16);
+  const int c = lane & 15, q = lane >> 4;
+  if (active) {
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft) {
+      const f32x4 gm = ldg4(gamma + 16 * (ft0 + ft) + 4 * q), bt = ldg4(beta + 16 * (ft0 + ft) + 4 * q);
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        const f32x4 y = xhat[ft][et] * gm + bt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[ft][et][r] = (y[r] > 0.f) ? g[ft][et][r] * gm[r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1 += g[ft][et][r];
+          s2 = fmaf(g[ft][et][r], xhat[ft][et][r], s2);
+        }
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      if (q == 0) {
+        red3[wave * TE + 16 * et + c] = s1;
+        red4[wave * TE + 16 * et + c] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        s1 += red3[w * TE + 16 * et + c];
+        s2 += red4[w * TE + 16 * et + c];
+      }
+      s1 *= inv_n;
+      s2 *= inv_n;
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+        g[ft][et] = (g[ft][et] - splat4(s1) - xhat[ft][et] * splat4(s2)) * splat4(rstd[et]);
+    }
+  }
+}
+
 // Sum over NOUT = NW*FTW*16 features of  w2[f] * z[row][f]  ->  one scalar per row, result broadcast
 // to every lane that holds row 16*et + c (used for the 256->1 and 32->1 heads of PosUpdate).
 // ALL threads call (one __syncthreads).  red: LDS scratch 4*TE floats.

@@ -101,6 +101,25 @@ __global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const flo
     for (int k = 0; k < K; ++k) onehot[(size_t)i * K + k] = (k == best) ? 1.f : 0.f;
 }
 
+// 'uncertainty' guidance objective (models/model.py:322-324): U = sum_h log sigmoid(-logsumexp_k logits[h,k]);
+// dU/dlogits[h,k] = -sigmoid(s_h) * softmax_k.   One thread per half-edge.
+__global__ void uncertainty_grad_kernel(const float* __restrict__ logits, int K, int n, float* __restrict__ glogits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, logits[(size_t)i * K + k]);
+  float sum = 0.f;
+  for (int k = 0; k < K; ++k) sum += expf(logits[(size_t)i * K + k] - m);
+  const float s = m + logf(sum);
+  const float sig = 1.0f / (1.0f + expf(-s));
+  for (int k = 0; k < K; ++k) glogits[(size_t)i * K + k] = -sig * (expf(logits[(size_t)i * K + k] - m) / sum);
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = dst[i] + src[i];
+}
+
 struct u4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
@@ -182,6 +201,16 @@ void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, co
     default: break;
   }
 #undef MDX_CP
+}
+
+void launch_uncertainty_grad(const float* logits, int K, int n, float* glogits, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(uncertainty_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, K, n, glogits);
+}
+
+void launch_add_inplace(float* dst, const float* src, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
 }
 
 void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s) {

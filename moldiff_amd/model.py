@@ -14,9 +14,14 @@ import ctypes
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn import Module
 
 from . import _lib
+
+# guidance objectives of models/model.py:317-359
+GUIDANCE_TYPES = ('entropy', 'uncertainty', 'uncertainty_bond', 'entropy_bond', 'logit_bond', 'logit', 'crossent',
+                  'crossent_bond')
 from .common import MLP, GaussianSmearing
 from .diffusion import get_beta_schedule
 from .graph import NodeEdgeNet, _sig
@@ -132,8 +137,17 @@ class _Sampler:
     def __init__(self, model, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
                  bond_predictor, guidance):
         _lib._need_gpu(batch_node, halfedge_index, batch_halfedge)
-        if guidance is not None and guidance[1] > 0:
-            raise NotImplementedError('bond-predictor guidance is not built yet (SURVEY.md section 8 rows a14/a15)')
+        self.guidance = None
+        if guidance is not None:
+            gui_type, gui_scale = guidance
+            if gui_scale > 0:
+                if bond_predictor is None:
+                    raise ValueError('guidance needs a bond_predictor')
+                if gui_type not in GUIDANCE_TYPES:
+                    raise NotImplementedError(f'Guidance type {gui_type} is not implemented')
+                self.guidance = (gui_type, float(gui_scale))
+                self.bp = bond_predictor
+                self.bp_eng = bond_predictor._engine()
         self.m = m = model
         self.dev = dev = batch_node.device
         self.T, self.Kn, self.Ke = m.num_timesteps, m.num_node_types, m.num_edge_types
@@ -157,6 +171,12 @@ class _Sampler:
         self.preds = (torch.empty(N, Kn, **f32), torch.empty(N, 3, **f32), torch.empty(Eh, Ke, **f32))
         self.log_node = [torch.empty(N, Kn, **f32), torch.empty(N, Kn, **f32)]
         self.log_half = [torch.empty(Eh, Ke, **f32), torch.empty(Eh, Ke, **f32)]
+        if self.guidance is not None:
+            Kb = self.bp.num_edge_types
+            self.bp_logits, self.bp_glogits = torch.empty(Eh, Kb, **f32), torch.empty(Eh, Kb, **f32)
+            self.delta = torch.empty(N, 3, **f32)
+            self.edge_index = edge_index
+            self.batch_edge = torch.cat([self.bh, self.bh], dim=0)
         self.cur = 0  # frame holding the current state
 
     def _frame(self, j):
@@ -209,7 +229,57 @@ class _Sampler:
                                        _lib.ptr(self.bh), Eh, _lib.ptr(self.log_half[ln]), st))
         _lib.check(L.mdx_gumbel_argmax(_lib.ptr(self.log_half[ln]), _lib.ptr(self.u_h), Ke, Eh, None,
                                        _lib.ptr(self.halfedge_traj[n]), st))
+        if self.guidance is not None:
+            self._guide(h_node, pos, self.pos_traj[n], self.halfedge_traj[n], self.log_half[ln])
         self.cur, self.lcur = n, ln
+
+    def _guide(self, h_node, pos, pos_prev, h_half_prev, log_half):
+        """models/model.py:309-362: pos_prev += delta, delta = -+scale * d f(bond logits) / d pos evaluated at the
+        step's INPUT state (h_node_pert, pos_pert).  The default 'uncertainty' objective runs entirely in HIP
+        (predictor forward with tape -> dU/dlogits -> hand-written backward); the other seven objectives are the
+        reference's torch expressions on the (Eh,5) logits, differentiated through the same HIP backward."""
+        L, g = _lib.lib(), self.g
+        gui_type, scale = self.guidance
+        if gui_type == 'uncertainty':
+            dev = self.dev
+            ws, nb = g.workspace(dev)
+            _, tptr, tbytes = g.tape(dev, self.bp.encoder.num_blocks)
+            st = _lib.stream()
+            _lib.check(L.mdx_bondpred_forward(self.bp_eng.h, g.h, _lib.ptr(h_node), _lib.ptr(pos), _lib.ptr(self.t),
+                                              _lib.ptr(self.bp_logits), ws, nb, tptr, tbytes, st))
+            _lib.check(L.mdx_guidance_uncertainty_grad(_lib.ptr(self.bp_logits), self.bp.num_edge_types, self.Eh,
+                                                       _lib.ptr(self.bp_glogits), st))
+            _lib.check(L.mdx_bondpred_backward(self.bp_eng.h, g.h, _lib.ptr(pos), _lib.ptr(self.bp_glogits), -scale,
+                                               _lib.ptr(self.delta), ws, nb, tptr, tbytes, st))
+            _lib.check(L.mdx_add_inplace(_lib.ptr(pos_prev), _lib.ptr(self.delta), 3 * self.N, st))
+            return
+        with torch.enable_grad():
+            pos_in = pos.detach().clone().requires_grad_(True)
+            pred = self.bp(h_node.detach(), pos_in, self.bn, self.edge_index, self.batch_edge, self.t, _graph=g)
+            sign = -1.0
+            if gui_type == 'entropy':
+                p = torch.softmax(pred, dim=-1)
+                obj = (-torch.sum(p * torch.log(p + 1e-12), dim=-1)).log().sum()
+            elif gui_type == 'uncertainty_bond':
+                p = torch.softmax(pred, dim=-1)
+                u = torch.sigmoid(-torch.logsumexp(pred, dim=-1)).log()
+                obj = (u * p[:, 1:].detach().sum(dim=-1)).sum()
+            elif gui_type == 'entropy_bond':
+                p = torch.softmax(pred, dim=-1)
+                ent = (-torch.sum(p * torch.log(p + 1e-12), dim=-1)).log()
+                obj = (ent * p[:, 1:].detach().sum(dim=-1)).sum()
+            elif gui_type in ('logit_bond', 'logit'):
+                cls = h_half_prev.argmax(dim=-1)
+                keep = ((cls >= 1) & (cls <= 4)) if gui_type == 'logit_bond' else (cls <= 4)
+                idx = keep.nonzero().squeeze(-1)
+                obj = pred[idx, cls[idx]].sum()
+                sign = 1.0
+            elif gui_type == 'crossent':
+                obj = F.cross_entropy(pred, log_half.exp()[:, :-1], reduction='none').log().sum()
+            else:  # 'crossent_bond'
+                obj = F.cross_entropy(pred[:, 1:], log_half.exp()[:, 1:-1], reduction='none').log().sum()
+            delta = sign * torch.autograd.grad(obj, pos_in)[0] * scale
+        pos_prev.add_(delta)
 
     def state(self):
         c = self.cur
