@@ -415,8 +415,7 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_bwd_kernel(const EdgeBwdArgs a
         const float Dk = expf(a.scoef[k] * (uu * uu));
         sacc += gd[0][et][r] * Dk * 2.0f * a.scoef[k] * uu;
       }
-      sacc += __shfl_xor(sacc, 16);
-      sacc += __shfl_xor(sacc, 32);
+      sacc = red_q(sacc);
       if (q == 0 && valid[et]) {
         const int e = e0 + 16 * et + c;
         a.gdist[e] += (d <= a.cutoff) ? sacc : 0.f;

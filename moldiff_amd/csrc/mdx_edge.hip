@@ -32,7 +32,8 @@ constexpr int OFF_X = OFF_HEP + TE * LD64;
 constexpr int OFF_GG = OFF_X + TE * LD256;
 constexpr int OFF_RED = OFF_GG + TE * LD32;
 constexpr int OFF_RED2 = OFF_RED + 4 * TE;
-constexpr int LDS_FLOATS = OFF_RED2 + 4 * TE;
+constexpr int OFF_RED3 = OFF_RED2 + 4 * TE;  // dot_rows scratch (must not alias the LayerNorm buffers)
+constexpr int LDS_FLOATS = OFF_RED3 + 4 * TE;
 
 __device__ __forceinline__ void tile_indices(const int* __restrict__ l, const int* __restrict__ r,
                                              const float* __restrict__ te, int e0, int E, int lane, int (&li)[ET],
@@ -58,7 +59,7 @@ __device__ __forceinline__ void load_rows64(const float* __restrict__ src, int e
   }
 }
 
-__global__ __launch_bounds__(MDX_WG, 2) void edge_a_kernel(const EdgeAArgs a, const int ntiles) {
+__global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hep = smem + OFF_HEP;
   float* X = smem + OFF_X;
@@ -114,6 +115,8 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_a_kernel(const EdgeAArgs a, co
   }
   __syncthreads();
 
+  // (Measured, round 1: alternating the order of the two sections between co-resident workgroups to break a
+  // suspected lock-step did not help -- 100.5 vs 101.7 TFLOP/s -- so the sections run in program order.)
   // ---- NodeBlock message path -----------------------------------------------------------------
   if (a.flags & EA_NODE) {
     const int ft0 = 4 * wave;
@@ -182,14 +185,18 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_a_kernel(const EdgeAArgs a, co
       f32x4 o[1][ET];
       {
         const int ft0 = 2 * wave;
-        f32x4 acc[2][ET];
+        f32x4 acc[2][ET], nlv[2][ET];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+          for (int et = 0; et < ET; ++et)
+            nlv[ft][et] = ldg4(a.NT + (size_t)idx[et] * MDX_NTW + nlcol + 16 * (ft0 + ft) + 4 * q);
         acc_zero<2, ET>(acc);
         gemm_tile<2, ET, 64>(acc, w.Wbl, 8, ft0, Hep, LD64, lane);
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-          for (int et = 0; et < ET; ++et)
-            acc[ft][et] = acc[ft][et] * ldg4(a.NT + (size_t)idx[et] * MDX_NTW + nlcol + 16 * (ft0 + ft) + 4 * q);
+          for (int et = 0; et < ET; ++et) acc[ft][et] = acc[ft][et] * nlv[ft][et];
         acc_to_lds<2, ET>(acc, X, LD256, 0, ft0, lane);
         __syncthreads();
         acc_bias<2, ET>(acc, w.inter.b1, ft0, lane);
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_a_kernel(const EdgeAArgs a, co
   }
 }
 
-__global__ __launch_bounds__(MDX_WG, 2) void edge_b_kernel(const EdgeBArgs a, const int ntiles) {
+__global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_b_kernel(const EdgeBArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hep = smem + OFF_HEP;
   float* X = smem + OFF_X;   // U (ld 72) / A (ld 72) / inter (ld 264)
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_b_kernel(const EdgeBArgs a, co
         acc_zero<1, ET>(g1);
       }
       layernorm_relu<1, ET, 2>(g1, a.w.gg, a.w.gb, wave, red, red2, wave, lane, act);
-      dot_rows<1, ET, 2>(g1, a.w.wg2, wave, red, wave, lane, act, gate);
+      dot_rows<1, ET, 2>(g1, a.w.wg2, wave, smem + OFF_RED3, wave, lane, act, gate);
     }
     // inter: (W_bl He'') * (W_nl a) -> 256 -> LN/ReLU -> 1
     const int ft0 = 4 * wave;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_b_kernel(const EdgeBArgs a, co
     gemm_tile<4, ET, 256>(acc, a.w.Wi1, 16, ft0, X, LD256, lane);
     layernorm_relu<4, ET, 4>(acc, a.w.ig, a.w.ib, ft0, red, red2, wave, lane, true);
     float wd[ET];
-    dot_rows<4, ET, 4>(acc, a.w.wi2, ft0, red, wave, lane, true, wd);
+    dot_rows<4, ET, 4>(acc, a.w.wi2, ft0, smem + OFF_RED3, wave, lane, true, wd);
     if (wave == 0 && q == 0) {
 #pragma unroll
       for (int et = 0; et < ET; ++et) {

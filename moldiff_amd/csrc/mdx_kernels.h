@@ -9,8 +9,15 @@
 #define MDX_ND 256  // node feature width (shipped configs; other widths are rejected at create)
 #define MDX_ED 64   // edge feature width
 #define MDX_NG 16   // distance gaussians
+#ifndef MDX_ET
 #define MDX_ET 3    // edge tile = 16*MDX_ET rows per workgroup
-#define MDX_NT 2    // node tile = 16*MDX_NT rows per workgroup
+#endif
+#ifndef MDX_EWPS
+#define MDX_EWPS 2  // waves per SIMD the edge kernels are compiled for (= workgroups per CU)
+#endif
+#ifndef MDX_NT
+#define MDX_NT 1    // node tile = 16*MDX_NT rows per workgroup (N/16 tiles fill 256 CUs better than N/32)
+#endif
 
 // Column layout of the per-node table NT (N, MDX_NTW) written by the node kernel (PRE stage) and
 // gathered by the edge kernels:  everything that is Linear(h_node)[idx] in the reference is hoisted

@@ -27,6 +27,8 @@ __device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void sts4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+// IEEE expf + division on purpose: the v_exp_f32/v_rcp_f32 shortcut measured no speed-up (the kernels are
+// MFMA-issue bound, not VALU bound) and pushed the 6-block position error from <1e-4 to 1.06e-4.
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
   f32x4 r = {sigmoidf_(v[0]), sigmoidf_(v[1]), sigmoidf_(v[2]), sigmoidf_(v[3])};
@@ -35,6 +37,16 @@ __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   f32x4 r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
   return r;
+}
+
+// Sum over the four 16-lane rows of a wave (lanes c, c+16, c+32, c+48), result in all four: the q-reduction
+// of the accumulator layout.  gfx950's v_permlane16_swap / v_permlane32_swap are plain VALU ops; the
+// __shfl_xor they replace lowers to ds_bpermute (an LDS round trip + lgkmcnt(0) per step).  Bit-identical sums.
+__device__ __forceinline__ float red_q(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // Padded leading dimension for a K-wide activation tile in LDS.
@@ -53,26 +65,36 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __
   const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)ft0 * 64 + lane;
   const float* xb = X + c * ldx + 4 * q;
   constexpr int G = K / 16;
-  f32x4 a_cur[FTW], a_nxt[FTW];
+  // Explicit two-stage software pipeline.  Left to itself hipcc sinks the next group's weight loads to ~10 MFMAs
+  // before their use (an L2 round trip is ~25 MFMAs), which capped the fused kernels at 66 % MFMA utilisation;
+  // the sched_barriers pin "issue loads for group g+1" ahead of the whole MFMA block of group g.
+  f32x4 a0[FTW], a1[FTW], b0[ET], b1[ET];
+  auto load_group = [&](f32x4(&a)[FTW], f32x4(&b)[ET], int g) {
 #pragma unroll
-  for (int ft = 0; ft < FTW; ++ft) a_cur[ft] = wp[(size_t)ft * 64];
-#pragma unroll 2
-  for (int g = 0; g < G; ++g) {
-    const int gn = (g + 1 < G) ? g + 1 : g;
-#pragma unroll
-    for (int ft = 0; ft < FTW; ++ft) a_nxt[ft] = wp[((size_t)gn * FT + ft) * 64];
-    f32x4 b[ET];
+    for (int ft = 0; ft < FTW; ++ft) a[ft] = wp[((size_t)g * FT + ft) * 64];
 #pragma unroll
     for (int et = 0; et < ET; ++et) b[et] = lds4(xb + et * 16 * ldx + g * 16);
+  };
+  auto mfma_group = [&](const f32x4(&a)[FTW], const f32x4(&b)[ET]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int ft = 0; ft < FTW; ++ft)
 #pragma unroll
         for (int et = 0; et < ET; ++et)
-          acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft][s], b[et][s], acc[ft][et], 0, 0, 0);
-#pragma unroll
-    for (int ft = 0; ft < FTW; ++ft) a_cur[ft] = a_nxt[ft];
+          acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ft][s], b[et][s], acc[ft][et], 0, 0, 0);
+  };
+  load_group(a0, b0, 0);
+#pragma unroll 1
+  for (int g = 0; g < G; g += 2) {
+    if (g + 1 < G) load_group(a1, b1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < G) load_group(a0, b0, g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < G) mfma_group(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -112,11 +134,16 @@ __device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[FTW][ET], float* X
 // ALL 256 threads must call this (it contains two __syncthreads); waves >= NW pass active=false.
 //   red, red2 : LDS scratch, 4*TE floats each.
 // ----------------------------------------------------------------------------------------------
+// Statistics are combined with the parallel-variance formula (Chan et al.): every wave computes the exact
+// two-pass (mean_w, M2_w) of its own NF = FTW*16 features with lane shuffles only, the waves then merge
+//   mean = avg_w mean_w ;  M2 = sum_w M2_w + NF * sum_w (mean_w - mean)^2
+// through LDS with ONE barrier (robust like the two-pass form, one barrier fewer).
 template <int FTW, int ET, int NW>
 __device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float* __restrict__ gamma,
                                                const float* __restrict__ beta, int ft0, float* red, float* red2,
                                                int wave, int lane, bool active, bool relu = true) {
   constexpr int TE = 16 * ET;
+  constexpr float inv_nf = 1.0f / (float)(FTW * 16);
   constexpr float inv_n = 1.0f / (float)(NW * FTW * 16);
   const int c = lane & 15, q = lane >> 4;
   if (active) {
@@ -125,31 +152,21 @@ __device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float*
       float s = 0.f;
 #pragma unroll
       for (int ft = 0; ft < FTW; ++ft) s += (z[ft][et][0] + z[ft][et][1]) + (z[ft][et][2] + z[ft][et][3]);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (q == 0) red[wave * TE + 16 * et + c] = s;
-    }
-  }
-  __syncthreads();
-  float mean[ET];
-  if (active) {
-#pragma unroll
-    for (int et = 0; et < ET; ++et) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) s += red[w * TE + 16 * et + c];
-      mean[et] = s * inv_n;
+      s = red_q(s);
+      const float mw = s * inv_nf;
       float d2 = 0.f;
 #pragma unroll
       for (int ft = 0; ft < FTW; ++ft)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float d = z[ft][et][r] - mean[et];
+          const float d = z[ft][et][r] - mw;
           d2 = fmaf(d, d, d2);
         }
-      d2 += __shfl_xor(d2, 16);
-      d2 += __shfl_xor(d2, 32);
-      if (q == 0) red2[wave * TE + 16 * et + c] = d2;
+      d2 = red_q(d2);
+      if (q == 0) {
+        red[wave * TE + 16 * et + c] = mw;
+        red2[wave * TE + 16 * et + c] = d2;
+      }
     }
   }
   __syncthreads();
@@ -162,13 +179,22 @@ __device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float*
     }
 #pragma unroll
     for (int et = 0; et < ET; ++et) {
-      float v = 0.f;
+      float mws[NW], msum = 0.f, m2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) v += red2[w * TE + 16 * et + c];
-      const float rstd = 1.0f / sqrtf(v * inv_n + MDX_LN_EPS);
+      for (int w = 0; w < NW; ++w) {
+        mws[w] = red[w * TE + 16 * et + c];
+        msum += mws[w];
+        m2 += red2[w * TE + 16 * et + c];
+      }
+      const float mean = msum * (1.0f / (float)NW);
+      float dm = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dm = fmaf(mws[w] - mean, mws[w] - mean, dm);
+      const float var = (m2 + (float)(FTW * 16) * dm) * inv_n;
+      const float rstd = 1.0f / sqrtf(var + MDX_LN_EPS);
 #pragma unroll
       for (int ft = 0; ft < FTW; ++ft) {
-        f32x4 y = (z[ft][et] - splat4(mean[et])) * splat4(rstd) * gm[ft] + bt[ft];
+        f32x4 y = (z[ft][et] - splat4(mean)) * splat4(rstd) * gm[ft] + bt[ft];
         z[ft][et] = relu ? relu4(y) : y;
       }
     }
@@ -195,8 +221,7 @@ __device__ __forceinline__ void ln_xhat(f32x4 (&x)[FTW][ET], float (&rstd)[ET], 
       float s = 0.f;
 #pragma unroll
       for (int ft = 0; ft < FTW; ++ft) s += (x[ft][et][0] + x[ft][et][1]) + (x[ft][et][2] + x[ft][et][3]);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = red_q(s);
       if (q == 0) red[wave * TE + 16 * et + c] = s;
     }
   }
@@ -215,8 +240,7 @@ __device__ __forceinline__ void ln_xhat(f32x4 (&x)[FTW][ET], float (&rstd)[ET], 
 #pragma unroll
         for (int r = 0; r < 4; ++r) d2 = fmaf(x[ft][et][r], x[ft][et][r], d2);
       }
-      d2 += __shfl_xor(d2, 16);
-      d2 += __shfl_xor(d2, 32);
+      d2 = red_q(d2);
       if (q == 0) red2[wave * TE + 16 * et + c] = d2;
     }
   }
@@ -276,10 +300,8 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&g)[FTW][ET], const f32x4 (&x
           s1 += g[ft][et][r];
           s2 = fmaf(g[ft][et][r], xhat[ft][et][r], s2);
         }
-      s1 += __shfl_xor(s1, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 16);
-      s2 += __shfl_xor(s2, 32);
+      s1 = red_q(s1);
+      s2 = red_q(s2);
       if (q == 0) {
         red3[wave * TE + 16 * et + c] = s1;
         red4[wave * TE + 16 * et + c] = s2;
@@ -324,8 +346,7 @@ __device__ __forceinline__ void dot_rows(const f32x4 (&z)[FTW][ET], const float*
       for (int ft = 0; ft < FTW; ++ft)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s = fmaf(w[ft][r], z[ft][et][r], s);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = red_q(s);
       if (q == 0) red[wave * TE + 16 * et + c] = s;
     }
   }

@@ -43,9 +43,13 @@ def _replay(kind, tag, window, guided=False):
         sm.step(i)
         got = sm.state()
         assert float(g[f"{pre}_{j}_node_margin_min"]) > 1e-4 and float(g[f"{pre}_{j}_halfedge_margin_min"]) > 1e-4
-        assert U.maxdiff(sm.preds[1], g[f'{pre}_{j}_pred_pos']) < 1e-4
+        # 'hi' window: random positions at unit scale put atom pairs 0.15 apart, and w*rel/d/(d+1) amplifies fp32
+        # rounding: the reference's own fp32 CPU result is 7.2e-5 away from an fp64 evaluation there (the HIP result
+        # 5.5e-5), so the position tolerance for that window is 2e-4; 'lo' (min distance 0.46) keeps 1e-4.
+        ptol = 2e-4 if window == 'hi' else 1e-4
+        assert U.maxdiff(sm.preds[1], g[f'{pre}_{j}_pred_pos']) < ptol
         assert U.maxdiff(sm.preds[0], g[f'{pre}_{j}_pred_node']) < 2e-5
-        assert U.maxdiff(got['pos'], g[f'{pre}_{j}_pos']) < 1e-4
+        assert U.maxdiff(got['pos'], g[f'{pre}_{j}_pos']) < ptol
         assert U.maxdiff(got['log_node'], g[f'{pre}_{j}_log_node']) < 1e-4
         assert U.maxdiff(got['log_halfedge'], g[f'{pre}_{j}_log_halfedge']) < 1e-4
         assert np.array_equal(got['h_node'].argmax(-1).cpu().numpy(), g[f'{pre}_{j}_node_type'])
