@@ -143,6 +143,19 @@ int mdx_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 int mdx_noise(mdx_graph_t g, uint64_t seed, int32_t draw, int32_t Kn, int32_t Ke, float* eps_pos, float* u_node,
               float* u_halfedge, void* stream);
 
+/* ---- harness consumer of the path's outputs (next-row) ---------------------------------------
+ * seperate_outputs (utils/sample.py:4-30) + FeaturizeMol.decode_output (utils/transforms.py:65-122) on the device:
+ * arg-max class + soft-max confidence per atom / half-edge, mask-type atoms (class >= num_element) dropped and the
+ * survivors re-indexed per molecule, bonds = half-edges with 0 < class <= num_bond_types whose atoms survived.
+ * Outputs are compacted IN PLACE at each molecule's original offsets (atoms at node offset, bonds at half-edge
+ * offset; order preserved): atom_type/atom_prob (N), atom_pos (N,3), n_atoms (n_graphs); bond_type/bond_prob (Eh),
+ * bond_index (2,Eh) molecule-local new atom indices, n_bonds (n_graphs).  One direction per bond (the reference
+ * mirrors them on the host). */
+int mdx_decode_output(mdx_graph_t g, const float* pred_node, int32_t Kn, const float* pred_pos, const float* pred_halfedge,
+                      int32_t Ke, int32_t num_element, int32_t num_bond_types, int32_t* atom_type, float* atom_prob,
+                      float* atom_pos, int32_t* n_atoms, int32_t* bond_type, float* bond_prob, int32_t* bond_index,
+                      int32_t* n_bonds, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
  * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
  * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass).  read() drains pending events. */

@@ -21,7 +21,7 @@ EXPORTS = [
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
-    'mdx_guidance_uncertainty_grad', 'mdx_add_inplace',
+    'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
     'mdx_profile_enable', 'mdx_profile_read',
 ]
 
@@ -71,6 +71,8 @@ def lib():
         L.mdx_noise.argtypes = [c_void_p, c_uint64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.mdx_guidance_uncertainty_grad.argtypes = [c_void_p, c_int32, c_int64, c_void_p, c_void_p]
         L.mdx_add_inplace.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
+        L.mdx_decode_output.argtypes = ([c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32] +
+                                        [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p])
         L.mdx_device_count.argtypes = [POINTER(c_int)]
         L.mdx_profile_enable.argtypes = [c_int32]
         L.mdx_profile_read.argtypes = [c_int32, POINTER(c_int64), POINTER(ctypes.c_double)]

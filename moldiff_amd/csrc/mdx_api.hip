@@ -393,7 +393,7 @@ struct mdx_graph_s {
   int32_t* dev = nullptr;   // one int32 slab
   int64_t* mol_ids = nullptr;
   const int32_t *left, *right, *int2ref, *ref2int, *row_ptr, *col_ptr, *col_eids, *node_graph, *node_local, *he_graph,
-      *he_local, *half_of_int;
+      *he_local, *half_of_int, *node_ptr, *he_ptr;
 };
 
 namespace {
@@ -495,6 +495,11 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   const size_t o_l = add(p.left), o_r = add(p.right), o_i2r = add(p.int2ref), o_r2i = add(p.ref2int), o_rp = add(p.row_ptr),
                o_cp = add(p.col_ptr), o_ce = add(p.col_eids), o_ng = add(node_graph), o_nl = add(node_local),
                o_hg = add(he_graph), o_hl = add(he_local);
+  std::vector<int32_t> node_ptr(B + 1, 0), he_ptr(B + 1, 0);
+  for (int64_t v = 0; v < N; ++v) node_ptr[bn[v] + 1]++;
+  for (int64_t h = 0; h < Eh; ++h) he_ptr[he_graph[h] + 1]++;
+  for (int64_t b = 0; b < B; ++b) { node_ptr[b + 1] += node_ptr[b]; he_ptr[b + 1] += he_ptr[b]; }
+  const size_t o_np = add(node_ptr), o_hp = add(he_ptr);
   std::vector<int32_t> half_of_int(E);
   for (int64_t i = 0; i < E; ++i) half_of_int[i] = Eh > 0 ? (int32_t)(p.int2ref[i] % Eh) : 0;
   const size_t o_hoi = add(half_of_int);
@@ -515,6 +520,8 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   g->row_ptr = g->dev + o_rp; g->col_ptr = g->dev + o_cp; g->col_eids = g->dev + o_ce; g->node_graph = g->dev + o_ng;
   g->node_local = g->dev + o_nl; g->he_graph = g->dev + o_hg; g->he_local = g->dev + o_hl;
   g->half_of_int = g->dev + o_hoi;
+  g->node_ptr = g->dev + o_np;
+  g->he_ptr = g->dev + o_hp;
   *out = g;
   return MDX_OK;
 }
@@ -1063,6 +1070,36 @@ extern "C" int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K,
                                  void* stream) {
   if (K < 1 || n < 0 || (n > 0 && (!logits || !u))) return fail(MDX_ERR_ARG, "bad argument");
   launch_gumbel_argmax(logits, u, K, (int)n, cls, onehot, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+void launch_decode_output(const float* pred_node, int Kn, const float* pred_pos, const float* pred_halfedge, int Ke, int N,
+                          int Eh, int B, const int* node_ptr, const int* he_ptr, const int* ref2int, const int* left,
+                          const int* right, int num_element, int num_bond_types, int* scratch_i, float* scratch_f,
+                          int* atom_type, float* atom_prob, float* atom_pos, int* n_atoms, int* bond_type,
+                          float* bond_prob, int* bond_index, int* n_bonds, hipStream_t s);
+
+extern "C" int mdx_decode_output(mdx_graph_t g, const float* pred_node, int32_t Kn, const float* pred_pos,
+                                 const float* pred_halfedge, int32_t Ke, int32_t num_element, int32_t num_bond_types,
+                                 int32_t* atom_type, float* atom_prob, float* atom_pos, int32_t* n_atoms,
+                                 int32_t* bond_type, float* bond_prob, int32_t* bond_index, int32_t* n_bonds, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (!g || !pred_node || !pred_pos || !pred_halfedge || !atom_type || !atom_prob || !atom_pos || !n_atoms || !bond_type ||
+      !bond_prob || !bond_index || !n_bonds)
+    return fail(MDX_ERR_ARG, "null argument");
+  if (Kn < 1 || Ke < 1) return fail(MDX_ERR_ARG, "bad class count");
+  if (!ws || ws_bytes < mdx_workspace_bytes(g->N, g->E)) return fail(MDX_ERR_STATE, "workspace too small");
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  if ((size_t)(2 * g->N + g->Eh) > (size_t)std::max<int64_t>(g->E, 1) * MDX_ND ||
+      (size_t)(g->N + g->Eh) > (size_t)std::max<int64_t>(g->E, 1) * 64)
+    return fail(MDX_ERR_UNSUPPORTED, "graph too sparse for the decode scratch layout");
+  // scratch: ints in M (>= 2N + Eh words), floats in HeA (>= N + Eh words)
+  launch_decode_output(pred_node, Kn, pred_pos, pred_halfedge, Ke, (int)g->N, (int)g->Eh, (int)g->B, g->node_ptr, g->he_ptr,
+                       g->ref2int, g->left, g->right, num_element, num_bond_types, reinterpret_cast<int*>(w.M), w.HeA,
+                       atom_type, atom_prob, atom_pos, n_atoms, bond_type, bond_prob, bond_index, n_bonds,
+                       (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return MDX_OK;
 }

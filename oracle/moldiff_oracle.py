@@ -360,6 +360,49 @@ def placeholder(n_graphs, max_size=None):
             'batch_halfedge': torch.from_numpy(np.concatenate(bh)) if bh else torch.zeros(0, dtype=torch.long)}
 
 
+def separate_outputs(pred, n_graphs, batch_node, halfedge_index, batch_halfedge):
+    """utils/sample.py:4-30 (`seperate_outputs`, pred part): split packed numpy arrays per molecule; the
+    half-edge index is re-based to the molecule's first node."""
+    out = []
+    for i in range(n_graphs):
+        mn, mh = batch_node == i, batch_halfedge == i
+        assert mn.sum() * (mn.sum() - 1) == mh.sum() * 2
+        he = halfedge_index[:, mh]
+        # like the reference, a molecule without half-edges (n <= 1) raises here (ValueError from .min() of an
+        # empty array); scripts/sample_drug3d.py:129-132 then drops the whole batch
+        assert np.nonzero(mn)[0].min() == he.min()
+        he = he - np.nonzero(mn)[0].min()
+        out.append({'pred': [pred[0][mn], pred[1][mn], pred[2][mh]], 'halfedge_index': he})
+    return out
+
+
+def decode_output(pred_node, pred_pos, pred_halfedge, halfedge_index, atomic_numbers=(6, 7, 8, 9, 15, 16, 17),
+                  num_bond_types=4):
+    """utils/transforms.py:65-122 (`FeaturizeMol.decode_output`), numpy: arg-max classes + soft-max confidences,
+    drop mask-type atoms (re-indexing bonds), keep half-edges whose type is a real bond, emit both directions."""
+    def softmax(x):
+        e = np.exp(x - x.max(-1, keepdims=True))
+        return e / e.sum(-1, keepdims=True)
+    num_element = len(atomic_numbers)
+    pa = softmax(pred_node)
+    atom_type, atom_prob = pa.argmax(-1), pa.max(-1)
+    keep = atom_type < num_element
+    changer = -np.ones(len(keep), dtype=np.int64)
+    changer[keep] = np.arange(keep.sum())
+    element = np.array([atomic_numbers[i] for i in atom_type[keep]])
+    ph = softmax(pred_halfedge)
+    edge_type, edge_prob = ph.argmax(-1), ph.max(-1)
+    is_bond = (edge_type > 0) & (edge_type <= num_bond_types)
+    bond_type, bond_prob, bond_index = edge_type[is_bond], edge_prob[is_bond], halfedge_index[:, is_bond]
+    if not keep.all():
+        bond_index = changer[bond_index]
+        ok = ~(bond_index < 0).any(axis=0)
+        bond_index, bond_type, bond_prob = bond_index[:, ok], bond_type[ok], bond_prob[ok]
+    return {'element': element, 'atom_pos': pred_pos[keep], 'atom_prob': atom_prob[keep],
+            'bond_type': np.concatenate([bond_type, bond_type]), 'bond_prob': np.concatenate([bond_prob, bond_prob]),
+            'bond_index': np.concatenate([bond_index, bond_index[::-1]], axis=1)}
+
+
 FROZEN_MARKERS = ('_transition.', '.coeff', '.offset', 'ce_loss.weight')
 
 
