@@ -246,6 +246,18 @@ def main():
             'kernel_ms_per_step': {'edge_a': ma / args.steps, 'edge_b': mb / args.steps, 'node': mn / args.steps,
                                    'aggregate': mg / args.steps},
         }
+        # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
+        # gfx950 correction applied) committed under profiles/; bench.py cannot collect PMCs itself.
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
+            if pm and args.batch == 256 and not args.guided:
+                ks = json.load(open(pm[-1]))['kernels']
+                out['roofline']['traffic'] = ks['edge_a_kernel']['hbm_bytes_per_launch']
+                out['roofline']['traffic_source'] = os.path.relpath(pm[-1], ROOT)
+                out['aggregation']['traffic'] = ks['seg_reduce_kernel<256>']['hbm_bytes_per_launch']
+        except Exception:
+            pass
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model.cpu(), ph_cpu, args.batch, args.cpu_budget,
                                                gkw['bond_predictor'].cpu() if args.guided else None)

@@ -69,9 +69,19 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  // Work units.  With gridDim.x == 3*ntiles the kernel is split into three independent units per tile, dispatched
+  // largest first: unit 0 = edge_embs (stored) + NodeBlock message path, units 1/2 = edge_embs (recomputed, +1.7 %
+  // FLOPs each) + BondFFN left / right.  The long units fill the chip round after round and the short FFN units
+  // pack the last partial round, which removes most of the ceil(tiles / resident workgroups) quantisation loss
+  // (3223 tiles on 512 slots = 6.3 rounds -> 7 with whole tiles).  gridDim.x == ntiles keeps the one-unit form.
+  const int unit = (gridDim.x == (unsigned)ntiles) ? -1 : (int)(blockIdx.x / (unsigned)ntiles);
+  const int tile = xcd_remap(unit < 0 ? blockIdx.x : blockIdx.x - unit * ntiles, ntiles);
   const int e0 = tile * TE;
   const int E = a.E;
+  const bool do_node = (a.flags & EA_NODE) && unit <= 0;
+  const bool do_ffn = (a.flags & EA_FFN) && unit != 0;
+  const int s_lo = unit == 2 ? 1 : 0, s_hi = unit == 1 ? 1 : 2;
+  const bool store_emb = unit <= 0;
 
   int li[ET], ri[ET];
   float tt[ET];
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
     acc_to_lds<1, ET>(acc, Hep, LD64, 0, wave, lane);
 #pragma unroll
     for (int et = 0; et < ET; ++et)
-      if (valid[et]) stg4(a.He_out + (size_t)(e0 + 16 * et + c) * 64 + 16 * wave + 4 * q, acc[0][et]);
+      if (valid[et] && store_emb) stg4(a.He_out + (size_t)(e0 + 16 * et + c) * 64 + 16 * wave + 4 * q, acc[0][et]);
   } else {
     load_rows64(a.He_in, e0, E, Hep, LD64, tid);
   }
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
   // (Measured, round 1: alternating the order of the two sections between co-resident workgroups to break a
   // suspected lock-step did not help -- 100.5 vs 101.7 TFLOP/s -- so the sections run in program order.)
   // ---- NodeBlock message path -----------------------------------------------------------------
-  if (a.flags & EA_NODE) {
+  if (do_node) {
     const int ft0 = 4 * wave;
     f32x4 sg[4][ET];
     {  // gate: sigmoid(W2 relu(LN(W1e He' + gx[r] + t*wt + b1)) + b2)
@@ -173,9 +183,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
   }
 
   // ---- EdgeBlock BondFFNs (left: node = l, reduced over r later; right: node = r) ----------------
-  if (a.flags & EA_FFN) {
+  if (do_ffn) {
 #pragma unroll 1
-    for (int s = 0; s < 2; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
       const FfnW& w = a.w.ffn[s];
       const int nlcol = s ? MDX_NT_NLR : MDX_NT_NLL;
       const int gxcol = s ? MDX_NT_GXR : MDX_NT_GXL;
@@ -374,7 +384,9 @@ void launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;
-  hipLaunchKernelGGL(edge_a_kernel, dim3(ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
+  const int all = EA_EMB | EA_NODE | EA_FFN;
+  const bool split = MDX_EA_SPLIT && (a.flags & all) == all && a.He_in != a.He_out;
+  hipLaunchKernelGGL(edge_a_kernel, dim3(split ? 3 * ntiles : ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
 }
 
 void launch_edge_b(const EdgeBArgs& a, hipStream_t s) {

@@ -12,6 +12,9 @@
 #ifndef MDX_ET
 #define MDX_ET 3    // edge tile = 16*MDX_ET rows per workgroup
 #endif
+#ifndef MDX_EA_SPLIT
+#define MDX_EA_SPLIT 0  // 1 = dispatch edge kernel A as 3 work units per tile (measured slower: 96.8 vs 102.4 TFLOP/s)
+#endif
 #ifndef MDX_EWPS
 #define MDX_EWPS 2  // waves per SIMD the edge kernels are compiled for (= workgroups per CU)
 #endif

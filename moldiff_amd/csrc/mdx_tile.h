@@ -20,6 +20,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MDX_WG 256
+#ifndef MDX_GEMM_PINNED
+#define MDX_GEMM_PINNED 1  // pin the two-stage prefetch of gemm_tile with sched_barriers (A/B in DESIGN.md)
+#endif
 #define MDX_LN_EPS 1e-5f
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -85,6 +88,7 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __
           acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ft][s], b[et][s], acc[ft][et], 0, 0, 0);
   };
   load_group(a0, b0, 0);
+#if MDX_GEMM_PINNED
 #pragma unroll 1
   for (int g = 0; g < G; g += 2) {
     if (g + 1 < G) load_group(a1, b1, g + 1);
@@ -96,6 +100,15 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __
     if (g + 1 < G) mfma_group(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
   }
+#else
+#pragma unroll 1
+  for (int g = 0; g < G; g += 2) {
+    if (g + 1 < G) load_group(a1, b1, g + 1);
+    mfma_group(a0, b0);
+    if (g + 2 < G) load_group(a0, b0, g + 2);
+    if (g + 1 < G) mfma_group(a1, b1);
+  }
+#endif
 }
 
 template <int FTW, int ET>
