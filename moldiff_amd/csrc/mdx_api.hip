@@ -540,8 +540,8 @@ extern "C" int mdx_graph_destroy(mdx_graph_t g) {
 namespace {
 struct Ws {
   float *Hn, *H, *NT, *NT2, *aggr, *SL, *SR, *Lf, *Rf, *tn, *posA, *posB;
-  float *HeA, *HeB, *M, *FL, *FR, *Fe, *te, *tmpE;  // tmpE: (E,64) scratch for boundary permutes
-  int64_t* tzero;  // (B) zeros? (unused)
+  float *HeA, *HeB, *M, *FL, *FR, *Fe, *te, *tnr, *tmpE;  // tmpE: (E,64) scratch for boundary permutes
+  bool tnr_set;  // tnr holds node_time[right] (only the bare NodeEdgeNet API can make it differ from te)
   size_t bytes;
 };
 
@@ -558,7 +558,7 @@ size_t ws_layout(int64_t N, int64_t E, char* base, Ws* w) {
   t.SL = take(n * 64); t.SR = take(n * 64); t.Lf = take(n * 64); t.Rf = take(n * 64); t.tn = take(n);
   t.posA = take(n * 3); t.posB = take(n * 3);
   t.HeA = take(e * 64); t.HeB = take(e * 64); t.M = take(e * MDX_ND); t.FL = take(e * 64); t.FR = take(e * 64);
-  t.Fe = take(e * 3); t.te = take(e); t.tmpE = take(e * 64);
+  t.Fe = take(e * 3); t.te = take(e); t.tnr = take(e); t.tmpE = take(e * 64);
   t.bytes = off;
   if (w) *w = t;
   return off;
@@ -677,7 +677,8 @@ namespace {
 EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i, const float* pos, const float* He_in,
                   float* He_out, int flags, const float* NT = nullptr) {
   EdgeAArgs a{};
-  a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.pos = pos; a.dist_in = nullptr;
+  a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.tn_r = w.tnr_set ? w.tnr : nullptr;
+  a.pos = pos; a.dist_in = nullptr;
   a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = NT ? NT : w.NT;
   a.M = w.M; a.F[0] = w.FL; a.F[1] = w.FR; a.w = m->blocks[i].ea;
   return a;
@@ -747,6 +748,8 @@ extern "C" int mdx_net_forward(mdx_model_t m, mdx_graph_t g, const float* h_node
   HIPCHK(hipMemcpyAsync(w.tn, node_time, (size_t)g->N * 4, hipMemcpyDeviceToDevice, s));
   gather_rows(h_edge, g->int2ref, w.HeA, g->E, 64, s);
   gather_rows(edge_time, g->int2ref, w.te, g->E, 1, s);
+  gather_rows(node_time, g->right, w.tnr, g->E, 1, s);
+  w.tnr_set = true;
   const float *He, *pf;
   run_blocks(m, g, w, pos, &He, &pf, s);
   if (h_node_out) HIPCHK(hipMemcpyAsync(h_node_out, w.Hn, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
@@ -845,7 +848,9 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
                                    void* stream) {
   CHECK_READY(m, g, ws, ws_bytes);
   if (m->cfg.kind != MDX_KIND_MOLDIFF) return fail(MDX_ERR_STATE, "not a MolDiff model handle");
-  if (!h_node_pert || !pos_pert || (!h_edge_pert && !h_halfedge_pert) || !t) return fail(MDX_ERR_ARG, "null input");
+  if (g->N == 0) return MDX_OK;  // empty batch: nothing to compute, outputs are empty
+  if (!h_node_pert || !pos_pert || (g->E > 0 && !h_edge_pert && !h_halfedge_pert) || !t)
+    return fail(MDX_ERR_ARG, "null input");
   if (g->E % 2) return fail(MDX_ERR_ARG, "MolDiff.forward needs E = 2*Eh directed edges");
   hipStream_t s = (hipStream_t)stream;
   Ws w;

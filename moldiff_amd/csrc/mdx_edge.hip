@@ -130,6 +130,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
   // ---- NodeBlock message path -----------------------------------------------------------------
   if (do_node) {
     const int ft0 = 4 * wave;
+    float tg[ET];  // the NodeBlock gate is fed node_time[col], the BondFFN gates edge_time
+#pragma unroll
+    for (int et = 0; et < ET; ++et) tg[et] = (a.tn_r && valid[et]) ? a.tn_r[e0 + 16 * et + c] : tt[et];
     f32x4 sg[4][ET];
     {  // gate: sigmoid(W2 relu(LN(W1e He' + gx[r] + t*wt + b1)) + b2)
       f32x4 acc[4][ET];
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
         const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
 #pragma unroll
         for (int et = 0; et < ET; ++et)
-          acc[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tt[et]) * wt;
+          acc[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tg[et]) * wt;
       }
       gemm_tile<4, ET, 64>(acc, a.w.Wg1e, 16, ft0, Hep, LD64, lane);
       layernorm_relu<4, ET, 4>(acc, a.w.gg, a.w.gb, ft0, red, red2, wave, lane, true);

@@ -79,7 +79,8 @@ struct NodeW {  // weights of the node kernel
 struct EdgeAArgs {
   int E, flags;
   const int *l, *r;       // internal order
-  const float* te;        // per-edge time t/T (internal order)
+  const float* te;        // per-edge time t/T (internal order): edge_time of EdgeBlock / PosUpdate
+  const float* tn_r;      // optional (E): node_time[right] seen by the NodeBlock gate (graph.py:46); nullptr = te
   const float* pos;       // (N,3)
   const float* dist_in;   // optional (E) internal order: use instead of |pos[l]-pos[r]| (unused in product path)
   const float *soff, *scoef;  // distance smearing tables (16)
