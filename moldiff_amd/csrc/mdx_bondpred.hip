@@ -106,13 +106,16 @@ constexpr int BTE = 16 * BET;
 constexpr int B_HEP = 0;                      // [BTE][72]  He'
 constexpr int B_X = B_HEP + BTE * LD64;       // [BTE][264]
 constexpr int B_Y = B_X + BTE * LD256;        // [BTE][264]
-constexpr int B_S = B_Y + BTE * LD256;        // [BTE][72]
+// S, S2, GG are only live in the BondFFN / edge_embs sections, Y only in the message-path section: they share
+// storage, which brings the workgroup to 78.8 KB of LDS = two workgroups per CU.
+constexpr int B_S = B_Y;                      // [BTE][72]
 constexpr int B_S2 = B_S + BTE * LD64;        // [BTE][72]
 constexpr int B_GG = B_S2 + BTE * LD64;       // [BTE][40]
-constexpr int B_RED = B_GG + BTE * LD32;      // 4 x (4*BTE)
+static_assert(B_GG + BTE * LD32 <= B_Y + BTE * LD256, "aliased buffers must fit inside Y");
+constexpr int B_RED = B_Y + BTE * LD256;      // 4 x (4*BTE)
 constexpr int B_TOTAL = B_RED + 16 * BTE;
 
-__global__ __launch_bounds__(MDX_WG, 1) void edge_bwd_kernel(const EdgeBwdArgs a, const int ntiles) {
+__global__ __launch_bounds__(MDX_WG, 2) void edge_bwd_kernel(const EdgeBwdArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hep = smem + B_HEP;
   float* X = smem + B_X;

@@ -68,9 +68,11 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __
   const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)ft0 * 64 + lane;
   const float* xb = X + c * ldx + 4 * q;
   constexpr int G = K / 16;
-  // Explicit two-stage software pipeline.  Left to itself hipcc sinks the next group's weight loads to ~10 MFMAs
-  // before their use (an L2 round trip is ~25 MFMAs), which capped the fused kernels at 66 % MFMA utilisation;
-  // the sched_barriers pin "issue loads for group g+1" ahead of the whole MFMA block of group g.
+  // Explicit two-stage software pipeline: the loads of group g+1 are issued ahead of the whole MFMA block of group g
+  // (pinned with sched_barriers; left alone hipcc sinks them to ~10 MFMAs before their use).  Measured (round 1):
+  // pinned == unpinned == a three-stage variant within 1 % -- the loop is not latency-bound.  What caps a lone wave
+  // at ~73 % of the MFMA rate in this loop is the issue cost of its 7 memory instructions per 48 MFMAs; a second
+  // wave on the SIMD fills those slots (micro-benchmark tools/ubench_gemm_tile.hip: 115 -> 140 TFLOP/s).
   f32x4 a0[FTW], a1[FTW], b0[ET], b1[ET];
   auto load_group = [&](f32x4(&a)[FTW], f32x4(&b)[ET], int g) {
 #pragma unroll
