@@ -161,14 +161,21 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (no CPU fallback).')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one process per GPU over RCCL.  MDX_BENCH_BACKEND=gloo (+ ranks sharing a GPU when there are fewer devices than
+    # ranks) exists only so the multi-rank control flow can be exercised on a 1-GPU box; it is never the default.
+    backend = os.environ.get('MDX_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from moldiff_amd import _lib
     model, ph_cpu, sizes = build_workload(args.batch, rank, None, 'MolDiff' if args.guided else 'MolDiff_simple')
@@ -205,7 +212,7 @@ def main():
     elapsed = time.perf_counter() - t0
     L.mdx_profile_enable(0)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -258,7 +265,7 @@ def main():
                 out['aggregation']['traffic'] = ks['seg_reduce_kernel<256>']['hbm_bytes_per_launch']
         except Exception:
             pass
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(model.cpu(), ph_cpu, args.batch, args.cpu_budget,
                                                gkw['bond_predictor'].cpu() if args.guided else None)
             out['speedup_vs_cpu_baseline'] = value / world / out['cpu_baseline']['value'] if world == 1 else None
