@@ -94,3 +94,13 @@ def log_sample_categorical(logits):
     """Gumbel-max draw using torch's generator (host/compat helper; the device path draws Philox noise)."""
     u = torch.rand_like(logits)
     return (logits - torch.log(-torch.log(u + 1e-30) + 1e-30)).argmax(dim=-1)
+
+
+def categorical_kl(log_prob1, log_prob2):
+    """KL(p1 || p2) over the last axis, both given as log-probabilities."""
+    return (log_prob1.exp() * (log_prob1 - log_prob2)).sum(dim=-1)
+
+
+def log_categorical(log_x_start, log_prob):
+    """log-likelihood of the (log one-hot) `log_x_start` under `log_prob`."""
+    return (log_x_start.exp() * log_prob).sum(dim=-1)

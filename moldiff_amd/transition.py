@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .diffusion import to_torch_const, index_to_log_onehot
+from .diffusion import to_torch_const, index_to_log_onehot, categorical_kl, log_categorical
 from . import _lib
 
 
@@ -34,13 +34,14 @@ class ContigousTransition(nn.Module):
         self.coef_xt = to_torch_const(np.sqrt(alphas) * (1 - abar_prev) / (1 - abar))
         self.std = to_torch_const(np.sqrt((1 - abar_prev) * betas / (1 - abar)))
 
-    def add_noise(self, x, time_step, batch):
-        """q(x_t | x_0); training-side helper (not on the sampling path), plain torch ops on `x`'s device."""
+    def add_noise(self, x, time_step, batch, eps=None):
+        """q(x_t | x_0); loss-side helper (not on the sampling path), plain torch ops on `x`'s device.
+        `eps` may be injected (parity tests), otherwise drawn from torch's generator like the reference."""
         if self.num_classes is not None:
             x = F.one_hot(x, self.num_classes).float()
         x = x / self.scaling
         a_bar = self.alphas_bar.index_select(0, time_step).index_select(0, batch).unsqueeze(-1)
-        pert = a_bar.sqrt() * x + (1 - a_bar).sqrt() * torch.randn_like(x)
+        pert = a_bar.sqrt() * x + (1 - a_bar).sqrt() * (torch.randn_like(x) if eps is None else eps)
         return pert if self.num_classes is None else (pert, x)
 
     def get_prev_from_recon(self, x_t, x_recon, t, batch, eps=None):
@@ -108,10 +109,19 @@ class GeneralCategoricalTransition(nn.Module):
         cls = _lib.gumbel_argmax(logits, torch.rand_like(logits) if u is None else u)
         return cls, index_to_log_onehot(cls, self.num_classes)
 
-    def add_noise(self, v, time_step, batch):
+    def add_noise(self, v, time_step, batch, u=None):
         log_v0 = index_to_log_onehot(v, self.num_classes)
-        cls, log_vt = self.q_vt_sample(log_v0, time_step, batch)
+        cls, log_vt = self.q_vt_sample(log_v0, time_step, batch, u)
         return F.one_hot(cls, self.num_classes).float(), log_vt, log_v0
+
+    def compute_v_Lt(self, log_v_post_true, log_v_post_pred, log_v0, t, batch):
+        """Per-row variational term: KL(q(v_{t-1}|v_t,v_0) || p) for t > 0, decoder NLL at t == 0."""
+        if log_v_post_true.ndim != 2:
+            raise NotImplementedError('ndim not supported')
+        kl_v = categorical_kl(log_v_post_true, log_v_post_pred)
+        nll_v = -log_categorical(log_v0, log_v_post_pred)
+        mask = (t == 0).float()[batch]
+        return mask * nll_v + (1 - mask) * kl_v
 
     def sample_init(self, n, u=None):
         """Draw from the prior by Gumbel-max on float64 logits (the reference's dtype at this point)."""

@@ -1,0 +1,118 @@
+"""Golden vectors for `MolDiff.get_loss` (models/model.py:128-201), the quantity the reference's validation loop
+evaluates under no_grad (scripts/train_drug3d.py:121-164).  BUILD-CONTAINER ONLY (needs /root/reference).
+
+The REAL reference model is run on CPU with recipe weights; its three sources of randomness are pinned for the
+duration of the call by temporarily replacing the torch entry points it draws from:
+  torch.randint        (sample_time, model.py:99-100)         -> the committed half-list of time steps
+  Tensor.normal_       (ContigousTransition.add_noise :35-36) -> committed eps_pos
+  torch.rand_like      (log_sample_categorical, diffusion.py:80) -> committed u_node, then u_halfedge
+Only inputs and the resulting losses are saved (tests/golden/loss.npz); the oracle restatement
+(`moldiff_oracle.moldiff_loss`) is compared in the same run and the difference recorded in PINNING.json.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import moldiff_oracle as O  # noqa: E402
+from oracle import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+SEED_MOLDIFF = 20230807
+
+
+class pinned_randomness:
+    def __init__(self, t_half, eps_pos, us):
+        self.t_half, self.eps_pos, self.us = t_half, eps_pos, list(us)
+
+    def __enter__(self):
+        self.saved = (torch.randint, torch.Tensor.normal_, torch.rand_like)
+        t_half, eps_pos, us = self.t_half, self.eps_pos, self.us
+
+        def randint(lo, hi, size, device=None, **kw):
+            assert tuple(size) == tuple(t_half.shape), (size, t_half.shape)
+            return t_half.clone()
+
+        def normal_(self_, *a, **kw):
+            assert self_.shape == eps_pos.shape
+            return self_.copy_(eps_pos)
+
+        def rand_like(x, **kw):
+            u = us.pop(0)
+            assert u.shape == x.shape
+            return u.to(x.dtype)
+
+        torch.randint, torch.Tensor.normal_, torch.rand_like = randint, normal_, rand_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint, torch.Tensor.normal_, torch.rand_like = self.saved
+        assert not self.us, 'a pinned uniform draw was not consumed'
+
+
+def main():
+    torch.set_num_threads(8)
+    MolDiff, BondPredictor, G, TR, DF, CM = ref_shim.load()
+    out, pins = {}, {}
+    for nm, yml in (('full', 'configs/train/train_MolDiff.yml'), ('simple', 'configs/train/train_MolDiff_simple.yml')):
+        cfg = ref_shim.load_yaml_cfg(yml)
+        m = MolDiff(cfg.model, 8, 6).eval()
+        sd = m.state_dict()
+        shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+        sd.update(O.recipe_state_dict(shapes, SEED_MOLDIFF))
+        m.load_state_dict(sd, strict=True)
+        P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+        g = np.random.Generator(np.random.PCG64(77 if nm == 'full' else 78))
+        sizes = [7, 5, 12, 9, 3]
+        bn, hei, bh, off = [], [], [], 0
+        for i, n in enumerate(sizes):
+            bn += [i] * n
+            tri = torch.triu_indices(n, n, 1) + off
+            hei.append(tri)
+            bh += [i] * tri.shape[1]
+            off += n
+        bn, hei, bh = torch.tensor(bn), torch.cat(hei, 1), torch.tensor(bh)
+        N, Eh, B = len(bn), len(bh), len(sizes)
+        node_type = torch.from_numpy(g.integers(0, 7, N))
+        node_pos = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32) * 2.0)
+        for i in range(B):   # centre per molecule like the training transforms do
+            node_pos[bn == i] -= node_pos[bn == i].mean(0, keepdim=True)
+        half_type = torch.from_numpy((g.random(Eh) < 0.25) * g.integers(1, 5, Eh))
+        # sample_time draws B//2+1 steps and mirrors them: [0, 437, 850] -> t = [0, 437, 850, 999, 562]
+        t_half = torch.tensor([0, 437, 850])
+        eps_pos = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32))
+        u_node = torch.from_numpy(g.random((N, 8)).astype(np.float32))
+        u_half = torch.from_numpy(g.random((Eh, 6)).astype(np.float32))
+        with torch.no_grad(), pinned_randomness(t_half, eps_pos, [u_node, u_half]):
+            ref = m.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
+        t = torch.cat([t_half, 1000 - t_half - 1])[:B]
+        tabs = {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')},
+                'node': {k: P['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
+                'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
+        cfgd = dict(num_timesteps=1000, num_blocks=6, cutoff=15)
+        with torch.no_grad():
+            orc = O.moldiff_loss(P, cfgd, tabs, node_type, node_pos, bn, half_type, hei, bh, B, t,
+                                 dict(eps_pos=eps_pos, u_node=u_node, u_halfedge=u_half))
+        for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+            d = abs(float(ref[k]) - float(orc[k]))
+            pins[f'get_loss_{nm}_{k}'] = d
+            print(nm, k, float(ref[k]), float(orc[k]), d)
+            out[f'{nm}_{k}'] = np.float32(float(ref[k]))
+        out.update({f'{nm}_sizes': np.array(sizes), f'{nm}_node_type': node_type.numpy(), f'{nm}_node_pos': node_pos.numpy(),
+                    f'{nm}_halfedge_type': half_type.numpy(), f'{nm}_t_half': t_half.numpy(), f'{nm}_t': t.numpy(),
+                    f'{nm}_eps_pos': eps_pos.numpy(), f'{nm}_u_node': u_node.numpy(), f'{nm}_u_halfedge': u_half.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
+    pf = os.path.join(OUT, 'PINNING.json')
+    allp = json.load(open(pf))
+    allp.update(pins)
+    with open(pf, 'w') as f:
+        json.dump(allp, f, indent=0, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -360,6 +360,46 @@ def placeholder(n_graphs, max_size=None):
             'batch_halfedge': torch.from_numpy(np.concatenate(bh)) if bh else torch.zeros(0, dtype=torch.long)}
 
 
+def cat_add_noise(tab, v, t, batch, u):
+    """GeneralCategoricalTransition.add_noise (transition.py:245-271): q(v_t | v_0) sample with the U[0,1) draw
+    passed in.  -> (one-hot float, log one-hot of the sample, log one-hot of v_0)."""
+    K = tab['q_mats'].shape[-1]
+    log_v0 = torch.log(F.one_hot(v, K).float().clamp(min=1e-30))
+    q = tab['q_mats'][t][batch]
+    log_q = torch.log(torch.einsum('...i,...ij->...j', log_v0.exp(), q) + 1e-30).clamp_min(-32.)
+    c = gumbel_argmax(log_q, u)
+    return F.one_hot(c, K).float(), torch.log(F.one_hot(c, K).float().clamp(min=1e-30)), log_v0
+
+
+def moldiff_loss(P, cfg, tabs, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol,
+                 time_step, noise):
+    """MolDiff.get_loss (models/model.py:128-201, discrete space, no bond_len_loss) with the random draws passed in:
+    time_step (num_mol,), noise = dict(eps_pos (N,3), u_node (N,Kn), u_halfedge (Eh,Ke)).  This is also exactly what
+    the reference's validation loop evaluates (scripts/train_drug3d.py:121-164)."""
+    t = time_step
+    a_bar = tabs['pos']['alphas_bar'][t][batch_node].unsqueeze(-1)
+    pos_pert = a_bar.sqrt() * node_pos + (1 - a_bar).sqrt() * noise['eps_pos']
+    hn, log_nt, log_n0 = cat_add_noise(tabs['node'], node_type, t, batch_node, noise['u_node'])
+    hh, log_ht, log_h0 = cat_add_noise(tabs['edge'], halfedge_type, t, batch_halfedge, noise['u_halfedge'])
+    edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], 1)
+    batch_edge = torch.cat([batch_halfedge, batch_halfedge], 0)
+    preds = moldiff_forward(P, cfg, hn, pos_pert, batch_node, torch.cat([hh, hh], 0), edge_index, batch_edge, t)
+    loss_pos = F.mse_loss(preds['pred_pos'], node_pos)
+
+    def v_loss(tab, logits, log_vt, log_v0, batch):
+        log_recon = F.log_softmax(logits, -1)
+        post_true = cat_posterior(tab, log_v0, log_vt, t, batch)
+        post_pred = cat_posterior(tab, log_recon, log_vt, t, batch)
+        kl = (post_true.exp() * (post_true - post_pred)).sum(-1)
+        nll = -(log_v0.exp() * post_pred).sum(-1)
+        mask = (t == 0).float()[batch]
+        return torch.mean(mask * nll + (1 - mask) * kl) * 100
+
+    loss_node = v_loss(tabs['node'], preds['pred_node'], log_nt, log_n0, batch_node)
+    loss_edge = v_loss(tabs['edge'], preds['pred_halfedge'], log_ht, log_h0, batch_halfedge)
+    return {'loss': loss_pos + loss_node + loss_edge, 'loss_pos': loss_pos, 'loss_node': loss_node, 'loss_edge': loss_edge}
+
+
 def separate_outputs(pred, n_graphs, batch_node, halfedge_index, batch_halfedge):
     """utils/sample.py:4-30 (`seperate_outputs`, pred part): split packed numpy arrays per molecule; the
     half-edge index is re-based to the molecule's first node."""

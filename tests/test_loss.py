@@ -1,0 +1,112 @@
+"""`MolDiff.get_loss` (reference models/model.py:128-201; what scripts/train_drug3d.py:121-164 validates with).
+
+Golden values come from the real reference with its random draws pinned (oracle/make_goldens_loss.py).
+CPU: oracle == golden.  GPU: the HIP-backed product == golden / oracle within the stated tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+from tests.util import O
+
+KEYS = ('loss', 'loss_pos', 'loss_node', 'loss_edge')
+# losses are means of O(1)..O(100) per-row terms computed from fp32 logits that agree to ~1e-5
+RTOL = 2e-5
+
+
+def _case(nm, device='cpu'):
+    z = U.gold('loss.npz')
+    sizes = [int(v) for v in z[f'{nm}_sizes']]
+    bn, hei, bh, _, _ = U.graph_from_sizes(sizes, device)
+    tt = lambda k, dt=None: torch.from_numpy(z[f'{nm}_{k}']).to(device)
+    args = (tt('node_type'), tt('node_pos'), bn, tt('halfedge_type'), hei, bh, len(sizes))
+    noise = dict(eps_pos=tt('eps_pos'), u_node=tt('u_node'), u_halfedge=tt('u_halfedge'))
+    want = {k: float(z[f'{nm}_{k}']) for k in KEYS}
+    return args, tt('t'), noise, want
+
+
+@pytest.mark.parametrize('nm,kind', [('full', 'MolDiff'), ('simple', 'MolDiff_simple')])
+def test_oracle_loss_matches_reference(nm, kind):
+    args, t, noise, want = _case(nm)
+    P = U.params(U.moldiff(kind))
+    with torch.no_grad():
+        got = O.moldiff_loss(P, U.CFG, U.tables(P), *args, t, noise)
+    for k in KEYS:
+        assert abs(float(got[k]) - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, float(got[k]), want[k])
+
+
+def test_sample_time_is_antithetic():
+    m = U.moldiff('MolDiff_simple')
+    torch.manual_seed(3)
+    for B in (1, 2, 5, 8):
+        t, pt = m.sample_time(B, 'cpu')
+        assert t.shape == (B,) and t.dtype == torch.int64 and pt.shape == (B,)
+        assert int(t.min()) >= 0 and int(t.max()) < 1000
+        h = B // 2 + 1
+        mirrored = 999 - t[:h]
+        assert torch.equal(t[h:], mirrored[:B - h])
+        assert torch.allclose(pt, torch.full((B,), 1e-3))
+
+
+def test_golden_time_steps_follow_sample_time():
+    z = U.gold('loss.npz')
+    th = z['full_t_half']
+    assert np.array_equal(z['full_t'], np.concatenate([th, 999 - th])[:len(z['full_sizes'])])
+    assert (z['full_t'] == 0).any()          # the decoder-NLL branch is exercised
+
+
+def test_get_loss_without_gpu_fails_loudly():
+    args, t, noise, _ = _case('simple')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        U.moldiff('MolDiff_simple').get_loss(*args, time_step=t, noise=noise)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nm,kind', [('full', 'MolDiff'), ('simple', 'MolDiff_simple')])
+def test_gpu_loss_matches_reference(nm, kind):
+    args, t, noise, want = _case(nm, 'cuda')
+    m = U.moldiff(kind, 'cuda')
+    got = m.get_loss(*args, time_step=t, noise=noise)
+    assert set(got) == set(KEYS)
+    for k in KEYS:
+        assert got[k].device.type == 'cuda' and got[k].ndim == 0 and not got[k].requires_grad
+        assert abs(float(got[k]) - want[k]) <= RTOL * max(1.0, abs(want[k])), (k, float(got[k]), want[k])
+    assert abs(float(got['loss']) - sum(float(got[k]) for k in KEYS[1:])) <= 1e-5 * want['loss']
+
+
+@pytest.mark.gpu
+def test_gpu_loss_random_batch_matches_oracle():
+    """Fresh seeded batch (bigger, ragged) scored by the product on the GPU and by the oracle on the same draws."""
+    g = U.rng(515)
+    sizes = [int(v) for v in g.integers(2, 24, 12)]
+    bn, hei, bh, _, _ = U.graph_from_sizes(sizes)
+    N, Eh, B = len(bn), len(bh), len(sizes)
+    node_type = torch.from_numpy(g.integers(0, 7, N))
+    node_pos = U.t32(g.standard_normal((N, 3)) * 2)
+    half_type = torch.from_numpy((g.random(Eh) < 0.2) * g.integers(1, 5, Eh))
+    t = torch.from_numpy(g.integers(0, 1000, B)); t[0] = 0; t[1] = 999
+    noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))), u_node=U.t32(g.random((N, 8))), u_halfedge=U.t32(g.random((Eh, 6))))
+    m = U.moldiff('MolDiff', 'cuda')
+    P = U.params(U.moldiff('MolDiff'))
+    with torch.no_grad():
+        want = O.moldiff_loss(P, U.CFG, U.tables(P), node_type, node_pos, bn, half_type, hei, bh, B, t, noise)
+    c = lambda x: x.cuda()
+    got = m.get_loss(c(node_type), c(node_pos), c(bn), c(half_type), c(hei), c(bh), B, time_step=c(t),
+                     noise={k: c(v) for k, v in noise.items()})
+    for k in KEYS:
+        assert abs(float(got[k]) - float(want[k])) <= RTOL * max(1.0, abs(float(want[k]))), (k, float(got[k]), float(want[k]))
+
+
+@pytest.mark.gpu
+def test_gpu_loss_default_draws_and_no_backward():
+    args, _, _, _ = _case('simple', 'cuda')
+    m = U.moldiff('MolDiff_simple', 'cuda')
+    torch.manual_seed(11)
+    a = m.get_loss(*args)
+    torch.manual_seed(11)
+    b = m.get_loss(*args)
+    assert all(torch.isfinite(a[k]) for k in KEYS)
+    assert all(float(a[k]) == float(b[k]) for k in KEYS)       # deterministic under torch's seed
+    with pytest.raises(RuntimeError):
+        a['loss'].backward()

@@ -67,6 +67,6 @@ def maxdiff(a, b):
 
 
 def tables(P):
-    return {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std')},
+    return {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')},
             'node': {k: P['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
             'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
