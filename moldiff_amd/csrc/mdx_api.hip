@@ -197,6 +197,22 @@ int pack_model(mdx_model_s* m) {
       c.packA(&f.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
       c.vec(&f.bg2, fp + ".gate.net.3.bias", ED);
     }
+    {  // fused first layers of both BondFFNs (see EdgeAW::Wffa)
+      std::vector<float> Wf((size_t)320 * ED, 0.f);
+      bool ok = true;
+      for (int wv = 0; wv < 4 && ok; ++wv) {
+        const int s = wv >> 1, h = wv & 1;
+        const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
+        const HostTensor* bl = c.get(fp + ".bond_linear.weight", {2 * ED, ED});
+        const HostTensor* g1 = c.get(fp + ".gate.net.0.weight", {32, GIN});
+        if (!bl || !g1) { ok = false; break; }
+        for (int r = 0; r < 64; ++r)
+          for (int k = 0; k < ED; ++k) Wf[(size_t)(80 * wv + r) * ED + k] = bl->data[(size_t)(64 * h + r) * ED + k];
+        for (int r = 0; r < 16; ++r)
+          for (int k = 0; k < ED; ++k) Wf[(size_t)(80 * wv + 64 + r) * ED + k] = g1->data[(size_t)(16 * h + r) * GIN + k];
+      }
+      if (ok) c.pack_dense(&b.ea.Wffa, Wf, 320, ED, 0, ED);
+    }
     // ---- edge kernel B
     c.packA(&b.eb.Wself, eb + ".self_ffn.weight", ED, ED, 0, ED);
     c.vec(&b.eb.bself, eb + ".self_ffn.bias", ED);

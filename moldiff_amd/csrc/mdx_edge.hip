@@ -17,6 +17,21 @@
 #include "mdx_kernels.h"
 #include "mdx_tile.h"
 
+// Phase trace (tools/trace_edge_a.py; build with `make EXTRA=-DMDX_TRACE`): thread 0 of every workgroup stamps the
+// shader clock at each phase boundary of edge_a into a 32-slot record.  Compiled out of the shipped library.
+#ifdef MDX_TRACE
+__device__ unsigned long long* mdx_trace_buf = nullptr;
+extern "C" int mdx_debug_set_trace(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdx_trace_buf), &p, sizeof(p));
+}
+#define MDX_STAMP(i)                                                                            \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && mdx_trace_buf) mdx_trace_buf[(size_t)blockIdx.x * 32 + (i)] = clock64(); \
+  } while (0)
+#else
+#define MDX_STAMP(i) ((void)0)
+#endif
+
 namespace {
 
 constexpr int ET = MDX_ET;
@@ -30,7 +45,7 @@ constexpr int LD32 = mdx_ld(32);    // 40
 constexpr int OFF_HEP = 0;
 constexpr int OFF_X = OFF_HEP + TE * LD64;
 constexpr int OFF_GG = OFF_X + TE * LD256;
-constexpr int OFF_RED = OFF_GG + TE * LD32;
+constexpr int OFF_RED = OFF_GG + TE * LD64;  // GG: both BondFFN gate hiddens side by side (2 x 32)
 constexpr int OFF_RED2 = OFF_RED + 4 * TE;
 constexpr int OFF_RED3 = OFF_RED2 + 4 * TE;  // dot_rows scratch (must not alias the LayerNorm buffers)
 constexpr int LDS_FLOATS = OFF_RED3 + 4 * TE;
@@ -69,61 +84,65 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  // Work units.  With gridDim.x == 3*ntiles the kernel is split into three independent units per tile, dispatched
-  // largest first: unit 0 = edge_embs (stored) + NodeBlock message path, units 1/2 = edge_embs (recomputed, +1.7 %
-  // FLOPs each) + BondFFN left / right.  The long units fill the chip round after round and the short FFN units
-  // pack the last partial round, which removes most of the ceil(tiles / resident workgroups) quantisation loss
-  // (3223 tiles on 512 slots = 6.3 rounds -> 7 with whole tiles).  gridDim.x == ntiles keeps the one-unit form.
-  const int unit = (gridDim.x == (unsigned)ntiles) ? -1 : (int)(blockIdx.x / (unsigned)ntiles);
-  const int tile = xcd_remap(unit < 0 ? blockIdx.x : blockIdx.x - unit * ntiles, ntiles);
+  const int tile = xcd_remap(blockIdx.x, ntiles);
   const int e0 = tile * TE;
   const int E = a.E;
-  const bool do_node = (a.flags & EA_NODE) && unit <= 0;
-  const bool do_ffn = (a.flags & EA_FFN) && unit != 0;
-  const int s_lo = unit == 2 ? 1 : 0, s_hi = unit == 1 ? 1 : 2;
-  const bool store_emb = unit <= 0;
+  const bool do_node = a.flags & EA_NODE;
+  const bool do_ffn = a.flags & EA_FFN;
 
   int li[ET], ri[ET];
   float tt[ET];
   bool valid[ET];
+  MDX_STAMP(0);
+#ifdef MDX_TRACE
+  if (threadIdx.x == 0 && mdx_trace_buf) {
+    mdx_trace_buf[(size_t)blockIdx.x * 32 + 30] = wall_clock64();
+    mdx_trace_buf[(size_t)blockIdx.x * 32 + 31] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
   tile_indices(a.l, a.r, a.te, e0, E, lane, li, ri, tt, valid);
 
   // ---- phase A/B: He' ---------------------------------------------------------------------
   if (a.flags & EA_EMB) {
     load_rows64(a.He_in, e0, E, X, LD80, tid);
-    if (tid < TE) {
-      const int e = e0 + tid;
-      float d = 0.f;
-      if (e < E) {
-        if (a.dist_in) {
-          d = a.dist_in[e];
-        } else {
-          const int nl = a.l[e], nr = a.r[e];
-          const float dx = a.pos[3 * nl + 0] - a.pos[3 * nr + 0];
-          const float dy = a.pos[3 * nl + 1] - a.pos[3 * nr + 1];
-          const float dz = a.pos[3 * nl + 2] - a.pos[3 * nr + 2];
-          d = sqrtf(dx * dx + dy * dy + dz * dz);
-        }
-      }
-      const float dc = fminf(fmaxf(d, 0.f), a.cutoff);
+    {  // Gaussian smearing of the edge length: thread -> (row = tid/16 + 16 j, gaussian k = tid%16)
+      static_assert(MDX_NG == 16 && MDX_WG == 256, "smearing thread map");
+      const int k = tid & 15;
+      const float off = a.soff[k], coef = a.scoef[k];
 #pragma unroll
-      for (int k = 0; k < MDX_NG; ++k) {
-        const float u = dc - a.soff[k];
-        X[tid * LD80 + 64 + k] = expf(a.scoef[k] * (u * u));
+      for (int j = 0; j < ET; ++j) {
+        const int row = (tid >> 4) + 16 * j, e = e0 + row;
+        float d = 0.f;
+        if (e < E) {
+          if (a.dist_in) {
+            d = a.dist_in[e];
+          } else {
+            const int nl = a.l[e], nr = a.r[e];
+            const float dx = a.pos[3 * nl + 0] - a.pos[3 * nr + 0];
+            const float dy = a.pos[3 * nl + 1] - a.pos[3 * nr + 1];
+            const float dz = a.pos[3 * nl + 2] - a.pos[3 * nr + 2];
+            d = sqrtf(dx * dx + dy * dy + dz * dz);
+          }
+        }
+        const float u = fminf(fmaxf(d, 0.f), a.cutoff) - off;
+        X[row * LD80 + 64 + k] = expf(coef * (u * u));
       }
     }
     __syncthreads();
+    MDX_STAMP(1);
     f32x4 acc[1][ET];
     acc_bias<1, ET>(acc, a.w.bemb, wave, lane);
     gemm_tile<1, ET, 80>(acc, a.w.Wemb, 4, wave, X, LD80, lane);
     acc_to_lds<1, ET>(acc, Hep, LD64, 0, wave, lane);
 #pragma unroll
     for (int et = 0; et < ET; ++et)
-      if (valid[et] && store_emb) stg4(a.He_out + (size_t)(e0 + 16 * et + c) * 64 + 16 * wave + 4 * q, acc[0][et]);
+      if (valid[et]) stg4(a.He_out + (size_t)(e0 + 16 * et + c) * 64 + 16 * wave + 4 * q, acc[0][et]);
   } else {
     load_rows64(a.He_in, e0, E, Hep, LD64, tid);
   }
   __syncthreads();
+  MDX_STAMP(2);
 
   // (Measured, round 1: alternating the order of the two sections between co-resident workgroups to break a
   // suspected lock-step did not help -- 100.5 vs 101.7 TFLOP/s -- so the sections run in program order.)
@@ -144,27 +163,36 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
         for (int et = 0; et < ET; ++et)
           acc[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tg[et]) * wt;
       }
+      MDX_STAMP(3);
       gemm_tile<4, ET, 64>(acc, a.w.Wg1e, 16, ft0, Hep, LD64, lane);
+      MDX_STAMP(4);
       layernorm_relu<4, ET, 4>(acc, a.w.gg, a.w.gb, ft0, red, red2, wave, lane, true);
       acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
       __syncthreads();
+      MDX_STAMP(5);
       acc_bias<4, ET>(acc, a.w.bg2, ft0, lane);
       gemm_tile<4, ET, 256>(acc, a.w.Wg2, 16, ft0, X, LD256, lane);
+      MDX_STAMP(6);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int et = 0; et < ET; ++et) sg[ft][et] = sigmoid4(acc[ft][et]);
-      __syncthreads();
+      // no barrier: X (read by the GEMM above) is next written after the barrier inside edge_net's LayerNorm,
+      // which every wave reaches only after it has left this GEMM
+      MDX_STAMP(7);
     }
     {  // edge_net, * h[r], msg_net
       f32x4 acc[4][ET];
       acc_bias<4, ET>(acc, a.w.en.b1, ft0, lane);
       gemm_tile<4, ET, 64>(acc, a.w.en.W1, 16, ft0, Hep, LD64, lane);
+      MDX_STAMP(8);
       layernorm_relu<4, ET, 4>(acc, a.w.en.g, a.w.en.be, ft0, red, red2, wave, lane, true);
       acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
       __syncthreads();
+      MDX_STAMP(9);
       acc_bias<4, ET>(acc, a.w.en.b2, ft0, lane);
       gemm_tile<4, ET, 256>(acc, a.w.en.W2, 16, ft0, X, LD256, lane);
+      MDX_STAMP(10);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
@@ -173,80 +201,88 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
       __syncthreads();
       acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
       __syncthreads();
+      MDX_STAMP(11);
       acc_bias<4, ET>(acc, a.w.bm, ft0, lane);
       gemm_tile<4, ET, 256>(acc, a.w.Wm, 16, ft0, X, LD256, lane);
+      MDX_STAMP(12);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int et = 0; et < ET; ++et)
           if (valid[et])
             stg4(a.M + (size_t)(e0 + 16 * et + c) * MDX_ND + 16 * (ft0 + ft) + 4 * q, acc[ft][et] * sg[ft][et]);
-      __syncthreads();
+      MDX_STAMP(13);  // no barrier: the BondFFN section writes X only after the barrier inside its gate LayerNorm
     }
   }
 
-  // ---- EdgeBlock BondFFNs (left: node = l, reduced over r later; right: node = r) ----------------
+  // ---- EdgeBlock BondFFNs, both sides at once: waves 0,1 own the left FFN (node = l), waves 2,3 the right (node = r) ----
+  //   GEMM A  He' -> [bond_linear_s (64 of 128 features) | gate layer 1 (16 of 32)] per wave, one fused 64 -> 320 pack
+  //   GEMM B  inter layer 1 (128 -> 128 per side, 64 per wave), GEMM C inter layer 2 (128 -> 64), GEMM D gate layer 2
   if (do_ffn) {
-#pragma unroll 1
-    for (int s = s_lo; s < s_hi; ++s) {
-      const FfnW& w = a.w.ffn[s];
-      const int nlcol = s ? MDX_NT_NLR : MDX_NT_NLL;
-      const int gxcol = s ? MDX_NT_GXR : MDX_NT_GXL;
-      int idx[ET];
+    const int s = __builtin_amdgcn_readfirstlane(wave >> 1), wh = __builtin_amdgcn_readfirstlane(wave & 1);
+    const FfnW& w = a.w.ffn[s];
+    const int nlcol = (s ? MDX_NT_NLR : MDX_NT_NLL) + 64 * wh;
+    const int gxcol = (s ? MDX_NT_GXR : MDX_NT_GXL) + 16 * wh + 4 * q;
+    int idx[ET];
 #pragma unroll
-      for (int et = 0; et < ET; ++et) idx[et] = s ? ri[et] : li[et];
-      f32x4 o[1][ET];
-      {
-        const int ft0 = 2 * wave;
-        f32x4 acc[2][ET], nlv[2][ET];
+    for (int et = 0; et < ET; ++et) idx[et] = s ? ri[et] : li[et];
+    {
+      f32x4 acc[5][ET], nlv[4][ET], gxv[ET];
+      const f32x4 bg = ldg4(w.bg1 + 16 * wh + 4 * q), wt = ldg4(w.wtg1 + 16 * wh + 4 * q);
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+      for (int et = 0; et < ET; ++et) {
+        gxv[et] = ldg4(a.NT + (size_t)idx[et] * MDX_NTW + gxcol);
 #pragma unroll
-          for (int et = 0; et < ET; ++et)
-            nlv[ft][et] = ldg4(a.NT + (size_t)idx[et] * MDX_NTW + nlcol + 16 * (ft0 + ft) + 4 * q);
-        acc_zero<2, ET>(acc);
-        gemm_tile<2, ET, 64>(acc, w.Wbl, 8, ft0, Hep, LD64, lane);
-#pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-          for (int et = 0; et < ET; ++et) acc[ft][et] = acc[ft][et] * nlv[ft][et];
-        acc_to_lds<2, ET>(acc, X, LD256, 0, ft0, lane);
-        __syncthreads();
-        acc_bias<2, ET>(acc, w.inter.b1, ft0, lane);
-        gemm_tile<2, ET, 128>(acc, w.inter.W1, 8, ft0, X, LD256, lane);
-        layernorm_relu<2, ET, 4>(acc, w.inter.g, w.inter.be, ft0, red, red2, wave, lane, true);
-        acc_to_lds<2, ET>(acc, X, LD256, 128, ft0, lane);
-        __syncthreads();
-        acc_bias<1, ET>(o, w.inter.b2, wave, lane);
-        gemm_tile<1, ET, 128>(o, w.inter.W2, 4, wave, X + 128, LD256, lane);
+        for (int ft = 0; ft < 4; ++ft) nlv[ft][et] = ldg4(a.NT + (size_t)idx[et] * MDX_NTW + nlcol + 16 * ft + 4 * q);
       }
-      {
-        f32x4 g1[1][ET];
-        const bool act = wave < 2;
-        if (act) {
-          const int f = 16 * wave + 4 * q;
-          const f32x4 b = ldg4(w.bg1 + f), wt = ldg4(w.wtg1 + f);
+      acc_zero<5, ET>(acc);
+      gemm_tile<5, ET, 64>(acc, a.w.Wffa, 20, 5 * wave, Hep, LD64, lane);
+      MDX_STAMP(14);
+      f32x4 g1[1][ET];
 #pragma unroll
-          for (int et = 0; et < ET; ++et)
-            g1[0][et] = b + ldg4(a.NT + (size_t)idx[et] * MDX_NTW + gxcol + f) + splat4(tt[et]) * wt;
-          gemm_tile<1, ET, 64>(g1, w.Wg1e, 2, wave, Hep, LD64, lane);
-        } else {
-          acc_zero<1, ET>(g1);
-        }
-        layernorm_relu<1, ET, 2>(g1, w.gg, w.gb, wave, red, red2, wave, lane, act);
-        if (act) acc_to_lds<1, ET>(g1, GG, LD32, 0, wave, lane);
-        __syncthreads();
-        f32x4 g2[1][ET];
-        acc_bias<1, ET>(g2, w.bg2, wave, lane);
-        gemm_tile<1, ET, 32>(g2, w.Wg2, 4, wave, GG, LD32, lane);
+      for (int et = 0; et < ET; ++et) g1[0][et] = ((acc[4][et] + bg) + gxv[et]) + splat4(tt[et]) * wt;
+      // (the barrier inside also orders the X writes below after every wave's msg_net GEMM reads)
+      layernorm_relu<1, ET, 2>(g1, w.gg, w.gb, wh, red, red2, wave, lane, true, true, 2 * s);
+      acc_to_lds<1, ET>(g1, GG, LD64, 0, wave, lane);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+          sts4(X + (16 * et + c) * LD256 + 64 * wave + 16 * ft + 4 * q, acc[ft][et] * nlv[ft][et]);
+    }
+    __syncthreads();
+    MDX_STAMP(15);
+    {
+      f32x4 h[4][ET];
+      acc_bias<4, ET>(h, w.inter.b1, 4 * wh, lane);
+      gemm_tile<4, ET, 128>(h, w.inter.W1, 8, 4 * wh, X + 128 * s, LD256, lane);
+      MDX_STAMP(16);
+      layernorm_relu<4, ET, 2>(h, w.inter.g, w.inter.be, 4 * wh, red, red2, wave, lane, true, true, 2 * s);
+      acc_to_lds<4, ET>(h, X, LD256, 128 * s, 4 * wh, lane);  // in place: every wave is past GEMM B (LN barrier)
+    }
+    __syncthreads();
+    MDX_STAMP(17);
+    {
+      f32x4 o[2][ET], g2[2][ET];
+      acc_bias<2, ET>(o, w.inter.b2, 2 * wh, lane);
+      gemm_tile<2, ET, 128>(o, w.inter.W2, 4, 2 * wh, X + 128 * s, LD256, lane);
+      MDX_STAMP(18);
+      acc_bias<2, ET>(g2, w.bg2, 2 * wh, lane);
+      gemm_tile<2, ET, 32>(g2, w.Wg2, 4, 2 * wh, GG + 32 * s, LD64, lane);
+      MDX_STAMP(19);
+      float* F = a.F[s];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
         for (int et = 0; et < ET; ++et)
           if (valid[et])
-            stg4(a.F[s] + (size_t)(e0 + 16 * et + c) * 64 + 16 * wave + 4 * q, o[0][et] * sigmoid4(g2[0][et]));
-      }
-      __syncthreads();
+            stg4(F + (size_t)(e0 + 16 * et + c) * 64 + 32 * wh + 16 * ft + 4 * q, o[ft][et] * sigmoid4(g2[ft][et]));
     }
+    MDX_STAMP(20);
   }
+#ifdef MDX_TRACE
+  if (threadIdx.x == 0 && mdx_trace_buf) mdx_trace_buf[(size_t)blockIdx.x * 32 + 29] = wall_clock64();
+#endif
 }
 
 __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_b_kernel(const EdgeBArgs a, const int ntiles) {
@@ -387,9 +423,7 @@ void launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;
-  const int all = EA_EMB | EA_NODE | EA_FFN;
-  const bool split = MDX_EA_SPLIT && (a.flags & all) == all && a.He_in != a.He_out;
-  hipLaunchKernelGGL(edge_a_kernel, dim3(split ? 3 * ntiles : ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
+  hipLaunchKernelGGL(edge_a_kernel, dim3(ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
 }
 
 void launch_edge_b(const EdgeBArgs& a, hipStream_t s) {

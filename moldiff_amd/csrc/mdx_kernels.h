@@ -12,9 +12,6 @@
 #ifndef MDX_ET
 #define MDX_ET 3    // edge tile = 16*MDX_ET rows per workgroup
 #endif
-#ifndef MDX_EA_SPLIT
-#define MDX_EA_SPLIT 0  // 1 = dispatch edge kernel A as 3 work units per tile (measured slower: 96.8 vs 102.4 TFLOP/s)
-#endif
 #ifndef MDX_EWPS
 #define MDX_EWPS 2  // waves per SIMD the edge kernels are compiled for (= workgroups per CU)
 #endif
@@ -53,6 +50,9 @@ struct EdgeAW {  // weights of edge kernel A for one block
   MlpW en;                                         // edge_net 64 -> 256 -> 256
   const float *Wm, *bm;                            // msg_net 256 x 256
   FfnW ffn[2];                                     // left, right
+  // first layers of both BondFFNs that read He', fused into one (320 x 64) pack: the 80 rows of wave w are
+  // [bond_linear_s rows 64h..64h+63 | gate layer-1 edge part rows 16h..16h+15], s = w/2, h = w%2
+  const float* Wffa;
 };
 
 struct EdgeBW {  // weights of edge kernel B for one block

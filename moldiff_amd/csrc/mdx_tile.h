@@ -145,8 +145,9 @@ __device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[FTW][ET], float* X
 
 // ----------------------------------------------------------------------------------------------
 // LayerNorm (biased variance, eps 1e-5, affine) + ReLU over NOUT = NW * FTW * 16 features that are
-// spread over the first NW waves of the workgroup.  Two-pass (mean, then centred second moment).
-// ALL 256 threads must call this (it contains two __syncthreads); waves >= NW pass active=false.
+// spread over the NW consecutive waves wbase .. wbase+NW-1 of the workgroup (several such groups may normalise
+// different feature sets side by side).  ALL 256 threads must call this (it contains one __syncthreads);
+// waves outside any group pass active=false.
 //   red, red2 : LDS scratch, 4*TE floats each.
 // ----------------------------------------------------------------------------------------------
 // Statistics are combined with the parallel-variance formula (Chan et al.): every wave computes the exact
@@ -156,7 +157,7 @@ __device__ __forceinline__ void acc_to_lds(const f32x4 (&acc)[FTW][ET], float* X
 template <int FTW, int ET, int NW>
 __device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float* __restrict__ gamma,
                                                const float* __restrict__ beta, int ft0, float* red, float* red2,
-                                               int wave, int lane, bool active, bool relu = true) {
+                                               int wave, int lane, bool active, bool relu = true, int wbase = 0) {
   constexpr int TE = 16 * ET;
   constexpr float inv_nf = 1.0f / (float)(FTW * 16);
   constexpr float inv_n = 1.0f / (float)(NW * FTW * 16);
@@ -184,22 +185,25 @@ __device__ __forceinline__ void layernorm_relu(f32x4 (&z)[FTW][ET], const float*
       }
     }
   }
-  __syncthreads();
+  // the affine parameters are fetched ahead of the barrier so their L2 latency overlaps the wait for the slowest wave
+  f32x4 gm[FTW], bt[FTW];
   if (active) {
-    f32x4 gm[FTW], bt[FTW];
 #pragma unroll
     for (int ft = 0; ft < FTW; ++ft) {
       gm[ft] = ldg4(gamma + 16 * (ft0 + ft) + 4 * q);
       bt[ft] = ldg4(beta + 16 * (ft0 + ft) + 4 * q);
     }
+  }
+  __syncthreads();
+  if (active) {
 #pragma unroll
     for (int et = 0; et < ET; ++et) {
       float mws[NW], msum = 0.f, m2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        mws[w] = red[w * TE + 16 * et + c];
+        mws[w] = red[(wbase + w) * TE + 16 * et + c];
         msum += mws[w];
-        m2 += red2[w * TE + 16 * et + c];
+        m2 += red2[(wbase + w) * TE + 16 * et + c];
       }
       const float mean = msum * (1.0f / (float)NW);
       float dm = 0.f;
