@@ -106,6 +106,45 @@ def main():
         out.update({f'{nm}_sizes': np.array(sizes), f'{nm}_node_type': node_type.numpy(), f'{nm}_node_pos': node_pos.numpy(),
                     f'{nm}_halfedge_type': half_type.numpy(), f'{nm}_t_half': t_half.numpy(), f'{nm}_t': t.numpy(),
                     f'{nm}_eps_pos': eps_pos.numpy(), f'{nm}_u_node': u_node.numpy(), f'{nm}_u_halfedge': u_half.numpy()})
+    # ---- BondPredictor.get_loss (models/bond_predictor.py:84-124): draws = randint, normal_ (pos), rand_like (node) ----
+    cfg = ref_shim.load_yaml_cfg('configs/train/train_bondpred.yml')
+    m = BondPredictor(cfg.model, 8, 5).eval()
+    sd = m.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+    sd.update(O.recipe_state_dict(shapes, 20230808))
+    m.load_state_dict(sd, strict=True)
+    Pb = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = np.random.Generator(np.random.PCG64(79))
+    sizes = [7, 5, 12, 9, 3]
+    bn, hei, bh, off = [], [], [], 0
+    for i, n in enumerate(sizes):
+        bn += [i] * n
+        tri = torch.triu_indices(n, n, 1) + off
+        hei.append(tri)
+        bh += [i] * tri.shape[1]
+        off += n
+    bn, hei, bh = torch.tensor(bn), torch.cat(hei, 1), torch.tensor(bh)
+    N, Eh, B = len(bn), len(bh), len(sizes)
+    node_type = torch.from_numpy(g.integers(0, 7, N))
+    node_pos = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32) * 2.0)
+    half_type = torch.from_numpy((g.random(Eh) < 0.25) * g.integers(1, 5, Eh))
+    t_half = torch.tensor([0, 311, 742])
+    eps_pos = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32))
+    u_node = torch.from_numpy(g.random((N, 8)).astype(np.float32))
+    with torch.no_grad(), pinned_randomness(t_half, eps_pos, [u_node]):
+        ref = m.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
+    t = torch.cat([t_half, 1000 - t_half - 1])[:B]
+    tabs = {'pos': {'alphas_bar': Pb['pos_transition.alphas_bar']}, 'node': {'q_mats': Pb['node_transition.q_mats']}}
+    with torch.no_grad():
+        orc = O.bondpred_loss(Pb, dict(num_timesteps=1000, num_blocks=8, cutoff=20), tabs, node_type, node_pos, bn, half_type,
+                              hei, bh, B, t, dict(eps_pos=eps_pos, u_node=u_node))
+    for k in ('loss', 'loss_edge'):
+        pins[f'get_loss_bondpred_{k}'] = abs(float(ref[k]) - float(orc[k]))
+        print('bondpred', k, float(ref[k]), float(orc[k]))
+        out[f'bond_{k}'] = np.float32(float(ref[k]))
+    out.update({'bond_sizes': np.array(sizes), 'bond_node_type': node_type.numpy(), 'bond_node_pos': node_pos.numpy(),
+                'bond_halfedge_type': half_type.numpy(), 'bond_t_half': t_half.numpy(), 'bond_t': t.numpy(),
+                'bond_eps_pos': eps_pos.numpy(), 'bond_u_node': u_node.numpy()})
     np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
     pf = os.path.join(OUT, 'PINNING.json')
     allp = json.load(open(pf))

@@ -400,6 +400,21 @@ def moldiff_loss(P, cfg, tabs, node_type, node_pos, batch_node, halfedge_type, h
     return {'loss': loss_pos + loss_node + loss_edge, 'loss_pos': loss_pos, 'loss_node': loss_node, 'loss_edge': loss_edge}
 
 
+def bondpred_loss(Pb, cfgb, tabs, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol,
+                  time_step, noise):
+    """BondPredictor.get_loss (models/bond_predictor.py:84-124) with the draws passed in: noise = dict(eps_pos, u_node).
+    `tabs` = {'pos': {'alphas_bar'}, 'node': {'q_mats'}} of the predictor's own schedules."""
+    t = time_step
+    a_bar = tabs['pos']['alphas_bar'][t][batch_node].unsqueeze(-1)
+    pos = a_bar.sqrt() * node_pos + (1 - a_bar).sqrt() * noise['eps_pos']
+    hn = cat_add_noise(tabs['node'], node_type, t, batch_node, noise['u_node'])[0]
+    edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], 1)
+    batch_edge = torch.cat([batch_halfedge, batch_halfedge], 0)
+    logits = bondpred_forward(Pb, cfgb, hn, pos, batch_node, edge_index, batch_edge, t)
+    loss = F.cross_entropy(logits, halfedge_type, weight=Pb['ce_loss.weight'])
+    return {'loss': loss, 'loss_edge': loss}
+
+
 def separate_outputs(pred, n_graphs, batch_node, halfedge_index, batch_halfedge):
     """utils/sample.py:4-30 (`seperate_outputs`, pred part): split packed numpy arrays per molecule; the
     half-edge index is re-based to the molecule's first node."""

@@ -110,3 +110,32 @@ def test_gpu_loss_default_draws_and_no_backward():
     assert all(float(a[k]) == float(b[k]) for k in KEYS)       # deterministic under torch's seed
     with pytest.raises(RuntimeError):
         a['loss'].backward()
+
+
+# ---- BondPredictor.get_loss (reference models/bond_predictor.py:84-124) ---------------------------------------------
+def _bond_case(device='cpu'):
+    z = U.gold('loss.npz')
+    sizes = [int(v) for v in z['bond_sizes']]
+    bn, hei, bh, _, _ = U.graph_from_sizes(sizes, device)
+    tt = lambda k: torch.from_numpy(z[f'bond_{k}']).to(device)
+    args = (tt('node_type'), tt('node_pos'), bn, tt('halfedge_type'), hei, bh, len(sizes))
+    return args, tt('t'), dict(eps_pos=tt('eps_pos'), u_node=tt('u_node')), float(z['bond_loss'])
+
+
+def test_oracle_bondpred_loss_matches_reference():
+    args, t, noise, want = _bond_case()
+    Pb = U.params(U.bondpred())
+    tabs = {'pos': {'alphas_bar': Pb['pos_transition.alphas_bar']}, 'node': {'q_mats': Pb['node_transition.q_mats']}}
+    with torch.no_grad():
+        got = O.bondpred_loss(Pb, U.CFGB, tabs, *args, t, noise)
+    assert abs(float(got['loss']) - want) <= 1e-6 * max(1.0, want)
+    assert float(got['loss_edge']) == float(got['loss'])
+
+
+@pytest.mark.gpu
+def test_gpu_bondpred_loss_matches_reference():
+    args, t, noise, want = _bond_case('cuda')
+    got = U.bondpred('cuda').get_loss(*args, time_step=t, noise=noise)
+    assert set(got) == {'loss', 'loss_edge'} and not got['loss'].requires_grad
+    assert abs(float(got['loss']) - want) <= RTOL * max(1.0, want), (float(got['loss']), want)
+    assert float(got['loss_edge']) == float(got['loss'])
