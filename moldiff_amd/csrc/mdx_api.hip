@@ -264,6 +264,29 @@ int pack_model(mdx_model_s* m) {
       if (const HostTensor* t = c.get(el + ".inter_module.net.3.bias", {1})) b.eb.bi2 = t->data[0];
       c.packA(&b.eb.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
       c.packA(&b.eb.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
+      {
+        const HostTensor* bl = c.get(el + ".bond_linear.weight", {ND, ED});
+        const HostTensor* nl = c.get(el + ".node_linear.weight", {ND, ED});
+        const HostTensor* g1 = c.get(el + ".gate.net.0.weight", {32, 2 * ED + 1});
+        if (bl && nl && g1) {
+          std::vector<float> Wb((size_t)320 * ED, 0.f), Wn((size_t)320 * ED, 0.f);
+          for (int wv = 0; wv < 4; ++wv) {
+            for (int r = 0; r < 64; ++r)
+              for (int k = 0; k < ED; ++k) {
+                Wb[(size_t)(80 * wv + r) * ED + k] = bl->data[(size_t)(64 * wv + r) * ED + k];
+                Wn[(size_t)(80 * wv + r) * ED + k] = nl->data[(size_t)(64 * wv + r) * ED + k];
+              }
+            if (wv < 2)
+              for (int r = 0; r < 16; ++r)
+                for (int k = 0; k < ED; ++k) {
+                  Wb[(size_t)(80 * wv + 64 + r) * ED + k] = g1->data[(size_t)(16 * wv + r) * (2 * ED + 1) + k];
+                  Wn[(size_t)(80 * wv + 64 + r) * ED + k] = g1->data[(size_t)(16 * wv + r) * (2 * ED + 1) + ED + k];
+                }
+          }
+          c.pack_dense(&b.eb.WblG, Wb, 320, ED, 0, ED);
+          c.pack_dense(&b.eb.WnlG, Wn, 320, ED, 0, ED);
+        }
+      }
       c.vec(&b.eb.bg1, el + ".gate.net.0.bias", 32);
       c.column(&b.eb.wtg1, el + ".gate.net.0.weight", 32, 2 * ED + 1, 2 * ED);
       c.vec(&b.eb.gg, el + ".gate.net.1.weight", 32);

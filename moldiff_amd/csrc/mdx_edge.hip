@@ -21,16 +21,21 @@
 // shader clock at each phase boundary of edge_a into a 32-slot record.  Compiled out of the shipped library.
 #ifdef MDX_TRACE
 __device__ unsigned long long* mdx_trace_buf = nullptr;
-extern "C" int mdx_debug_set_trace(void* p) {
+__device__ int mdx_trace_sel = 0;  // 0: edge_a, 1: edge_b
+extern "C" int mdx_debug_set_trace(void* p, int which) {
+  hipMemcpyToSymbol(HIP_SYMBOL(mdx_trace_sel), &which, sizeof(which));
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdx_trace_buf), &p, sizeof(p));
 }
-#define MDX_STAMP(i)                                                                            \
-  do {                                                                                          \
-    if (threadIdx.x == 0 && mdx_trace_buf) mdx_trace_buf[(size_t)blockIdx.x * 32 + (i)] = clock64(); \
+#define MDX_STAMP_K(k, i)                                                                                   \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && mdx_trace_buf && mdx_trace_sel == (k))                                          \
+      mdx_trace_buf[(size_t)blockIdx.x * 32 + (i)] = ((i) >= 29) ? wall_clock64() : clock64();              \
   } while (0)
 #else
-#define MDX_STAMP(i) ((void)0)
+#define MDX_STAMP_K(k, i) ((void)0)
 #endif
+#define MDX_STAMP(i) MDX_STAMP_K(0, i)
+#define MDX_STAMPB(i) MDX_STAMP_K(1, i)
 
 namespace {
 
@@ -94,14 +99,28 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
   float tt[ET];
   bool valid[ET];
   MDX_STAMP(0);
-#ifdef MDX_TRACE
-  if (threadIdx.x == 0 && mdx_trace_buf) {
-    mdx_trace_buf[(size_t)blockIdx.x * 32 + 30] = wall_clock64();
-    mdx_trace_buf[(size_t)blockIdx.x * 32 + 31] =
-        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
-  }
-#endif
+  MDX_STAMP(30);
   tile_indices(a.l, a.r, a.te, e0, E, lane, li, ri, tt, valid);
+
+  // Requested ahead of the first barrier so the latency overlaps the tile load: the edge_embs weight slice (register
+  // resident, 5 fragments per wave) and the NodeBlock gate's per-node term b + gx[r] + t*wt (its accumulator's start).
+  f32x4 wemb[5][1], ginit[4][ET];
+  f32x4 wpre[4];  // first weight fragments of the next 256-wide layer (load_w0)
+  if (a.flags & EA_EMB) load_wfrag<1, 80>(wemb, a.w.Wemb, 4, wave, lane);
+  if (do_node) {
+    load_w0<4>(wpre, a.w.Wg1e, 4 * wave, lane);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const int f = 16 * (4 * wave + ft) + 4 * q;
+      const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        // the NodeBlock gate is fed node_time[col], the BondFFN gates edge_time
+        const float tg = (a.tn_r && valid[et]) ? a.tn_r[e0 + 16 * et + c] : tt[et];
+        ginit[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tg) * wt;
+      }
+    }
+  }
 
   // ---- phase A/B: He' ---------------------------------------------------------------------
   if (a.flags & EA_EMB) {
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
     MDX_STAMP(1);
     f32x4 acc[1][ET];
     acc_bias<1, ET>(acc, a.w.bemb, wave, lane);
-    gemm_tile<1, ET, 80>(acc, a.w.Wemb, 4, wave, X, LD80, lane);
+    gemm_tile_reg<1, ET, 80>(acc, wemb, X, LD80, lane);
     acc_to_lds<1, ET>(acc, Hep, LD64, 0, wave, lane);
 #pragma unroll
     for (int et = 0; et < ET; ++et)
@@ -149,30 +168,25 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
   // ---- NodeBlock message path -----------------------------------------------------------------
   if (do_node) {
     const int ft0 = 4 * wave;
-    float tg[ET];  // the NodeBlock gate is fed node_time[col], the BondFFN gates edge_time
-#pragma unroll
-    for (int et = 0; et < ET; ++et) tg[et] = (a.tn_r && valid[et]) ? a.tn_r[e0 + 16 * et + c] : tt[et];
     f32x4 sg[4][ET];
     {  // gate: sigmoid(W2 relu(LN(W1e He' + gx[r] + t*wt + b1)) + b2)
       f32x4 acc[4][ET];
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        const int f = 16 * (ft0 + ft) + 4 * q;
-        const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
+      for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-        for (int et = 0; et < ET; ++et)
-          acc[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tg[et]) * wt;
-      }
+        for (int et = 0; et < ET; ++et) acc[ft][et] = ginit[ft][et];
       MDX_STAMP(3);
-      gemm_tile<4, ET, 64>(acc, a.w.Wg1e, 16, ft0, Hep, LD64, lane);
+      gemm_tile_pre<4, ET, 64>(acc, wpre, a.w.Wg1e, 16, ft0, Hep, LD64, lane);
       MDX_STAMP(4);
+      load_w0<4>(wpre, a.w.Wg2, ft0, lane);
       layernorm_relu<4, ET, 4>(acc, a.w.gg, a.w.gb, ft0, red, red2, wave, lane, true);
       acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
       __syncthreads();
       MDX_STAMP(5);
       acc_bias<4, ET>(acc, a.w.bg2, ft0, lane);
-      gemm_tile<4, ET, 256>(acc, a.w.Wg2, 16, ft0, X, LD256, lane);
+      gemm_tile_pre<4, ET, 256>(acc, wpre, a.w.Wg2, 16, ft0, X, LD256, lane);
       MDX_STAMP(6);
+      load_w0<4>(wpre, a.w.en.W1, ft0, lane);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
@@ -184,15 +198,17 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
     {  // edge_net, * h[r], msg_net
       f32x4 acc[4][ET];
       acc_bias<4, ET>(acc, a.w.en.b1, ft0, lane);
-      gemm_tile<4, ET, 64>(acc, a.w.en.W1, 16, ft0, Hep, LD64, lane);
+      gemm_tile_pre<4, ET, 64>(acc, wpre, a.w.en.W1, 16, ft0, Hep, LD64, lane);
       MDX_STAMP(8);
+      load_w0<4>(wpre, a.w.en.W2, ft0, lane);
       layernorm_relu<4, ET, 4>(acc, a.w.en.g, a.w.en.be, ft0, red, red2, wave, lane, true);
       acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
       __syncthreads();
       MDX_STAMP(9);
       acc_bias<4, ET>(acc, a.w.en.b2, ft0, lane);
-      gemm_tile<4, ET, 256>(acc, a.w.en.W2, 16, ft0, X, LD256, lane);
+      gemm_tile_pre<4, ET, 256>(acc, wpre, a.w.en.W2, 16, ft0, X, LD256, lane);
       MDX_STAMP(10);
+      load_w0<4>(wpre, a.w.Wm, ft0, lane);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
       __syncthreads();
       MDX_STAMP(11);
       acc_bias<4, ET>(acc, a.w.bm, ft0, lane);
-      gemm_tile<4, ET, 256>(acc, a.w.Wm, 16, ft0, X, LD256, lane);
+      gemm_tile_pre<4, ET, 256>(acc, wpre, a.w.Wm, 16, ft0, X, LD256, lane);
       MDX_STAMP(12);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
@@ -227,7 +243,8 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
 #pragma unroll
     for (int et = 0; et < ET; ++et) idx[et] = s ? ri[et] : li[et];
     {
-      f32x4 acc[5][ET], nlv[4][ET], gxv[ET];
+      f32x4 acc[5][ET], nlv[4][ET], gxv[ET], wa[5];
+      load_w0<5>(wa, a.w.Wffa, 5 * wave, lane);
       const f32x4 bg = ldg4(w.bg1 + 16 * wh + 4 * q), wt = ldg4(w.wtg1 + 16 * wh + 4 * q);
 #pragma unroll
       for (int et = 0; et < ET; ++et) {
@@ -236,8 +253,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
         for (int ft = 0; ft < 4; ++ft) nlv[ft][et] = ldg4(a.NT + (size_t)idx[et] * MDX_NTW + nlcol + 16 * ft + 4 * q);
       }
       acc_zero<5, ET>(acc);
-      gemm_tile<5, ET, 64>(acc, a.w.Wffa, 20, 5 * wave, Hep, LD64, lane);
+      gemm_tile_pre<5, ET, 64>(acc, wa, a.w.Wffa, 20, 5 * wave, Hep, LD64, lane);
       MDX_STAMP(14);
+      load_w0<4>(wpre, w.inter.W1, 4 * wh, lane);
       f32x4 g1[1][ET];
 #pragma unroll
       for (int et = 0; et < ET; ++et) g1[0][et] = ((acc[4][et] + bg) + gxv[et]) + splat4(tt[et]) * wt;
@@ -252,11 +270,14 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
     }
     __syncthreads();
     MDX_STAMP(15);
+    f32x4 wc[2], wd[2];
     {
       f32x4 h[4][ET];
       acc_bias<4, ET>(h, w.inter.b1, 4 * wh, lane);
-      gemm_tile<4, ET, 128>(h, w.inter.W1, 8, 4 * wh, X + 128 * s, LD256, lane);
+      gemm_tile_pre<4, ET, 128>(h, wpre, w.inter.W1, 8, 4 * wh, X + 128 * s, LD256, lane);
       MDX_STAMP(16);
+      load_w0<2>(wc, w.inter.W2, 2 * wh, lane);
+      load_w0<2>(wd, w.Wg2, 2 * wh, lane);
       layernorm_relu<4, ET, 2>(h, w.inter.g, w.inter.be, 4 * wh, red, red2, wave, lane, true, true, 2 * s);
       acc_to_lds<4, ET>(h, X, LD256, 128 * s, 4 * wh, lane);  // in place: every wave is past GEMM B (LN barrier)
     }
@@ -265,10 +286,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
     {
       f32x4 o[2][ET], g2[2][ET];
       acc_bias<2, ET>(o, w.inter.b2, 2 * wh, lane);
-      gemm_tile<2, ET, 128>(o, w.inter.W2, 4, 2 * wh, X + 128 * s, LD256, lane);
+      gemm_tile_pre<2, ET, 128>(o, wc, w.inter.W2, 4, 2 * wh, X + 128 * s, LD256, lane);
       MDX_STAMP(18);
       acc_bias<2, ET>(g2, w.bg2, 2 * wh, lane);
-      gemm_tile<2, ET, 32>(g2, w.Wg2, 4, 2 * wh, GG + 32 * s, LD64, lane);
+      gemm_tile_pre<2, ET, 32>(g2, wd, w.Wg2, 4, 2 * wh, GG + 32 * s, LD64, lane);
       MDX_STAMP(19);
       float* F = a.F[s];
 #pragma unroll
@@ -280,16 +301,13 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
     }
     MDX_STAMP(20);
   }
-#ifdef MDX_TRACE
-  if (threadIdx.x == 0 && mdx_trace_buf) mdx_trace_buf[(size_t)blockIdx.x * 32 + 29] = wall_clock64();
-#endif
+  MDX_STAMP(29);
 }
 
 __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_b_kernel(const EdgeBArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hep = smem + OFF_HEP;
-  float* X = smem + OFF_X;   // U (ld 72) / A (ld 72) / inter (ld 264)
-  float* GG = smem + OFF_GG;
+  float* X = smem + OFF_X;  // U (ld 72) / A (ld 72) / inter (ld 264)
   float* red = smem + OFF_RED;
   float* red2 = smem + OFF_RED2;
 
@@ -298,17 +316,23 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_b_kernel(const EdgeBArg
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int e0 = tile * TE;
   const int E = a.E;
+  const bool do_edge = a.flags & EB_EDGE, do_pos = a.flags & EB_POS;
+  const int f = 16 * wave + 4 * q;
 
   int li[ET], ri[ET];
   float tt[ET];
   bool valid[ET];
+  MDX_STAMPB(0);
+  MDX_STAMPB(30);
   tile_indices(a.l, a.r, a.te, e0, E, lane, li, ri, tt, valid);
-  load_rows64(a.Hep, e0, E, Hep, LD64, tid);
-  __syncthreads();
 
-  if (a.flags & EB_EDGE) {
-    const int f = 16 * wave + 4 * q;
-    f32x4 u[1][ET];
+  // Everything that depends only on the tile's indices is requested here, ahead of the first barrier, so that its
+  // latency overlaps the He' tile load: the two 64x64 weight slices (register resident, 8 fragments per wave), the
+  // per-node gathers of the EdgeBlock tail, the Lf[l]*Rf[r] rows and the edge geometry of PosUpdate.
+  f32x4 wself[4][1], wout[4][1], u[1][ET];
+  if (do_edge) {
+    load_wfrag<1, 64>(wself, a.w.Wself, 4, wave, lane);
+    load_wfrag<1, 64>(wout, a.w.Wout, 4, wave, lane);
     const f32x4 bs = ldg4(a.w.bself + f);
 #pragma unroll
     for (int et = 0; et < ET; ++et) {
@@ -317,96 +341,135 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_b_kernel(const EdgeBArg
       v = v + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_NFR + f);
       u[0][et] = v + bs;
     }
-    gemm_tile<1, ET, 64>(u, a.w.Wself, 4, wave, Hep, LD64, lane);
+  }
+  f32x4 lfv[ET], rfv[ET];  // A-tile element (row = tid/16 + 16 j, columns 4*(tid%16)..)
+  float rx[ET], ry[ET], rz[ET], dd[ET];
+  if (do_pos) {
+#pragma unroll
+    for (int j = 0; j < ET; ++j) {
+      const int e = e0 + (tid >> 4) + 16 * j;
+      lfv[j] = splat4(0.f);
+      rfv[j] = splat4(0.f);
+      if (e < E) {
+        lfv[j] = ldg4(a.Lf + (size_t)a.l[e] * 64 + 4 * (tid & 15));
+        rfv[j] = ldg4(a.Rf + (size_t)a.r[e] * 64 + 4 * (tid & 15));
+      }
+    }
+    if (wave == 0 && q == 0) {
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        const int e = e0 + 16 * et + c;
+        rx[et] = ry[et] = rz[et] = 0.f;
+        dd[et] = 1.f;
+        if (!valid[et]) continue;
+        if (a.rel_in) {
+          rx[et] = a.rel_in[3 * (size_t)e + 0]; ry[et] = a.rel_in[3 * (size_t)e + 1]; rz[et] = a.rel_in[3 * (size_t)e + 2];
+          dd[et] = a.dist_in[e];
+        } else {
+          rx[et] = a.pos[3 * li[et] + 0] - a.pos[3 * ri[et] + 0];
+          ry[et] = a.pos[3 * li[et] + 1] - a.pos[3 * ri[et] + 1];
+          rz[et] = a.pos[3 * li[et] + 2] - a.pos[3 * ri[et] + 2];
+          dd[et] = sqrtf(rx[et] * rx[et] + ry[et] * ry[et] + rz[et] * rz[et]);
+        }
+      }
+    }
+  }
+  load_rows64(a.Hep, e0, E, Hep, LD64, tid);
+  __syncthreads();
+  MDX_STAMPB(1);
+
+  if (do_edge) {
+    MDX_STAMPB(2);
+    gemm_tile_reg<1, ET, 64>(u, wself, Hep, LD64, lane);
+    MDX_STAMPB(3);
     layernorm_relu<1, ET, 4>(u, a.w.lng, a.w.lnb, wave, red, red2, wave, lane, true);
     acc_to_lds<1, ET>(u, X, LD64, 0, wave, lane);
     __syncthreads();
+    MDX_STAMPB(4);
     f32x4 d[1][ET];
     acc_bias<1, ET>(d, a.w.bout, wave, lane);
-    gemm_tile<1, ET, 64>(d, a.w.Wout, 4, wave, X, LD64, lane);
+    gemm_tile_reg<1, ET, 64>(d, wout, X, LD64, lane);
+    MDX_STAMPB(5);
 #pragma unroll
     for (int et = 0; et < ET; ++et) {
       if (!(a.flags & EB_DELTA)) d[0][et] = d[0][et] + lds4(Hep + (16 * et + c) * LD64 + f);
       if (valid[et]) stg4(a.He_out + (size_t)(e0 + 16 * et + c) * 64 + f, d[0][et]);
     }
-    __syncthreads();  // every wave is done reading Hep (self_ffn) and X (U)
-    acc_to_lds<1, ET>(d, Hep, LD64, 0, wave, lane);
-    __syncthreads();
-  }
-
-  if (a.flags & EB_POS) {
-    float* A = X;  // (TE x 64, ld 72): a = Lf[l] * Rf[r]
-    for (int i = tid; i < TE * 16; i += MDX_WG) {
-      const int row = i >> 4, c4 = i & 15;
-      const int e = e0 + row;
-      f32x4 v = splat4(0.f);
-      if (e < E) v = ldg4(a.Lf + (size_t)a.l[e] * 64 + 4 * c4) * ldg4(a.Rf + (size_t)a.r[e] * 64 + 4 * c4);
-      sts4(A + row * LD64 + 4 * c4, v);
+    if (do_pos) {
+      __syncthreads();  // every wave is done reading Hep (self_ffn, residual) and X (U)
+      acc_to_lds<1, ET>(d, Hep, LD64, 0, wave, lane);
     }
+  }
+  MDX_STAMPB(6);
+
+  if (do_pos) {
+    float* A = X;  // (TE x 64, ld 72): a = Lf[l] * Rf[r]
+    f32x4 wa[5], wa2[5];
+    load_w0<5>(wa, a.w.WblG, 5 * wave, lane);
+    load_w0<5>(wa2, a.w.WnlG, 5 * wave, lane);
+#pragma unroll
+    for (int j = 0; j < ET; ++j) sts4(A + ((tid >> 4) + 16 * j) * LD64 + 4 * (tid & 15), lfv[j] * rfv[j]);
     __syncthreads();
-    // gate: 129 -> 32 -> 1
+    MDX_STAMPB(7);
+    // (W_bl He'') and (W_nl a), 256 features each, with the 129 -> 32 gate layer riding along as a fifth feature tile
+    // of waves 0,1 (its accumulator is chained through both GEMMs: ((b + t wt) + W_h He'') + W_a a, as in the reference)
+    const int ft0 = 4 * wave;
+    const bool act = wave < 2;
+    f32x4 acc[5][ET], acc2[5][ET], wi[4];
+    acc_zero<5, ET>(acc);
+    acc_zero<5, ET>(acc2);
+    if (act) {
+      const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
+#pragma unroll
+      for (int et = 0; et < ET; ++et) acc[4][et] = b + splat4(tt[et]) * wt;
+    }
+    gemm_tile_pre<5, ET, 64>(acc, wa, a.w.WblG, 20, 5 * wave, Hep, LD64, lane);
+#pragma unroll
+    for (int et = 0; et < ET; ++et) acc2[4][et] = acc[4][et];
+    gemm_tile_pre<5, ET, 64>(acc2, wa2, a.w.WnlG, 20, 5 * wave, A, LD64, lane);
+    MDX_STAMPB(8);
+    load_w0<4>(wi, a.w.Wi1, ft0, lane);
     float gate[ET];
     {
       f32x4 g1[1][ET];
-      const bool act = wave < 2;
-      if (act) {
-        const int f = 16 * wave + 4 * q;
-        const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
 #pragma unroll
-        for (int et = 0; et < ET; ++et) g1[0][et] = b + splat4(tt[et]) * wt;
-        gemm_tile<1, ET, 64>(g1, a.w.Wg1h, 2, wave, Hep, LD64, lane);
-        gemm_tile<1, ET, 64>(g1, a.w.Wg1a, 2, wave, A, LD64, lane);
-      } else {
-        acc_zero<1, ET>(g1);
-      }
+      for (int et = 0; et < ET; ++et) g1[0][et] = acc2[4][et];
+      // (the barrier inside also tells every wave that A, which aliases X, has been consumed)
       layernorm_relu<1, ET, 2>(g1, a.w.gg, a.w.gb, wave, red, red2, wave, lane, act);
       dot_rows<1, ET, 2>(g1, a.w.wg2, wave, smem + OFF_RED3, wave, lane, act, gate);
     }
-    // inter: (W_bl He'') * (W_nl a) -> 256 -> LN/ReLU -> 1
-    const int ft0 = 4 * wave;
-    f32x4 acc[4][ET];
-    {
-      f32x4 acc2[4][ET];
-      acc_zero<4, ET>(acc);
-      acc_zero<4, ET>(acc2);
-      gemm_tile<4, ET, 64>(acc, a.w.Wbl, 16, ft0, Hep, LD64, lane);
-      gemm_tile<4, ET, 64>(acc2, a.w.Wnl, 16, ft0, A, LD64, lane);
+    MDX_STAMPB(9);
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
+    for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-        for (int et = 0; et < ET; ++et) acc[ft][et] = acc[ft][et] * acc2[ft][et];
-    }
-    __syncthreads();  // A (aliases X) fully consumed
-    acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
+      for (int et = 0; et < ET; ++et)
+        sts4(X + (16 * et + c) * LD256 + 16 * (ft0 + ft) + 4 * q, acc[ft][et] * acc2[ft][et]);
+    MDX_STAMPB(10);
     __syncthreads();
-    acc_bias<4, ET>(acc, a.w.bi1, ft0, lane);
-    gemm_tile<4, ET, 256>(acc, a.w.Wi1, 16, ft0, X, LD256, lane);
-    layernorm_relu<4, ET, 4>(acc, a.w.ig, a.w.ib, ft0, red, red2, wave, lane, true);
+    MDX_STAMPB(11);
+    f32x4 h[4][ET];
+    acc_bias<4, ET>(h, a.w.bi1, ft0, lane);
+    gemm_tile_pre<4, ET, 256>(h, wi, a.w.Wi1, 16, ft0, X, LD256, lane);
+    MDX_STAMPB(12);
+    layernorm_relu<4, ET, 4>(h, a.w.ig, a.w.ib, ft0, red, red2, wave, lane, true);
     float wd[ET];
-    dot_rows<4, ET, 4>(acc, a.w.wi2, ft0, smem + OFF_RED3, wave, lane, true, wd);
+    dot_rows<4, ET, 4>(h, a.w.wi2, ft0, smem + OFF_RED3, wave, lane, true, wd);
+    MDX_STAMPB(13);
     if (wave == 0 && q == 0) {
 #pragma unroll
       for (int et = 0; et < ET; ++et) {
         if (!valid[et]) continue;
         const int e = e0 + 16 * et + c;
         const float w = (wd[et] + a.w.bi2) * sigmoidf_(gate[et] + a.w.bg2);
-        float rx, ry, rz, d;
-        if (a.rel_in) {
-          rx = a.rel_in[3 * (size_t)e + 0]; ry = a.rel_in[3 * (size_t)e + 1]; rz = a.rel_in[3 * (size_t)e + 2];
-          d = a.dist_in[e];
-        } else {
-          rx = a.pos[3 * li[et] + 0] - a.pos[3 * ri[et] + 0];
-          ry = a.pos[3 * li[et] + 1] - a.pos[3 * ri[et] + 1];
-          rz = a.pos[3 * li[et] + 2] - a.pos[3 * ri[et] + 2];
-          d = sqrtf(rx * rx + ry * ry + rz * rz);
-        }
-        const float dp = d + 1.0f;
-        a.Fe[3 * (size_t)e + 0] = w * rx / d / dp;
-        a.Fe[3 * (size_t)e + 1] = w * ry / d / dp;
-        a.Fe[3 * (size_t)e + 2] = w * rz / d / dp;
+        const float d = dd[et], dp = d + 1.0f;
+        a.Fe[3 * (size_t)e + 0] = w * rx[et] / d / dp;
+        a.Fe[3 * (size_t)e + 1] = w * ry[et] / d / dp;
+        a.Fe[3 * (size_t)e + 2] = w * rz[et] / d / dp;
       }
     }
   }
+  MDX_STAMPB(14);
+  MDX_STAMPB(29);
 }
 
 }  // namespace

@@ -59,6 +59,9 @@ struct EdgeBW {  // weights of edge kernel B for one block
   const float *Wself, *bself, *lng, *lnb, *Wout, *bout;  // EdgeBlock tail
   // PosUpdate.edge_lin (BondFFN bond 64, node 64, inter 256, out 1)
   const float *Wbl, *Wnl;          // 256 x 64 each, no bias
+  // the same two with the gate's first layer riding along: (320 x 64) packs whose 80 rows for wave w are
+  // [rows 64w..64w+63 of Wbl (Wnl) | rows 16w..16w+15 of the gate's He (a) part for w < 2, zeros for w >= 2]
+  const float *WblG, *WnlG;
   const float *Wi1, *bi1, *ig, *ib;  // inter_module first layer 256x256 + LN
   const float *wi2;                // (256) second layer row
   float bi2;

@@ -55,14 +55,19 @@ __device__ __forceinline__ float red_q(float v) {
 // Padded leading dimension for a K-wide activation tile in LDS.
 __host__ __device__ constexpr int mdx_ld(int K) { return K + 8; }
 
-// ----------------------------------------------------------------------------------------------
-// acc[ft][et] += W[16*(ft0+ft) .. +16][0..K) * X[16*et .. +16][0..K)^T
-//   Wp : packed weights, float4 index ((g*FT + ft)*64 + lane), g = k/16   (host: mdx_pack.cpp)
-//   X  : LDS tile, row-major, leading dimension ldx (floats, multiple of 4)
-// ----------------------------------------------------------------------------------------------
-template <int FTW, int ET, int K>
-__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __restrict__ Wp, int FT, int ft0,
-                                          const float* X, int ldx, int lane) {
+// First-group weight fragments of a layer, fetched ahead of time (before the previous layer's epilogue / barrier) so the
+// L2 latency of a GEMM's first loads does not sit on the critical path between two layers (measured: with weights served
+// from L1 the edge kernels run 10 % faster and the node kernel 24 %, all of it first-load latency).
+template <int FTW>
+__device__ __forceinline__ void load_w0(f32x4 (&a)[FTW], const float* __restrict__ Wp, int ft0, int lane) {
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)ft0 * 64 + lane;
+#pragma unroll
+  for (int ft = 0; ft < FTW; ++ft) a[ft] = wp[(size_t)ft * 64];
+}
+
+template <int FTW, int ET, int K, bool PRE>
+__device__ __forceinline__ void gemm_tile_impl(f32x4 (&acc)[FTW][ET], f32x4 (&a0)[FTW], const float* __restrict__ Wp, int FT,
+                                               int ft0, const float* X, int ldx, int lane) {
   static_assert(K % 16 == 0, "K must be a multiple of 16");
   const int c = lane & 15, q = lane >> 4;
   const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)ft0 * 64 + lane;
@@ -70,13 +75,19 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __
   constexpr int G = K / 16;
   // Explicit two-stage software pipeline: the loads of group g+1 are issued ahead of the whole MFMA block of group g
   // (pinned with sched_barriers; left alone hipcc sinks them to ~10 MFMAs before their use).  Measured (round 1):
-  // pinned == unpinned == a three-stage variant within 1 % -- the loop is not latency-bound.  What caps a lone wave
-  // at ~73 % of the MFMA rate in this loop is the issue cost of its 7 memory instructions per 48 MFMAs; a second
-  // wave on the SIMD fills those slots (micro-benchmark tools/ubench_gemm_tile.hip: 115 -> 140 TFLOP/s).
-  f32x4 a0[FTW], a1[FTW], b0[ET], b1[ET];
-  auto load_group = [&](f32x4(&a)[FTW], f32x4(&b)[ET], int g) {
+  // pinned == unpinned == a three-stage variant within 1 %.  What caps a lone wave at ~73 % of the MFMA rate in this
+  // loop is the issue cost of its 7 memory instructions per 48 MFMAs; a second wave on the SIMD fills those slots
+  // (micro-benchmark tools/ubench_gemm_tile.hip: 115 -> 140 TFLOP/s).
+  f32x4 a1[FTW], b0[ET], b1[ET];
+  auto load_a = [&](f32x4(&a)[FTW], int g) {
 #pragma unroll
+#ifdef MDX_ABL_WL1  // ablation: every group re-reads group 0 (weights stay in L1); results are wrong, timing only
+    for (int ft = 0; ft < FTW; ++ft) a[ft] = wp[((size_t)(g & 0) * FT + ft) * 64];
+#else
     for (int ft = 0; ft < FTW; ++ft) a[ft] = wp[((size_t)g * FT + ft) * 64];
+#endif
+  };
+  auto load_b = [&](f32x4(&b)[ET], int g) {
 #pragma unroll
     for (int et = 0; et < ET; ++et) b[et] = lds4(xb + et * 16 * ldx + g * 16);
   };
@@ -89,28 +100,81 @@ __device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __
         for (int et = 0; et < ET; ++et)
           acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ft][s], b[et][s], acc[ft][et], 0, 0, 0);
   };
-  load_group(a0, b0, 0);
+  if (!PRE) load_a(a0, 0);
+  load_b(b0, 0);
+#pragma unroll 1
+  for (int g = 0; g < G; g += 2) {
+    if (g + 1 < G) {
+      load_a(a1, g + 1);
+      load_b(b1, g + 1);
+    }
 #if MDX_GEMM_PINNED
-#pragma unroll 1
-  for (int g = 0; g < G; g += 2) {
-    if (g + 1 < G) load_group(a1, b1, g + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < G) load_group(a0, b0, g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 1 < G) mfma_group(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#else
-#pragma unroll 1
-  for (int g = 0; g < G; g += 2) {
-    if (g + 1 < G) load_group(a1, b1, g + 1);
-    mfma_group(a0, b0);
-    if (g + 2 < G) load_group(a0, b0, g + 2);
-    if (g + 1 < G) mfma_group(a1, b1);
-  }
 #endif
+    mfma_group(a0, b0);
+#if MDX_GEMM_PINNED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (g + 2 < G) {
+      load_a(a0, g + 2);
+      load_b(b0, g + 2);
+    }
+#if MDX_GEMM_PINNED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (g + 1 < G) mfma_group(a1, b1);
+#if MDX_GEMM_PINNED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// acc[ft][et] += W[16*(ft0+ft) .. +16][0..K) * X[16*et .. +16][0..K)^T
+//   Wp : packed weights, float4 index ((g*FT + ft)*64 + lane), g = k/16   (host: PackCtx::pack_dense)
+//   X  : LDS tile, row-major, leading dimension ldx (floats, multiple of 4)
+// gemm_tile_pre: same, with the group-0 weight fragments already in `a0` (load_w0); a0 is clobbered.
+// ----------------------------------------------------------------------------------------------
+template <int FTW, int ET, int K>
+__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[FTW][ET], const float* __restrict__ Wp, int FT, int ft0,
+                                          const float* X, int ldx, int lane) {
+  f32x4 a0[FTW];
+  gemm_tile_impl<FTW, ET, K, false>(acc, a0, Wp, FT, ft0, X, ldx, lane);
+}
+template <int FTW, int ET, int K>
+__device__ __forceinline__ void gemm_tile_pre(f32x4 (&acc)[FTW][ET], f32x4 (&a0)[FTW], const float* __restrict__ Wp, int FT,
+                                              int ft0, const float* X, int ldx, int lane) {
+  gemm_tile_impl<FTW, ET, K, true>(acc, a0, Wp, FT, ft0, X, ldx, lane);
+}
+
+// Small layers (FTW*K/16 <= ~20 fragments per wave): fetch the wave's whole weight slice into registers ahead of time
+// (e.g. before the tile's first barrier, so the L2 latency overlaps the tile load) and run the GEMM from LDS only.
+template <int FTW, int K>
+__device__ __forceinline__ void load_wfrag(f32x4 (&a)[K / 16][FTW], const float* __restrict__ Wp, int FT, int ft0, int lane) {
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + (size_t)ft0 * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < K / 16; ++g)
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft) a[g][ft] = wp[((size_t)g * FT + ft) * 64];
+}
+template <int FTW, int ET, int K>
+__device__ __forceinline__ void gemm_tile_reg(f32x4 (&acc)[FTW][ET], const f32x4 (&a)[K / 16][FTW], const float* X, int ldx,
+                                              int lane) {
+  const int c = lane & 15, q = lane >> 4;
+  const float* xb = X + c * ldx + 4 * q;
+#pragma unroll
+  for (int g = 0; g < K / 16; ++g) {
+    f32x4 b[ET];
+#pragma unroll
+    for (int et = 0; et < ET; ++et) b[et] = lds4(xb + et * 16 * ldx + g * 16);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+          acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][ft][s], b[et][s], acc[ft][et], 0, 0, 0);
+  }
 }
 
 template <int FTW, int ET>
