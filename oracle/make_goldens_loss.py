@@ -8,6 +8,9 @@ duration of the call by temporarily replacing the torch entry points it draws fr
   torch.rand_like      (log_sample_categorical, diffusion.py:80) -> committed u_node, then u_halfedge
 Only inputs and the resulting losses are saved (tests/golden/loss.npz); the oracle restatement
 (`moldiff_oracle.moldiff_loss`) is compared in the same run and the difference recorded in PINNING.json.
+The same call is then differentiated with the reference's own autograd: the gradient of `loss` wrt every trainable
+parameter is the golden for the training path (tests/golden/loss_grads.npz: the L2 norm of every gradient tensor and
+the full tensor where it has <= 256 elements), and autograd through the oracle is pinned against it.
 """
 import json
 import os
@@ -57,7 +60,7 @@ class pinned_randomness:
 def main():
     torch.set_num_threads(8)
     MolDiff, BondPredictor, G, TR, DF, CM = ref_shim.load()
-    out, pins = {}, {}
+    out, pins, grads_out = {}, {}, {}
     for nm, yml in (('full', 'configs/train/train_MolDiff.yml'), ('simple', 'configs/train/train_MolDiff_simple.yml')):
         cfg = ref_shim.load_yaml_cfg(yml)
         m = MolDiff(cfg.model, 8, 6).eval()
@@ -88,16 +91,32 @@ def main():
         eps_pos = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32))
         u_node = torch.from_numpy(g.random((N, 8)).astype(np.float32))
         u_half = torch.from_numpy(g.random((Eh, 6)).astype(np.float32))
-        with torch.no_grad(), pinned_randomness(t_half, eps_pos, [u_node, u_half]):
+        with pinned_randomness(t_half, eps_pos, [u_node, u_half]):
             ref = m.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
+        m.zero_grad()
+        ref['loss'].backward()          # the reference's own autograd: golden parameter gradients
+        ref_grads = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+        no_grad = [k for k, v in m.named_parameters() if v.requires_grad and v.grad is None]
+        print('trainable parameters the loss does not reach:', no_grad)
+        ref = {k: v.detach() for k, v in ref.items()}
         t = torch.cat([t_half, 1000 - t_half - 1])[:B]
         tabs = {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')},
                 'node': {k: P['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
                 'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
         cfgd = dict(num_timesteps=1000, num_blocks=6, cutoff=15)
-        with torch.no_grad():
-            orc = O.moldiff_loss(P, cfgd, tabs, node_type, node_pos, bn, half_type, hei, bh, B, t,
-                                 dict(eps_pos=eps_pos, u_node=u_node, u_halfedge=u_half))
+        Pg = {k: (v.clone().requires_grad_(True) if k in ref_grads else v) for k, v in P.items()}
+        orc = O.moldiff_loss(Pg, cfgd, tabs, node_type, node_pos, bn, half_type, hei, bh, B, t,
+                             dict(eps_pos=eps_pos, u_node=u_node, u_halfedge=u_half))
+        orc['loss'].backward()
+        gd = max(float((Pg[k].grad - g).abs().max()) for k, g in ref_grads.items())
+        gs = max(float(g.abs().max()) for g in ref_grads.values())
+        pins[f'get_loss_{nm}_param_grads'] = gd
+        print(nm, 'param grads: oracle-vs-reference max abs diff', gd, 'of max |g|', gs, 'over', len(ref_grads), 'tensors')
+        orc = {k: v.detach() for k, v in orc.items()}
+        for k, g in ref_grads.items():
+            grads_out[f'{nm}/norm/{k}'] = np.float64(g.double().norm())
+            if g.numel() <= 256:
+                grads_out[f'{nm}/full/{k}'] = g.numpy()
         for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
             d = abs(float(ref[k]) - float(orc[k]))
             pins[f'get_loss_{nm}_{k}'] = d
@@ -131,13 +150,28 @@ def main():
     t_half = torch.tensor([0, 311, 742])
     eps_pos = torch.from_numpy(g.standard_normal((N, 3)).astype(np.float32))
     u_node = torch.from_numpy(g.random((N, 8)).astype(np.float32))
-    with torch.no_grad(), pinned_randomness(t_half, eps_pos, [u_node]):
+    with pinned_randomness(t_half, eps_pos, [u_node]):
         ref = m.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
+    m.zero_grad()
+    ref['loss'].backward()
+    ref_grads = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+    print('trainable parameters the loss does not reach:', [k for k, v in m.named_parameters() if v.requires_grad and v.grad is None])
+    ref = {k: v.detach() for k, v in ref.items()}
     t = torch.cat([t_half, 1000 - t_half - 1])[:B]
     tabs = {'pos': {'alphas_bar': Pb['pos_transition.alphas_bar']}, 'node': {'q_mats': Pb['node_transition.q_mats']}}
-    with torch.no_grad():
-        orc = O.bondpred_loss(Pb, dict(num_timesteps=1000, num_blocks=8, cutoff=20), tabs, node_type, node_pos, bn, half_type,
-                              hei, bh, B, t, dict(eps_pos=eps_pos, u_node=u_node))
+    Pg = {k: (v.clone().requires_grad_(True) if k in ref_grads else v) for k, v in Pb.items()}
+    orc = O.bondpred_loss(Pg, dict(num_timesteps=1000, num_blocks=8, cutoff=20), tabs, node_type, node_pos, bn, half_type,
+                          hei, bh, B, t, dict(eps_pos=eps_pos, u_node=u_node))
+    orc['loss'].backward()
+    gd = max(float((Pg[k].grad - g).abs().max()) for k, g in ref_grads.items())
+    pins['get_loss_bondpred_param_grads'] = gd
+    print('bondpred param grads: oracle-vs-reference max abs diff', gd, 'over', len(ref_grads), 'tensors')
+    orc = {k: v.detach() for k, v in orc.items()}
+    for k, g in ref_grads.items():
+        grads_out[f'bond/norm/{k}'] = np.float64(g.double().norm())
+        if g.numel() <= 256:
+            grads_out[f'bond/full/{k}'] = g.numpy()
+    np.savez_compressed(os.path.join(OUT, 'loss_grads.npz'), **grads_out)
     for k in ('loss', 'loss_edge'):
         pins[f'get_loss_bondpred_{k}'] = abs(float(ref[k]) - float(orc[k]))
         print('bondpred', k, float(ref[k]), float(orc[k]))

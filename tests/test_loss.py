@@ -139,3 +139,36 @@ def test_gpu_bondpred_loss_matches_reference():
     assert set(got) == {'loss', 'loss_edge'} and not got['loss'].requires_grad
     assert abs(float(got['loss']) - want) <= RTOL * max(1.0, want), (float(got['loss']), want)
     assert float(got['loss_edge']) == float(got['loss'])
+
+
+# ---- parameter gradients of the loss (golden = the reference's own autograd; oracle/make_goldens_loss.py) ------------
+def _check_grads(prefix, P, loss):
+    z = U.gold('loss_grads.npz')
+    names = [k[len(prefix) + 6:] for k in z.files if k.startswith(prefix + '/norm/')]
+    assert len(names) > 500
+    Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    loss(Pg).backward()
+    gmax = max(float(z[f'{prefix}/norm/{k}']) for k in names)
+    for k in names:
+        g = Pg[k].grad
+        assert g is not None, k
+        want = float(z[f'{prefix}/norm/{k}'])
+        assert abs(float(g.double().norm()) - want) <= 2e-5 * max(want, 1e-3 * gmax), (k, float(g.double().norm()), want)
+        fk = f'{prefix}/full/{k}'
+        if fk in z.files:
+            w = torch.from_numpy(z[fk])
+            assert float((g - w).abs().max()) <= 2e-5 * max(float(w.abs().max()), 1e-3 * gmax), k
+
+
+@pytest.mark.parametrize('nm,kind', [('full', 'MolDiff'), ('simple', 'MolDiff_simple')])
+def test_oracle_loss_gradients_match_reference_autograd(nm, kind):
+    args, t, noise, _ = _case(nm)
+    P = U.params(U.moldiff(kind))
+    _check_grads(nm, P, lambda Pg: O.moldiff_loss(Pg, U.CFG, U.tables(Pg), *args, t, noise)['loss'])
+
+
+def test_oracle_bondpred_loss_gradients_match_reference_autograd():
+    args, t, noise, _ = _bond_case()
+    Pb = U.params(U.bondpred())
+    tabs = lambda P: {'pos': {'alphas_bar': P['pos_transition.alphas_bar']}, 'node': {'q_mats': P['node_transition.q_mats']}}
+    _check_grads('bond', Pb, lambda Pg: O.bondpred_loss(Pg, U.CFGB, tabs(Pg), *args, t, noise)['loss'])
