@@ -336,6 +336,7 @@ class _Sampler:
 
     def set_state(self, h_node, pos, h_halfedge, log_node, log_halfedge, frame=0):
         """Teacher-forcing hook for the parity tests."""
+        frame = self._frame(frame)
         self.node_traj[frame].copy_(h_node); self.pos_traj[frame].copy_(pos); self.halfedge_traj[frame].copy_(h_halfedge)
         self.log_node[0].copy_(log_node); self.log_half[0].copy_(log_halfedge)
         self.cur, self.lcur = frame, 0
