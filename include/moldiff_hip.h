@@ -156,6 +156,50 @@ int mdx_decode_output(mdx_graph_t g, const float* pred_node, int32_t Kn, const f
                       float* atom_pos, int32_t* n_atoms, int32_t* bond_type, float* bond_prob, int32_t* bond_index,
                       int32_t* n_bonds, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- layer-level operators of the training path (next-row) ---------------------------------
+ * The loss forward + backward of MolDiff.get_loss / BondPredictor.get_loss (models/model.py:128-201,
+ * models/bond_predictor.py:84-124 + torch.autograd) is composed from these forward/backward pairs, one layer at a
+ * time, by moldiff_amd/train_ops.py; activations stay in HBM between them.  All fp32, row-major, device pointers.
+ *
+ * sgemm_nt: C[M,N] (ldc) = A[M,K] (lda) * B[N,K]^T (ldb) + bias[N] (bias may be NULL).  nn.Linear forward (B = weight),
+ *   its data gradient (B = weight^T) and, with splits > 1 and `partial` = splits*M*N floats, its weight gradient
+ *   (A = dY^T, B = X^T, K = number of rows; partial sums are combined in a fixed order -> deterministic).
+ * transpose: out[Cn,R] (ldo) = in[R,Cn]^T (ldi).
+ * colreduce: out[N] = sum over M rows of X[M,N] (ld), times Y element-wise if Y != NULL (bias / LayerNorm parameter
+ *   gradients); ws = ceil(M/512)*N floats. */
+int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, int64_t M,
+                    int64_t N, int64_t K, int32_t splits, float* partial, void* stream);
+int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream);
+int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream);
+/* y = relu?(LayerNorm(x) * gamma + beta) over F <= 1024 features (nn.LayerNorm eps 1e-5, models/common.py MLP);
+ * stats (M,2) receives (mean, rstd) for the backward.  Backward: dx (M,F), dgamma (F), dbeta (F); ws =
+ * mdx_op_ln_relu_bwd_ws(M, F) bytes. */
+int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, float* y,
+                       float* stats, void* stream);
+int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
+                       int32_t F, int32_t relu, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F);
+/* element-wise pairs, op: 0 a+b, 1 a-b, 2 a*b, 3 a*sigmoid(b).  Backward writes da / db (either may be NULL). */
+int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream);
+int mdx_op_ew_bwd(int32_t op, const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream);
+/* y[i] = x[idx[i]] (rows of F floats) and its adjoint out[r] = sum_{j in [ptr[r],ptr[r+1])} src[order[j]]
+ * (torch_scatter.scatter_sum with `order` = stable argsort of the index; sequential per output -> deterministic). */
+int mdx_op_gather_rows(const float* x, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream);
+int mdx_op_segsum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, float* out, void* stream);
+/* rel = pos[l] - pos[r], dist = |rel| (models/graph.py:349-350); backward: g (E,3) = drel + ddist * rel / dist, the
+ * caller scatters +g to l and -g to r.  drel / ddist may be NULL. */
+int mdx_op_edge_geom_fwd(const float* pos, const int64_t* l, const int64_t* r, int64_t E, float* rel, float* dist, void* stream);
+int mdx_op_edge_geom_bwd(const float* rel, const float* dist, const float* drel, const float* ddist, int64_t E, float* g, void* stream);
+/* GaussianSmearing (models/common.py): out[e,k] = exp(coef[k] * (clamp(d[e], lo, hi) - off[k])^2) and d/dd. */
+int mdx_op_smear_fwd(const float* d, const float* off, const float* coef, int32_t G, float lo, float hi, int64_t E, float* out,
+                     void* stream);
+int mdx_op_smear_bwd(const float* d, const float* off, const float* coef, int32_t G, float lo, float hi, int64_t E, const float* gout,
+                     float* gd, void* stream);
+/* PosUpdate force (models/graph.py:393): out[e] = w[e] * rel[e] / d[e] / (d[e] + 1) and its three gradients. */
+int mdx_op_force_fwd(const float* w, const float* rel, const float* d, int64_t E, float* out, void* stream);
+int mdx_op_force_bwd(const float* w, const float* rel, const float* d, const float* g, int64_t E, float* gw, float* grel, float* gd,
+                     void* stream);
+
 /* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
  * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
  * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass).  read() drains pending events. */

@@ -23,6 +23,9 @@ EXPORTS = [
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
     'mdx_profile_enable', 'mdx_profile_read',
+    'mdx_op_sgemm_nt', 'mdx_op_transpose', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
+    'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
+    'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd',
 ]
 
 
@@ -76,6 +79,25 @@ def lib():
         L.mdx_device_count.argtypes = [POINTER(c_int)]
         L.mdx_profile_enable.argtypes = [c_int32]
         L.mdx_profile_read.argtypes = [c_int32, POINTER(c_int64), POINTER(ctypes.c_double)]
+        # layer-level training operators
+        L.mdx_op_sgemm_nt.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                      c_int32, c_void_p, c_void_p]
+        L.mdx_op_transpose.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]
+        L.mdx_op_colreduce.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_ln_relu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_ln_relu_bwd.argtypes = [c_void_p] * 5 + [c_int64, c_int32, c_int32] + [c_void_p] * 5
+        L.mdx_op_ln_relu_bwd_ws.restype = c_size_t
+        L.mdx_op_ln_relu_bwd_ws.argtypes = [c_int64, c_int32]
+        L.mdx_op_ew_fwd.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+        L.mdx_op_ew_bwd.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+        L.mdx_op_gather_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
+        L.mdx_op_segsum_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
+        L.mdx_op_edge_geom_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_edge_geom_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+        L.mdx_op_smear_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p]
+        L.mdx_op_smear_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_force_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+        L.mdx_op_force_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         _lib = L
     return _lib
 

@@ -23,6 +23,7 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+int mdx_set_error(int code, const char* msg) { return fail(code, "%s", msg); }  // for the other translation units
 #define HIPCHK(x)                                                                           \
   do {                                                                                      \
     hipError_t e_ = (x);                                                                    \

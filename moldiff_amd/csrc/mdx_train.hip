@@ -1,0 +1,551 @@
+// Layer-level operators of the training path (gfx950): every O(rows x features) piece of the loss forward/backward
+// (reference models/model.py:128-201 get_loss + torch.autograd) as an explicit forward/backward kernel pair, driven
+// one layer at a time from moldiff_amd/train_ops.py.  Unlike the sampling path these are NOT fused across layers:
+// activations live in HBM between operators (288 GB makes that a non-issue) so that every parameter gradient is a
+// plain contraction over stored tensors.  All arithmetic is fp32; contractions run on v_mfma_f32_16x16x4_f32.
+//
+//   sgemm_nt      C[M,N] = A[M,K] B[N,K]^T (+ bias)     forward of nn.Linear, dgrad (B = W^T), wgrad (split-K over rows)
+//   transpose     out[C,R] = in[R,C]^T                   operand preparation for dgrad / wgrad
+//   colreduce     out[N] = sum_rows X (* Y)              bias / LayerNorm-parameter gradients (two deterministic stages)
+//   ln_relu       y = relu(LN(x) * gamma + beta)         forward (saves mean, rstd) and backward (dx, dgamma, dbeta)
+//   ew            add / sub / mul / a*sigmoid(b)         forward and backward
+//   gather/segsum y = x[idx] ; out[r] = sum_{j in seg r} src[order[j]]   (each is the other's backward; no atomics)
+//   edge_geom, smear, force                              rel/dist of an edge, Gaussian smearing, w*rel/d/(d+1) + backwards
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/moldiff_hip.h"
+#include "mdx_tile.h"
+
+int mdx_set_error(int code, const char* msg);  // mdx_api.hip
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// SGEMM  C = A B^T: workgroup tile 128 rows x 64 features, K consumed in chunks of 32 through LDS; wave w owns rows
+// 32w..32w+31 (2 row tiles) x all 64 features (4 feature tiles) -> acc[4][2].  Operand roles follow gemm_tile: the
+// MFMA A-operand is the B matrix (features), the B-operand the A matrix (rows), so acc[ft][et][r] =
+// C[row 16 et + c][feature 16 ft + 4 q + r] and stores are 16-byte vectors along the feature axis.
+// gridDim.z > 1 = split-K: split z handles k in [z*kper, (z+1)*kper) and writes its partial to P[z][M][N].
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int G_TM = 128, G_TN = 64, G_KC = 32, G_LD = G_KC + 8;
+
+__device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ p, int k, int K, bool row_ok, bool vec_ok) {
+  // 4 consecutive k-values of one row, zero beyond K or outside the matrix
+  if (!row_ok || k >= K) return splat4(0.f);
+  if (vec_ok && k + 3 < K) return ldg4(p + k);
+  f32x4 v = splat4(0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k + j < K) v[j] = p[k + j];
+  return v;
+}
+
+__global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        const float* __restrict__ bias, float* __restrict__ C, int ldc, int M,
+                                                        int N, int K, int kper, float* __restrict__ P) {
+  __shared__ __attribute__((aligned(16))) float As[G_TM * G_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[G_TN * G_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * G_TN;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
+  const bool veca = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  f32x4 acc[4][2];
+  acc_zero<4, 2>(acc);
+  for (int k0 = kbeg; k0 < kend; k0 += G_KC) {
+    // stage the two tiles (8 float4 per row): A 128 rows -> 4 slots per thread, B 64 rows -> 2 slots per thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 3, k4 = (slot & 7) * 4;
+      const int gm = m0 + row;
+      sts4(As + row * G_LD + k4, load4_guard(A + (size_t)gm * lda, k0 + k4, kend, gm < M, veca));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 3, k4 = (slot & 7) * 4;
+      const int gn = n0 + row;
+      sts4(Bs + row * G_LD + k4, load4_guard(B + (size_t)gn * ldb, k0 + k4, kend, gn < N, vecb));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G_KC / 16; ++g) {
+      f32x4 a[4], b[2];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) a[ft] = lds4(Bs + (16 * ft + c) * G_LD + 16 * g + 4 * q);
+#pragma unroll
+      for (int et = 0; et < 2; ++et) b[et] = lds4(As + (32 * wave + 16 * et + c) * G_LD + 16 * g + 4 * q);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+          for (int et = 0; et < 2; ++et)
+            acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ft][s], b[et][s], acc[ft][et], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* out = P ? P + (size_t)blockIdx.z * M * N : C;
+  const int ldo = P ? N : ldc;
+  const bool veco = ((ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    const int col = n0 + 16 * ft + 4 * q;
+    f32x4 bv = splat4(0.f);
+    if (bias && !P) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col + r < N) bv[r] = bias[col + r];
+    }
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+      const int row = m0 + 32 * wave + 16 * et + c;
+      if (row >= M || col >= N) continue;
+      const f32x4 v = acc[ft][et] + bv;
+      float* o = out + (size_t)row * ldo + col;
+      if (veco && col + 3 < N) {
+        stg4(o, v);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < N) o[r] = v[r];
+      }
+    }
+  }
+}
+
+// C[i][j] = bias[j] + sum_z P[z][i][j]   (fixed order -> deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ P, int S, int M, int N, const float* __restrict__ bias,
+                                       float* __restrict__ C, int ldc) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int row = (int)(i / N), col = (int)(i % N);
+  float s = bias ? bias[col] : 0.f;
+  for (int z = 0; z < S; ++z) s += P[(size_t)z * M * N + i];
+  C[(size_t)row * ldc + col] = s;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, int ldi, int R, int Cn, float* __restrict__ out, int ldo) {
+  __shared__ float t[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, cc = c0 + tx;
+    t[j][tx] = (r < R && cc < Cn) ? in[(size_t)r * ldi + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int cc = c0 + j, r = r0 + tx;
+    if (cc < Cn && r < R) out[(size_t)cc * ldo + r] = t[tx][j];
+  }
+}
+
+// stage kernel of the column reduction: block b sums rows [b*rows_per, ...) of X (* Y) for every column
+__global__ void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y, int ld, int M, int N, int rows_per,
+                                 float* __restrict__ out /* [gridDim.x][N] */) {
+  const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  for (int col = threadIdx.x; col < N; col += blockDim.x) {
+    float s = 0.f;
+    if (Y) {
+      for (int r = r0; r < r1; ++r) s = fmaf(X[(size_t)r * ld + col], Y[(size_t)r * ld + col], s);
+    } else {
+      for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + col];
+    }
+    out[(size_t)blockIdx.x * N + col] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm (+ReLU), one wave per row, F <= 1024.  Lane holds features lane, lane+64, ...
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXJ = 16;
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ln_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int M, int F, int relu,
+                                                           float* __restrict__ y, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int J = (F + 63) >> 6;
+  float v[LN_MAXJ];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    v[j] = (j < J && f < F) ? x[(size_t)row * F + f] : 0.f;
+    s += v[j];
+  }
+  const float mean = wave_sum(s) / (float)F;
+  float d2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    if (j < J && f < F) {
+      const float d = v[j] - mean;
+      d2 = fmaf(d, d, d2);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(d2) / (float)F + MDX_LN_EPS);
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    if (j < J && f < F) {
+      const float o = (v[j] - mean) * rstd * gamma[f] + beta[f];
+      y[(size_t)row * F + f] = relu ? fmaxf(o, 0.f) : o;
+    }
+  }
+  if (lane == 0) {
+    stats[2 * (size_t)row] = mean;
+    stats[2 * (size_t)row + 1] = rstd;
+  }
+}
+
+// each wave walks `rows_per` consecutive rows: dx per row, and its own partial of dgamma / dbeta (registers) which it
+// writes to part[wave_global][2F] (dgamma first); the caller column-reduces `part`.
+__global__ __launch_bounds__(256) void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int M, int F, int relu, int rows_per,
+                                                           float* __restrict__ dx, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r0 = wg * rows_per, r1 = min(M, r0 + rows_per);
+  const int J = (F + 63) >> 6;
+  float gm[LN_MAXJ], bt[LN_MAXJ], dg[LN_MAXJ], db[LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    const bool ok = j < J && f < F;
+    gm[j] = ok ? gamma[f] : 0.f;
+    bt[j] = ok ? beta[f] : 0.f;
+    dg[j] = db[j] = 0.f;
+  }
+  for (int row = r0; row < r1; ++row) {
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    float xh[LN_MAXJ], gh[LN_MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      xh[j] = gh[j] = 0.f;
+      if (j < J && f < F) {
+        xh[j] = (x[(size_t)row * F + f] - mean) * rstd;
+        float g = dy[(size_t)row * F + f];
+        if (relu && !(xh[j] * gm[j] + bt[j] > 0.f)) g = 0.f;
+        dg[j] = fmaf(g, xh[j], dg[j]);
+        db[j] += g;
+        gh[j] = g * gm[j];
+        s1 += gh[j];
+        s2 = fmaf(gh[j], xh[j], s2);
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)F, m2 = wave_sum(s2) / (float)F;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+      const int f = lane + 64 * j;
+      if (j < J && f < F) dx[(size_t)row * F + f] = rstd * (gh[j] - m1 - xh[j] * m2);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < LN_MAXJ; ++j) {
+    const int f = lane + 64 * j;
+    if (j < J && f < F) {
+      part[(size_t)wg * 2 * F + f] = dg[j];
+      part[(size_t)wg * 2 * F + F + f] = db[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// element-wise pairs.  op: 0 add, 1 sub, 2 mul, 3 gate (a * sigmoid(b))
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void ew_fwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = a[i], y = b[i];
+  float r;
+  switch (op) {
+    case 0: r = x + y; break;
+    case 1: r = x - y; break;
+    case 2: r = x * y; break;
+    default: r = x * sigmoidf_(y); break;
+  }
+  o[i] = r;
+}
+__global__ void ew_bwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                              float* __restrict__ da, float* __restrict__ db, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float go = g[i];
+  float ga, gb;
+  switch (op) {
+    case 0: ga = go; gb = go; break;
+    case 1: ga = go; gb = -go; break;
+    case 2: ga = go * b[i]; gb = go * a[i]; break;
+    default: {
+      const float s = sigmoidf_(b[i]);
+      ga = go * s;
+      gb = go * a[i] * s * (1.0f - s);
+    }
+  }
+  if (da) da[i] = ga;
+  if (db) db[i] = gb;
+}
+
+// y[i] = x[idx[i]]  (rows of F floats)
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t M, int F,
+                                   float* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * F) return;
+  const int64_t row = i / F;
+  const int f = (int)(i % F);
+  y[i] = x[(size_t)idx[row] * F + f];
+}
+// out[r] = sum_{j in [ptr[r], ptr[r+1])} src[order[j]]   (sequential per element: bitwise deterministic)
+__global__ void segsum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
+                                   int64_t R, int F, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * F) return;
+  const int64_t r = i / F;
+  const int f = (int)(i % F);
+  float s = 0.f;
+  for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) s += src[(size_t)order[j] * F + f];
+  out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// edge geometry / smearing / force (reference models/graph.py:349-352, common.py GaussianSmearing, graph.py:391-394)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void edge_geom_fwd_kernel(const float* __restrict__ pos, const int64_t* __restrict__ l, const int64_t* __restrict__ r,
+                                     int64_t E, float* __restrict__ rel, float* __restrict__ dist) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t a = l[e], b = r[e];
+  const float dx = pos[3 * a] - pos[3 * b], dy = pos[3 * a + 1] - pos[3 * b + 1], dz = pos[3 * a + 2] - pos[3 * b + 2];
+  rel[3 * e] = dx; rel[3 * e + 1] = dy; rel[3 * e + 2] = dz;
+  dist[e] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+// g[e] = drel[e] + ddist[e] * rel[e] / dist[e]   (d|v|/dv = v/|v|; the reference's torch.norm has the 0/0 -> nan there too)
+__global__ void edge_geom_bwd_kernel(const float* __restrict__ rel, const float* __restrict__ dist, const float* __restrict__ drel,
+                                     const float* __restrict__ ddist, int64_t E, float* __restrict__ g) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float k = ddist ? ddist[e] / dist[e] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) g[3 * e + j] = (drel ? drel[3 * e + j] : 0.f) + k * rel[3 * e + j];
+}
+__global__ void smear_fwd_kernel(const float* __restrict__ d, const float* __restrict__ off, const float* __restrict__ coef, int G,
+                                 float lo, float hi, int64_t E, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)E * G) return;
+  const int64_t e = i / G;
+  const int k = (int)(i % G);
+  const float u = fminf(fmaxf(d[e], lo), hi) - off[k];
+  out[i] = expf(coef[k] * (u * u));
+}
+__global__ void smear_bwd_kernel(const float* __restrict__ d, const float* __restrict__ off, const float* __restrict__ coef, int G,
+                                 float lo, float hi, int64_t E, const float* __restrict__ gout, float* __restrict__ gd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float dv = d[e];
+  float s = 0.f;
+  if (dv >= lo && dv <= hi) {  // clamp passes the gradient on the closed interval (torch.clamp semantics)
+    for (int k = 0; k < G; ++k) {
+      const float u = dv - off[k];
+      s += gout[(size_t)e * G + k] * expf(coef[k] * (u * u)) * 2.0f * coef[k] * u;
+    }
+  }
+  gd[e] = s;
+}
+// F = w * rel / d / (d + 1)
+__global__ void force_fwd_kernel(const float* __restrict__ w, const float* __restrict__ rel, const float* __restrict__ d, int64_t E,
+                                 float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float dv = d[e], dp = dv + 1.0f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) out[3 * e + j] = w[e] * rel[3 * e + j] / dv / dp;
+}
+__global__ void force_bwd_kernel(const float* __restrict__ w, const float* __restrict__ rel, const float* __restrict__ d,
+                                 const float* __restrict__ g, int64_t E, float* __restrict__ gw, float* __restrict__ grel,
+                                 float* __restrict__ gd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float dv = d[e], dp = dv + 1.0f, wv = w[e];
+  const float inv = 1.0f / (dv * dp);
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    dot = fmaf(g[3 * e + j], rel[3 * e + j], dot);
+    grel[3 * e + j] = g[3 * e + j] * wv * inv;
+  }
+  gw[e] = dot * inv;
+  // d/dd [1/(d (d+1))] = -(2d + 1) / (d (d+1))^2
+  gd[e] = -wv * dot * (2.0f * dv + 1.0f) * inv * inv;
+}
+
+inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+inline int bad(const char* m) { return mdx_set_error(MDX_ERR_ARG, m); }
+inline int launched() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, hipGetErrorString(e));
+}
+
+}  // namespace
+
+extern "C" int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
+  if (M <= 0 || N <= 0) return MDX_OK;
+  if (!A || !B || !C || K < 0) return bad("sgemm_nt: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  if (splits <= 1) {
+    dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), 1);
+    hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, C, (int)ldc, (int)M, (int)N, (int)K,
+                       (int)((K + G_KC - 1) / G_KC * G_KC), (float*)nullptr);
+    return launched();
+  }
+  if (!partial) return bad("sgemm_nt: split-K needs a partial buffer of splits*M*N floats");
+  int kper = (int)((K + splits - 1) / splits);
+  kper = (kper + G_KC - 1) / G_KC * G_KC;
+  const int S = (int)((K + kper - 1) / kper);
+  dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), (unsigned)S);
+  hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, (const float*)nullptr, C, (int)ldc, (int)M,
+                     (int)N, (int)K, kper, partial);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)M * N)), dim3(256), 0, s, partial, S, (int)M, (int)N, bias, C, (int)ldc);
+  return launched();
+}
+
+extern "C" int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream) {
+  if (R <= 0 || Cn <= 0) return MDX_OK;
+  if (!in || !out) return bad("transpose: null operand");
+  dim3 grid((unsigned)((Cn + 31) / 32), (unsigned)((R + 31) / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (int)ldi, (int)R, (int)Cn, out, (int)ldo);
+  return launched();
+}
+
+// out[N] = sum over the M rows of X (element-wise times Y when Y != NULL).  ws: ceil(M/512)*N floats.
+extern "C" int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream) {
+  if (N <= 0) return MDX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0) return hipMemsetAsync(out, 0, (size_t)N * 4, s) == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "memset");
+  const int RP = 512;
+  const int nb = (int)((M + RP - 1) / RP);
+  if (nb == 1) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, X, Y, (int)ld, (int)M, (int)N, RP, out);
+    return launched();
+  }
+  if (!ws) return bad("colreduce: workspace of ceil(M/512)*N floats required");
+  hipLaunchKernelGGL(colreduce_kernel, dim3(nb), dim3(256), 0, s, X, Y, (int)ld, (int)M, (int)N, RP, ws);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (const float*)nullptr, (int)N, nb, (int)N, nb, out);
+  return launched();
+}
+
+extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, float* y,
+                                  float* stats, void* stream) {
+  if (M <= 0) return MDX_OK;
+  if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
+  hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (int)M, F,
+                     relu, y, stats);
+  return launched();
+}
+
+// dx (M,F); dgamma, dbeta (F).  ws: (ceil(M/64) + ceil(ceil(M/64)/512)) * 2F floats.
+extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
+                                  int32_t F, int32_t relu, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
+  if (M <= 0) {
+    hipMemsetAsync(dgamma, 0, (size_t)F * 4, s);
+    hipMemsetAsync(dbeta, 0, (size_t)F * 4, s);
+    return MDX_OK;
+  }
+  if (!ws) return bad("ln_relu_bwd: workspace required");
+  const int RPW = 64;
+  const int nw = (int)((M + RPW - 1) / RPW);     // waves
+  const int nwp = (nw + 3) / 4 * 4;              // rows of `part` actually written (whole workgroups)
+  float* part = ws;
+  float* ws2 = ws + (size_t)nwp * 2 * F;
+  hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, F, relu, RPW, dx,
+                     part);
+  // column-reduce part (nwp x 2F) into [dgamma | dbeta]
+  const int RP = 512;
+  const int nb = (nwp + RP - 1) / RP;
+  float* red = nb == 1 ? nullptr : ws2;
+  float* tmp = ws2 + (size_t)nb * 2 * F;  // final 2F row
+  if (nb == 1) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, tmp);
+  } else {
+    hipLaunchKernelGGL(colreduce_kernel, dim3(nb), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, red);
+    hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, (const float*)red, (const float*)nullptr, 2 * F, nb, 2 * F, nb, tmp);
+  }
+  hipMemcpyAsync(dgamma, tmp, (size_t)F * 4, hipMemcpyDeviceToDevice, s);
+  hipMemcpyAsync(dbeta, tmp + F, (size_t)F * 4, hipMemcpyDeviceToDevice, s);
+  return launched();
+}
+extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
+  const int64_t nw = (M + 63) / 64, nwp = (nw + 3) / 4 * 4, nb = (nwp + 511) / 512;
+  return (size_t)(nwp + nb + 1) * 2 * F * sizeof(float);
+}
+
+extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (op < 0 || op > 3) return bad("ew: unknown op");
+  hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, (size_t)n);
+  return launched();
+}
+extern "C" int mdx_op_ew_bwd(int32_t op, const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (op < 0 || op > 3) return bad("ew: unknown op");
+  hipLaunchKernelGGL(ew_bwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, g, da, db, (size_t)n);
+  return launched();
+}
+extern "C" int mdx_op_gather_rows(const float* x, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
+  if (M <= 0 || F <= 0) return MDX_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)M * F)), dim3(256), 0, (hipStream_t)stream, x, idx, M, F, y);
+  return launched();
+}
+extern "C" int mdx_op_segsum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, float* out,
+                                  void* stream) {
+  if (R <= 0 || F <= 0) return MDX_OK;
+  hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, src, order, ptr, R, F, out);
+  return launched();
+}
+extern "C" int mdx_op_edge_geom_fwd(const float* pos, const int64_t* l, const int64_t* r, int64_t E, float* rel, float* dist, void* stream) {
+  if (E <= 0) return MDX_OK;
+  hipLaunchKernelGGL(edge_geom_fwd_kernel, dim3(nblk((size_t)E)), dim3(256), 0, (hipStream_t)stream, pos, l, r, E, rel, dist);
+  return launched();
+}
+extern "C" int mdx_op_edge_geom_bwd(const float* rel, const float* dist, const float* drel, const float* ddist, int64_t E, float* g,
+                                    void* stream) {
+  if (E <= 0) return MDX_OK;
+  hipLaunchKernelGGL(edge_geom_bwd_kernel, dim3(nblk((size_t)E)), dim3(256), 0, (hipStream_t)stream, rel, dist, drel, ddist, E, g);
+  return launched();
+}
+extern "C" int mdx_op_smear_fwd(const float* d, const float* off, const float* coef, int32_t G, float lo, float hi, int64_t E, float* out,
+                                void* stream) {
+  if (E <= 0) return MDX_OK;
+  hipLaunchKernelGGL(smear_fwd_kernel, dim3(nblk((size_t)E * G)), dim3(256), 0, (hipStream_t)stream, d, off, coef, G, lo, hi, E, out);
+  return launched();
+}
+extern "C" int mdx_op_smear_bwd(const float* d, const float* off, const float* coef, int32_t G, float lo, float hi, int64_t E,
+                                const float* gout, float* gd, void* stream) {
+  if (E <= 0) return MDX_OK;
+  hipLaunchKernelGGL(smear_bwd_kernel, dim3(nblk((size_t)E)), dim3(256), 0, (hipStream_t)stream, d, off, coef, G, lo, hi, E, gout, gd);
+  return launched();
+}
+extern "C" int mdx_op_force_fwd(const float* w, const float* rel, const float* d, int64_t E, float* out, void* stream) {
+  if (E <= 0) return MDX_OK;
+  hipLaunchKernelGGL(force_fwd_kernel, dim3(nblk((size_t)E)), dim3(256), 0, (hipStream_t)stream, w, rel, d, E, out);
+  return launched();
+}
+extern "C" int mdx_op_force_bwd(const float* w, const float* rel, const float* d, const float* g, int64_t E, float* gw, float* grel,
+                                float* gd, void* stream) {
+  if (E <= 0) return MDX_OK;
+  hipLaunchKernelGGL(force_bwd_kernel, dim3(nblk((size_t)E)), dim3(256), 0, (hipStream_t)stream, w, rel, d, g, E, gw, grel, gd);
+  return launched();
+}

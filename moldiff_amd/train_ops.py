@@ -1,0 +1,292 @@
+"""Differentiable layer operators of the training path: ``torch.autograd.Function`` shells around the HIP forward /
+backward kernels of ``csrc/mdx_train.hip`` (C-ABI ``mdx_op_*``).
+
+torch is the graph engine and the allocator here (it records which operator produced which tensor and calls the
+backward entry points in reverse order); every O(rows x features) computation -- Linear forward, data and weight
+gradients (MFMA SGEMM), LayerNorm(+ReLU), gates, gathers / segmented sums, edge geometry -- runs in the library.  There
+is no CPU fallback: CPU tensors raise.  Replaces, for training, ``torch.nn.functional.linear / layer_norm / relu``,
+``torch_scatter.scatter_sum`` and index_select as used by the reference's models/graph.py and models/common.py.
+"""
+import torch
+
+from . import _lib
+from ._lib import ptr, stream, check
+
+ADD, SUB, MUL, GATE = 0, 1, 2, 3
+
+
+def _L():
+    return _lib.lib()
+
+
+def _c(t):
+    _lib._need_gpu(t)
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def sgemm_nt(a, b, bias=None, splits=1):
+    """a (M,K) @ b (N,K)^T + bias -> (M,N)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    part = torch.empty(splits * M * N, dtype=torch.float32, device=a.device) if splits > 1 else None
+    check(_L().mdx_op_sgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(out), N, M, N, K, splits, ptr(part), stream()))
+    return out
+
+
+def transpose(x, pad=4):
+    """(R,C) -> contiguous-rows (C,R) view whose leading dimension is padded to a multiple of `pad` floats (so that the
+    SGEMM's 16-byte loads stay aligned for any R)."""
+    R, C = x.shape
+    ld = (R + pad - 1) // pad * pad
+    buf = torch.empty(C, ld, dtype=torch.float32, device=x.device)
+    check(_L().mdx_op_transpose(ptr(x), x.stride(0), R, C, ptr(buf), ld, stream()))
+    return buf[:, :R]
+
+
+def colreduce(x, y=None):
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = torch.empty(((M + 511) // 512) * N, dtype=torch.float32, device=x.device) if M > 512 else None
+    check(_L().mdx_op_colreduce(ptr(x), ptr(y), x.stride(0), M, N, ptr(out), ptr(ws), stream()))
+    return out
+
+
+def _splits_for(rows):
+    # weight gradient = contraction over `rows`: enough K-splits to fill the chip, each at least 2048 rows long
+    return max(1, min(256, rows // 2048))
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xc, wc = _c(x), _c(w)
+        ctx.save_for_backward(xc, wc)
+        ctx.has_bias = b is not None
+        return sgemm_nt(xc, wc, _c(b) if b is not None else None)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _c(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = sgemm_nt(gy, transpose(w))                       # (M,N) @ (K,N)^T
+        if ctx.needs_input_grad[1]:
+            gw = sgemm_nt(transpose(gy), transpose(x), splits=_splits_for(x.shape[0]))   # (N,M) @ (K,M)^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = colreduce(gy)
+        return gx, gw, gb
+
+
+def linear(x, w, b=None):
+    """y = x @ w.T + b for 2-D x (rows, in_features)."""
+    return _Linear.apply(x, w, b)
+
+
+class _LnRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu):
+        xc, g, b = _c(x), _c(gamma), _c(beta)
+        M, F = xc.shape
+        y = torch.empty_like(xc)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=xc.device)
+        check(_L().mdx_op_ln_relu_fwd(ptr(xc), ptr(g), ptr(b), M, F, int(relu), ptr(y), ptr(stats), stream()))
+        ctx.save_for_backward(xc, g, b, stats)
+        ctx.relu = int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g, b, stats = ctx.saved_tensors
+        gy = _c(gy)
+        M, F = x.shape
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(g), torch.empty_like(b)
+        ws = torch.empty(_L().mdx_op_ln_relu_bwd_ws(M, F) // 4 + 1, dtype=torch.float32, device=x.device)
+        check(_L().mdx_op_ln_relu_bwd(ptr(gy), ptr(x), ptr(stats), ptr(g), ptr(b), M, F, ctx.relu, ptr(dx), ptr(dg), ptr(db), ptr(ws),
+                                      stream()))
+        return dx, dg, db, None
+
+
+def ln_relu(x, gamma, beta, relu=True):
+    return _LnRelu.apply(x, gamma, beta, relu)
+
+
+class _Ew(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, a, b):
+        ac, bc = _c(a), _c(b)
+        assert ac.shape == bc.shape, (ac.shape, bc.shape)
+        out = torch.empty_like(ac)
+        check(_L().mdx_op_ew_fwd(op, ptr(ac), ptr(bc), ptr(out), ac.numel(), stream()))
+        ctx.op = op
+        ctx.save_for_backward(ac, bc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _c(g)
+        da = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+        check(_L().mdx_op_ew_bwd(ctx.op, ptr(a), ptr(b), ptr(g), ptr(da), ptr(db), a.numel(), stream()))
+        return None, da, db
+
+
+def add(a, b):
+    return _Ew.apply(ADD, a, b)
+
+
+def sub(a, b):
+    return _Ew.apply(SUB, a, b)
+
+
+def mul(a, b):
+    return _Ew.apply(MUL, a, b)
+
+
+def gate(a, b):
+    """a * sigmoid(b)"""
+    return _Ew.apply(GATE, a, b)
+
+
+class IndexPlan:
+    """An index vector (rows -> targets in [0, n)) with the CSR needed to sum rows per target without atomics:
+    `order` = stable argsort, `ptr` = segment starts.  Built once per batch (index bookkeeping, not arithmetic)."""
+
+    def __init__(self, index, n):
+        _lib._need_gpu(index)
+        self.index = index.detach().to(torch.int64).contiguous()
+        self.n = int(n)
+        self.order = torch.sort(self.index, stable=True).indices.contiguous()
+        counts = torch.bincount(self.index, minlength=self.n)
+        self.ptr = torch.zeros(self.n + 1, dtype=torch.int64, device=index.device)
+        self.ptr[1:] = torch.cumsum(counts, 0)
+
+
+def _gather_raw(x, plan):
+    M, F = plan.index.numel(), x.shape[1]
+    y = torch.empty(M, F, dtype=torch.float32, device=x.device)
+    check(_L().mdx_op_gather_rows(ptr(x), ptr(plan.index), M, F, ptr(y), stream()))
+    return y
+
+
+def _segsum_raw(src, plan):
+    F = src.shape[1]
+    out = torch.empty(plan.n, F, dtype=torch.float32, device=src.device)
+    check(_L().mdx_op_segsum_rows(ptr(src), ptr(plan.order), ptr(plan.ptr), plan.n, F, ptr(out), stream()))
+    return out
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        return _gather_raw(_c(x), plan)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _segsum_raw(_c(g), ctx.plan), None
+
+
+class _SegSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, plan):
+        ctx.plan = plan
+        return _segsum_raw(_c(src), plan)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _gather_raw(_c(g), ctx.plan), None
+
+
+def gather(x, plan):
+    """x[plan.index] for 2-D x."""
+    return _Gather.apply(x, plan)
+
+
+def scatter_sum(src, plan):
+    """torch_scatter.scatter_sum(src, plan.index, dim=0, dim_size=plan.n)."""
+    return _SegSum.apply(src, plan)
+
+
+class _EdgeGeom(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, pl, pr):
+        p = _c(pos)
+        E = pl.index.numel()
+        rel = torch.empty(E, 3, dtype=torch.float32, device=p.device)
+        dist = torch.empty(E, dtype=torch.float32, device=p.device)
+        check(_L().mdx_op_edge_geom_fwd(ptr(p), ptr(pl.index), ptr(pr.index), E, ptr(rel), ptr(dist), stream()))
+        ctx.pl, ctx.pr = pl, pr
+        ctx.save_for_backward(rel, dist)
+        return rel, dist
+
+    @staticmethod
+    def backward(ctx, grel, gdist):
+        rel, dist = ctx.saved_tensors
+        E = rel.shape[0]
+        g = torch.empty_like(rel)
+        check(_L().mdx_op_edge_geom_bwd(ptr(rel), ptr(dist), ptr(_c(grel) if grel is not None else None),
+                                        ptr(_c(gdist) if gdist is not None else None), E, ptr(g), stream()))
+        gl, gr = _segsum_raw(g, ctx.pl), _segsum_raw(g, ctx.pr)
+        out = torch.empty_like(gl)
+        check(_L().mdx_op_ew_fwd(SUB, ptr(gl), ptr(gr), ptr(out), gl.numel(), stream()))
+        return out, None, None
+
+
+def edge_geom(pos, plan_left, plan_right):
+    """rel = pos[left] - pos[right] (E,3), dist = |rel| (E,)."""
+    return _EdgeGeom.apply(pos, plan_left, plan_right)
+
+
+class _Smear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dist, offset, coeff, lo, hi):
+        d, off, co = _c(dist), _c(offset), _c(coeff)
+        E, G = d.numel(), off.numel()
+        out = torch.empty(E, G, dtype=torch.float32, device=d.device)
+        check(_L().mdx_op_smear_fwd(ptr(d), ptr(off), ptr(co), G, float(lo), float(hi), E, ptr(out), stream()))
+        ctx.save_for_backward(d, off, co)
+        ctx.lohi = (float(lo), float(hi))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, off, co = ctx.saved_tensors
+        gd = torch.empty_like(d)
+        check(_L().mdx_op_smear_bwd(ptr(d), ptr(off), ptr(co), off.numel(), ctx.lohi[0], ctx.lohi[1], d.numel(), ptr(_c(g)), ptr(gd),
+                                    stream()))
+        return gd, None, None, None, None
+
+
+def smear(dist, offset, coeff, lo, hi):
+    """GaussianSmearing with per-gaussian coefficients: exp(coeff_k (clamp(d, lo, hi) - offset_k)^2)."""
+    return _Smear.apply(dist, offset, coeff, lo, hi)
+
+
+class _Force(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, rel, dist):
+        wc, rc, dc = _c(w).reshape(-1), _c(rel), _c(dist)
+        out = torch.empty_like(rc)
+        check(_L().mdx_op_force_fwd(ptr(wc), ptr(rc), ptr(dc), dc.numel(), ptr(out), stream()))
+        ctx.save_for_backward(wc, rc, dc)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, rel, d = ctx.saved_tensors
+        gw, grel, gd = torch.empty_like(w), torch.empty_like(rel), torch.empty_like(d)
+        check(_L().mdx_op_force_bwd(ptr(w), ptr(rel), ptr(d), ptr(_c(g)), d.numel(), ptr(gw), ptr(grel), ptr(gd), stream()))
+        return gw.reshape(ctx.wshape), grel, gd
+
+
+def force(w, rel, dist):
+    """w * rel / dist / (dist + 1) per edge (PosUpdate, models/graph.py:393)."""
+    return _Force.apply(w, rel, dist)

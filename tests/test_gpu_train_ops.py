@@ -1,0 +1,130 @@
+"""Each layer operator of the training path (csrc/mdx_train.hip via moldiff_amd/train_ops.py) against the torch op it
+replaces: forward values and every gradient, on awkward shapes (K, N not multiples of 4/16, ragged segments, empty
+segments).  fp32; tolerances relative to the magnitude of the quantity compared."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util as U
+from moldiff_amd import train_ops as T
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def _leaf(g, *shape, scale=1.0):
+    return (U.t32(g.standard_normal(shape)) * scale).to(DEV).requires_grad_(True)
+
+
+@pytest.mark.parametrize('M,K,N', [(1, 8, 246), (37, 321, 256), (1000, 64, 64), (5003, 129, 32), (4097, 80, 64), (300, 256, 1),
+                                   (513, 6, 54), (20000, 256, 256)])
+def test_linear_forward_and_all_gradients(M, K, N):
+    g = U.rng(M + K + N)
+    x, w, b = _leaf(g, M, K), _leaf(g, N, K, scale=K ** -0.5), _leaf(g, N)
+    gy = U.t32(g.standard_normal((M, N))).to(DEV)
+    y = T.linear(x, w, b)
+    y.backward(gy)
+    x2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    y2 = F.linear(x2.double(), w2.double(), b2.double())
+    y2.backward(gy.double())
+    assert _rel(y, y2) < 2e-6
+    assert _rel(x.grad, x2.grad) < 2e-6 and _rel(w.grad, w2.grad) < 5e-6 and _rel(b.grad, b2.grad) < 5e-6
+
+
+def test_linear_without_bias_and_noncontiguous_input():
+    g = U.rng(5)
+    big = _leaf(g, 700, 100)
+    w = _leaf(g, 30, 50, scale=0.1)
+    y = T.linear(big[:, 25:75], w)
+    y.sum().backward()
+    b2, w2 = big.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    F.linear(b2[:, 25:75], w2).sum().backward()
+    assert _rel(big.grad, b2.grad) < 2e-6 and _rel(w.grad, w2.grad) < 5e-6
+
+
+@pytest.mark.parametrize('M,Fdim,relu', [(1, 32, True), (777, 64, True), (4099, 128, True), (5000, 256, True), (333, 256, False),
+                                         (100, 246, True)])
+def test_layernorm_relu(M, Fdim, relu):
+    g = U.rng(M + Fdim)
+    x, ga, be = _leaf(g, M, Fdim, scale=2.0), _leaf(g, Fdim), _leaf(g, Fdim, scale=0.3)
+    gy = U.t32(g.standard_normal((M, Fdim))).to(DEV)
+    y = T.ln_relu(x, ga, be, relu)
+    y.backward(gy)
+    x2, g2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, ga, be))
+    y2 = F.layer_norm(x2, (Fdim,), g2, b2, 1e-5)
+    y2 = F.relu(y2) if relu else y2
+    y2.backward(gy)
+    assert _rel(y, y2) < 5e-6
+    assert _rel(x.grad, x2.grad) < 2e-5 and _rel(ga.grad, g2.grad) < 2e-5 and _rel(be.grad, b2.grad) < 2e-5
+
+
+@pytest.mark.parametrize('op,fn', [(T.add, lambda a, b: a + b), (T.sub, lambda a, b: a - b), (T.mul, lambda a, b: a * b),
+                                   (T.gate, lambda a, b: a * torch.sigmoid(b))])
+def test_elementwise_pairs(op, fn):
+    g = U.rng(9)
+    a, b = _leaf(g, 1234, 7), _leaf(g, 1234, 7)
+    gy = U.t32(g.standard_normal((1234, 7))).to(DEV)
+    op(a, b).backward(gy)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    fn(a2, b2).backward(gy)
+    assert _rel(op(a, b), fn(a2, b2)) < 1e-6 and _rel(a.grad, a2.grad) < 2e-6 and _rel(b.grad, b2.grad) < 2e-6
+
+
+def test_gather_and_scatter_sum_are_adjoint_and_match_torch():
+    g = U.rng(11)
+    n, M, Fd = 50, 2000, 24
+    idx = torch.from_numpy(g.integers(0, n - 5, M)).to(DEV)      # targets n-5..n-1 stay empty
+    plan = T.IndexPlan(idx, n)
+    x, src = _leaf(g, n, Fd), _leaf(g, M, Fd)
+    gy, gs = U.t32(g.standard_normal((M, Fd))).to(DEV), U.t32(g.standard_normal((n, Fd))).to(DEV)
+    T.gather(x, plan).backward(gy)
+    T.scatter_sum(src, plan).backward(gs)
+    x2, s2 = x.detach().clone().requires_grad_(True), src.detach().clone().requires_grad_(True)
+    x2[idx].backward(gy)
+    torch.zeros(n, Fd, device=DEV).index_add(0, idx, s2).backward(gs)
+    assert torch.equal(T.gather(x, plan), x2[idx])
+    assert _rel(T.scatter_sum(src, plan), torch.zeros(n, Fd, device=DEV).index_add(0, idx, s2)) < 2e-6
+    assert _rel(x.grad, x2.grad) < 2e-6 and torch.equal(src.grad, s2.grad)
+    assert torch.equal(T.scatter_sum(src, plan), T.scatter_sum(src, plan))          # deterministic
+
+
+def test_edge_geometry_smearing_and_force():
+    g = U.rng(13)
+    n, E = 40, 900
+    l = torch.from_numpy(g.integers(0, n, E)).to(DEV)
+    r = (l + 1 + torch.from_numpy(g.integers(0, n - 1, E)).to(DEV)) % n          # never equal to l
+    pl, pr = T.IndexPlan(l, n), T.IndexPlan(r, n)
+    pos, w = _leaf(g, n, 3, scale=3.0), _leaf(g, E, 1)
+    off = torch.linspace(0, 15, 16, device=DEV)
+    coef = -0.5 / (off[1] - off[0]) ** 2 * torch.linspace(1.0, 0.3, 16, device=DEV)
+    gs, gf = U.t32(g.standard_normal((E, 16))).to(DEV), U.t32(g.standard_normal((E, 3))).to(DEV)
+
+    def ours(pos, w):
+        rel, d = T.edge_geom(pos, pl, pr)
+        return T.smear(d, off, coef, 0.0, 5.0), T.force(w, rel, d)
+
+    def ref(pos, w):
+        rel = pos[l] - pos[r]
+        d = torch.norm(rel, dim=-1)
+        sm = torch.exp(coef * (d.clamp(0.0, 5.0).unsqueeze(-1) - off) ** 2)
+        return sm, w * rel / d.unsqueeze(-1) / (d.unsqueeze(-1) + 1)
+
+    a = ours(pos, w)
+    (a[0] * gs).sum().backward(retain_graph=True)
+    (a[1] * gf).sum().backward()
+    p2, w2 = pos.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    b = ref(p2, w2)
+    ((b[0] * gs).sum() + (b[1] * gf).sum()).backward()
+    assert _rel(a[0], b[0]) < 2e-6 and _rel(a[1], b[1]) < 2e-6
+    assert _rel(pos.grad, p2.grad) < 2e-5 and _rel(w.grad, w2.grad) < 2e-6
+
+
+def test_cpu_tensors_raise():
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        T.linear(torch.zeros(4, 4), torch.zeros(4, 4))
