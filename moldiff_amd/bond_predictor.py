@@ -107,20 +107,27 @@ class BondPredictor(Module):
         ts = torch.cat([ts, T - ts - 1], dim=0)[:num_graphs]
         return ts, torch.ones_like(ts).float() / T
 
-    @torch.no_grad()
     def get_loss(self, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol, *,
                  time_step=None, noise=None):
-        """Class-weighted cross-entropy of the predicted bond types on a noised batch (forward only: the quantity the
-        reference's validation loop reports; no weight-gradient path, ``loss.backward()`` raises).
+        """Class-weighted cross-entropy of the predicted bond types on a noised batch (models/bond_predictor.py:84-124).
+        Under ``no_grad`` it runs on the fused kernels; with grad enabled on the differentiable layer operators
+        (``train_graph.bondpred_forward``) and ``loss.backward()`` fills every parameter's ``.grad``.
         time_step (num_mol,) / noise = dict(eps_pos, u_node) may be injected; default: torch's generator."""
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         noise = noise or {}
-        t = self.sample_time(num_mol, node_pos.device)[0] if time_step is None else time_step
-        pos = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
-        h_node = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))[0]
-        edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
-        batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
-        pred_halfedge = self(h_node, pos, batch_node, edge_index, batch_edge, t)
-        loss_edge = self.ce_loss(pred_halfedge, halfedge_type)
+        with torch.no_grad():
+            t = self.sample_time(num_mol, node_pos.device)[0] if time_step is None else time_step
+            pos = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
+            h_node = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))[0]
+            edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
+            batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
+        with torch.enable_grad() if train else torch.no_grad():
+            if train:
+                from . import train_graph
+                pred_halfedge = train_graph.bondpred_forward(self, h_node, pos, batch_node, edge_index, batch_edge, t)
+            else:
+                pred_halfedge = self(h_node, pos, batch_node, edge_index, batch_edge, t)
+            loss_edge = self.ce_loss(pred_halfedge, halfedge_type)
         return {'loss': loss_edge, 'loss_edge': loss_edge}
 
     def forward(self, h_node, pos_node, batch_node, edge_index, batch_edge, t, _graph=None):

@@ -3,8 +3,9 @@
 Drop-in for the reference's ``models/model.py`` ``MolDiff`` on the path BASELINE.json names:
 ``__init__`` (:13-46), ``define_betas_alphas`` (:49-95), ``forward`` (:204-234), ``sample`` (:236-378).
 Same constructor arguments, same ``state_dict`` keys/shapes (strict checkpoint load), same call
-signatures and return layout.  ``get_loss`` (:128-201) is built forward-only, i.e. what the reference's validation
-loop calls under ``no_grad`` (scripts/train_drug3d.py:121-164); there is no weight-gradient path yet.
+signatures and return layout.  ``get_loss`` (:128-201): under ``no_grad`` (the reference's validation loop) it runs on
+the fused sampling kernels; with grad enabled it runs layer by layer on the differentiable HIP operators of
+``train_ops`` / ``train_graph`` so that ``loss.backward()`` yields every parameter gradient.
 
 All arithmetic runs in ``libmoldiff_hip.so``; torch is used for device memory, streams and the output
 containers only.  Differences a caller can see, all opt-in keyword arguments with reference defaults:
@@ -87,31 +88,46 @@ class MolDiff(Module):
         ts = torch.cat([ts, T - ts - 1], dim=0)[:num_graphs]
         return ts, torch.ones_like(ts).float() / T
 
-    @torch.no_grad()
     def get_loss(self, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol, *,
                  time_step=None, noise=None):
-        """Diffusion loss of a clean batch, as the reference's validation loop evaluates it (forward only).
+        """Diffusion loss of a clean batch (models/model.py:128-201).
 
-        Perturb (pos, node types, bond types) to a random step, denoise with the HIP network, and score:
-        MSE on positions, 100 x mean per-row {KL of the categorical posteriors | decoder NLL at t == 0} on node and
-        bond types.  Returns {'loss', 'loss_pos', 'loss_node', 'loss_edge'} (0-d tensors on the device).  The denoiser
-        and the categorical posteriors run in the HIP kernels; the O(N K) loss algebra on their outputs is torch device
-        ops.  There is no weight-gradient path yet: the result does not require grad, so ``loss.backward()`` raises.
+        Perturb (pos, node types, bond types) to a random step, denoise, and score: MSE on positions, 100 x mean per-row
+        {KL of the categorical posteriors | decoder NLL at t == 0} on node and bond types.  Returns {'loss', 'loss_pos',
+        'loss_node', 'loss_edge'} (0-d device tensors).
+        * Under ``torch.no_grad()`` (the reference's validation loop, scripts/train_drug3d.py:121-164) the denoiser and
+          the posteriors run in the fused sampling kernels and the result carries no graph.
+        * With grad enabled the denoiser is evaluated layer by layer with the differentiable HIP operators of
+          ``train_ops`` (``train_graph.moldiff_forward``) and ``loss.backward()`` fills every parameter's ``.grad``.
+        In both modes the O(rows x classes) loss algebra on the logits is torch tensor ops.
         time_step (num_mol,) / noise = dict(eps_pos, u_node, u_halfedge) may be injected (parity tests); by default they
         are drawn from torch's generator in the reference's order.
         """
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        with torch.enable_grad() if train else torch.no_grad():
+            return self._get_loss(train, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge,
+                                  num_mol, time_step, noise)
+
+    def _get_loss(self, train, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol,
+                  time_step, noise):
         if self.categorical_space != 'discrete':
             raise NotImplementedError(self.categorical_space)
         dev = node_pos.device
         noise = noise or {}
-        t = self.sample_time(num_mol, dev)[0] if time_step is None else time_step
-        pos_pert = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
-        h_node, log_node_t, log_node_0 = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))
-        h_half, log_half_t, log_half_0 = self.edge_transition.add_noise(halfedge_type, t, batch_halfedge,
-                                                                        noise.get('u_halfedge'))
-        edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
-        batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
-        preds = self(h_node, pos_pert, batch_node, torch.cat([h_half, h_half], dim=0), edge_index, batch_edge, t)
+        with torch.no_grad():
+            t = self.sample_time(num_mol, dev)[0] if time_step is None else time_step
+            pos_pert = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
+            h_node, log_node_t, log_node_0 = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))
+            h_half, log_half_t, log_half_0 = self.edge_transition.add_noise(halfedge_type, t, batch_halfedge,
+                                                                            noise.get('u_halfedge'))
+            edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
+            batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
+            h_edge = torch.cat([h_half, h_half], dim=0)
+        if train:
+            from . import train_graph
+            preds = train_graph.moldiff_forward(self, h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t)
+        else:
+            preds = self(h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t)
 
         loss_pos = F.mse_loss(preds['pred_pos'], node_pos)
         out = {}
@@ -120,7 +136,8 @@ class MolDiff(Module):
                 ('loss_edge', self.edge_transition, preds['pred_halfedge'], log_half_t, log_half_0, batch_halfedge)):
             log_recon = F.log_softmax(logits, dim=-1)
             post_true = tr.q_v_posterior(log_0, log_t, t, batch, v0_prob=True)
-            post_pred = tr.q_v_posterior(log_recon, log_t, t, batch, v0_prob=True)
+            post_pred = (tr.q_v_posterior_autograd(log_recon, log_t, t, batch) if train
+                         else tr.q_v_posterior(log_recon, log_t, t, batch, v0_prob=True))
             out[name] = torch.mean(tr.compute_v_Lt(post_true, post_pred, log_0, t=t, batch=batch)) * 100
         if self.bond_len_loss:
             bond_index = halfedge_index[:, halfedge_type > 0]

@@ -1,0 +1,137 @@
+"""Differentiable (training) forward of the networks, one layer operator at a time.
+
+The sampling path runs each NodeEdgeNet block as three fused kernels and keeps nothing; a training step needs every
+layer's input for the weight gradients, so here the same modules (same parameters, same state_dict) are evaluated
+layer by layer with the operators of ``train_ops`` (HIP forward/backward kernels behind the C ABI), activations in HBM,
+and torch.autograd as the tape.  The composition follows the reference's live classes: models/common.py MLP :181-201,
+models/graph.py NodeBlock :29-55, BondFFN :133-141, EdgeBlock :268-295, PosUpdate :384-396, NodeEdgeNet :348-374,
+models/model.py MolDiff.forward :204-234, models/bond_predictor.py BondPredictor.forward :128-162.
+
+Only index bookkeeping (one-hot, concatenation of feature blocks, per-batch CSR plans) and the O(rows x classes) loss
+tail (models/model.py:170-189) use torch tensor ops; every O(rows x features) product runs in the library.
+"""
+import torch
+
+from . import train_ops as T
+
+
+class TrainGraph:
+    """Index plans of one packed batch in the reference's edge order [half-edges, flipped half-edges]."""
+
+    def __init__(self, edge_index, n_nodes):
+        self.edge_index = edge_index
+        self.N, self.E = int(n_nodes), int(edge_index.shape[1])
+        self.left = T.IndexPlan(edge_index[0], n_nodes)
+        self.right = T.IndexPlan(edge_index[1], n_nodes)
+
+
+def cat(*xs):
+    return torch.cat(xs, dim=-1)
+
+
+def mlp(m, x):
+    """common.MLP: Linear -> (LayerNorm -> ReLU -> Linear)*"""
+    mods = list(m.net)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        x = T.linear(x, lin.weight, lin.bias)
+        i += 1
+        if i < len(mods):      # LayerNorm, ReLU follow every Linear but the last
+            ln = mods[i]
+            x = T.ln_relu(x, ln.weight, ln.bias, True)
+            i += 2
+    return x
+
+
+def smear(gs, d):
+    return T.smear(d, gs.offset, gs.coeff, float(gs.start), float(gs.stop))
+
+
+def node_block(m, x, g, edge_attr, node_time):
+    h_node = mlp(m.node_net, x)
+    h_edge = mlp(m.edge_net, edge_attr)
+    msg = T.linear(T.mul(h_edge, T.gather(h_node, g.right)), m.msg_net.weight, m.msg_net.bias)
+    gt = mlp(m.gate, cat(edge_attr, T.gather(x, g.right), node_time[g.right.index]))
+    msg = T.gate(msg, gt)
+    out = T.add(T.linear(x, m.centroid_lin.weight, m.centroid_lin.bias), T.scatter_sum(msg, g.left))
+    out = T.ln_relu(out, m.layer_norm.weight, m.layer_norm.bias, True)
+    return T.linear(out, m.out_transform.weight, m.out_transform.bias)
+
+
+def bond_ffn(m, bond_in, node_in, time):
+    inter = T.mul(T.linear(bond_in, m.bond_linear.weight), T.linear(node_in, m.node_linear.weight))
+    inter = mlp(m.inter_module, inter)
+    return T.gate(inter, mlp(m.gate, cat(bond_in, node_in, time)))
+
+
+def edge_block(m, h_bond, g, h_node, bond_time):
+    hl, hr = T.gather(h_node, g.left), T.gather(h_node, g.right)
+    ml = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_left, h_bond, hl, bond_time), g.right), g.left)
+    mr = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, hr, bond_time), g.left), g.right)
+    h = T.add(T.add(ml, mr), T.add(T.linear(hl, m.node_ffn_left.weight, m.node_ffn_left.bias),
+                                   T.linear(hr, m.node_ffn_right.weight, m.node_ffn_right.bias)))
+    h = T.add(h, T.linear(h_bond, m.self_ffn.weight, m.self_ffn.bias))
+    h = T.ln_relu(h, m.layer_norm.weight, m.layer_norm.bias, True)
+    return T.linear(h, m.out_transform.weight, m.out_transform.bias)
+
+
+def pos_update(m, h_node, h_edge, g, rel, dist, edge_time):
+    lf = mlp(m.left_lin_edge, T.gather(h_node, g.left))
+    rf = mlp(m.right_lin_edge, T.gather(h_node, g.right))
+    w = bond_ffn(m.edge_lin, h_edge, T.mul(lf, rf), edge_time)
+    return T.scatter_sum(T.force(w, rel, dist), g.left)
+
+
+def node_edge_net(net, h_node, pos, h_edge, g, node_time, edge_time):
+    rel = dist = h_dist = None
+    for i in range(net.num_blocks):
+        if net.update_pos or i == 0:
+            rel, dist = T.edge_geom(pos, g.left, g.right)
+            h_dist = smear(net.distance_expansion, dist)
+        emb = net.edge_embs[i]
+        h_edge = T.linear(cat(h_edge, h_dist) if net.update_edge else h_dist, emb.weight, emb.bias)
+        upd = node_block(net.node_blocks_with_edge[i], h_node, g, h_edge, node_time)
+        if net.update_edge:
+            h_edge = T.add(h_edge, edge_block(net.edge_blocks[i], h_edge, g, h_node, edge_time))
+        h_node = T.add(h_node, upd)
+        if net.update_pos:
+            pos = T.add(pos, pos_update(net.pos_blocks[i], h_node, h_edge, g, rel, dist, edge_time))
+    return h_node, pos, h_edge
+
+
+def time_embedding(gs, t_rows):
+    # GaussianSmearing of the (integer) step: a constant of the batch, no gradient flows into it
+    with torch.no_grad():
+        return smear(gs, t_rows.float())
+
+
+def moldiff_forward(model, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_index, batch_edge, t):
+    g = TrainGraph(edge_index, h_node_pert.shape[0])
+    ts = model.time_emb[0]
+    tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
+    h_node = cat(T.linear(h_node_pert, model.node_embedder.weight), time_embedding(ts, tn))
+    h_edge = cat(T.linear(h_edge_pert, model.edge_embedder.weight), time_embedding(ts, te))
+    T_ = float(model.num_timesteps)
+    h_node, pos, h_edge = node_edge_net(model.denoiser, h_node, pos_pert, h_edge, g,
+                                        (tn.unsqueeze(-1) / T_).float(), (te.unsqueeze(-1) / T_).float())
+    n_half = h_edge.shape[0] // 2
+    pred_node = mlp(model.node_decoder, h_node)
+    pred_half = mlp(model.edge_decoder, T.add(h_edge[:n_half].contiguous(), h_edge[n_half:].contiguous()))
+    return {'pred_node': pred_node, 'pred_pos': pos, 'pred_halfedge': pred_half}
+
+
+def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge, t):
+    g = TrainGraph(edge_index, h_node.shape[0])
+    tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
+    h_edge = cat(h_node[edge_index[0]], h_node[edge_index[1]])            # one-hot pairs: pure indexing
+    h_node = cat(T.linear(h_node, model.node_embedder.weight), time_embedding(model.time_emb, tn))
+    h_edge = cat(T.linear(h_edge, model.edge_embedder.weight), time_embedding(model.time_emb, te))
+    T_ = float(model.num_timesteps)
+    h_node, _, h_edge = node_edge_net(model.encoder, h_node, pos_node, h_edge, g,
+                                      (tn.unsqueeze(-1) / T_).float(), (te.unsqueeze(-1) / T_).float())
+    n_half = h_edge.shape[0] // 2
+    he = T.add(h_edge[:n_half].contiguous(), h_edge[n_half:].contiguous())
+    li, ri = T.IndexPlan(edge_index[0, :n_half], g.N), T.IndexPlan(edge_index[1, :n_half], g.N)
+    hn = T.add(T.gather(h_node, li), T.gather(h_node, ri))
+    return mlp(model.edge_decoder, cat(he, hn))

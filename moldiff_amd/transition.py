@@ -100,6 +100,17 @@ class GeneralCategoricalTransition(nn.Module):
             raise NotImplementedError('ndim not supported')
         return _lib.cat_posterior(self.q_mats, self.transpopse_q_onestep_mats, log_v0, log_vt, t, batch)
 
+    def q_v_posterior_autograd(self, log_v0, log_vt, t, batch):
+        """Same quantity as a chain of differentiable torch tensor ops on (rows, K <= 8) tensors: the loss tail of the
+        training path (the gradient wrt `log_v0` = log-softmax of the predicted logits flows through here)."""
+        tb = t[batch]
+        tm1 = torch.clamp(t - 1, min=0)[batch]
+        f1 = torch.einsum('bj,bjk->bk', log_vt.exp(), self.transpopse_q_onestep_mats[tb])
+        f2 = torch.einsum('bj,bjk->bk', log_v0.exp(), self.q_mats[tm1])
+        out = torch.log(f1 + self.eps).clamp_min(-32.) + torch.log(f2 + self.eps).clamp_min(-32.)
+        out = out - torch.logsumexp(out, dim=-1, keepdim=True)
+        return torch.where((tb == 0).unsqueeze(-1), log_v0, out)
+
     def q_vt_pred(self, log_v0, t, batch):
         q = self.q_mats[t][batch]
         return torch.log(torch.einsum('...i,...ij->...j', log_v0.exp(), q) + self.eps).clamp_min(-32.)

@@ -67,7 +67,8 @@ def test_get_loss_without_gpu_fails_loudly():
 def test_gpu_loss_matches_reference(nm, kind):
     args, t, noise, want = _case(nm, 'cuda')
     m = U.moldiff(kind, 'cuda')
-    got = m.get_loss(*args, time_step=t, noise=noise)
+    with torch.no_grad():          # the validation loop's mode: fused sampling kernels, no graph
+        got = m.get_loss(*args, time_step=t, noise=noise)
     assert set(got) == set(KEYS)
     for k in KEYS:
         assert got[k].device.type == 'cuda' and got[k].ndim == 0 and not got[k].requires_grad
@@ -92,24 +93,30 @@ def test_gpu_loss_random_batch_matches_oracle():
     with torch.no_grad():
         want = O.moldiff_loss(P, U.CFG, U.tables(P), node_type, node_pos, bn, half_type, hei, bh, B, t, noise)
     c = lambda x: x.cuda()
-    got = m.get_loss(c(node_type), c(node_pos), c(bn), c(half_type), c(hei), c(bh), B, time_step=c(t),
-                     noise={k: c(v) for k, v in noise.items()})
+    with torch.no_grad():
+        got = m.get_loss(c(node_type), c(node_pos), c(bn), c(half_type), c(hei), c(bh), B, time_step=c(t),
+                         noise={k: c(v) for k, v in noise.items()})
     for k in KEYS:
         assert abs(float(got[k]) - float(want[k])) <= RTOL * max(1.0, abs(float(want[k]))), (k, float(got[k]), float(want[k]))
 
 
 @pytest.mark.gpu
-def test_gpu_loss_default_draws_and_no_backward():
+def test_gpu_loss_default_draws_and_modes():
     args, _, _, _ = _case('simple', 'cuda')
     m = U.moldiff('MolDiff_simple', 'cuda')
-    torch.manual_seed(11)
-    a = m.get_loss(*args)
-    torch.manual_seed(11)
-    b = m.get_loss(*args)
+    with torch.no_grad():
+        torch.manual_seed(11)
+        a = m.get_loss(*args)
+        torch.manual_seed(11)
+        b = m.get_loss(*args)
     assert all(torch.isfinite(a[k]) for k in KEYS)
     assert all(float(a[k]) == float(b[k]) for k in KEYS)       # deterministic under torch's seed
-    with pytest.raises(RuntimeError):
-        a['loss'].backward()
+    assert not a['loss'].requires_grad
+    torch.manual_seed(11)
+    c = m.get_loss(*args)                                       # grad mode: layer-operator path, same draws
+    assert c['loss'].requires_grad
+    for k in KEYS:
+        assert abs(float(c[k]) - float(a[k])) <= RTOL * max(1.0, abs(float(a[k]))), k
 
 
 # ---- BondPredictor.get_loss (reference models/bond_predictor.py:84-124) ---------------------------------------------
@@ -135,7 +142,8 @@ def test_oracle_bondpred_loss_matches_reference():
 @pytest.mark.gpu
 def test_gpu_bondpred_loss_matches_reference():
     args, t, noise, want = _bond_case('cuda')
-    got = U.bondpred('cuda').get_loss(*args, time_step=t, noise=noise)
+    with torch.no_grad():
+        got = U.bondpred('cuda').get_loss(*args, time_step=t, noise=noise)
     assert set(got) == {'loss', 'loss_edge'} and not got['loss'].requires_grad
     assert abs(float(got['loss']) - want) <= RTOL * max(1.0, want), (float(got['loss']), want)
     assert float(got['loss_edge']) == float(got['loss'])
@@ -172,3 +180,55 @@ def test_oracle_bondpred_loss_gradients_match_reference_autograd():
     Pb = U.params(U.bondpred())
     tabs = lambda P: {'pos': {'alphas_bar': P['pos_transition.alphas_bar']}, 'node': {'q_mats': P['node_transition.q_mats']}}
     _check_grads('bond', Pb, lambda Pg: O.bondpred_loss(Pg, U.CFGB, tabs(Pg), *args, t, noise)['loss'])
+
+
+# ---- training path on the GPU: loss.backward() through the HIP layer operators vs the reference's autograd ------------
+GTOL = 1e-4   # gradients: relative to max(|g|_2 of the tensor, 1e-3 x the largest tensor norm); fp32 through ~60 layers
+
+
+def _check_param_grads(prefix, module):
+    z = U.gold('loss_grads.npz')
+    names = [k[len(prefix) + 6:] for k in z.files if k.startswith(prefix + '/norm/')]
+    P = dict(module.named_parameters())
+    assert set(names) == {k for k, v in P.items() if v.requires_grad}
+    gmax = max(float(z[f'{prefix}/norm/{k}']) for k in names)
+    worst = 0.0
+    for k in names:
+        g = P[k].grad
+        assert g is not None, f'no gradient reached {k}'
+        want = float(z[f'{prefix}/norm/{k}'])
+        scale = max(want, 1e-3 * gmax)
+        err = abs(float(g.double().norm()) - want) / scale
+        fk = f'{prefix}/full/{k}'
+        if fk in z.files:
+            w = torch.from_numpy(z[fk]).to(g.device)
+            err = max(err, float((g - w).double().norm()) / scale)
+        worst = max(worst, err)
+        assert err <= GTOL, (k, err)
+    return worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nm,kind', [('full', 'MolDiff'), ('simple', 'MolDiff_simple')])
+def test_gpu_training_loss_and_parameter_gradients_match_reference(nm, kind):
+    args, t, noise, want = _case(nm, 'cuda')
+    m = U.moldiff(kind, 'cuda')
+    m.zero_grad(set_to_none=True)
+    got = m.get_loss(*args, time_step=t, noise=noise)
+    for k in KEYS:
+        assert abs(float(got[k]) - want[k]) <= RTOL * max(1.0, abs(want[k])), (k, float(got[k]), want[k])
+    got['loss'].backward()
+    _check_param_grads(nm, m)
+    m.zero_grad(set_to_none=True)
+
+
+@pytest.mark.gpu
+def test_gpu_bondpred_training_loss_and_parameter_gradients_match_reference():
+    args, t, noise, want = _bond_case('cuda')
+    m = U.bondpred('cuda')
+    m.zero_grad(set_to_none=True)
+    got = m.get_loss(*args, time_step=t, noise=noise)
+    assert abs(float(got['loss']) - want) <= RTOL * max(1.0, want)
+    got['loss'].backward()
+    _check_param_grads('bond', m)
+    m.zero_grad(set_to_none=True)
