@@ -200,6 +200,14 @@ int mdx_op_force_fwd(const float* w, const float* rel, const float* d, int64_t E
 int mdx_op_force_bwd(const float* w, const float* rel, const float* d, const float* g, int64_t E, float* gw, float* grel, float* gd,
                      void* stream);
 
+/* Optimizer step on flat buffers (torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, reference utils/train.py:64-70,
+ * scripts/train_drug3d.py:107-108).  sumsq: out[0] = sum x^2 (fixed-order two-stage; ws = 1024 floats).  adamw: one
+ * decoupled-weight-decay Adam step, step = 1, 2, ...; when gnorm2 != NULL the gradient is scaled by
+ * min(max_norm / (sqrt(*gnorm2) + 1e-6), 1) on the fly. */
+int mdx_op_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
+int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int64_t step, const float* gnorm2, float max_norm, void* stream);
+
 /* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
  * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
  * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass).  read() drains pending events. */

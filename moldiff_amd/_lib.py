@@ -25,7 +25,7 @@ EXPORTS = [
     'mdx_profile_enable', 'mdx_profile_read',
     'mdx_op_sgemm_nt', 'mdx_op_transpose', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
-    'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd',
+    'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
 ]
 
 
@@ -98,6 +98,9 @@ def lib():
         L.mdx_op_smear_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_op_force_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_op_force_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_adamw.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                   c_int64, c_void_p, c_float, c_void_p]
         _lib = L
     return _lib
 

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/moldiff_hip.h"
 #include "mdx_tile.h"
 
@@ -389,6 +391,48 @@ __global__ void force_bwd_kernel(const float* __restrict__ w, const float* __res
   gd[e] = -wv * dot * (2.0f * dv + 1.0f) * inv * inv;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// optimizer step on the flat parameter buffer (torch.optim.AdamW semantics, utils/train.py:64-70 of the reference):
+//   sumsq   : sum of squares of the flat gradient in two fixed-order stages (-> global norm for clip_grad_norm_)
+//   adamw   : g *= gscale ; p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//             p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const size_t per = (n + gridDim.x - 1) / gridDim.x;
+  const size_t i0 = (size_t)blockIdx.x * per, i1 = min(n, i0 + per);
+  float s = 0.f;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) s = fmaf(x[i], x[i], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void sum_small_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += x[i];
+    out[0] = s;
+  }
+}
+// gnorm2: device scalar holding the squared global gradient norm (or NULL = no clipping)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                             const float* __restrict__ gnorm2, float max_norm) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gs = 1.0f;
+  if (gnorm2) gs = fminf(max_norm / (sqrtf(gnorm2[0]) + 1e-6f), 1.0f);
+  const float gi = g[i] * gs;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  p[i] = pi;
+}
+
 inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 inline int bad(const char* m) { return mdx_set_error(MDX_ERR_ARG, m); }
 inline int launched() {
@@ -547,5 +591,27 @@ extern "C" int mdx_op_force_bwd(const float* w, const float* rel, const float* d
                                 float* gd, void* stream) {
   if (E <= 0) return MDX_OK;
   hipLaunchKernelGGL(force_bwd_kernel, dim3(nblk((size_t)E)), dim3(256), 0, (hipStream_t)stream, w, rel, d, g, E, gw, grel, gd);
+  return launched();
+}
+
+// out[0] = sum x[i]^2 over the flat buffer (two fixed-order stages; ws: 1024 floats).
+extern "C" int mdx_op_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!out || !ws) return bad("sumsq: null output / workspace");
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 65535) / 65536));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, x, (size_t)std::max<int64_t>(n, 0), ws);
+  hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, nb, out);
+  return launched();
+}
+// One AdamW step over flat (p, g, m, v); step = 1, 2, ...  gnorm2 (device scalar, may be NULL) + max_norm apply
+// torch.nn.utils.clip_grad_norm_ to g on the fly (g itself is left unscaled).
+extern "C" int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int64_t step, const float* gnorm2, float max_norm, void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (step < 1) return bad("adamw: step counts from 1");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, gnorm2, max_norm);
   return launched();
 }

@@ -78,3 +78,42 @@ def test_two_rank_gather_reassembles_global_order():
     assert np.array_equal(out[1][:, 0], ids[full['batch_node'].numpy()].astype(np.float32) + 0.5)
     assert out[2].shape == (len(full['batch_halfedge']), 6)
     assert np.array_equal(out[2][:, 0], ids[full['batch_halfedge'].numpy()].astype(np.float32))
+
+
+# ---- data-parallel training: flat gradient buffer averaged over ranks (moldiff_amd/trainer.py) -----------------------
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from moldiff_amd.trainer import FlatParams, allreduce_mean_
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)                       # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 2))
+    flat = FlatParams(net)
+    x = torch.arange(12, dtype=torch.float32).reshape(2, 6) * (rank + 1)       # a different shard per rank
+    flat.zero_grad()
+    net(x).square().sum().backward()           # autograd accumulates straight into the flat buffer
+    local = flat.grad.clone()
+    w = allreduce_mean_(flat.grad)
+    q.put((rank, w, local.numpy(), flat.grad.numpy().copy(), [p.grad.data_ptr() - flat.grad.data_ptr() for p in flat.params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_over_the_flat_buffer():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, w0, l0, a0, off0), (_, w1, l1, a1, off1) = res
+    assert w0 == w1 == 2
+    assert np.abs(l0 - l1).max() > 0                                   # the shards really differ
+    assert np.array_equal(a0, a1)                                      # every rank ends with the same gradient
+    assert np.allclose(a0, 0.5 * (l0 + l1), rtol=1e-6, atol=1e-6)      # ... the mean of the per-rank gradients
+    assert off0 == off1 and off0[0] == 0 and all(b > a for a, b in zip(off0, off0[1:]))   # .grad are views, in order

@@ -1,0 +1,85 @@
+"""Optimizer step and whole training steps on the GPU (reference: scripts/train_drug3d.py:88-109, utils/train.py:64-70)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util as U
+from moldiff_amd import _lib
+from moldiff_amd.trainer import Trainer, FlatParams
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_clip_and_adamw_kernels_match_torch_optim():
+    g = U.rng(3)
+    shapes = [(33, 7), (256,), (64, 129), (1,), (300, 300)]
+    ps = [torch.nn.Parameter(U.t32(g.standard_normal(s)).to(DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mod = torch.nn.Module()
+    mod.ps = torch.nn.ParameterList(ps)
+    tr = Trainer(mod, lr=1e-2, betas=(0.99, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=5.0)
+    opt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.99, 0.999), eps=1e-8, weight_decay=1e-3)
+    for it in range(4):
+        grads = [U.t32(g.standard_normal(s) * (30.0 if it % 2 == 0 else 0.01)).to(DEV) for s in shapes]   # clipped / not clipped
+        tr.zero_grad()
+        loss = sum((p * gr).sum() for p, gr in zip(ps, grads))
+        gn = tr.backward_and_step(loss)
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        gn_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt.step()
+        assert abs(float(gn) - float(gn_ref)) <= 1e-5 * float(gn_ref)
+        for p, r in zip(ps, ref):
+            assert U.maxdiff(p, r) <= 2e-6 * max(1.0, float(r.abs().max()))
+
+
+def test_flat_views_alias_the_parameters():
+    m = torch.nn.Linear(5, 3).to(DEV)
+    f = FlatParams(m)
+    assert f.numel == 18 and m.weight.data_ptr() == f.data.data_ptr()
+    m.weight.grad.fill_(2.0)
+    assert float(f.grad[:15].sum()) == 30.0
+    f.zero_grad()
+    assert float(m.weight.grad.abs().sum()) == 0.0
+
+
+def _tiny_batch(seed, sizes=(6, 9, 5, 11)):
+    g = U.rng(seed)
+    bn, hei, bh, _, _ = U.graph_from_sizes(list(sizes), DEV)
+    N, Eh = len(bn), len(bh)
+    pos = U.t32(g.standard_normal((N, 3)) * 1.5).to(DEV)
+    return (torch.from_numpy(g.integers(0, 7, N)).to(DEV), pos, bn,
+            torch.from_numpy((g.random(Eh) < 0.3) * g.integers(1, 5, Eh)).to(DEV), hei, bh, len(sizes))
+
+
+@pytest.mark.parametrize('which', ['moldiff', 'bondpred'])
+def test_training_steps_reduce_the_loss_and_refresh_the_fused_engine(which):
+    import copy
+    base = U.moldiff('MolDiff_simple', DEV) if which == 'moldiff' else U.bondpred(DEV)
+    m = copy.deepcopy(base)
+    for mod in m.modules():                 # deepcopy must not share the cached engine with the fixture model
+        if hasattr(mod, '_eng'):
+            mod._eng, mod._eng_sig = None, None
+    tr = Trainer(m, lr=2e-4, max_grad_norm=50.0)
+    batch = _tiny_batch(7)
+    t = torch.tensor([120, 480, 700, 930], device=DEV)
+    g = U.rng(8)
+    N, Eh = batch[1].shape[0], batch[3].shape[0]
+    noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))).to(DEV), u_node=U.t32(g.random((N, 8))).to(DEV),
+                 u_halfedge=U.t32(g.random((Eh, 6))).to(DEV))
+    if which == 'bondpred':
+        noise.pop('u_halfedge')
+    with torch.no_grad():
+        before = float(m.get_loss(*batch, time_step=t, noise=noise)['loss'])
+    first = None
+    for it in range(12):
+        out = tr.step(*batch, time_step=t, noise=noise)
+        first = float(out['loss']) if first is None else first
+        assert torch.isfinite(out['loss']) and torch.isfinite(out['grad_norm'])
+    assert abs(first - before) <= 2e-5 * max(1.0, abs(before))          # train-mode forward == fused forward
+    with torch.no_grad():
+        after_fused = float(m.get_loss(*batch, time_step=t, noise=noise)['loss'])    # fused engine sees the NEW weights
+    after_train = float(m.get_loss(*batch, time_step=t, noise=noise)['loss'])
+    assert after_fused < before * 0.98
+    assert abs(after_fused - after_train) <= 2e-5 * max(1.0, abs(after_train))
