@@ -161,14 +161,15 @@ int mdx_decode_output(mdx_graph_t g, const float* pred_node, int32_t Kn, const f
  * models/bond_predictor.py:84-124 + torch.autograd) is composed from these forward/backward pairs, one layer at a
  * time, by moldiff_amd/train_ops.py; activations stay in HBM between them.  All fp32, row-major, device pointers.
  *
- * sgemm_nt: C[M,N] (ldc) = A[M,K] (lda) * B[N,K]^T (ldb) + bias[N] (bias may be NULL).  nn.Linear forward (B = weight),
+ * sgemm_nt: C[M,N] (ldc) = A[M,K] (lda) * B[N,K]^T (ldb) + bias[N] + addend[M,N] (ldd) (bias / addend may be NULL; the
+ *   addend carries the per-node part of a layer whose input is a concatenation).  nn.Linear forward (B = weight),
  *   its data gradient (B = weight^T) and, with splits > 1 and `partial` = splits*M*N floats, its weight gradient
  *   (A = dY^T, B = X^T, K = number of rows; partial sums are combined in a fixed order -> deterministic).
  * transpose: out[Cn,R] (ldo) = in[R,Cn]^T (ldi).
  * colreduce: out[N] = sum over M rows of X[M,N] (ld), times Y element-wise if Y != NULL (bias / LayerNorm parameter
  *   gradients); ws = ceil(M/512)*N floats. */
-int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, int64_t M,
-                    int64_t N, int64_t K, int32_t splits, float* partial, void* stream);
+int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ldd,
+                    float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t splits, float* partial, void* stream);
 int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream);
 int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream);
 /* y = relu?(LayerNorm(x) * gamma + beta) over F <= 1024 features (nn.LayerNorm eps 1e-5, models/common.py MLP);

@@ -80,8 +80,8 @@ def lib():
         L.mdx_profile_enable.argtypes = [c_int32]
         L.mdx_profile_read.argtypes = [c_int32, POINTER(c_int64), POINTER(ctypes.c_double)]
         # layer-level training operators
-        L.mdx_op_sgemm_nt.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                      c_int32, c_void_p, c_void_p]
+        L.mdx_op_sgemm_nt.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                      c_int64, c_int64, c_int32, c_void_p, c_void_p]
         L.mdx_op_transpose.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]
         L.mdx_op_colreduce.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_op_ln_relu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]

@@ -44,8 +44,9 @@ __device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ p, int k,
 }
 
 __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                        const float* __restrict__ bias, float* __restrict__ C, int ldc, int M,
-                                                        int N, int K, int kper, float* __restrict__ P) {
+                                                        const float* __restrict__ bias, const float* __restrict__ addend,
+                                                        int ldd, float* __restrict__ C, int ldc, int M, int N, int K, int kper,
+                                                        float* __restrict__ P) {
   __shared__ __attribute__((aligned(16))) float As[G_TM * G_LD];
   __shared__ __attribute__((aligned(16))) float Bs[G_TN * G_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,7 +105,12 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__
     for (int et = 0; et < 2; ++et) {
       const int row = m0 + 32 * wave + 16 * et + c;
       if (row >= M || col >= N) continue;
-      const f32x4 v = acc[ft][et] + bv;
+      f32x4 v = acc[ft][et] + bv;
+      if (addend && !P) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < N) v[r] += addend[(size_t)row * ldd + col + r];
+      }
       float* o = out + (size_t)row * ldo + col;
       if (veco && col + 3 < N) {
         stg4(o, v);
@@ -143,19 +149,39 @@ __global__ void transpose_kernel(const float* __restrict__ in, int ldi, int R, i
   }
 }
 
-// stage kernel of the column reduction: block b sums rows [b*rows_per, ...) of X (* Y) for every column
-__global__ void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y, int ld, int M, int N, int rows_per,
-                                 float* __restrict__ out /* [gridDim.x][N] */) {
-  const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
-  for (int col = threadIdx.x; col < N; col += blockDim.x) {
-    float s = 0.f;
+// stage kernel of the column reduction: block (bx, by) sums rows [by*rows_per, ...) of the 64-column strip bx of
+// X (* Y).  256 threads = 64 columns x 4 row lanes, 4 independent partial sums per thread (memory-level parallelism),
+// combined in a fixed order.
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ X, const float* __restrict__ Y, int ld, int M, int N,
+                                                         int rows_per, float* __restrict__ out /* [gridDim.y][N] */) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < N) {
+    int r = r0 + ty;
     if (Y) {
-      for (int r = r0; r < r1; ++r) s = fmaf(X[(size_t)r * ld + col], Y[(size_t)r * ld + col], s);
+      for (; r + 12 < r1; r += 16) {
+        s0 = fmaf(X[(size_t)r * ld + col], Y[(size_t)r * ld + col], s0);
+        s1 = fmaf(X[(size_t)(r + 4) * ld + col], Y[(size_t)(r + 4) * ld + col], s1);
+        s2 = fmaf(X[(size_t)(r + 8) * ld + col], Y[(size_t)(r + 8) * ld + col], s2);
+        s3 = fmaf(X[(size_t)(r + 12) * ld + col], Y[(size_t)(r + 12) * ld + col], s3);
+      }
+      for (; r < r1; r += 4) s0 = fmaf(X[(size_t)r * ld + col], Y[(size_t)r * ld + col], s0);
     } else {
-      for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + col];
+      for (; r + 12 < r1; r += 16) {
+        s0 += X[(size_t)r * ld + col];
+        s1 += X[(size_t)(r + 4) * ld + col];
+        s2 += X[(size_t)(r + 8) * ld + col];
+        s3 += X[(size_t)(r + 12) * ld + col];
+      }
+      for (; r < r1; r += 4) s0 += X[(size_t)r * ld + col];
     }
-    out[(size_t)blockIdx.x * N + col] = s;
   }
+  sh[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && col < N) out[(size_t)blockIdx.y * N + col] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -442,24 +468,26 @@ inline int launched() {
 
 }  // namespace
 
-extern "C" int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
-                               int64_t M, int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
+extern "C" int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
+                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t splits, float* partial,
+                               void* stream) {
   if (M <= 0 || N <= 0) return MDX_OK;
   if (!A || !B || !C || K < 0) return bad("sgemm_nt: null operand");
   hipStream_t s = (hipStream_t)stream;
   if (splits <= 1) {
     dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), 1);
-    hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, C, (int)ldc, (int)M, (int)N, (int)K,
-                       (int)((K + G_KC - 1) / G_KC * G_KC), (float*)nullptr);
+    hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M,
+                       (int)N, (int)K, (int)((K + G_KC - 1) / G_KC * G_KC), (float*)nullptr);
     return launched();
   }
   if (!partial) return bad("sgemm_nt: split-K needs a partial buffer of splits*M*N floats");
+  if (addend) return bad("sgemm_nt: addend is not supported together with split-K");
   int kper = (int)((K + splits - 1) / splits);
   kper = (kper + G_KC - 1) / G_KC * G_KC;
   const int S = (int)((K + kper - 1) / kper);
   dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), (unsigned)S);
-  hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, (const float*)nullptr, C, (int)ldc, (int)M,
-                     (int)N, (int)K, kper, partial);
+  hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, (const float*)nullptr, (const float*)nullptr, 0, C,
+                     (int)ldc, (int)M, (int)N, (int)K, kper, partial);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)M * N)), dim3(256), 0, s, partial, S, (int)M, (int)N, bias, C, (int)ldc);
   return launched();
 }
@@ -479,13 +507,14 @@ extern "C" int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int6
   if (M <= 0) return hipMemsetAsync(out, 0, (size_t)N * 4, s) == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "memset");
   const int RP = 512;
   const int nb = (int)((M + RP - 1) / RP);
+  const unsigned gx = (unsigned)((N + 63) / 64);
   if (nb == 1) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, X, Y, (int)ld, (int)M, (int)N, RP, out);
+    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, s, X, Y, (int)ld, (int)M, (int)N, RP, out);
     return launched();
   }
   if (!ws) return bad("colreduce: workspace of ceil(M/512)*N floats required");
-  hipLaunchKernelGGL(colreduce_kernel, dim3(nb), dim3(256), 0, s, X, Y, (int)ld, (int)M, (int)N, RP, ws);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (const float*)nullptr, (int)N, nb, (int)N, nb, out);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, nb), dim3(256), 0, s, X, Y, (int)ld, (int)M, (int)N, RP, ws);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)ws, (const float*)nullptr, (int)N, nb, (int)N, nb, out);
   return launched();
 }
 
@@ -521,11 +550,12 @@ extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* 
   const int nb = (nwp + RP - 1) / RP;
   float* red = nb == 1 ? nullptr : ws2;
   float* tmp = ws2 + (size_t)nb * 2 * F;  // final 2F row
+  const unsigned gx = (unsigned)((2 * F + 63) / 64);
   if (nb == 1) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, tmp);
+    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, tmp);
   } else {
-    hipLaunchKernelGGL(colreduce_kernel, dim3(nb), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, red);
-    hipLaunchKernelGGL(colreduce_kernel, dim3(1), dim3(256), 0, s, (const float*)red, (const float*)nullptr, 2 * F, nb, 2 * F, nb, tmp);
+    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, nb), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, red);
+    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)red, (const float*)nullptr, 2 * F, nb, 2 * F, nb, tmp);
   }
   hipMemcpyAsync(dgamma, tmp, (size_t)F * 4, hipMemcpyDeviceToDevice, s);
   hipMemcpyAsync(dbeta, tmp + F, (size_t)F * 4, hipMemcpyDeviceToDevice, s);

@@ -29,57 +29,77 @@ def cat(*xs):
     return torch.cat(xs, dim=-1)
 
 
+def mlp_from_pre(m, pre):
+    """common.MLP given the output of its first Linear: (LayerNorm -> ReLU -> Linear)*"""
+    mods = list(m.net)
+    x, i = pre, 1
+    while i < len(mods):
+        ln = mods[i]
+        x = T.ln_relu(x, ln.weight, ln.bias, True)
+        lin = mods[i + 2]
+        x = T.linear(x, lin.weight, lin.bias)
+        i += 3
+    return x
+
+
 def mlp(m, x):
     """common.MLP: Linear -> (LayerNorm -> ReLU -> Linear)*"""
-    mods = list(m.net)
-    i = 0
-    while i < len(mods):
-        lin = mods[i]
-        x = T.linear(x, lin.weight, lin.bias)
-        i += 1
-        if i < len(mods):      # LayerNorm, ReLU follow every Linear but the last
-            ln = mods[i]
-            x = T.ln_relu(x, ln.weight, ln.bias, True)
-            i += 2
-    return x
+    first = m.net[0]
+    return mlp_from_pre(m, T.linear(x, first.weight, first.bias))
 
 
 def smear(gs, d):
     return T.smear(d, gs.offset, gs.coeff, float(gs.start), float(gs.stop))
 
 
+# Row-wise layers commute with row gathers: Linear(h[idx]) == Linear(h)[idx].  Every layer the reference applies to a
+# gathered node tensor is therefore evaluated once per NODE and gathered afterwards (N rows instead of E = 25 N), and a
+# layer whose input is the concatenation [edge part | node part | time] is split by columns of its weight: the edge part
+# is the E-row GEMM, the node/time part rides in as the GEMM's addend.  Same function, same gradients (autograd sums the
+# weight-slice gradients back into the full matrix), ~35 % fewer FLOPs and no unaligned 321-wide operand.
+
 def node_block(m, x, g, edge_attr, node_time):
     h_node = mlp(m.node_net, x)
     h_edge = mlp(m.edge_net, edge_attr)
     msg = T.linear(T.mul(h_edge, T.gather(h_node, g.right)), m.msg_net.weight, m.msg_net.bias)
-    gt = mlp(m.gate, cat(edge_attr, T.gather(x, g.right), node_time[g.right.index]))
+    g0, ed = m.gate.net[0], edge_attr.shape[1]
+    per_node = T.linear(cat(x, node_time), g0.weight[:, ed:])                      # x[col] and node_time[col] columns
+    gt = mlp_from_pre(m.gate, T.linear(edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right)))
     msg = T.gate(msg, gt)
-    out = T.add(T.linear(x, m.centroid_lin.weight, m.centroid_lin.bias), T.scatter_sum(msg, g.left))
+    out = T.linear(x, m.centroid_lin.weight, m.centroid_lin.bias, addend=T.scatter_sum(msg, g.left))
     out = T.ln_relu(out, m.layer_norm.weight, m.layer_norm.bias, True)
     return T.linear(out, m.out_transform.weight, m.out_transform.bias)
 
 
-def bond_ffn(m, bond_in, node_in, time):
-    inter = T.mul(T.linear(bond_in, m.bond_linear.weight), T.linear(node_in, m.node_linear.weight))
-    inter = mlp(m.inter_module, inter)
-    return T.gate(inter, mlp(m.gate, cat(bond_in, node_in, time)))
+def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
+    """BondFFN on (bond_in, node_in, time) where node_in is either node_rows[plan.index] (hoisted) or node_edges (E rows)."""
+    g0, bd = m.gate.net[0], bond_in.shape[1]
+    nd = g0.weight.shape[1] - bd - 1
+    if node_edges is None:
+        node_feat = T.gather(T.linear(node_rows, m.node_linear.weight), plan)
+        gate_node = T.gather(T.linear(node_rows, g0.weight[:, bd:bd + nd]), plan)
+    else:
+        node_feat = T.linear(node_edges, m.node_linear.weight)
+        gate_node = T.linear(node_edges, g0.weight[:, bd:bd + nd])
+    inter = mlp(m.inter_module, T.mul(T.linear(bond_in, m.bond_linear.weight), node_feat))
+    pre = T.linear(bond_in, g0.weight[:, :bd], g0.bias, addend=T.linear(time, g0.weight[:, bd + nd:], None, addend=gate_node))
+    return T.gate(inter, mlp_from_pre(m.gate, pre))
 
 
 def edge_block(m, h_bond, g, h_node, bond_time):
-    hl, hr = T.gather(h_node, g.left), T.gather(h_node, g.right)
-    ml = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_left, h_bond, hl, bond_time), g.right), g.left)
-    mr = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, hr, bond_time), g.left), g.right)
-    h = T.add(T.add(ml, mr), T.add(T.linear(hl, m.node_ffn_left.weight, m.node_ffn_left.bias),
-                                   T.linear(hr, m.node_ffn_right.weight, m.node_ffn_right.bias)))
-    h = T.add(h, T.linear(h_bond, m.self_ffn.weight, m.self_ffn.bias))
+    ml = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_left, h_bond, bond_time, h_node, g.left), g.right), g.left)
+    mr = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, bond_time, h_node, g.right), g.left), g.right)
+    nl = T.gather(T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias), g.left)
+    nr = T.gather(T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias), g.right)
+    h = T.linear(h_bond, m.self_ffn.weight, m.self_ffn.bias, addend=T.add(T.add(ml, mr), T.add(nl, nr)))
     h = T.ln_relu(h, m.layer_norm.weight, m.layer_norm.bias, True)
     return T.linear(h, m.out_transform.weight, m.out_transform.bias)
 
 
 def pos_update(m, h_node, h_edge, g, rel, dist, edge_time):
-    lf = mlp(m.left_lin_edge, T.gather(h_node, g.left))
-    rf = mlp(m.right_lin_edge, T.gather(h_node, g.right))
-    w = bond_ffn(m.edge_lin, h_edge, T.mul(lf, rf), edge_time)
+    lf = T.gather(mlp(m.left_lin_edge, h_node), g.left)
+    rf = T.gather(mlp(m.right_lin_edge, h_node), g.right)
+    w = bond_ffn(m.edge_lin, h_edge, edge_time, node_edges=T.mul(lf, rf))
     return T.scatter_sum(T.force(w, rel, dist), g.left)
 
 

@@ -27,13 +27,15 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def sgemm_nt(a, b, bias=None, splits=1):
-    """a (M,K) @ b (N,K)^T + bias -> (M,N)."""
+def sgemm_nt(a, b, bias=None, splits=1, addend=None):
+    """a (M,K) @ b (N,K)^T + bias + addend -> (M,N).  Rows of a / b may be strided (column slices of a wider matrix)."""
     M, K = a.shape
     N = b.shape[0]
+    assert a.stride(1) == 1 and b.stride(1) == 1
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     part = torch.empty(splits * M * N, dtype=torch.float32, device=a.device) if splits > 1 else None
-    check(_L().mdx_op_sgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(out), N, M, N, K, splits, ptr(part), stream()))
+    check(_L().mdx_op_sgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0, ptr(out),
+                               N, M, N, K, splits, ptr(part), stream()))
     return out
 
 
@@ -60,13 +62,22 @@ def _splits_for(rows):
     return max(1, min(256, rows // 2048))
 
 
+def _rows(t):
+    """fp32 device matrix whose rows are contiguous (row stride arbitrary: column slices of a weight stay views)."""
+    _lib._need_gpu(t)
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
-        xc, wc = _c(x), _c(w)
+    def forward(ctx, x, w, b, addend):
+        xc, wc = _rows(x), _rows(w)
         ctx.save_for_backward(xc, wc)
-        ctx.has_bias = b is not None
-        return sgemm_nt(xc, wc, _c(b) if b is not None else None)
+        ctx.has_bias, ctx.has_addend = b is not None, addend is not None
+        return sgemm_nt(xc, wc, _c(b) if b is not None else None, addend=_c(addend) if addend is not None else None)
 
     @staticmethod
     def backward(ctx, gy):
@@ -79,12 +90,13 @@ class _Linear(torch.autograd.Function):
             gw = sgemm_nt(transpose(gy), transpose(x), splits=_splits_for(x.shape[0]))   # (N,M) @ (K,M)^T
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = colreduce(gy)
-        return gx, gw, gb
+        return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None)
 
 
-def linear(x, w, b=None):
-    """y = x @ w.T + b for 2-D x (rows, in_features)."""
-    return _Linear.apply(x, w, b)
+def linear(x, w, b=None, addend=None):
+    """y = x @ w.T + b + addend for 2-D x (rows, in_features); `addend` (rows, out_features) is added in the GEMM epilogue
+    (used for the per-node part of a layer whose reference input is a concatenation [edge part | node part | time])."""
+    return _Linear.apply(x, w, b, addend)
 
 
 class _LnRelu(torch.autograd.Function):
