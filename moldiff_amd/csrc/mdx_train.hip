@@ -57,21 +57,37 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__
   const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   f32x4 acc[4][2];
   acc_zero<4, 2>(acc);
-  for (int k0 = kbeg; k0 < kend; k0 += G_KC) {
-    // stage the two tiles (8 float4 per row): A 128 rows -> 4 slots per thread, B 64 rows -> 2 slots per thread
+  // tile slots of this thread (8 float4 per row): A 128 rows -> 4 slots, B 64 rows -> 2 slots; the next chunk's global
+  // loads are issued before the MFMA block of the current one (register double buffering)
+  f32x4 ra[4], rb[2];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int slot = tid + 256 * j, row = slot >> 3, k4 = (slot & 7) * 4;
       const int gm = m0 + row;
-      sts4(As + row * G_LD + k4, load4_guard(A + (size_t)gm * lda, k0 + k4, kend, gm < M, veca));
+      ra[j] = load4_guard(A + (size_t)gm * lda, k0 + k4, kend, gm < M, veca);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int slot = tid + 256 * j, row = slot >> 3, k4 = (slot & 7) * 4;
       const int gn = n0 + row;
-      sts4(Bs + row * G_LD + k4, load4_guard(B + (size_t)gn * ldb, k0 + k4, kend, gn < N, vecb));
+      rb[j] = load4_guard(B + (size_t)gn * ldb, k0 + k4, kend, gn < N, vecb);
+    }
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += G_KC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j;
+      sts4(As + (slot >> 3) * G_LD + (slot & 7) * 4, ra[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = tid + 256 * j;
+      sts4(Bs + (slot >> 3) * G_LD + (slot & 7) * 4, rb[j]);
     }
     __syncthreads();
+    if (k0 + G_KC < kend) fetch(k0 + G_KC);
 #pragma unroll
     for (int g = 0; g < G_KC / 16; ++g) {
       f32x4 a[4], b[2];
@@ -121,6 +137,77 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__
       }
     }
   }
+}
+
+// Weight gradient without transposes: P[z][n][k] = sum_{m in split z} G[m][n] * X[m][k]   (G = dY (M,N), X (M,K) row-major).
+// Workgroup tile 64 (n) x 64 (k); 32 rows of G and X are staged per step in their memory layout [m][cols] (coalesced
+// 16-byte loads); the MFMA contraction index runs over m, so operands are read from LDS as scalars down a column
+// (leading dimension 68: the four row groups of a wave land in disjoint banks).  Wave w owns a 32 x 32 quadrant.
+constexpr int W_T = 64, W_MC = 32, W_LD = W_T + 4;
+__global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                              int M, int N, int K, int mper, float* __restrict__ P) {
+  __shared__ __attribute__((aligned(16))) float Gs[W_MC * W_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[W_MC * W_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * W_T, k0 = blockIdx.x * W_T;
+  const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+  const bool vecg = ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0);
+  const bool vecx = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  f32x4 acc[2][2];
+  acc_zero<2, 2>(acc);
+  // 32 rows x 16 float4 per tile = 512 slots -> 2 per thread per tile
+  f32x4 rg[2], rx[2];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
+      const int gm = m0 + row;
+      rg[j] = load4_guard(G + (size_t)gm * ldg + n0, c4, N - n0, gm < mend, vecg && ((n0 & 3) == 0));
+      rx[j] = load4_guard(X + (size_t)gm * ldx + k0, c4, K - k0, gm < mend, vecx && ((k0 & 3) == 0));
+    }
+  };
+  if (mbeg < mend) fetch(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += W_MC) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
+      sts4(Gs + row * W_LD + c4, rg[j]);
+      sts4(Xs + row * W_LD + c4, rx[j]);
+    }
+    __syncthreads();
+    if (m0 + W_MC < mend) fetch(m0 + W_MC);
+#pragma unroll
+    for (int mm = 0; mm < W_MC; mm += 16) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int r = mm + 4 * q + s;
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = Gs[r * W_LD + wn + 16 * i + c];
+          b[i] = Xs[r * W_LD + wk + 16 * i + c];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // acc[i][j][r] = P[n = n0 + wn + 16 i + 4 q + r][k = k0 + wk + 16 j + c]
+  float* out = P + (size_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + 16 * i + 4 * q + r, k = k0 + wk + 16 * j + c;
+        if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
 }
 
 // C[i][j] = bias[j] + sum_z P[z][i][j]   (fixed order -> deterministic)
@@ -643,5 +730,24 @@ extern "C" int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_
   const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2s, gnorm2, max_norm);
+  return launched();
+}
+
+// Weight gradient of a Linear layer: dW[N,K] = G[M,N]^T X[M,K] (row-major operands as stored by the forward/backward;
+// no transposes).  The M rows are cut into `splits` ranges whose partial products (partial: splits*N*K floats) are
+// summed in a fixed order.
+extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, int64_t M, int64_t N,
+                               int64_t K, int32_t splits, float* partial, void* stream) {
+  if (N <= 0 || K <= 0) return MDX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!G || !X || !dW || !partial) return bad("sgemm_tn: null operand / partial buffer");
+  if (splits < 1) splits = 1;
+  int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
+  mper = (mper + W_MC - 1) / W_MC * W_MC;
+  const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
+  dim3 grid((unsigned)((K + W_T - 1) / W_T), (unsigned)((N + W_T - 1) / W_T), (unsigned)S);
+  hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)N * K)), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K,
+                     (const float*)nullptr, dW, (int)ldw);
   return launched();
 }

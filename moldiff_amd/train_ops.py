@@ -39,6 +39,17 @@ def sgemm_nt(a, b, bias=None, splits=1, addend=None):
     return out
 
 
+def sgemm_tn(g, x, splits):
+    """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors."""
+    M, N = g.shape
+    K = x.shape[1]
+    splits = max(1, int(splits))
+    out = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    part = torch.empty(splits * N * K, dtype=torch.float32, device=g.device)
+    check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, M, N, K, splits, ptr(part), stream()))
+    return out
+
+
 def transpose(x, pad=4):
     """(R,C) -> contiguous-rows (C,R) view whose leading dimension is padded to a multiple of `pad` floats (so that the
     SGEMM's 16-byte loads stay aligned for any R)."""
@@ -57,9 +68,10 @@ def colreduce(x, y=None):
     return out
 
 
-def _splits_for(rows):
-    # weight gradient = contraction over `rows`: enough K-splits to fill the chip, each at least 2048 rows long
-    return max(1, min(256, rows // 2048))
+def _splits_for(rows, n, k):
+    # weight gradient = contraction over `rows`: enough row ranges to put ~1000 workgroups on the chip, each >= 512 rows
+    tiles = ((n + 63) // 64) * ((k + 63) // 64)
+    return max(1, min(rows // 512, (1024 + tiles - 1) // tiles))
 
 
 def _rows(t):
@@ -87,7 +99,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = sgemm_nt(gy, transpose(w))                       # (M,N) @ (K,N)^T
         if ctx.needs_input_grad[1]:
-            gw = sgemm_nt(transpose(gy), transpose(x), splits=_splits_for(x.shape[0]))   # (N,M) @ (K,M)^T
+            gw = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = colreduce(gy)
         return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None)
