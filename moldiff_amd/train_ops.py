@@ -69,9 +69,9 @@ def colreduce(x, y=None):
 
 
 def _splits_for(rows, n, k):
-    # weight gradient = contraction over `rows`: enough row ranges to put ~1000 workgroups on the chip, each >= 512 rows
+    # weight gradient = contraction over `rows`: enough row ranges to put ~512 workgroups (2 per CU) on the chip, each >= 512 rows
     tiles = ((n + 63) // 64) * ((k + 63) // 64)
-    return max(1, min(rows // 512, (1024 + tiles - 1) // tiles))
+    return max(1, min(rows // 512, (512 + tiles - 1) // tiles))
 
 
 def _rows(t):
