@@ -129,6 +129,13 @@ class PosUpdate(_Block):
 
 
 class NodeEdgeNet(Module):
+    def __getstate__(self):
+        # the packed-weight engine is a device handle: never copied or pickled (deepcopy / torch.save of the module
+        # rebuild it lazily from the state_dict on first use)
+        d = self.__dict__.copy()
+        d['_eng'], d['_eng_sig'] = None, None
+        return d
+
     def __init__(self, node_dim, edge_dim, num_blocks, cutoff, use_gate, **kwargs):
         super().__init__()
         self.node_dim, self.edge_dim, self.num_blocks = node_dim, edge_dim, num_blocks

@@ -31,6 +31,13 @@ from .transition import ContigousTransition, GeneralCategoricalTransition
 
 
 class MolDiff(Module):
+    def __getstate__(self):
+        # the packed-weight engine is a device handle: never copied or pickled (deepcopy / torch.save of the module
+        # rebuild it lazily from the state_dict on first use)
+        d = self.__dict__.copy()
+        d['_eng'], d['_eng_sig'] = None, None
+        return d
+
     def __init__(self, config, num_node_types, num_edge_types, **kwargs):
         super().__init__()
         self.config = config

@@ -1,0 +1,135 @@
+"""Training entry point -- the MI355X counterpart of the reference's ``scripts/train_drug3d.py`` / ``scripts/train_bond.py``.
+
+    python -m moldiff_amd.train_drug3d --config configs/train_MolDiff.yml --device cuda:0 --logdir ./logs [--max_iters N]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m moldiff_amd.train_drug3d ...
+
+Same loop (scripts/train_drug3d.py:88-190): per iteration a batch, ``pos_noise_std`` jitter on the coordinates,
+``model.get_loss``, backward, clip_grad_norm_(max_grad_norm), AdamW; every ``val_freq`` iterations a validation pass
+under no_grad, the plateau scheduler on the validation loss and a checkpoint ``{config, model, optimizer, scheduler,
+iteration}`` under ``<logdir>/checkpoints/<it>.pt`` that ``sample_drug3d`` loads.  What differs, deliberately:
+  * forward/backward run on the HIP layer operators, the optimizer on flat buffers (``trainer.Trainer``), fp32 (no AMP);
+  * data parallelism is one process per GPU with one gradient all-reduce per step (torch.distributed / RCCL); every rank
+    draws its own batches (seed + rank), rank 0 validates, logs and checkpoints;
+  * the GEOM-Drugs pipeline (SDF parsing, RDKit featurisation, LMDB: utils/dataset.py, utils/transforms.py) is CPU
+    chemistry outside this path.  The loader seam is ``batches(it)`` below: anything yielding the seven fields
+    (node_type (N), node_pos (N,3), batch_node (N), halfedge_type (Eh), halfedge_index (2,Eh), batch_halfedge (Eh),
+    num_graphs) of the reference's collated ``Drug3DData`` batch can replace the built-in synthetic generator.
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import BondPredictor, MolDiff
+from .harness import load_config, placeholder_from_sizes, seed_all
+from .trainer import PlateauScheduler, Trainer
+
+
+class SyntheticMolecules:
+    """Random 'molecules' with the size statistics of GEOM-Drugs: uniform element types, ~25 % bonded pairs, Gaussian
+    coordinates.  Exercises every code path of training; it is NOT chemistry."""
+
+    def __init__(self, cfg, batch_size, seed, device, num_bond_classes=5):
+        self.g = np.random.Generator(np.random.PCG64(seed))
+        self.mean, self.std = float(cfg.get('mean_atoms', 24.92)), float(cfg.get('std_atoms', 5.52))
+        self.batch_size, self.device, self.nb = batch_size, device, num_bond_classes
+
+    def __call__(self, it):
+        g = self.g
+        sizes = np.maximum(g.normal(self.mean, self.std, self.batch_size).astype(np.int64), 2)
+        ph = placeholder_from_sizes(sizes, self.device)
+        N, Eh = int(ph['batch_node'].numel()), int(ph['batch_halfedge'].numel())
+        node_type = torch.from_numpy(g.integers(0, 7, N)).to(self.device)
+        pos = torch.from_numpy((g.standard_normal((N, 3)) * 2.0).astype(np.float32)).to(self.device)
+        half = torch.from_numpy((g.random(Eh) < 0.25) * g.integers(1, self.nb, Eh)).to(self.device)
+        return node_type, pos, ph['batch_node'], half, ph['halfedge_index'], ph['batch_halfedge'], len(sizes)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', type=str, default='./configs/train_MolDiff.yml')
+    ap.add_argument('--device', type=str, default='cuda:0')
+    ap.add_argument('--logdir', type=str, default='./logs')
+    ap.add_argument('--max_iters', type=int, default=0, help='override train.max_iters')
+    ap.add_argument('--val_batches', type=int, default=4)
+    ap.add_argument('--recipe-weights', action='store_true', help='start from the deterministic synthetic weights of the tests')
+    args = ap.parse_args(argv)
+    config = load_config(args.config)
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+    device = torch.device(args.device if world == 1 else f'cuda:{local_rank}')
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    seed_all(config.train.seed + rank)
+    is_bond = config.model.name == 'bond_predictor'
+    if is_bond:
+        model = BondPredictor(config.model, 8, 5)
+    else:
+        model = MolDiff(config.model, 8, 6)
+    if args.recipe_weights:
+        from .harness import recipe_state_dict
+        model.load_state_dict(recipe_state_dict(model, 20230808 if is_bond else 20230807))
+    model = model.to(device).train()
+    oc = config.train.optimizer
+    if oc.type != 'adamw':
+        raise NotImplementedError('Optimizer not supported: %s' % oc.type)
+    trainer = Trainer(model, lr=oc.lr, betas=(oc.beta1, oc.beta2), weight_decay=oc.weight_decay, max_grad_norm=config.train.max_grad_norm)
+    sc = config.train.scheduler
+    if sc.type != 'plateau':
+        raise NotImplementedError('Scheduler not supported: %s' % sc.type)
+    scheduler = PlateauScheduler(trainer, factor=sc.factor, patience=sc.patience, min_lr=sc.min_lr)
+    if config.dataset.name != 'synthetic':
+        raise NotImplementedError("only `dataset: {name: synthetic}` is built in; plug a loader into batches(it) (module docstring)")
+    nbc = 5 if is_bond else 5
+    batches = SyntheticMolecules(config.dataset, config.train.batch_size, config.train.seed + 1000 * rank, device, nbc)
+    val_batches = SyntheticMolecules(config.dataset, config.train.batch_size, config.train.seed + 777, device, nbc)
+    ckpt_dir = os.path.join(args.logdir, 'checkpoints')
+    if rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+    log = (lambda s: print(s, flush=True)) if rank == 0 else (lambda s: None)
+    max_iters = args.max_iters or config.train.max_iters
+
+    def validate(it):
+        sums, n = {}, 0
+        with torch.no_grad():
+            for j in range(args.val_batches):
+                b = val_batches(j)
+                out = model.get_loss(*b)
+                for k, v in out.items():
+                    sums[k] = sums.get(k, 0.0) + float(v)
+                n += 1
+        avg = {k: v / n for k, v in sums.items()}
+        scheduler.step(avg['loss'])
+        log('[Validate] Iter %05d | ' % it + ' | '.join('%s: %.6f' % kv for kv in avg.items()))
+        return avg['loss']
+
+    t0 = time.time()
+    for it in range(1, max_iters + 1):
+        b = list(batches(it))
+        b[1] = b[1] + torch.randn_like(b[1]) * config.train.pos_noise_std
+        out = trainer.step(*b)
+        if rank == 0 and (it % 10 == 0 or it == 1 or it == max_iters):
+            log('[Train] Iter %d | ' % it + ' | '.join('%s: %.6f' % (k, float(v)) for k, v in out.items()) +
+                ' | lr %.2e | %.1f it/s' % (trainer.lr, it / (time.time() - t0)))
+        if it % config.train.val_freq == 0 or it == max_iters:
+            if rank == 0:
+                validate(it)
+                torch.save({'config': config, 'model': model.state_dict(), 'optimizer': trainer.state_dict(),
+                            'scheduler': scheduler.state_dict(), 'iteration': it}, os.path.join(ckpt_dir, '%d.pt' % it))
+            if world > 1:
+                lr = torch.tensor([trainer.lr], dtype=torch.float64, device=device)
+                torch.distributed.broadcast(lr, 0)        # rank 0's scheduler decides the learning rate for everyone
+                trainer.lr = float(lr.item())
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())
