@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
 // LayerNorm (+ReLU), one wave per row, F <= 1024.  Lane holds features lane, lane+64, ...
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXJ = 16;
+#define MDX_LN_RPW 16  // rows per wave in the backward (16: 9.7 k waves for E = 155 k rows; 64 left the chip half empty)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -614,7 +615,7 @@ extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const floa
   return launched();
 }
 
-// dx (M,F); dgamma, dbeta (F).  ws: (ceil(M/64) + ceil(ceil(M/64)/512)) * 2F floats.
+// dx (M,F); dgamma, dbeta (F).  ws: mdx_op_ln_relu_bwd_ws(M, F) bytes.
 extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
                                   int32_t F, int32_t relu, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -625,7 +626,7 @@ extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* 
     return MDX_OK;
   }
   if (!ws) return bad("ln_relu_bwd: workspace required");
-  const int RPW = 64;
+  const int RPW = MDX_LN_RPW;
   const int nw = (int)((M + RPW - 1) / RPW);     // waves
   const int nwp = (nw + 3) / 4 * 4;              // rows of `part` actually written (whole workgroups)
   float* part = ws;
@@ -649,7 +650,7 @@ extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* 
   return launched();
 }
 extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
-  const int64_t nw = (M + 63) / 64, nwp = (nw + 3) / 4 * 4, nb = (nwp + 511) / 512;
+  const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW, nwp = (nw + 3) / 4 * 4, nb = (nwp + 511) / 512;
   return (size_t)(nwp + nb + 1) * 2 * F * sizeof(float);
 }
 

@@ -95,6 +95,17 @@ class MolDiff(Module):
         ts = torch.cat([ts, T - ts - 1], dim=0)[:num_graphs]
         return ts, torch.ones_like(ts).float() / T
 
+    @torch.no_grad()
+    def add_noise(self, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol, t,
+                  bond_predictor=None, **kwargs):
+        """Perturb a clean batch to step `t` (the same step for every molecule): [h_node_pert, pos_pert, h_halfedge_pert]
+        (models/model.py:106-126)."""
+        time_step = t * torch.ones(num_mol, device=node_pos.device).long()
+        pos_pert = self.pos_transition.add_noise(node_pos, time_step, batch_node)
+        h_node_pert = self.node_transition.add_noise(node_type, time_step, batch_node)[0]
+        h_halfedge_pert = self.edge_transition.add_noise(halfedge_type, time_step, batch_halfedge)[0]
+        return [h_node_pert, pos_pert, h_halfedge_pert]
+
     def get_loss(self, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol, *,
                  time_step=None, noise=None):
         """Diffusion loss of a clean batch (models/model.py:128-201).

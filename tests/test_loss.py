@@ -232,3 +232,17 @@ def test_gpu_bondpred_training_loss_and_parameter_gradients_match_reference():
     got['loss'].backward()
     _check_param_grads('bond', m)
     m.zero_grad(set_to_none=True)
+
+
+@pytest.mark.gpu
+def test_gpu_add_noise_helper_layout_and_limits():
+    """MolDiff.add_noise (models/model.py:106-126): at t = 0 the batch is (almost) untouched, at t = T-1 it is the prior."""
+    args, _, _, _ = _case('simple', 'cuda')
+    m = U.moldiff('MolDiff_simple', 'cuda')
+    node_type, node_pos = args[0], args[1]
+    torch.manual_seed(5)
+    hn, pos, hh = m.add_noise(*args, 0)
+    assert hn.shape == (node_type.numel(), 8) and pos.shape == node_pos.shape and hh.shape == (args[3].numel(), 6)
+    assert torch.equal(hn.argmax(-1), node_type) and float((pos - node_pos).abs().max()) < 0.1
+    hn, pos, hh = m.add_noise(*args, 999)
+    assert (hn.argmax(-1) == 7).float().mean() > 0.95 and (hh.argmax(-1) == 0).float().mean() > 0.9   # tomask / absorb priors
