@@ -246,3 +246,37 @@ def test_gpu_add_noise_helper_layout_and_limits():
     assert torch.equal(hn.argmax(-1), node_type) and float((pos - node_pos).abs().max()) < 0.1
     hn, pos, hh = m.add_noise(*args, 999)
     assert (hn.argmax(-1) == 7).float().mean() > 0.95 and (hh.argmax(-1) == 0).float().mean() > 0.9   # tomask / absorb priors
+
+
+@pytest.mark.gpu
+def test_gpu_training_gradients_match_oracle_autograd_on_degenerate_molecules():
+    """Sizes (1, 2, 5, 17): a single atom has no edges at all.  Every parameter gradient of the GPU training path vs autograd
+    through the CPU oracle (itself pinned to the reference's autograd on the golden batch)."""
+    g = U.rng(99)
+    sizes = [1, 2, 5, 17]
+    bn, hei, bh, _, _ = U.graph_from_sizes(sizes)
+    N, Eh, B = len(bn), len(bh), len(sizes)
+    node_type = torch.from_numpy(g.integers(0, 7, N))
+    node_pos = U.t32(g.standard_normal((N, 3)) * 2)
+    half_type = torch.from_numpy((g.random(Eh) < 0.3) * g.integers(1, 5, Eh))
+    t = torch.tensor([0, 250, 700, 999])
+    noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))), u_node=U.t32(g.random((N, 8))), u_halfedge=U.t32(g.random((Eh, 6))))
+    m = U.moldiff('MolDiff', 'cuda')
+    m.zero_grad(set_to_none=True)
+    c = lambda x: x.cuda()
+    got = m.get_loss(c(node_type), c(node_pos), c(bn), c(half_type), c(hei), c(bh), B, time_step=c(t),
+                     noise={k: c(v) for k, v in noise.items()})
+    got['loss'].backward()
+    P = U.params(U.moldiff('MolDiff'))
+    names = [k for k, p in m.named_parameters() if p.requires_grad]
+    Pg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in P.items()}
+    want = O.moldiff_loss(Pg, U.CFG, U.tables(Pg), node_type, node_pos, bn, half_type, hei, bh, B, t, noise)
+    want['loss'].backward()
+    assert abs(float(got['loss']) - float(want['loss'])) <= RTOL * max(1.0, abs(float(want['loss'])))
+    gmax = max(float(Pg[k].grad.norm()) for k in names)
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            w = Pg[k].grad
+            err = float((p.grad.cpu() - w).double().norm()) / max(float(w.double().norm()), 1e-3 * gmax)
+            assert err <= GTOL, (k, err)
+    m.zero_grad(set_to_none=True)
