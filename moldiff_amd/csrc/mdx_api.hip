@@ -932,6 +932,7 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
 namespace {
 struct TapeBlock {
   float *Hep, *Hn, *H, *NT, *aggr, *SL, *SR;
+  float *SG, *HE, *M;  // (E,256): sigmoid(gate), edge_net output, gated message -- read back by edge_bwd instead of recomputed
 };
 struct Tape {
   std::vector<TapeBlock> b;
@@ -953,6 +954,7 @@ size_t tape_layout(int64_t N, int64_t E, int nb, char* base, Tape* t) {
     TapeBlock& k = tp.b[i];
     k.Hep = take(e * 64); k.Hn = take(n * MDX_ND); k.H = take(n * MDX_ND); k.NT = take(n * MDX_NTW);
     k.aggr = take(n * MDX_ND); k.SL = take(n * 64); k.SR = take(n * 64);
+    k.SG = take(e * MDX_ND); k.HE = take(e * MDX_ND); k.M = take(e * MDX_ND);
   }
   tp.HeF = take(e * 64); tp.HnF = take(n * MDX_ND); tp.te = take(e);
   tp.GGX = take(e * MDX_ND); tp.GNL0 = take(e * 128); tp.GNL1 = take(e * 128); tp.GGXS0 = take(e * 32);
@@ -998,12 +1000,19 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
     float* Hep = wr.HeB;
     if (tape) {
       const TapeBlock& k = tp.b[i];
-      wi.H = k.H; wi.NT = k.NT; wi.aggr = k.aggr; wi.SL = k.SL; wi.SR = k.SR;
+      wi.H = k.H; wi.NT = k.NT; wi.aggr = k.aggr; wi.SL = k.SL; wi.SR = k.SR; wi.M = k.M;
       Hep = k.Hep;
       HIPCHK(hipMemcpyAsync(k.Hn, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
     }
     if (i == 0 || tape) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
-    launch_edge_a(make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN, wi.NT), s);
+    {
+      EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN, wi.NT);
+      if (tape) {
+        ea_args.tSG = tp.b[i].SG;
+        ea_args.tHE = tp.b[i].HE;
+      }
+      launch_edge_a(ea_args, s);
+    }
     launch_seg_reduce(wi.M, g->row_ptr, nullptr, wi.aggr, nullptr, (int)g->N, 256, s);
     launch_seg_reduce(wi.FL, g->col_ptr, g->col_eids, wi.SL, nullptr, (int)g->N, 64, s);
     launch_seg_reduce(wi.FR, g->row_ptr, nullptr, wi.SR, nullptr, (int)g->N, 64, s);
@@ -1069,6 +1078,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
     eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
+    eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i];
     launch_edge_bwd(eb, s);

@@ -154,50 +154,9 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_bwd_kernel(const EdgeBwdArgs a
   const int ft0 = 4 * wave;
   // ---------------- NodeBlock message path ------------------------------------------------------
   {
-    f32x4 sg[4][BET], m0[4][BET], he[4][BET];
-    {  // forward: gate -> sg
-      f32x4 acc[4][BET];
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        const int f = 16 * (ft0 + ft) + 4 * q;
-        const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
-#pragma unroll
-        for (int et = 0; et < BET; ++et)
-          acc[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tt[et]) * wt;
-      }
-      gemm_tile<4, BET, 64>(acc, a.w.Wg1e, 16, ft0, Hep, LD64, lane);
-      layernorm_relu<4, BET, 4>(acc, a.w.gg, a.w.gb, ft0, red, red2, wave, lane, true);
-      acc_to_lds<4, BET>(acc, X, LD256, 0, ft0, lane);
-      __syncthreads();
-      acc_bias<4, BET>(acc, a.w.bg2, ft0, lane);
-      gemm_tile<4, BET, 256>(acc, a.w.Wg2, 16, ft0, X, LD256, lane);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et) sg[ft][et] = sigmoid4(acc[ft][et]);
-      __syncthreads();
-    }
-    {  // forward: he, m0
-      f32x4 acc[4][BET];
-      acc_bias<4, BET>(acc, a.w.en.b1, ft0, lane);
-      gemm_tile<4, BET, 64>(acc, a.w.en.W1, 16, ft0, Hep, LD64, lane);
-      layernorm_relu<4, BET, 4>(acc, a.w.en.g, a.w.en.be, ft0, red, red2, wave, lane, true);
-      acc_to_lds<4, BET>(acc, X, LD256, 0, ft0, lane);
-      __syncthreads();
-      acc_bias<4, BET>(he, a.w.en.b2, ft0, lane);
-      gemm_tile<4, BET, 256>(he, a.w.en.W2, 16, ft0, X, LD256, lane);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et)
-          acc[ft][et] = he[ft][et] * ldg4(a.H + (size_t)ri[et] * MDX_ND + 16 * (ft0 + ft) + 4 * q);
-      __syncthreads();
-      acc_to_lds<4, BET>(acc, X, LD256, 0, ft0, lane);
-      __syncthreads();
-      acc_bias<4, BET>(m0, a.w.bm, ft0, lane);
-      gemm_tile<4, BET, 256>(m0, a.w.Wm, 16, ft0, X, LD256, lane);
-    }
-    // backward: gm = dL/d(aggr)[l];  m = m0 * sg
+    // forward values of this section come from the tape the forward kernel wrote (sigmoid(gate), edge_net output, gated
+    // message): three (E,256) reads replace ~390 kFLOP/edge of recomputation (gate and edge_net second layers, msg_net)
+    // backward: gm = dL/d(aggr)[l];  M = m0 * sg
     f32x4 gg2[4][BET];
     {
       f32x4 gm0[4][BET];
@@ -205,9 +164,12 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_bwd_kernel(const EdgeBwdArgs a
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int et = 0; et < BET; ++et) {
+          const size_t o = (size_t)(e0 + 16 * et + c) * MDX_ND + 16 * (ft0 + ft) + 4 * q;
+          const f32x4 sg = valid[et] ? ldg4(a.SG + o) : splat4(0.f);
+          const f32x4 mg = valid[et] ? ldg4(a.M + o) : splat4(0.f);
           const f32x4 gm = ldg4(a.GNT + (size_t)li[et] * MDX_NTW + MDX_NT_C + 16 * (ft0 + ft) + 4 * q);
-          gm0[ft][et] = gm * sg[ft][et];
-          gg2[ft][et] = gm * m0[ft][et] * sg[ft][et] * (splat4(1.f) - sg[ft][et]);
+          gm0[ft][et] = gm * sg;
+          gg2[ft][et] = gm * mg * (splat4(1.f) - sg);  // m0 * sg = M
         }
       acc_to_lds<4, BET>(gm0, Y, LD256, 0, ft0, lane);
     }
@@ -222,7 +184,10 @@ __global__ __launch_bounds__(MDX_WG, 2) void edge_bwd_kernel(const EdgeBwdArgs a
 #pragma unroll
         for (int et = 0; et < BET; ++et) {
           const int f = 16 * (ft0 + ft) + 4 * q;
-          if (valid[et]) stg4(a.GH + (size_t)(e0 + 16 * et + c) * MDX_ND + f, gp[ft][et] * he[ft][et]);
+          if (valid[et]) {
+            const size_t o = (size_t)(e0 + 16 * et + c) * MDX_ND + f;
+            stg4(a.GH + o, gp[ft][et] * ldg4(a.HE + o));
+          }
           gp[ft][et] = gp[ft][et] * ldg4(a.H + (size_t)ri[et] * MDX_ND + f);
         }
       __syncthreads();  // all waves done reading Y (gm0)

@@ -190,7 +190,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-        for (int et = 0; et < ET; ++et) sg[ft][et] = sigmoid4(acc[ft][et]);
+        for (int et = 0; et < ET; ++et) {
+          sg[ft][et] = sigmoid4(acc[ft][et]);
+          if (a.tSG && valid[et]) stg4(a.tSG + (size_t)(e0 + 16 * et + c) * MDX_ND + 16 * (ft0 + ft) + 4 * q, sg[ft][et]);
+        }
       // no barrier: X (read by the GEMM above) is next written after the barrier inside edge_net's LayerNorm,
       // which every wave reaches only after it has left this GEMM
       MDX_STAMP(7);
@@ -212,8 +215,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_EWPS) void edge_a_kernel(const EdgeAArg
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-        for (int et = 0; et < ET; ++et)
+        for (int et = 0; et < ET; ++et) {
+          if (a.tHE && valid[et]) stg4(a.tHE + (size_t)(e0 + 16 * et + c) * MDX_ND + 16 * (ft0 + ft) + 4 * q, acc[ft][et]);
           acc[ft][et] = acc[ft][et] * ldg4(a.H + (size_t)ri[et] * MDX_ND + 16 * (ft0 + ft) + 4 * q);
+        }
       __syncthreads();
       acc_to_lds<4, ET>(acc, X, LD256, 0, ft0, lane);
       __syncthreads();

@@ -94,6 +94,7 @@ struct EdgeAArgs {
   const float* NT;        // (N,960)
   float* M;               // (E,256) gated messages
   float* F[2];            // (E,64) bond_ffn_left / right outputs
+  float *tSG, *tHE;       // optional tape for the guidance backward: sigmoid(gate) and edge_net output, (E,256) each
   EdgeAW w;
 };
 #define EA_EMB 1
@@ -170,6 +171,7 @@ struct EdgeBwdArgs {
   float cutoff;
   const float *Hep, *GHEP;     // (E,64)
   const float *H, *NT;         // tape node tables of this block
+  const float *SG, *HE, *M;    // tape (E,256): sigmoid(gate), edge_net output, gated message (M = msg_net(he*h[r]) * SG)
   const float* GNT;            // (N,960) gradient table: C cols = dL/d(aggr), NFL cols = A_l, NFR cols = A_r
   float* gHe_out;              // (E,64) dL/dHe_i
   float* gdist;                // (E) accumulated over blocks
