@@ -101,3 +101,45 @@ def test_train_entry_point_end_to_end(tmp_path):
     m.load_state_dict(ck['model'], strict=True)
     ref = U.moldiff('MolDiff_simple')
     assert any(not torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))    # weights moved
+
+
+def _dp_rank(rank, world, port, q):
+    """Two data-parallel ranks sharing the one GPU of the test box (gloo carries the all-reduce; on a real node it is
+    RCCL, same code path): different batches per rank, identical parameters on every rank after every step."""
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    m = U.moldiff('MolDiff_simple', DEV).train()
+    tr = Trainer(m, lr=3e-4)
+    norms = []
+    for it in range(3):
+        batch = _tiny_batch(100 + 10 * it + rank, sizes=(5 + rank, 8, 6))
+        torch.manual_seed(50 + it + 7 * rank)
+        out = tr.step(*batch)
+        norms.append(float(out['grad_norm']))
+    flat = tr.flat.data.detach().cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, norms, bool(all(torch.equal(gathered[0], g) for g in gathered)), float(flat.abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_data_parallel_ranks_stay_in_lockstep():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][2] and res[1][2]                       # bit-identical parameters across ranks
+    assert res[0][1] == res[1][1]                        # same (averaged) gradient norm seen by both
+    assert res[0][3] == res[1][3]

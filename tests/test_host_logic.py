@@ -208,3 +208,22 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(ROOT, 'moldiff_amd', fn)).read()
             assert 'import oracle' not in src and 'from oracle' not in src, fn
+
+
+def test_plateau_scheduler_follows_torch_reduce_on_plateau():
+    """trainer.PlateauScheduler vs torch.optim.lr_scheduler.ReduceLROnPlateau (the reference's 'plateau' scheduler,
+    utils/train.py:75-82) on a noisy, flattening loss curve."""
+    import types
+    from moldiff_amd.trainer import PlateauScheduler
+    g = np.random.Generator(np.random.PCG64(4))
+    losses = [2.0 * np.exp(-i / 15.0) + 0.5 + 0.01 * g.standard_normal() for i in range(120)]
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-3)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.6, patience=3, min_lr=1e-5)
+    tr = types.SimpleNamespace(lr=1e-3)
+    mine = PlateauScheduler(tr, factor=0.6, patience=3, min_lr=1e-5)
+    for x in losses:
+        ref.step(x)
+        mine.step(x)
+        assert abs(tr.lr - opt.param_groups[0]['lr']) < 1e-12
+    assert tr.lr < 1e-3
