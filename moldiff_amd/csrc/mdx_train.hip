@@ -210,15 +210,26 @@ __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __rest
       }
 }
 
-// C[i][j] = bias[j] + sum_z P[z][i][j]   (fixed order -> deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ P, int S, int M, int N, const float* __restrict__ bias,
-                                       float* __restrict__ C, int ldc) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * N) return;
-  const int row = (int)(i / N), col = (int)(i % N);
-  float s = bias ? bias[col] : 0.f;
-  for (int z = 0; z < S; ++z) s += P[(size_t)z * M * N + i];
-  C[(size_t)row * ldc + col] = s;
+// C[i][j] = bias[j] + sum_z P[z][i][j].  Block = 32 consecutive outputs x 8 split lanes: lane z sums splits z, z+8, ...
+// (coalesced 128-byte reads), the 8 lane sums are combined in lane order -> a fixed summation tree, deterministic.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, int S, int M, int N,
+                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc) {
+  __shared__ float sh[8][32];
+  const int o = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const size_t total = (size_t)M * N;
+  const size_t i = (size_t)blockIdx.x * 32 + o;
+  float s = 0.f;
+  if (i < total)
+    for (int k = z; k < S; k += 8) s += P[(size_t)k * total + i];
+  sh[z][o] = s;
+  __syncthreads();
+  if (z == 0 && i < total) {
+    const int row = (int)(i / N), col = (int)(i % N);
+    float r = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += sh[k][o];
+    C[(size_t)row * ldc + col] = r;
+  }
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, int ldi, int R, int Cn, float* __restrict__ out, int ldo) {
@@ -576,7 +587,7 @@ extern "C" int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int6
   dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), (unsigned)S);
   hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, (const float*)nullptr, (const float*)nullptr, 0, C,
                      (int)ldc, (int)M, (int)N, (int)K, kper, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)M * N)), dim3(256), 0, s, partial, S, (int)M, (int)N, bias, C, (int)ldc);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)M * N, 32)), dim3(256), 0, s, partial, S, (int)M, (int)N, bias, C, (int)ldc);
   return launched();
 }
 
@@ -748,7 +759,7 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
   dim3 grid((unsigned)((K + W_T - 1) / W_T), (unsigned)((N + W_T - 1) / W_T), (unsigned)S);
   hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)N * K)), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)N * K, 32)), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K,
                      (const float*)nullptr, dW, (int)ldw);
   return launched();
 }

@@ -69,9 +69,9 @@ def colreduce(x, y=None):
 
 
 def _splits_for(rows, n, k):
-    # weight gradient = contraction over `rows`: enough row ranges to put ~512 workgroups (2 per CU) on the chip, each >= 512 rows
+    # weight gradient = contraction over `rows`: enough row ranges to put ~2048 workgroups on the chip (each loops over its rows in 32-row steps, so many short loops hide the load latency better than few long ones), each >= 128 rows
     tiles = ((n + 63) // 64) * ((k + 63) // 64)
-    return max(1, min(rows // 512, (512 + tiles - 1) // tiles))
+    return max(1, min(rows // 128, (2048 + tiles - 1) // tiles))
 
 
 def _rows(t):
