@@ -87,7 +87,7 @@ def lib():
         L.mdx_op_transpose.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]
         L.mdx_op_colreduce.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_op_ln_relu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
-        L.mdx_op_ln_relu_bwd.argtypes = [c_void_p] * 5 + [c_int64, c_int32, c_int32] + [c_void_p] * 5
+        L.mdx_op_ln_relu_bwd.argtypes = [c_void_p] * 5 + [c_int64, c_int32, c_int32] + [c_void_p] * 4
         L.mdx_op_ln_relu_bwd_ws.restype = c_size_t
         L.mdx_op_ln_relu_bwd_ws.argtypes = [c_int64, c_int32]
         L.mdx_op_ew_fwd.argtypes = [c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]

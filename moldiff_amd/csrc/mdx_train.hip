@@ -211,16 +211,18 @@ __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __rest
 }
 
 // C[i][j] = bias[j] + sum_z P[z][i][j].  Block = 32 consecutive outputs x 8 split lanes: lane z sums splits z, z+8, ...
-// (coalesced 128-byte reads), the 8 lane sums are combined in lane order -> a fixed summation tree, deterministic.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, int S, int M, int N,
+// of its chunk (coalesced 128-byte reads), the 8 lane sums are combined in lane order -> a fixed summation tree,
+// deterministic.  blockIdx.y selects a chunk of `chunk` splits and writes row blockIdx.y of the output (two-stage use).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, int S, int chunk, int M, int N,
                                                                const float* __restrict__ bias, float* __restrict__ C, int ldc) {
   __shared__ float sh[8][32];
   const int o = threadIdx.x & 31, z = threadIdx.x >> 5;
   const size_t total = (size_t)M * N;
   const size_t i = (size_t)blockIdx.x * 32 + o;
+  const int s0 = blockIdx.y * chunk, s1 = min(S, s0 + chunk);
   float s = 0.f;
   if (i < total)
-    for (int k = z; k < S; k += 8) s += P[(size_t)k * total + i];
+    for (int k = s0 + z; k < s1; k += 8) s += P[(size_t)k * total + i];
   sh[z][o] = s;
   __syncthreads();
   if (z == 0 && i < total) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     float r = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) r += sh[k][o];
-    C[(size_t)row * ldc + col] = r;
+    C[(size_t)blockIdx.y * total + (size_t)row * ldc + col] = r;
   }
 }
 
@@ -560,6 +562,22 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 inline int bad(const char* m) { return mdx_set_error(MDX_ERR_ARG, m); }
+// out (M x N, ld) = bias + sum over the S partial copies in P; more than 256 copies go through `scratch`
+// (ceil(S/256) * M * N floats) in two fixed-order stages.
+constexpr int RED_CHUNK = 256;
+inline size_t reduce_scratch_floats(int64_t S, int64_t total) { return S > RED_CHUNK ? (size_t)((S + RED_CHUNK - 1) / RED_CHUNK) * total : 0; }
+inline void launch_reduce_partials(const float* P, int S, int M, int N, const float* bias, float* out, int ld, float* scratch,
+                                   hipStream_t s) {
+  const size_t total = (size_t)M * N;
+  const unsigned gx = (unsigned)((total + 31) / 32);
+  if (S <= RED_CHUNK || !scratch) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, P, S, S, M, N, bias, out, ld);
+    return;
+  }
+  const int nc = (S + RED_CHUNK - 1) / RED_CHUNK;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, nc), dim3(256), 0, s, P, S, RED_CHUNK, M, N, (const float*)nullptr, scratch, N);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)scratch, nc, nc, M, N, bias, out, ld);
+}
 inline int launched() {
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, hipGetErrorString(e));
@@ -587,7 +605,7 @@ extern "C" int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int6
   dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), (unsigned)S);
   hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, (const float*)nullptr, (const float*)nullptr, 0, C,
                      (int)ldc, (int)M, (int)N, (int)K, kper, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)M * N, 32)), dim3(256), 0, s, partial, S, (int)M, (int)N, bias, C, (int)ldc);
+  launch_reduce_partials(partial, S, (int)M, (int)N, bias, C, (int)ldc, nullptr, s);
   return launched();
 }
 
@@ -626,43 +644,24 @@ extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const floa
   return launched();
 }
 
-// dx (M,F); dgamma, dbeta (F).  ws: mdx_op_ln_relu_bwd_ws(M, F) bytes.
+// dx (M,F); dgb (2F) = [dgamma | dbeta].  ws: mdx_op_ln_relu_bwd_ws(M, F) bytes.
 extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
-                                  int32_t F, int32_t relu, float* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+                                  int32_t F, int32_t relu, float* dx, float* dgb, float* ws, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
-  if (M <= 0) {
-    hipMemsetAsync(dgamma, 0, (size_t)F * 4, s);
-    hipMemsetAsync(dbeta, 0, (size_t)F * 4, s);
-    return MDX_OK;
-  }
+  if (M <= 0) return hipMemsetAsync(dgb, 0, (size_t)F * 8, s) == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "memset");
   if (!ws) return bad("ln_relu_bwd: workspace required");
   const int RPW = MDX_LN_RPW;
   const int nw = (int)((M + RPW - 1) / RPW);     // waves
   const int nwp = (nw + 3) / 4 * 4;              // rows of `part` actually written (whole workgroups)
-  float* part = ws;
-  float* ws2 = ws + (size_t)nwp * 2 * F;
-  hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, F, relu, RPW, dx,
-                     part);
-  // column-reduce part (nwp x 2F) into [dgamma | dbeta]
-  const int RP = 512;
-  const int nb = (nwp + RP - 1) / RP;
-  float* red = nb == 1 ? nullptr : ws2;
-  float* tmp = ws2 + (size_t)nb * 2 * F;  // final 2F row
-  const unsigned gx = (unsigned)((2 * F + 63) / 64);
-  if (nb == 1) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, tmp);
-  } else {
-    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, nb), dim3(256), 0, s, (const float*)part, (const float*)nullptr, 2 * F, nwp, 2 * F, RP, red);
-    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)red, (const float*)nullptr, 2 * F, nb, 2 * F, nb, tmp);
-  }
-  hipMemcpyAsync(dgamma, tmp, (size_t)F * 4, hipMemcpyDeviceToDevice, s);
-  hipMemcpyAsync(dbeta, tmp + F, (size_t)F * 4, hipMemcpyDeviceToDevice, s);
+  hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, F, relu, RPW, dx, ws);
+  // [dgamma | dbeta] = sum over the nwp per-wave partial rows, fixed-order parallel reduction
+  launch_reduce_partials(ws, nwp, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)nwp * 2 * F, s);
   return launched();
 }
 extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
-  const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW, nwp = (nw + 3) / 4 * 4, nb = (nwp + 511) / 512;
-  return (size_t)(nwp + nb + 1) * 2 * F * sizeof(float);
+  const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW, nwp = (nw + 3) / 4 * 4;
+  return ((size_t)std::max<int64_t>(nwp, 1) * 2 * F + reduce_scratch_floats(nwp, 2 * F)) * sizeof(float);
 }
 
 extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
@@ -746,8 +745,8 @@ extern "C" int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_
 }
 
 // Weight gradient of a Linear layer: dW[N,K] = G[M,N]^T X[M,K] (row-major operands as stored by the forward/backward;
-// no transposes).  The M rows are cut into `splits` ranges whose partial products (partial: splits*N*K floats) are
-// summed in a fixed order.
+// no transposes).  The M rows are cut into `splits` ranges whose partial products are summed in a fixed order
+// (partial: (splits + ceil(splits/256)) * N*K floats: the partial products plus the first reduction stage).
 extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, int64_t M, int64_t N,
                                int64_t K, int32_t splits, float* partial, void* stream) {
   if (N <= 0 || K <= 0) return MDX_OK;
@@ -759,7 +758,6 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
   dim3 grid((unsigned)((K + W_T - 1) / W_T), (unsigned)((N + W_T - 1) / W_T), (unsigned)S);
   hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk((size_t)N * K, 32)), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K,
-                     (const float*)nullptr, dW, (int)ldw);
+  launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, partial + (size_t)S * N * K, s);
   return launched();
 }

@@ -45,7 +45,7 @@ def sgemm_tn(g, x, splits):
     K = x.shape[1]
     splits = max(1, int(splits))
     out = torch.empty(N, K, dtype=torch.float32, device=g.device)
-    part = torch.empty(splits * N * K, dtype=torch.float32, device=g.device)
+    part = torch.empty((splits + (splits + 255) // 256) * N * K, dtype=torch.float32, device=g.device)
     check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, M, N, K, splits, ptr(part), stream()))
     return out
 
@@ -129,11 +129,10 @@ class _LnRelu(torch.autograd.Function):
         gy = _c(gy)
         M, F = x.shape
         dx = torch.empty_like(x)
-        dg, db = torch.empty_like(g), torch.empty_like(b)
+        dgb = torch.empty(2 * F, dtype=torch.float32, device=x.device)
         ws = torch.empty(_L().mdx_op_ln_relu_bwd_ws(M, F) // 4 + 1, dtype=torch.float32, device=x.device)
-        check(_L().mdx_op_ln_relu_bwd(ptr(gy), ptr(x), ptr(stats), ptr(g), ptr(b), M, F, ctx.relu, ptr(dx), ptr(dg), ptr(db), ptr(ws),
-                                      stream()))
-        return dx, dg, db, None
+        check(_L().mdx_op_ln_relu_bwd(ptr(gy), ptr(x), ptr(stats), ptr(g), ptr(b), M, F, ctx.relu, ptr(dx), ptr(dgb), ptr(ws), stream()))
+        return dx, dgb[:F], dgb[F:], None
 
 
 def ln_relu(x, gamma, beta, relu=True):
