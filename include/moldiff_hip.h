@@ -171,9 +171,10 @@ int mdx_decode_output(mdx_graph_t g, const float* pred_node, int32_t Kn, const f
 int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ldd,
                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t splits, float* partial, void* stream);
 /* sgemm_tn: dW[N,K] (ldw) = G[M,N]^T (ldg) * X[M,K] (ldx), the weight gradient straight from the stored row-major
- *   tensors; `splits` ranges of rows, partial = (splits + ceil(splits/256))*N*K floats, fixed-order two-stage reduction. */
-int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, int64_t M, int64_t N, int64_t K,
-                    int32_t splits, float* partial, void* stream);
+ *   tensors; `splits` ranges of rows, partial = (splits + ceil(splits/256))*(N*K + N) floats, fixed-order two-stage
+ *   reduction; db (may be NULL) receives the bias gradient = column sums of G from the same pass. */
+int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, float* partial, void* stream);
 int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream);
 int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream);
 /* y = relu?(LayerNorm(x) * gamma + beta) over F <= 1024 features (nn.LayerNorm eps 1e-5, models/common.py MLP);

@@ -82,8 +82,8 @@ def lib():
         # layer-level training operators
         L.mdx_op_sgemm_nt.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                       c_int64, c_int64, c_int32, c_void_p, c_void_p]
-        L.mdx_op_sgemm_tn.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int32,
-                                      c_void_p, c_void_p]
+        L.mdx_op_sgemm_tn.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                      c_int32, c_void_p, c_void_p]
         L.mdx_op_transpose.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p]
         L.mdx_op_colreduce.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_op_ln_relu_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]

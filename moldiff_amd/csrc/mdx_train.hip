@@ -144,8 +144,11 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__
 // 16-byte loads); the MFMA contraction index runs over m, so operands are read from LDS as scalars down a column
 // (leading dimension 68: the four row groups of a wave land in disjoint banks).  Wave w owns a 32 x 32 quadrant.
 constexpr int W_T = 64, W_MC = 32, W_LD = W_T + 4;
+// Pb != NULL: the workgroups of the first k-tile also produce the bias gradient partials Pb[z][n] = sum_m G[m][n] of their
+// row range from the G tile they stage anyway (saves a second pass over dY).
 __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
-                                                              int M, int N, int K, int mper, float* __restrict__ P) {
+                                                              int M, int N, int K, int mper, float* __restrict__ P,
+                                                              float* __restrict__ Pb) {
   __shared__ __attribute__((aligned(16))) float Gs[W_MC * W_LD];
   __shared__ __attribute__((aligned(16))) float Xs[W_MC * W_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,6 +160,8 @@ __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __rest
   const bool vecx = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   f32x4 acc[2][2];
   acc_zero<2, 2>(acc);
+  const bool do_bias = Pb && blockIdx.x == 0 && tid < W_T;
+  float bsum = 0.f;
   // 32 rows x 16 float4 per tile = 512 slots -> 2 per thread per tile
   f32x4 rg[2], rx[2];
   auto fetch = [&](int m0) {
@@ -178,6 +183,10 @@ __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __rest
     }
     __syncthreads();
     if (m0 + W_MC < mend) fetch(m0 + W_MC);
+    if (do_bias) {
+#pragma unroll
+      for (int r = 0; r < W_MC; ++r) bsum += Gs[r * W_LD + tid];   // rows past mend were staged as zeros
+    }
 #pragma unroll
     for (int mm = 0; mm < W_MC; mm += 16) {
 #pragma unroll
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __rest
     }
     __syncthreads();
   }
+  if (do_bias && n0 + tid < N) Pb[(size_t)blockIdx.z * N + n0 + tid] = bsum;
   // acc[i][j][r] = P[n = n0 + wn + 16 i + 4 q + r][k = k0 + wk + 16 j + c]
   float* out = P + (size_t)blockIdx.z * N * K;
 #pragma unroll
@@ -746,9 +756,10 @@ extern "C" int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_
 
 // Weight gradient of a Linear layer: dW[N,K] = G[M,N]^T X[M,K] (row-major operands as stored by the forward/backward;
 // no transposes).  The M rows are cut into `splits` ranges whose partial products are summed in a fixed order
-// (partial: (splits + ceil(splits/256)) * N*K floats: the partial products plus the first reduction stage).
-extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, int64_t M, int64_t N,
-                               int64_t K, int32_t splits, float* partial, void* stream) {
+// (partial: (splits + ceil(splits/256)) * (N*K + N) floats: the partial products plus the first reduction stage, for dW
+// and for the optional bias gradient db[N] = column sums of G, which rides along in the first k-tile's workgroups).
+extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
+                               int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
   if (N <= 0 || K <= 0) return MDX_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!G || !X || !dW || !partial) return bad("sgemm_tn: null operand / partial buffer");
@@ -757,7 +768,12 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   mper = (mper + W_MC - 1) / W_MC * W_MC;
   const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
   dim3 grid((unsigned)((K + W_T - 1) / W_T), (unsigned)((N + W_T - 1) / W_T), (unsigned)S);
-  hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial);
-  launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, partial + (size_t)S * N * K, s);
+  // partial layout: [S][N*K] products | [ceil(S/256)][N*K] first reduction stage | [S][N] bias partials | [ceil(S/256)][N]
+  const size_t nc = (size_t)(S + RED_CHUNK - 1) / RED_CHUNK;
+  float* scratch = partial + (size_t)S * N * K;
+  float* pb = db ? scratch + nc * N * K : nullptr;
+  hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+  launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
+  if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
   return launched();
 }

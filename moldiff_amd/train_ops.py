@@ -39,15 +39,17 @@ def sgemm_nt(a, b, bias=None, splits=1, addend=None):
     return out
 
 
-def sgemm_tn(g, x, splits):
-    """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors."""
+def sgemm_tn(g, x, splits, want_bias=False):
+    """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors; with want_bias also the
+    column sums of g (the bias gradient) from the same pass -> (dW, db)."""
     M, N = g.shape
     K = x.shape[1]
     splits = max(1, int(splits))
     out = torch.empty(N, K, dtype=torch.float32, device=g.device)
-    part = torch.empty((splits + (splits + 255) // 256) * N * K, dtype=torch.float32, device=g.device)
-    check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, M, N, K, splits, ptr(part), stream()))
-    return out
+    db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
+    part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
+    check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), stream()))
+    return (out, db) if want_bias else out
 
 
 def transpose(x, pad=4):
@@ -98,9 +100,11 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = sgemm_nt(gy, transpose(w))                       # (M,N) @ (K,N)^T
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
+            gw, gb = r if want_b else (r, None)
+        elif want_b:
             gb = colreduce(gy)
         return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None)
 
