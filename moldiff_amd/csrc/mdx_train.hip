@@ -416,6 +416,40 @@ __global__ void ew_fwd_kernel(int op, const float* __restrict__ a, const float* 
   }
   o[i] = r;
 }
+template <typename V>
+__device__ __forceinline__ V ew_apply(int op, V x, V y);
+template <>
+__device__ __forceinline__ f32x4 ew_apply<f32x4>(int op, f32x4 x, f32x4 y) {
+  switch (op) {
+    case 0: return x + y;
+    case 1: return x - y;
+    case 2: return x * y;
+    default: return x * sigmoid4(y);
+  }
+}
+__global__ void ew_fwd4_kernel(int op, const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) o[i] = ew_apply<f32x4>(op, a[i], b[i]);
+}
+__global__ void ew_bwd4_kernel(int op, const f32x4* __restrict__ a, const f32x4* __restrict__ b, const f32x4* __restrict__ g,
+                               f32x4* __restrict__ da, f32x4* __restrict__ db, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 go = g[i];
+  f32x4 ga, gb;
+  switch (op) {
+    case 0: ga = go; gb = go; break;
+    case 1: ga = go; gb = splat4(0.f) - go; break;
+    case 2: ga = go * b[i]; gb = go * a[i]; break;
+    default: {
+      const f32x4 sg = sigmoid4(b[i]);
+      ga = go * sg;
+      gb = go * a[i] * sg * (splat4(1.f) - sg);
+    }
+  }
+  if (da) da[i] = ga;
+  if (db) db[i] = gb;
+}
 __global__ void ew_bwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
                               float* __restrict__ da, float* __restrict__ db, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,6 +478,24 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* _
   const int64_t row = i / F;
   const int f = (int)(i % F);
   y[i] = x[(size_t)idx[row] * F + f];
+}
+// 16-byte variants (F % 4 == 0, 16-byte aligned bases): one thread per (row, 4 features)
+__global__ void gather_rows4_kernel(const f32x4* __restrict__ x, const int64_t* __restrict__ idx, int64_t M, int F4,
+                                    f32x4* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * F4) return;
+  const int64_t row = i / F4;
+  y[i] = x[(size_t)idx[row] * F4 + (int)(i % F4)];
+}
+__global__ void segsum_rows4_kernel(const f32x4* __restrict__ src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
+                                    int64_t R, int F4, f32x4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * F4) return;
+  const int64_t r = i / F4;
+  const int f = (int)(i % F4);
+  f32x4 s = splat4(0.f);
+  for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) s = s + src[(size_t)order[j] * F4 + f];
+  out[i] = s;
 }
 // out[r] = sum_{j in [ptr[r], ptr[r+1])} src[order[j]]   (sequential per element: bitwise deterministic)
 __global__ void segsum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
@@ -677,24 +729,40 @@ extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
 extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
   if (n <= 0) return MDX_OK;
   if (op < 0 || op > 3) return bad("ew: unknown op");
-  hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, (size_t)n);
+  if ((n & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(ew_fwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, (const f32x4*)a, (const f32x4*)b,
+                       (f32x4*)out, (size_t)n / 4);
+  else
+    hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, (size_t)n);
   return launched();
 }
 extern "C" int mdx_op_ew_bwd(int32_t op, const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream) {
   if (n <= 0) return MDX_OK;
   if (op < 0 || op > 3) return bad("ew: unknown op");
-  hipLaunchKernelGGL(ew_bwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, g, da, db, (size_t)n);
+  if ((n & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)g | (uintptr_t)da | (uintptr_t)db) & 15) == 0)
+    hipLaunchKernelGGL(ew_bwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, (const f32x4*)a, (const f32x4*)b,
+                       (const f32x4*)g, (f32x4*)da, (f32x4*)db, (size_t)n / 4);
+  else
+    hipLaunchKernelGGL(ew_bwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, g, da, db, (size_t)n);
   return launched();
 }
 extern "C" int mdx_op_gather_rows(const float* x, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
   if (M <= 0 || F <= 0) return MDX_OK;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)M * F)), dim3(256), 0, (hipStream_t)stream, x, idx, M, F, y);
+  if ((F & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+    hipLaunchKernelGGL(gather_rows4_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, idx, M,
+                       F / 4, (f32x4*)y);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)M * F)), dim3(256), 0, (hipStream_t)stream, x, idx, M, F, y);
   return launched();
 }
 extern "C" int mdx_op_segsum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, float* out,
                                   void* stream) {
   if (R <= 0 || F <= 0) return MDX_OK;
-  hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, src, order, ptr, R, F, out);
+  if ((F & 3) == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, order,
+                       ptr, R, F / 4, (f32x4*)out);
+  else
+    hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, src, order, ptr, R, F, out);
   return launched();
 }
 extern "C" int mdx_op_edge_geom_fwd(const float* pos, const int64_t* l, const int64_t* r, int64_t E, float* rel, float* dist, void* stream) {

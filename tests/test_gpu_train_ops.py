@@ -66,10 +66,11 @@ def test_layernorm_relu(M, Fdim, relu):
 
 @pytest.mark.parametrize('op,fn', [(T.add, lambda a, b: a + b), (T.sub, lambda a, b: a - b), (T.mul, lambda a, b: a * b),
                                    (T.gate, lambda a, b: a * torch.sigmoid(b))])
-def test_elementwise_pairs(op, fn):
+@pytest.mark.parametrize('shape', [(1234, 7), (1024, 8)])      # scalar path / 16-byte vector path
+def test_elementwise_pairs(op, fn, shape):
     g = U.rng(9)
-    a, b = _leaf(g, 1234, 7), _leaf(g, 1234, 7)
-    gy = U.t32(g.standard_normal((1234, 7))).to(DEV)
+    a, b = _leaf(g, *shape), _leaf(g, *shape)
+    gy = U.t32(g.standard_normal(shape)).to(DEV)
     op(a, b).backward(gy)
     a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
     fn(a2, b2).backward(gy)
