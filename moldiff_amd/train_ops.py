@@ -71,9 +71,9 @@ def colreduce(x, y=None):
 
 
 def _splits_for(rows, n, k):
-    # weight gradient = contraction over `rows`: enough row ranges to put ~2048 workgroups on the chip (each loops over its rows in 32-row steps, so many short loops hide the load latency better than few long ones), each >= 128 rows
+    # weight gradient = contraction over `rows`: enough row ranges to put ~1024 workgroups on the chip (flat between 512 and 4096) (each loops over its rows in 32-row steps, so many short loops hide the load latency better than few long ones), each >= 128 rows
     tiles = ((n + 63) // 64) * ((k + 63) // 64)
-    return max(1, min(rows // 128, (2048 + tiles - 1) // tiles))
+    return max(1, min(rows // 128, (1024 + tiles - 1) // tiles))
 
 
 def _rows(t):
