@@ -143,3 +143,23 @@ def test_two_data_parallel_ranks_stay_in_lockstep():
     assert res[0][2] and res[1][2]                       # bit-identical parameters across ranks
     assert res[0][1] == res[1][1]                        # same (averaged) gradient norm seen by both
     assert res[0][3] == res[1][3]
+
+
+def test_checkpoint_written_by_training_is_sampled_by_the_sampling_entry_point(tmp_path):
+    """train_drug3d -> checkpoints/<it>.pt -> sample_drug3d --config (model.checkpoint = that file): the loop closes."""
+    import yaml
+    from moldiff_amd import sample_drug3d, train_drug3d
+    cfg = yaml.safe_load(open('configs/train_MolDiff_simple.yml'))
+    cfg['train'].update(batch_size=4, max_iters=2, val_freq=2)
+    tp = tmp_path / 'train.yml'
+    tp.write_text(yaml.safe_dump(cfg))
+    assert train_drug3d.main(['--config', str(tp), '--device', DEV, '--logdir', str(tmp_path / 'logs'), '--val_batches', '1',
+                              '--recipe-weights']) == 0
+    scfg = yaml.safe_load(open('configs/sample_MolDiff_simple.yml'))
+    scfg['model']['checkpoint'] = str(tmp_path / 'logs' / 'checkpoints' / '2.pt')
+    scfg['sample'].update(num_mols=3, batch_size=3)
+    sp = tmp_path / 'sample.yml'
+    sp.write_text(yaml.safe_dump(scfg))
+    log_dir = sample_drug3d.main(['--config', str(sp), '--outdir', str(tmp_path / 'out'), '--device', DEV, '--batch_size', '3'])
+    pool = torch.load(str(log_dir) + '/samples_all.pt', weights_only=False)
+    assert len(pool['finished']) + len(pool['failed']) >= 3
