@@ -114,9 +114,17 @@ def main(argv=None):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        args.device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        # one process per GPU over RCCL; MDX_DIST_BACKEND=gloo (ranks may then share a GPU) exists only so that the
+        # multi-rank control flow can be exercised on a single-GPU test box
+        backend = os.environ.get('MDX_DIST_BACKEND', 'nccl')
+        lr = int(os.environ.get('LOCAL_RANK', '0'))
+        args.device = f"cuda:{lr if backend == 'nccl' else lr % torch.cuda.device_count()}"
         torch.cuda.set_device(torch.device(args.device))
-        dist.init_process_group('nccl', device_id=torch.device(args.device))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(args.device))
+        else:
+            dist.init_process_group(backend)
     device = torch.device(args.device)
 
     config = load_config(args.config)
