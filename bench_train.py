@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--model', default='MolDiff', choices=['MolDiff', 'MolDiff_simple', 'bondpred'])
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help="GEMM operand precision ('bf16' = mixed precision)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def main():
         model = M.MolDiff(default_config(args.model), 8, 6)
         model.load_state_dict(M.recipe_state_dict(model, 20230807), strict=True)
     model = model.to(dev).train()
-    tr = Trainer(model, lr=1e-4, betas=(0.99, 0.999), weight_decay=1e-8, max_grad_norm=50.0)
+    tr = Trainer(model, lr=1e-4, betas=(0.99, 0.999), weight_decay=1e-8, max_grad_norm=50.0, precision=args.precision)
     batch = clean_batch([int(s) for s in sizes], 100 + rank, dev)
     torch.manual_seed(2023 + rank)
     losses = []
@@ -149,7 +150,8 @@ def main():
         N, E = int(batch[1].shape[0]), 2 * int(batch[3].shape[0])
         out = {'metric': 'molecules/sec (training step: forward + backward + all-reduce + clip + AdamW)', 'value': args.batch * world / (ms / 1e3),
                'unit': 'molecules/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32' if args.precision == 'f32' else 'bf16 GEMM operands, f32 accumulate / elsewhere', 'data': 'synthetic',
                'config': {'workload': f'train_{args.model}.yml: batch_size={args.batch} molecules/GPU (rank 0: N={N} atoms, E={E} directed '
                                       f'edges), AdamW lr 1e-4 betas (0.99,0.999) wd 1e-8, max_grad_norm 50; recipe weights',
                           'parallelism': f'data-parallel x{world}, one flat-gradient all-reduce per step',

@@ -175,6 +175,13 @@ int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, co
  *   reduction; db (may be NULL) receives the bias gradient = column sums of G from the same pass. */
 int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
                     int64_t K, int32_t splits, float* partial, void* stream);
+/* hgemm_nt / hgemm_tn: the same two products with bf16-rounded operands on v_mfma_f32_16x16x32_bf16 and fp32
+ *   accumulation / outputs (mixed-precision training; the reference trains under fp16 autocast).  Tensors stay fp32 in
+ *   memory.  hgemm_nt has no split-K form. */
+int mdx_op_hgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ldd,
+                    float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, float* partial, void* stream);
 int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream);
 int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream);
 /* y = relu?(LayerNorm(x) * gamma + beta) over F <= 1024 features (nn.LayerNorm eps 1e-5, models/common.py MLP);

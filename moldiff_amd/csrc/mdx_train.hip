@@ -139,11 +139,199 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 variants of the two GEMMs for mixed-precision training (the reference trains under fp16 autocast, use_amp: True in
+// its train configs): operands are rounded to bf16 (RNE) while they are staged into LDS, products run on
+// v_mfma_f32_16x16x32_bf16 (16x the fp32 matrix rate), accumulation and outputs stay fp32.  Tensors in HBM stay fp32, so
+// these kernels are bound by streaming their operands.  Lane (c = lane & 15, q = lane >> 4) feeds 8 consecutive k-values
+// starting at 8 q of its row/column; C/D mapping is the same as the fp32 16x16x4 form.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int W_T = 64, W_MC = 32, W_LD = W_T + 4;  // weight-gradient tile (both precisions)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7fffu + ((ua >> 16) & 1u);
+  ub += 0x7fffu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xffff0000u);
+}
+__device__ __forceinline__ uint16_t to_bf16(float a) {
+  uint32_t u = __float_as_uint(a);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ bf16x8_t lds_bf16x8(const uint16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+constexpr int H_KC = 64, H_LD = H_KC + 8;  // bf16 elements per staged row (+8 = 16 bytes of padding)
+
+__global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        const float* __restrict__ bias, const float* __restrict__ addend,
+                                                        int ldd, float* __restrict__ C, int ldc, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) uint16_t As[G_TM * H_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[G_TN * H_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * G_TN;
+  const bool veca = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  f32x4 acc[4][2];
+  acc_zero<4, 2>(acc);
+  f32x4 ra[8], rb[4];   // 16 float4 per row of 64 k: A 128 rows -> 8 slots per thread, B 64 rows -> 4
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 4, k4 = (slot & 15) * 4;
+      const int gm = m0 + row;
+      ra[j] = load4_guard(A + (size_t)gm * lda, k0 + k4, K, gm < M, veca);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 4, k4 = (slot & 15) * 4;
+      const int gn = n0 + row;
+      rb[j] = load4_guard(B + (size_t)gn * ldb, k0 + k4, K, gn < N, vecb);
+    }
+  };
+  if (K > 0) fetch(0);
+  for (int k0 = 0; k0 < K; k0 += H_KC) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int slot = tid + 256 * j;
+      uint2 v = {pack_bf16x2(ra[j][0], ra[j][1]), pack_bf16x2(ra[j][2], ra[j][3])};
+      *reinterpret_cast<uint2*>(As + (slot >> 4) * H_LD + (slot & 15) * 4) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j;
+      uint2 v = {pack_bf16x2(rb[j][0], rb[j][1]), pack_bf16x2(rb[j][2], rb[j][3])};
+      *reinterpret_cast<uint2*>(Bs + (slot >> 4) * H_LD + (slot & 15) * 4) = v;
+    }
+    __syncthreads();
+    if (k0 + H_KC < K) fetch(k0 + H_KC);
+#pragma unroll
+    for (int ks = 0; ks < H_KC / 32; ++ks) {
+      bf16x8_t a[4], b[2];
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) a[ft] = lds_bf16x8(Bs + (16 * ft + c) * H_LD + 32 * ks + 8 * q);
+#pragma unroll
+      for (int et = 0; et < 2; ++et) b[et] = lds_bf16x8(As + (32 * wave + 16 * et + c) * H_LD + 32 * ks + 8 * q);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int et = 0; et < 2; ++et) acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ft], b[et], acc[ft][et], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const bool veco = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft) {
+    const int col = n0 + 16 * ft + 4 * q;
+    f32x4 bv = splat4(0.f);
+    if (bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col + r < N) bv[r] = bias[col + r];
+    }
+#pragma unroll
+    for (int et = 0; et < 2; ++et) {
+      const int row = m0 + 32 * wave + 16 * et + c;
+      if (row >= M || col >= N) continue;
+      f32x4 v = acc[ft][et] + bv;
+      if (addend) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < N) v[r] += addend[(size_t)row * ldd + col + r];
+      }
+      float* o = C + (size_t)row * ldc + col;
+      if (veco && col + 3 < N) {
+        stg4(o, v);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < N) o[r] = v[r];
+      }
+    }
+  }
+}
+
+// bf16 weight gradient: 64 rows of G and X per step are transposed into LDS ([column][row], so that the 8 consecutive
+// contraction values a lane needs are one 16-byte read); otherwise the structure of sgemm_tn_split_kernel.
+constexpr int HW_MC = 64;
+__global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+                                                              int M, int N, int K, int mper, float* __restrict__ P,
+                                                              float* __restrict__ Pb) {
+  __shared__ __attribute__((aligned(16))) uint16_t Gt[W_T * H_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Xt[W_T * H_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * W_T, k0 = blockIdx.x * W_T;
+  const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+  const bool vecg = ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0) && ((n0 & 3) == 0);
+  const bool vecx = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((k0 & 3) == 0);
+  f32x4 acc[2][2];
+  acc_zero<2, 2>(acc);
+  const bool do_bias = Pb && blockIdx.x == 0 && tid < W_T;
+  float bsum = 0.f;
+  f32x4 rg[4], rx[4];   // 64 rows x 16 float4 = 1024 slots per tile -> 4 per thread
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
+      const int gm = m0 + row;
+      rg[j] = load4_guard(G + (size_t)gm * ldg + n0, c4, N - n0, gm < mend, vecg);
+      rx[j] = load4_guard(X + (size_t)gm * ldx + k0, c4, K - k0, gm < mend, vecx);
+    }
+  };
+  if (mbeg < mend) fetch(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += HW_MC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Gt[(c4 + e) * H_LD + row] = to_bf16(rg[j][e]);
+        Xt[(c4 + e) * H_LD + row] = to_bf16(rx[j][e]);
+      }
+    }
+    __syncthreads();
+    if (m0 + HW_MC < mend) fetch(m0 + HW_MC);
+    if (do_bias) {  // bias gradient partial: column tid of the staged (bf16-rounded) G tile, fp32 sum
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < HW_MC; ++r) sacc += __uint_as_float((uint32_t)Gt[tid * H_LD + r] << 16);
+      bsum += sacc;
+    }
+#pragma unroll
+    for (int ks = 0; ks < HW_MC / 32; ++ks) {
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = lds_bf16x8(Gt + (wn + 16 * i + c) * H_LD + 32 * ks + 8 * q);
+        b[i] = lds_bf16x8(Xt + (wk + 16 * i + c) * H_LD + 32 * ks + 8 * q);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (do_bias && n0 + tid < N) Pb[(size_t)blockIdx.z * N + n0 + tid] = bsum;
+  float* out = P + (size_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + 16 * i + 4 * q + r, k = k0 + wk + 16 * j + c;
+        if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
+}
+
 // Weight gradient without transposes: P[z][n][k] = sum_{m in split z} G[m][n] * X[m][k]   (G = dY (M,N), X (M,K) row-major).
 // Workgroup tile 64 (n) x 64 (k); 32 rows of G and X are staged per step in their memory layout [m][cols] (coalesced
 // 16-byte loads); the MFMA contraction index runs over m, so operands are read from LDS as scalars down a column
 // (leading dimension 68: the four row groups of a wave land in disjoint banks).  Wave w owns a 32 x 32 quadrant.
-constexpr int W_T = 64, W_MC = 32, W_LD = W_T + 4;
 // Pb != NULL: the workgroups of the first k-tile also produce the bias gradient partials Pb[z][n] = sum_m G[m][n] of their
 // row range from the G tile they stage anyway (saves a second pass over dY).
 __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
@@ -841,6 +1029,35 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
   hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+  launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
+  if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
+  return launched();
+}
+
+// bf16-operand forms of sgemm_nt / sgemm_tn (same arguments; no split-K for the forward form).
+extern "C" int mdx_op_hgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
+                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (M <= 0 || N <= 0) return MDX_OK;
+  if (!A || !B || !C || K < 0) return bad("hgemm_nt: null operand");
+  dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), 1);
+  hipLaunchKernelGGL(hgemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C,
+                     (int)ldc, (int)M, (int)N, (int)K);
+  return launched();
+}
+extern "C" int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
+                               int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
+  if (N <= 0 || K <= 0) return MDX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!G || !X || !dW || !partial) return bad("hgemm_tn: null operand / partial buffer");
+  if (splits < 1) splits = 1;
+  int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
+  mper = (mper + HW_MC - 1) / HW_MC * HW_MC;
+  const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
+  dim3 grid((unsigned)((K + W_T - 1) / W_T), (unsigned)((N + W_T - 1) / W_T), (unsigned)S);
+  const size_t nc = (size_t)(S + RED_CHUNK - 1) / RED_CHUNK;
+  float* scratch = partial + (size_t)S * N * K;
+  float* pb = db ? scratch + nc * N * K : nullptr;
+  hipLaunchKernelGGL(hgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
   launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
   if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
   return launched();

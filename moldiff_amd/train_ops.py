@@ -27,12 +27,39 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_GEMM_BF16 = False
+
+
+class precision:
+    """Context manager selecting the GEMM operand precision of `linear` (forward, data and weight gradients):
+    'f32' (default: exact fp32 MFMA) or 'bf16' (operands rounded to bf16, fp32 accumulate -- mixed-precision training in
+    the spirit of the reference's fp16 autocast; everything outside the GEMMs stays fp32)."""
+
+    def __init__(self, kind):
+        if kind not in ('f32', 'bf16'):
+            raise ValueError(kind)
+        self.kind = kind
+
+    def __enter__(self):
+        global _GEMM_BF16
+        self.prev, _GEMM_BF16 = _GEMM_BF16, self.kind == 'bf16'
+        return self
+
+    def __exit__(self, *exc):
+        global _GEMM_BF16
+        _GEMM_BF16 = self.prev
+
+
 def sgemm_nt(a, b, bias=None, splits=1, addend=None):
     """a (M,K) @ b (N,K)^T + bias + addend -> (M,N).  Rows of a / b may be strided (column slices of a wider matrix)."""
     M, K = a.shape
     N = b.shape[0]
     assert a.stride(1) == 1 and b.stride(1) == 1
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if _GEMM_BF16 and splits <= 1:
+        check(_L().mdx_op_hgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0,
+                                   ptr(out), N, M, N, K, stream()))
+        return out
     part = torch.empty(splits * M * N, dtype=torch.float32, device=a.device) if splits > 1 else None
     check(_L().mdx_op_sgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0, ptr(out),
                                N, M, N, K, splits, ptr(part), stream()))
@@ -48,7 +75,8 @@ def sgemm_tn(g, x, splits, want_bias=False):
     out = torch.empty(N, K, dtype=torch.float32, device=g.device)
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
     part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
-    check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), stream()))
+    fn = _L().mdx_op_hgemm_tn if _GEMM_BF16 else _L().mdx_op_sgemm_tn
+    check(fn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), stream()))
     return (out, db) if want_bias else out
 
 
@@ -91,6 +119,7 @@ class _Linear(torch.autograd.Function):
         xc, wc = _rows(x), _rows(w)
         ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.has_addend = b is not None, addend is not None
+        ctx.prec = 'bf16' if _GEMM_BF16 else 'f32'     # the backward of this layer runs in the forward's precision
         return sgemm_nt(xc, wc, _c(b) if b is not None else None, addend=_c(addend) if addend is not None else None)
 
     @staticmethod
@@ -98,14 +127,15 @@ class _Linear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = _c(gy)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = sgemm_nt(gy, transpose(w))                       # (M,N) @ (K,N)^T
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
-            gw, gb = r if want_b else (r, None)
-        elif want_b:
-            gb = colreduce(gy)
+        with precision(ctx.prec):
+            if ctx.needs_input_grad[0]:
+                gx = sgemm_nt(gy, transpose(w))                       # (M,N) @ (K,N)^T
+            if ctx.needs_input_grad[1]:
+                r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
+                gw, gb = r if want_b else (r, None)
+            elif want_b:
+                gb = colreduce(gy)
         return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None)
 
 

@@ -81,10 +81,12 @@ class PlateauScheduler:
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-4, betas=(0.99, 0.999), eps=1e-8, weight_decay=1e-8, max_grad_norm=50.0, group=None):
+    def __init__(self, model, lr=1e-4, betas=(0.99, 0.999), eps=1e-8, weight_decay=1e-8, max_grad_norm=50.0, group=None,
+                 precision='f32'):
         p0 = next(model.parameters())
         _lib._need_gpu(p0)
         self.model, self.group = model, group
+        self.precision = precision      # 'f32' | 'bf16' (GEMM operands only, see train_ops.precision)
         self.flat = FlatParams(model)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         dev = p0.device
@@ -123,8 +125,10 @@ class Trainer:
 
     def step(self, *batch, **kw):
         """zero_grad -> model.get_loss(*batch) -> backward_and_step.  Returns the loss dict plus 'grad_norm'."""
+        from . import train_ops
         self.zero_grad()
-        out = self.model.get_loss(*batch, **kw)
+        with train_ops.precision(self.precision):
+            out = self.model.get_loss(*batch, **kw)
         gn = self.backward_and_step(out['loss'])
         res = {k: v.detach() for k, v in out.items()}
         res['grad_norm'] = gn

@@ -129,3 +129,27 @@ def test_edge_geometry_smearing_and_force():
 def test_cpu_tensors_raise():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         T.linear(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def _bf(x):
+    return x.detach().bfloat16().float()
+
+
+@pytest.mark.parametrize('M,K,N', [(37, 321, 256), (5003, 129, 32), (4097, 80, 64), (20000, 256, 256), (513, 6, 54)])
+def test_bf16_operand_linear_equals_fp32_gemm_of_bf16_rounded_operands(M, K, N):
+    """precision('bf16'): products of bf16-rounded operands are exact in fp32, so forward and all three gradients must equal
+    an fp32 (here fp64) GEMM of the rounded tensors up to fp32 summation order."""
+    g = U.rng(M + K + N + 1)
+    x, w, b = _leaf(g, M, K), _leaf(g, N, K, scale=K ** -0.5), _leaf(g, N)
+    gy = U.t32(g.standard_normal((M, N))).to(DEV)
+    with T.precision('bf16'):
+        y = T.linear(x, w, b)
+    y.backward(gy)                       # outside the context: the layer remembers its precision
+    xr, wr, gr = _bf(x).double(), _bf(w).double(), _bf(gy).double()
+    assert _rel(y, xr @ wr.T + b.detach().double()) < 3e-6
+    assert _rel(x.grad, gr @ wr) < 3e-6
+    assert _rel(w.grad, gr.T @ xr) < 1e-5
+    assert _rel(b.grad, gr.sum(0)) < 1e-5
+    # and it is close to, but not the same as, the fp32 result
+    y32 = T.linear(x, w, b)
+    assert 1e-5 < _rel(y, y32) < 2e-2

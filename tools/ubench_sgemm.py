@@ -11,6 +11,9 @@ from moldiff_amd import train_ops as T  # noqa: E402
 
 E = 154666
 dev = 'cuda:0'
+prec = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+T.precision(prec).__enter__()
+print('GEMM operand precision:', prec)
 for (M, K, N) in [(E, 256, 256), (E, 64, 256), (E, 256, 64), (E, 64, 64), (E, 128, 128), (E, 80, 64), (6279, 256, 960)]:
     a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); g = torch.randn(M, N, device=dev)
     for name, fn, flops, byts in (('nt  fwd ', lambda: T.sgemm_nt(a, w), 2.0 * M * K * N, 4.0 * (M * K + M * N)),
