@@ -252,6 +252,90 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
   }
 }
 
+// EXPERIMENT (tools/ubench_sgemm.py bf16x3): fp32 product emulated with three-way bf16 splits x = h + m + l (each piece
+// exactly representable, so x is reproduced to 24 bits); six of the nine cross products (h*h, h*m, m*h, m*m, h*l, l*h;
+// the dropped ones are below 2^-32 relative) run on the bf16 matrix pipe, smallest first, fp32 accumulation.  Measures
+// what an "fp32-accurate" GEMM costs on the 16x faster pipe; not used by any product path.
+constexpr int H3_KC = 32, H3_LD = H3_KC + 8;
+__device__ __forceinline__ void split3(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  h = to_bf16(x);
+  const float r1 = x - __uint_as_float((uint32_t)h << 16);
+  m = to_bf16(r1);
+  const float r2 = r1 - __uint_as_float((uint32_t)m << 16);
+  l = to_bf16(r2);
+}
+__global__ __launch_bounds__(256) void hgemm3_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                         float* __restrict__ C, int ldc, int M, int N, int K) {
+  constexpr int ASZ = G_TM * H3_LD, BSZ = G_TN * H3_LD;
+  __shared__ __attribute__((aligned(16))) uint16_t As[3 * ASZ];   // pieces h, m, l
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[3 * BSZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * G_TN;
+  const bool veca = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  f32x4 acc[4][2];
+  acc_zero<4, 2>(acc);
+  f32x4 ra[4], rb[2];   // 8 float4 per row of 32 k
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 3, k4 = (slot & 7) * 4;
+      ra[j] = load4_guard(A + (size_t)(m0 + row) * lda, k0 + k4, K, m0 + row < M, veca);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = tid + 256 * j, row = slot >> 3, k4 = (slot & 7) * 4;
+      rb[j] = load4_guard(B + (size_t)(n0 + row) * ldb, k0 + k4, K, n0 + row < N, vecb);
+    }
+  };
+  auto stage = [&](uint16_t* dst, int piece_stride, const f32x4& v, int slot) {
+    uint16_t h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(v[e], h[e], m[e], l[e]);
+    const int o = (slot >> 3) * H3_LD + (slot & 7) * 4;
+    *reinterpret_cast<uint2*>(dst + o) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+    *reinterpret_cast<uint2*>(dst + piece_stride + o) = uint2{(uint32_t)m[0] | ((uint32_t)m[1] << 16), (uint32_t)m[2] | ((uint32_t)m[3] << 16)};
+    *reinterpret_cast<uint2*>(dst + 2 * piece_stride + o) = uint2{(uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16)};
+  };
+  if (K > 0) fetch(0);
+  for (int k0 = 0; k0 < K; k0 += H3_KC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage(As, ASZ, ra[j], tid + 256 * j);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) stage(Bs, BSZ, rb[j], tid + 256 * j);
+    __syncthreads();
+    if (k0 + H3_KC < K) fetch(k0 + H3_KC);
+    bf16x8_t a[3][4], b[3][2];   // [piece][tile]: a = features (matrix B), b = rows (matrix A)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) a[p][ft] = lds_bf16x8(Bs + p * BSZ + (16 * ft + c) * H3_LD + 8 * q);
+#pragma unroll
+      for (int et = 0; et < 2; ++et) b[p][et] = lds_bf16x8(As + p * ASZ + (32 * wave + 16 * et + c) * H3_LD + 8 * q);
+    }
+    // smallest terms first: (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); pieces: 0 = h, 1 = m, 2 = l
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+          acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[t]][ft], b[PB[t]][et], acc[ft][et], 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 32 * wave + 16 * et + c, col = n0 + 16 * ft + 4 * q + r;
+        if (row < M && col < N) C[(size_t)row * ldc + col] = acc[ft][et][r];
+      }
+}
+
 // bf16 weight gradient: 64 rows of G and X per step are transposed into LDS ([column][row], so that the 8 consecutive
 // contraction values a lane needs are one 16-byte read); otherwise the structure of sgemm_tn_split_kernel.
 constexpr int HW_MC = 64;
@@ -1062,3 +1146,15 @@ extern "C" int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int6
   if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
   return launched();
 }
+
+// Experimental: fp32-accurate product on the bf16 matrix pipe (three-way operand split, 6 MFMAs per k-step); benchmark only,
+// compiled with `make EXTRA=-DMDX_EXPERIMENTAL` (tools/ubench_bf16x3.py), absent from the shipped library.
+#ifdef MDX_EXPERIMENTAL
+extern "C" int mdx_debug_hgemm3_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                                   int64_t K, void* stream) {
+  if (M <= 0 || N <= 0) return MDX_OK;
+  dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), 1);
+  hipLaunchKernelGGL(hgemm3_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (int)lda, B, (int)ldb, C, (int)ldc, (int)M, (int)N, (int)K);
+  return launched();
+}
+#endif
