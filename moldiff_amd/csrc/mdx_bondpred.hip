@@ -15,7 +15,6 @@
 namespace {
 
 constexpr int LD64 = mdx_ld(64);
-constexpr int LD128 = mdx_ld(128);
 constexpr int LD256 = mdx_ld(256);
 constexpr int LD32 = mdx_ld(32);
 constexpr int LD16 = mdx_ld(16);

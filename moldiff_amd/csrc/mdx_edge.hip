@@ -44,7 +44,6 @@ constexpr int TE = 16 * ET;
 constexpr int LD64 = mdx_ld(64);    // 72
 constexpr int LD80 = mdx_ld(80);    // 88
 constexpr int LD256 = mdx_ld(256);  // 264
-constexpr int LD32 = mdx_ld(32);    // 40
 
 // LDS carve (floats)
 constexpr int OFF_HEP = 0;

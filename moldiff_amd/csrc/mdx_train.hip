@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
   }
 }
 
-// EXPERIMENT (tools/ubench_sgemm.py bf16x3): fp32 product emulated with three-way bf16 splits x = h + m + l (each piece
+#ifdef MDX_EXPERIMENTAL
+// EXPERIMENT (tools/ubench_bf16x3.py): fp32 product emulated with three-way bf16 splits x = h + m + l (each piece
 // exactly representable, so x is reproduced to 24 bits); six of the nine cross products (h*h, h*m, m*h, m*m, h*l, l*h;
 // the dropped ones are below 2^-32 relative) run on the bf16 matrix pipe, smallest first, fp32 accumulation.  Measures
 // what an "fp32-accurate" GEMM costs on the 16x faster pipe; not used by any product path.
@@ -335,6 +336,8 @@ __global__ __launch_bounds__(256) void hgemm3_nt_kernel(const float* __restrict_
         if (row < M && col < N) C[(size_t)row * ldc + col] = acc[ft][et][r];
       }
 }
+
+#endif  // MDX_EXPERIMENTAL
 
 // bf16 weight gradient: 64 rows of G and X per step are transposed into LDS ([column][row], so that the 8 consecutive
 // contraction values a lane needs are one 16-byte read); otherwise the structure of sgemm_tn_split_kernel.
