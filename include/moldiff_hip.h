@@ -143,6 +143,28 @@ int mdx_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 int mdx_noise(mdx_graph_t g, uint64_t seed, int32_t draw, int32_t Kn, int32_t Ke, float* eps_pos, float* u_node,
               float* u_halfedge, void* stream);
 
+/* ---- one iteration of the reverse chain in a single call (models/model.py:272-308: denoiser forward, Gaussian
+ * posterior on the positions, categorical posteriors + Gumbel-max draws on atom and bond types).  Guidance, when wanted,
+ * is applied by the caller afterwards (mdx_bondpred_forward / mdx_guidance_uncertainty_grad / mdx_bondpred_backward /
+ * mdx_add_inplace).  All pointers are device pointers; `cur` is read, `next` and `pred_*` are written.
+ *   tables: the frozen schedule tensors of the checkpoint (pos_transition.coef_x0 / coef_xt / std (T);
+ *           node/edge_transition.q_mats and transpopse_q_onestep_mats (T,K,K)).
+ *   t (B) int64 must hold `step` for every molecule; batch_node (N) / batch_halfedge (Eh) int64 as in the reference.
+ *   eps_pos (N,3) ~ N(0,1), u_node (N,Kn), u_halfedge (Eh,Ke) ~ U[0,1): this step's draws (mdx_noise or the caller's own). */
+typedef struct {
+  const float *pos_coef_x0, *pos_coef_xt, *pos_std;
+  const float *node_q_mats, *node_qT_onestep;
+  const float *edge_q_mats, *edge_qT_onestep;
+} mdx_tables;
+typedef struct {
+  float *h_node, *pos, *h_halfedge;   /* (N,Kn) one-hot, (N,3), (Eh,Ke) one-hot */
+  float *log_node, *log_halfedge;     /* (N,Kn), (Eh,Ke) log-probabilities of the current types */
+} mdx_state;
+int mdx_sample_step(mdx_model_t m, mdx_graph_t g, const mdx_tables* tables, const int64_t* t, const int64_t* batch_node,
+                    const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node, float* pred_pos,
+                    float* pred_halfedge, const float* eps_pos, const float* u_node, const float* u_halfedge, void* ws,
+                    size_t ws_bytes, void* stream);
+
 /* ---- harness consumer of the path's outputs (next-row) ---------------------------------------
  * seperate_outputs (utils/sample.py:4-30) + FeaturizeMol.decode_output (utils/transforms.py:65-122) on the device:
  * arg-max class + soft-max confidence per atom / half-edge, mask-type atoms (class >= num_element) dropped and the

@@ -19,7 +19,7 @@ EXPORTS = [
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
-    'mdx_moldiff_forward', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
+    'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
     'mdx_profile_enable', 'mdx_profile_read',
@@ -27,6 +27,15 @@ EXPORTS = [
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
 ]
+
+
+class MdxTables(ctypes.Structure):   # == struct mdx_tables
+    _fields_ = [(n, c_void_p) for n in ('pos_coef_x0', 'pos_coef_xt', 'pos_std', 'node_q_mats', 'node_qT_onestep', 'edge_q_mats',
+                                        'edge_qT_onestep')]
+
+
+class MdxState(ctypes.Structure):    # == struct mdx_state
+    _fields_ = [(n, c_void_p) for n in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')]
 
 
 class MdxConfig(ctypes.Structure):
@@ -62,6 +71,8 @@ def lib():
         L.mdx_pos_update.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
         L.mdx_segment_sum.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]
         L.mdx_moldiff_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_sample_step.argtypes = [c_void_p, c_void_p, POINTER(MdxTables), c_void_p, c_void_p, c_void_p, POINTER(MdxState),
+                                      POINTER(MdxState)] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
         L.mdx_bondpred_forward.argtypes = [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
         L.mdx_bondpred_backward.argtypes = [c_void_p] * 4 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                                             c_void_p]

@@ -926,6 +926,35 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
   return MDX_OK;
 }
 
+extern "C" int mdx_sample_step(mdx_model_t m, mdx_graph_t g, const mdx_tables* tb, const int64_t* t, const int64_t* batch_node,
+                               const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node,
+                               float* pred_pos, float* pred_halfedge, const float* eps_pos, const float* u_node,
+                               const float* u_halfedge, void* ws, size_t ws_bytes, void* stream) {
+  if (!tb || !cur || !next) return fail(MDX_ERR_ARG, "null tables / state");
+  if (!m || !g) return fail(MDX_ERR_ARG, "null handle");
+  const int N = (int)g->N, Eh = (int)g->Eh;
+  if (N == 0) return MDX_OK;
+  if (!pred_node || !pred_pos || (Eh > 0 && !pred_halfedge) || !eps_pos || !u_node || (Eh > 0 && !u_halfedge) || !batch_node ||
+      (Eh > 0 && !batch_halfedge))
+    return fail(MDX_ERR_ARG, "null buffer");
+  int rc = mdx_moldiff_forward(m, g, cur->h_node, cur->pos, nullptr, cur->h_halfedge, t, pred_node, pred_pos, pred_halfedge, ws,
+                               ws_bytes, stream);
+  if (rc != MDX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const mdx_config& cf = m->cfg;
+  launch_pos_posterior(tb->pos_coef_x0, tb->pos_coef_xt, tb->pos_std, cur->pos, pred_pos, eps_pos, t, batch_node, N, next->pos, s);
+  launch_cat_posterior(tb->node_q_mats, tb->node_qT_onestep, cf.num_node_types, cf.num_timesteps, pred_node, 1, cur->log_node, t,
+                       batch_node, N, next->log_node, s);
+  launch_gumbel_argmax(next->log_node, u_node, cf.num_node_types, N, nullptr, next->h_node, s);
+  if (Eh > 0) {
+    launch_cat_posterior(tb->edge_q_mats, tb->edge_qT_onestep, cf.num_edge_types, cf.num_timesteps, pred_halfedge, 1,
+                         cur->log_halfedge, t, batch_halfedge, Eh, next->log_halfedge, s);
+    launch_gumbel_argmax(next->log_halfedge, u_halfedge, cf.num_edge_types, Eh, nullptr, next->h_halfedge, s);
+  }
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bond predictor: forward with a per-block tape, and the data-gradient backward w.r.t. positions
 // ------------------------------------------------------------------------------------------------

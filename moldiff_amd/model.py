@@ -260,6 +260,9 @@ class _Sampler:
             self.delta = torch.empty(N, 3, **f32)
             self.edge_index = edge_index
             self.batch_edge = torch.cat([self.bh, self.bh], dim=0)
+        pt, ntr, etr = m.pos_transition, m.node_transition, m.edge_transition
+        self.tables = _lib.MdxTables(*(_lib.ptr(x) for x in (pt.coef_x0, pt.coef_xt, pt.std, ntr.q_mats, ntr.transpopse_q_onestep_mats,
+                                                             etr.q_mats, etr.transpopse_q_onestep_mats)))
         self.cur = 0  # frame holding the current state
 
     def _frame(self, j):
@@ -296,22 +299,15 @@ class _Sampler:
         self._draw(i + 1)
         c, n = self._frame(i), self._frame(i + 1)
         h_node, pos, h_half = self.node_traj[c], self.pos_traj[c], self.halfedge_traj[c]
-        m._forward_raw(self.eng, self.g, h_node, pos, None, h_half, self.t, out=self.preds)
         lc, ln = self.lcur, 1 - self.lcur
-        pt, ntr, etr, st = m.pos_transition, m.node_transition, m.edge_transition, _lib.stream()
-        _lib.check(L.mdx_pos_posterior(_lib.ptr(pt.coef_x0), _lib.ptr(pt.coef_xt), _lib.ptr(pt.std), _lib.ptr(pos),
-                                       _lib.ptr(self.preds[1]), _lib.ptr(self.eps), _lib.ptr(self.t), _lib.ptr(self.bn), N,
-                                       _lib.ptr(self.pos_traj[n]), st))
-        _lib.check(L.mdx_cat_posterior(_lib.ptr(ntr.q_mats), _lib.ptr(ntr.transpopse_q_onestep_mats), Kn, T,
-                                       _lib.ptr(self.preds[0]), 1, _lib.ptr(self.log_node[lc]), _lib.ptr(self.t),
-                                       _lib.ptr(self.bn), N, _lib.ptr(self.log_node[ln]), st))
-        _lib.check(L.mdx_gumbel_argmax(_lib.ptr(self.log_node[ln]), _lib.ptr(self.u_n), Kn, N, None,
-                                       _lib.ptr(self.node_traj[n]), st))
-        _lib.check(L.mdx_cat_posterior(_lib.ptr(etr.q_mats), _lib.ptr(etr.transpopse_q_onestep_mats), Ke, T,
-                                       _lib.ptr(self.preds[2]), 1, _lib.ptr(self.log_half[lc]), _lib.ptr(self.t),
-                                       _lib.ptr(self.bh), Eh, _lib.ptr(self.log_half[ln]), st))
-        _lib.check(L.mdx_gumbel_argmax(_lib.ptr(self.log_half[ln]), _lib.ptr(self.u_h), Ke, Eh, None,
-                                       _lib.ptr(self.halfedge_traj[n]), st))
+        P = _lib.ptr
+        cur = _lib.MdxState(P(h_node), P(pos), P(h_half), P(self.log_node[lc]), P(self.log_half[lc]))
+        nxt = _lib.MdxState(P(self.node_traj[n]), P(self.pos_traj[n]), P(self.halfedge_traj[n]), P(self.log_node[ln]),
+                            P(self.log_half[ln]))
+        ws, nb = self.g.workspace(self.dev)
+        _lib.check(L.mdx_sample_step(self.eng.h, self.g.h, ctypes.byref(self.tables), P(self.t), P(self.bn), P(self.bh),
+                                     ctypes.byref(cur), ctypes.byref(nxt), P(self.preds[0]), P(self.preds[1]), P(self.preds[2]),
+                                     P(self.eps), P(self.u_n), P(self.u_h), ws, nb, _lib.stream()))
         if self.guidance is not None:
             self._guide(h_node, pos, self.pos_traj[n], self.halfedge_traj[n], self.log_half[ln])
         self.cur, self.lcur = n, ln
