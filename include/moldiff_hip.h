@@ -221,6 +221,11 @@ int mdx_op_ew_bwd(int32_t op, const float* a, const float* b, const float* g, fl
  * (torch_scatter.scatter_sum with `order` = stable argsort of the index; sequential per output -> deterministic). */
 int mdx_op_gather_rows(const float* x, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream);
 int mdx_op_segsum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, float* out, void* stream);
+/* y = a * t[idx] (product with a gathered per-node row, e.g. h_edge * h_node[col], models/graph.py:44) without the
+ * gathered (rows x F) intermediate; backward: da = g * t[idx], dt[r] = sum over the rows of segment r of g * a. */
+int mdx_op_mul_gather_fwd(const float* a, const float* t, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream);
+int mdx_op_mul_gather_bwd(const float* g, const float* a, const float* t, const int64_t* idx, const int64_t* order, const int64_t* ptr,
+                          int64_t M, int64_t R, int32_t F, float* da, float* dt, void* stream);
 /* rel = pos[l] - pos[r], dist = |rel| (models/graph.py:349-350); backward: g (E,3) = drel + ddist * rel / dist, the
  * caller scatters +g to l and -g to r.  drel / ddist may be NULL. */
 int mdx_op_edge_geom_fwd(const float* pos, const int64_t* l, const int64_t* r, int64_t E, float* rel, float* dist, void* stream);

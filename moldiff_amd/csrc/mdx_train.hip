@@ -772,6 +772,29 @@ __global__ void segsum_rows4_kernel(const f32x4* __restrict__ src, const int64_t
   for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) s = s + src[(size_t)order[j] * F4 + f];
   out[i] = s;
 }
+// y[i] = a[i] * t[idx[i]] and its two gradients (da = g * t[idx];  dt[r] = sum_{j in seg r} g[order[j]] * a[order[j]]):
+// the product with a gathered per-node row without materialising the gathered (rows x F) tensor.  F % 4 == 0.
+__global__ void mulg_fwd_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ t, const int64_t* __restrict__ idx, int64_t M,
+                                int F4, const f32x4* __restrict__ g, f32x4* __restrict__ y) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * F4) return;
+  const int64_t row = i / F4;
+  const f32x4 tv = t[(size_t)idx[row] * F4 + (int)(i % F4)];
+  y[i] = (g ? g[i] : a[i]) * tv;      // forward: a * t[idx];  backward wrt a: g * t[idx]
+}
+__global__ void mulg_segsum_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ a, const int64_t* __restrict__ order,
+                                   const int64_t* __restrict__ ptr, int64_t R, int F4, f32x4* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * F4) return;
+  const int64_t r = i / F4;
+  const int f = (int)(i % F4);
+  f32x4 s = splat4(0.f);
+  for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) {
+    const size_t o = (size_t)order[j] * F4 + f;
+    s = s + g[o] * a[o];
+  }
+  out[i] = s;
+}
 // out[r] = sum_{j in [ptr[r], ptr[r+1])} src[order[j]]   (sequential per element: bitwise deterministic)
 __global__ void segsum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
                                    int64_t R, int F, float* __restrict__ out) {
@@ -1161,3 +1184,25 @@ extern "C" int mdx_debug_hgemm3_nt(const float* A, int64_t lda, const float* B, 
   return launched();
 }
 #endif
+
+// y = a * t[idx] (rows of F floats, F % 4 == 0) and its gradients; see mulg_*_kernel.
+extern "C" int mdx_op_mul_gather_fwd(const float* a, const float* t, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
+  if (M <= 0 || F <= 0) return MDX_OK;
+  if (F & 3) return bad("mul_gather: F must be a multiple of 4");
+  hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (const f32x4*)t,
+                     idx, M, F / 4, (const f32x4*)nullptr, (f32x4*)y);
+  return launched();
+}
+extern "C" int mdx_op_mul_gather_bwd(const float* g, const float* a, const float* t, const int64_t* idx, const int64_t* order,
+                                     const int64_t* ptr, int64_t M, int64_t R, int32_t F, float* da, float* dt, void* stream) {
+  if (F <= 0) return MDX_OK;
+  if (F & 3) return bad("mul_gather: F must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  if (da && M > 0)
+    hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, s, (const f32x4*)a, (const f32x4*)t, idx, M, F / 4,
+                       (const f32x4*)g, (f32x4*)da);
+  if (dt && R > 0)
+    hipLaunchKernelGGL(mulg_segsum_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, s, (const f32x4*)g, (const f32x4*)a, order, ptr, R,
+                       F / 4, (f32x4*)dt);
+  return launched();
+}

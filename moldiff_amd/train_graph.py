@@ -61,7 +61,7 @@ def smear(gs, d):
 def node_block(m, x, g, edge_attr, node_time):
     h_node = mlp(m.node_net, x)
     h_edge = mlp(m.edge_net, edge_attr)
-    msg = T.linear(T.mul(h_edge, T.gather(h_node, g.right)), m.msg_net.weight, m.msg_net.bias)
+    msg = T.linear(T.mul_gather(h_edge, h_node, g.right), m.msg_net.weight, m.msg_net.bias)
     g0, ed = m.gate.net[0], edge_attr.shape[1]
     per_node = T.linear(cat(x, node_time), g0.weight[:, ed:])                      # x[col] and node_time[col] columns
     gt = mlp_from_pre(m.gate, T.linear(edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right)))
@@ -75,13 +75,14 @@ def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
     """BondFFN on (bond_in, node_in, time) where node_in is either node_rows[plan.index] (hoisted) or node_edges (E rows)."""
     g0, bd = m.gate.net[0], bond_in.shape[1]
     nd = g0.weight.shape[1] - bd - 1
+    bond_feat = T.linear(bond_in, m.bond_linear.weight)
     if node_edges is None:
-        node_feat = T.gather(T.linear(node_rows, m.node_linear.weight), plan)
+        prod = T.mul_gather(bond_feat, T.linear(node_rows, m.node_linear.weight), plan)
         gate_node = T.gather(T.linear(node_rows, g0.weight[:, bd:bd + nd]), plan)
     else:
-        node_feat = T.linear(node_edges, m.node_linear.weight)
+        prod = T.mul(bond_feat, T.linear(node_edges, m.node_linear.weight))
         gate_node = T.linear(node_edges, g0.weight[:, bd:bd + nd])
-    inter = mlp(m.inter_module, T.mul(T.linear(bond_in, m.bond_linear.weight), node_feat))
+    inter = mlp(m.inter_module, prod)
     pre = T.linear(bond_in, g0.weight[:, :bd], g0.bias, addend=T.linear(time, g0.weight[:, bd + nd:], None, addend=gate_node))
     return T.gate(inter, mlp_from_pre(m.gate, pre))
 
@@ -98,8 +99,7 @@ def edge_block(m, h_bond, g, h_node, bond_time):
 
 def pos_update(m, h_node, h_edge, g, rel, dist, edge_time):
     lf = T.gather(mlp(m.left_lin_edge, h_node), g.left)
-    rf = T.gather(mlp(m.right_lin_edge, h_node), g.right)
-    w = bond_ffn(m.edge_lin, h_edge, edge_time, node_edges=T.mul(lf, rf))
+    w = bond_ffn(m.edge_lin, h_edge, edge_time, node_edges=T.mul_gather(lf, mlp(m.right_lin_edge, h_node), g.right))
     return T.scatter_sum(T.force(w, rel, dist), g.left)
 
 

@@ -271,6 +271,36 @@ def scatter_sum(src, plan):
     return _SegSum.apply(src, plan)
 
 
+class _MulGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, table, plan):
+        ac, tc = _c(a), _c(table)
+        M, F = ac.shape
+        y = torch.empty_like(ac)
+        check(_L().mdx_op_mul_gather_fwd(ptr(ac), ptr(tc), ptr(plan.index), M, F, ptr(y), stream()))
+        ctx.plan = plan
+        ctx.save_for_backward(ac, tc)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, t = ctx.saved_tensors
+        g, plan = _c(g), ctx.plan
+        M, F = a.shape
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        dt = torch.empty_like(t) if ctx.needs_input_grad[1] else None
+        check(_L().mdx_op_mul_gather_bwd(ptr(g), ptr(a), ptr(t), ptr(plan.index), ptr(plan.order), ptr(plan.ptr), M, plan.n, F, ptr(da),
+                                         ptr(dt), stream()))
+        return da, dt, None
+
+
+def mul_gather(a, table, plan):
+    """a * table[plan.index] for 2-D a (rows, F), F % 4 == 0, without materialising the gathered rows."""
+    if a.shape[1] % 4:
+        return mul(a, gather(table, plan))
+    return _MulGather.apply(a, table, plan)
+
+
 class _EdgeGeom(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, pl, pr):

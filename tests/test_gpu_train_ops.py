@@ -153,3 +153,19 @@ def test_bf16_operand_linear_equals_fp32_gemm_of_bf16_rounded_operands(M, K, N):
     # and it is close to, but not the same as, the fp32 result
     y32 = T.linear(x, w, b)
     assert 1e-5 < _rel(y, y32) < 2e-2
+
+
+def test_mul_gather_matches_mul_of_gather():
+    g = U.rng(21)
+    n, M, Fd = 60, 3000, 64
+    idx = torch.from_numpy(g.integers(0, n - 3, M)).to(DEV)
+    plan = T.IndexPlan(idx, n)
+    a, t = _leaf(g, M, Fd), _leaf(g, n, Fd)
+    gy = U.t32(g.standard_normal((M, Fd))).to(DEV)
+    y = T.mul_gather(a, t, plan)
+    y.backward(gy)
+    a2, t2 = a.detach().clone().requires_grad_(True), t.detach().clone().requires_grad_(True)
+    y2 = a2 * t2[idx]
+    y2.backward(gy)
+    assert torch.equal(y, y2) and torch.equal(a.grad, a2.grad)
+    assert _rel(t.grad, t2.grad) < 2e-6
