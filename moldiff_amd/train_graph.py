@@ -88,11 +88,12 @@ def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
 
 
 def edge_block(m, h_bond, g, h_node, bond_time):
-    ml = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_left, h_bond, bond_time, h_node, g.left), g.right), g.left)
-    mr = T.gather(T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, bond_time, h_node, g.right), g.left), g.right)
-    nl = T.gather(T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias), g.left)
-    nr = T.gather(T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias), g.right)
-    h = T.linear(h_bond, m.self_ffn.weight, m.self_ffn.bias, addend=T.add(T.add(ml, mr), T.add(nl, nr)))
+    # per-node sums first (N rows), then ONE gather per endpoint: (S_L + node_ffn_left(h))[left] + (S_R + node_ffn_right(h))[right]
+    sl = T.scatter_sum(bond_ffn(m.bond_ffn_left, h_bond, bond_time, h_node, g.left), g.right)
+    sr = T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, bond_time, h_node, g.right), g.left)
+    by_left = T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias, addend=sl)
+    by_right = T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias, addend=sr)
+    h = T.linear(h_bond, m.self_ffn.weight, m.self_ffn.bias, addend=T.add(T.gather(by_left, g.left), T.gather(by_right, g.right)))
     h = T.ln_relu(h, m.layer_norm.weight, m.layer_norm.bias, True)
     return T.linear(h, m.out_transform.weight, m.out_transform.bias)
 
