@@ -4,8 +4,8 @@ This file restates, in plain torch-CPU fp32 (functional style, no nn.Module), th
 algorithm of the reference's sampling path so that the HIP kernels in
 ``moldiff_amd/csrc`` can be parity-checked without the reference being present
 (``/root/reference`` does not exist on the GPU box).  Only ``tests/``,
-``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it;
-the product path (``moldiff_amd``) never does.
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` legs of ``bench.py`` (sampling and ``--train``) may
+import it; the product path (``moldiff_amd``) never does.
 
 Pinning: every function below is checked against the *real* reference (imported with
 third-party shims by ``oracle/make_goldens.py`` in the build container) and against the
@@ -26,6 +26,8 @@ Reference citations are relative to the upstream tree (tag 2024_08_07):
   models/model.py:236-378    MolDiff.sample           -> sample()
   models/bond_predictor.py:128-162 BondPredictor.forward -> bondpred_forward()
   models/model.py:309-325    'uncertainty' guidance   -> guidance_delta()
+  models/model.py:128-201    MolDiff.get_loss         -> moldiff_loss()   (differentiable: autograd = the training oracle)
+  models/bond_predictor.py:84-124 BondPredictor.get_loss -> bondpred_loss()
   models/transition.py:9-69  ContigousTransition      -> pos_tables() / pos_posterior()
   models/transition.py:178-339 GeneralCategoricalTransition -> cat_tables() / cat_posterior()
   models/diffusion.py:79-85  log_sample_categorical   -> gumbel_argmax()
