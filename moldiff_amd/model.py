@@ -260,6 +260,13 @@ class _Sampler:
             self.delta = torch.empty(N, 3, **f32)
             self.edge_index = edge_index
             self.batch_edge = torch.cat([self.bh, self.bh], dim=0)
+            # the default objective runs on a side stream with its own workspace, concurrently with the denoiser's forward
+            # of the same step (both only read the step's input state); kernels of the two chains fill each other's tails
+            self.side = torch.cuda.Stream(device=dev) if self.guidance[0] == 'uncertainty' else None
+            if self.side is not None:
+                nbytes = _lib.lib().mdx_workspace_bytes(self.N, 2 * self.Eh)
+                self._ws2 = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+                self._ev_in, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
         pt, ntr, etr = m.pos_transition, m.node_transition, m.edge_transition
         self.tables = _lib.MdxTables(*(_lib.ptr(x) for x in (pt.coef_x0, pt.coef_xt, pt.std, ntr.q_mats, ntr.transpopse_q_onestep_mats,
                                                              etr.q_mats, etr.transpopse_q_onestep_mats)))
@@ -304,13 +311,39 @@ class _Sampler:
         cur = _lib.MdxState(P(h_node), P(pos), P(h_half), P(self.log_node[lc]), P(self.log_half[lc]))
         nxt = _lib.MdxState(P(self.node_traj[n]), P(self.pos_traj[n]), P(self.halfedge_traj[n]), P(self.log_node[ln]),
                             P(self.log_half[ln]))
+        overlapped = self.guidance is not None and self.side is not None
+        if overlapped:
+            self._launch_guidance_on_side_stream(h_node, pos)
         ws, nb = self.g.workspace(self.dev)
         _lib.check(L.mdx_sample_step(self.eng.h, self.g.h, ctypes.byref(self.tables), P(self.t), P(self.bn), P(self.bh),
                                      ctypes.byref(cur), ctypes.byref(nxt), P(self.preds[0]), P(self.preds[1]), P(self.preds[2]),
                                      P(self.eps), P(self.u_n), P(self.u_h), ws, nb, _lib.stream()))
-        if self.guidance is not None:
+        if overlapped:
+            torch.cuda.current_stream().wait_event(self._ev_done)
+            _lib.check(L.mdx_add_inplace(_lib.ptr(self.pos_traj[n]), _lib.ptr(self.delta), 3 * self.N, _lib.stream()))
+        elif self.guidance is not None:
             self._guide(h_node, pos, self.pos_traj[n], self.halfedge_traj[n], self.log_half[ln])
         self.cur, self.lcur = n, ln
+
+    def _launch_guidance_on_side_stream(self, h_node, pos):
+        """'uncertainty' guidance of this step (predictor forward with tape -> dU/dlogits -> hand-written backward -> delta)
+        enqueued on the side stream; the main stream adds `delta` after its own posteriors."""
+        L, g = _lib.lib(), self.g
+        main = torch.cuda.current_stream()
+        self._ev_in.record(main)               # state, t and (last step's) delta consumption are ordered before this point
+        self.side.wait_event(self._ev_in)
+        off = (-self._ws2.data_ptr()) % 256
+        ws, nb = ctypes.c_void_p(self._ws2.data_ptr() + off), ctypes.c_size_t(self._ws2.numel() - off)
+        _, tptr, tbytes = g.tape(self.dev, self.bp.encoder.num_blocks)
+        with torch.cuda.stream(self.side):
+            st = _lib.stream()
+            _lib.check(L.mdx_bondpred_forward(self.bp_eng.h, g.h, _lib.ptr(h_node), _lib.ptr(pos), _lib.ptr(self.t),
+                                              _lib.ptr(self.bp_logits), ws, nb, tptr, tbytes, st))
+            _lib.check(L.mdx_guidance_uncertainty_grad(_lib.ptr(self.bp_logits), self.bp.num_edge_types, self.Eh,
+                                                       _lib.ptr(self.bp_glogits), st))
+            _lib.check(L.mdx_bondpred_backward(self.bp_eng.h, g.h, _lib.ptr(pos), _lib.ptr(self.bp_glogits), -self.guidance[1],
+                                               _lib.ptr(self.delta), ws, nb, tptr, tbytes, st))
+            self._ev_done.record(self.side)
 
     def _guide(self, h_node, pos, pos_prev, h_half_prev, log_half):
         """models/model.py:309-362: pos_prev += delta, delta = -+scale * d f(bond logits) / d pos evaluated at the
