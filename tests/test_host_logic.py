@@ -227,3 +227,18 @@ def test_plateau_scheduler_follows_torch_reduce_on_plateau():
         mine.step(x)
         assert abs(tr.lr - opt.param_groups[0]['lr']) < 1e-12
     assert tr.lr < 1e-3
+
+
+def test_bench_workload_is_the_reference_recipe():
+    """bench.py's batch = the reference's size recipe with seed 2920: first sizes, N, Eh at B = 8 / 256."""
+    import bench
+    _, ph8, s8 = bench.build_workload(8, 0, None)
+    assert list(s8) == [24, 30, 28, 19, 21, 29, 26, 27]
+    assert int(ph8['batch_node'].numel()) == 204 and int(ph8['batch_halfedge'].numel()) == 2552
+    _, ph, s = bench.build_workload(256, 0, None)
+    assert int(ph['batch_node'].numel()) == 6279 and int(ph['batch_halfedge'].numel()) == 77333
+    assert int(s.min()) == 12 and int(s.max()) == 39
+    _, ph1, s1 = bench.build_workload(256, 1, None)            # rank 1 gets the next 256 draws of the same stream
+    np.random.seed(2920)
+    allsz = np.random.normal(24.923464980477522, 5.516291901819105, size=512).astype('int64')
+    assert np.array_equal(s, allsz[:256]) and np.array_equal(s1, allsz[256:])
