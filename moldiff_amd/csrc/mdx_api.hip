@@ -119,6 +119,28 @@ struct PackCtx {
     if (!t) return;
     pack_dense(slot, t->data, F, ldw, col0, K);
   }
+  // "stream pack" of the row-owner kernels (mdx_row.h rgemm): the same fragments in consumption order --
+  // float index ((((ftp*KG + g)*2 + j)*64 + lane)*4 + s) <- W[16*(2 ftp + j) + (lane & 15)][col0 + 16 g + 4 (lane >> 4) + s];
+  // F is padded to a multiple of 32 with zero rows, plus MDX_RING steps of zero tail so a ring may over-fetch
+  void pack_stream(const float** slot, const std::vector<float>& W, int F, int ldw, int col0, int K) {
+    const int FTP = (F + 31) / 32, KG = K / 16;
+    size_t off = pk.reserve((size_t)FTP * KG * 512 + 2 * 512);
+    float* o = pk.host.data() + off;
+    for (int ftp = 0; ftp < FTP; ++ftp)
+      for (int g = 0; g < KG; ++g)
+        for (int j = 0; j < 2; ++j)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int s = 0; s < 4; ++s) {
+              const int f = 16 * (2 * ftp + j) + (lane & 15), k = 16 * g + 4 * (lane >> 4) + s;
+              o[((((size_t)ftp * KG + g) * 2 + j) * 64 + lane) * 4 + s] = f < F ? W[(size_t)f * ldw + col0 + k] : 0.f;
+            }
+    pk.bind(slot, off);
+  }
+  void packS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    pack_stream(slot, t->data, F, ldw, col0, K);
+  }
   // transpose pack: out[k][f] = W[f][col0 + k]  (contraction over the forward's output features, zero padded to 16)
   void packT(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
     const HostTensor* t = get(key, {F, ldw});
@@ -185,6 +207,12 @@ int pack_model(mdx_model_s* m) {
     c.mlp(&b.ea.en, nb + ".edge_net", ED, ND, ND);
     c.packA(&b.ea.Wm, nb + ".msg_net.weight", ND, ND, 0, ND);
     c.vec(&b.ea.bm, nb + ".msg_net.bias", ND);
+    c.packS(&b.ea.s.Wemb, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, 0, ED + MDX_NG);
+    c.packS(&b.ea.s.Wg1e, nb + ".gate.net.0.weight", ND, GIN, 0, ED);
+    c.packS(&b.ea.s.Wg2, nb + ".gate.net.3.weight", ND, ND, 0, ND);
+    c.packS(&b.ea.s.W1, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
+    c.packS(&b.ea.s.W2, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
+    c.packS(&b.ea.s.Wm, nb + ".msg_net.weight", ND, ND, 0, ND);
     for (int s = 0; s < 2; ++s) {
       FfnW& f = b.ea.ffn[s];
       const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
@@ -197,6 +225,12 @@ int pack_model(mdx_model_s* m) {
       c.vec(&f.gb, fp + ".gate.net.1.bias", 32);
       c.packA(&f.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
       c.vec(&f.bg2, fp + ".gate.net.3.bias", ED);
+      FfnS& fs = b.ea.s.ffn[s];
+      c.packS(&fs.Wbl, fp + ".bond_linear.weight", 2 * ED, ED, 0, ED);
+      c.packS(&fs.Wg1e, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
+      c.packS(&fs.W1, fp + ".inter_module.net.0.weight", 2 * ED, 2 * ED, 0, 2 * ED);
+      c.packS(&fs.W2, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
+      c.packS(&fs.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
     }
     {  // fused first layers of both BondFFNs (see EdgeAW::Wffa)
       std::vector<float> Wf((size_t)320 * ED, 0.f);
@@ -221,6 +255,8 @@ int pack_model(mdx_model_s* m) {
     c.vec(&b.eb.lnb, eb + ".layer_norm.bias", ED);
     c.packA(&b.eb.Wout, eb + ".out_transform.weight", ED, ED, 0, ED);
     c.vec(&b.eb.bout, eb + ".out_transform.bias", ED);
+    c.packS(&b.eb.s.Wself, eb + ".self_ffn.weight", ED, ED, 0, ED);
+    c.packS(&b.eb.s.Wout, eb + ".out_transform.weight", ED, ED, 0, ED);
     // ---- node kernel
     c.vec(&b.nd.lng, nb + ".layer_norm.weight", ND);
     c.vec(&b.nd.lnb, nb + ".layer_norm.bias", ND);
@@ -265,6 +301,11 @@ int pack_model(mdx_model_s* m) {
       if (const HostTensor* t = c.get(el + ".inter_module.net.3.bias", {1})) b.eb.bi2 = t->data[0];
       c.packA(&b.eb.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
       c.packA(&b.eb.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
+      c.packS(&b.eb.s.Wbl, el + ".bond_linear.weight", ND, ED, 0, ED);
+      c.packS(&b.eb.s.Wnl, el + ".node_linear.weight", ND, ED, 0, ED);
+      c.packS(&b.eb.s.Wi1, el + ".inter_module.net.0.weight", ND, ND, 0, ND);
+      c.packS(&b.eb.s.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
+      c.packS(&b.eb.s.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
       {
         const HostTensor* bl = c.get(el + ".bond_linear.weight", {ND, ED});
         const HostTensor* nl = c.get(el + ".node_linear.weight", {ND, ED});

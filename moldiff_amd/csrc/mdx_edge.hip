@@ -488,6 +488,7 @@ static void ensure_attr() {
 
 void launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
+  if (mdx_use_rowowner()) return launch_edge_a2(a, s);
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;
   hipLaunchKernelGGL(edge_a_kernel, dim3(ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
@@ -495,6 +496,7 @@ void launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
 
 void launch_edge_b(const EdgeBArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
+  if (mdx_use_rowowner()) return launch_edge_b2(a, s);
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;
   hipLaunchKernelGGL(edge_b_kernel, dim3(ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);

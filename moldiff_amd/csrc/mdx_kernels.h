@@ -44,6 +44,18 @@ struct FfnW {  // BondFFN of the EdgeBlock (bond 64, node 256 hoisted, inter 128
   const float *Wg2, *bg2;      // gate second layer (64 x 32)
 };
 
+// "stream packs" of the row-owner kernels (mdx_row.h, mdx_edge2.hip): the same matrices in consumption order
+struct FfnS {
+  const float *Wbl, *Wg1e, *W1, *W2, *Wg2;
+};
+struct EdgeAS {
+  const float *Wemb, *Wg1e, *Wg2, *W1, *W2, *Wm;
+  FfnS ffn[2];
+};
+struct EdgeBS {
+  const float *Wself, *Wout, *Wbl, *Wnl, *Wg1h, *Wg1a, *Wi1;
+};
+
 struct EdgeAW {  // weights of edge kernel A for one block
   const float *Wemb, *bemb;                        // edge_embs (64 x 80)
   const float *Wg1e, *bg1, *wtg1, *gg, *gb, *Wg2, *bg2;  // NodeBlock gate: edge part (256x64), bias, time col, LN, 256x256
@@ -53,6 +65,7 @@ struct EdgeAW {  // weights of edge kernel A for one block
   // first layers of both BondFFNs that read He', fused into one (320 x 64) pack: the 80 rows of wave w are
   // [bond_linear_s rows 64h..64h+63 | gate layer-1 edge part rows 16h..16h+15], s = w/2, h = w%2
   const float* Wffa;
+  EdgeAS s;
 };
 
 struct EdgeBW {  // weights of edge kernel B for one block
@@ -68,6 +81,7 @@ struct EdgeBW {  // weights of edge kernel B for one block
   const float *Wg1h, *Wg1a, *bg1, *wtg1, *gg, *gb;  // gate first layer split: He part (32x64), a part (32x64), bias, time col, LN
   const float *wg2;                // (32)
   float bg2;
+  EdgeBS s;
 };
 
 struct NodeW {  // weights of the node kernel
@@ -223,6 +237,10 @@ void launch_dist_to_pos(const float* gdist, const float* pos, const int* l, cons
 
 void launch_edge_a(const EdgeAArgs& a, hipStream_t s);
 void launch_edge_b(const EdgeBArgs& a, hipStream_t s);
+// row-owner versions (mdx_edge2.hip); launch_edge_a/b dispatch to them unless MDX_TILE_KERNELS=1 is set in the environment
+void launch_edge_a2(const EdgeAArgs& a, hipStream_t s);
+void launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
+bool mdx_use_rowowner();
 void launch_node(const NodeArgs& a, hipStream_t s);
 
 // out[v][0..C) (+)= sum_{j in ptr[v]..ptr[v+1]} src[(eids ? eids[j] : j)][0..C)

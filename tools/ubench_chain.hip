@@ -1,0 +1,394 @@
+// Micro-benchmark for the round-2 "row-owner" tile design: one wave owns 16*R rows and ALL output features of
+// every layer, activations never leave the wave's registers (the accumulator layout of v_mfma_f32_16x16x4_f32 is the B-operand
+// layout of the next layer when the weights are packed with k in the order (16 g + 4 q + s)), LayerNorm is wave-local, there is
+// no barrier and no LDS traffic; weights stream L2 -> VGPR through a DEPTH-deep register ring.
+//   hipcc --offload-arch=gfx950 -O3 -o ubench_chain ubench_chain.hip
+// Prints TFLOP/s of an NL-layer 256 -> 256 (LN, ReLU) chain for several (R, DEPTH, waves/SIMD) and weight working sets.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- guarantees static register-array indices
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+__device__ __forceinline__ float red_q(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// y[ft][rt] (+)= sum_g W(ft,g) x[g][rt]; fragment stream order: ((ftg*KG + g)*NF + j)*64 + lane, ft = NF ftg + j
+// MODE 0: pinned with sched_barriers; 1: unpinned (compiler schedules); 2: no weight loads at all (pure MFMA rate)
+template <int KG, int FT, int R, int DEPTH, int NF, int MODE>
+__device__ __forceinline__ void gemm_chain(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R], const f32x4* __restrict__ wbase, unsigned loff = 0) {
+  const f32x4* __restrict__ w = wbase + loff;
+  constexpr int NP = (FT / NF) * KG;  // steps
+  f32x4 ring[DEPTH][NF];
+#pragma unroll
+  for (int p = 0; p < DEPTH && p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) ring[p][j] = w[(size_t)(NF * p + j) * 64];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int ftg = p / KG, g = p % KG;
+    f32x4 a[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) a[j] = ring[p % DEPTH][j];
+    if (MODE != 2 && p + DEPTH < NP) {
+#pragma unroll
+      for (int j = 0; j < NF; ++j) ring[p % DEPTH][j] = w[(size_t)(NF * (p + DEPTH) + j) * 64];
+    }
+    if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          y[NF * ftg + j][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][s], x[g][rt][s], y[NF * ftg + j][rt], 0, 0, 0);
+    if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 3) {
+      constexpr int NM = 4 * R * NF;  // MFMAs per step
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, (NM - 1) / NF, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, (NM - 1) % NF, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int FT, int R>
+__device__ __forceinline__ void ln_relu(f32x4 (&y)[FT][R], const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
+  constexpr float inv_n = 1.0f / (FT * 16);
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) {
+    float s = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) s += (y[ft][rt][0] + y[ft][rt][1]) + (y[ft][rt][2] + y[ft][rt][3]);
+    const float mean = red_q(s) * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = y[ft][rt][r] - mean;
+        d2 = fmaf(d, d, d2);
+      }
+    const float rstd = 1.0f / sqrtf(red_q(d2) * inv_n + 1e-5f);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      // keep the affine-parameter loads next to their use (hoisted together they cost 2*FT*4 registers)
+      if (ft % 2 == 0) __builtin_amdgcn_sched_barrier(0);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * ft + 4 * q);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * ft + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[ft][rt][r] = fmaxf((y[ft][rt][r] - mean) * rstd * gm[r] + bt[r], 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R, int DEPTH, int WPS, int NL, bool LN, int NF, int MODE, bool DESYNC, bool UNI>
+__global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict__ W, const float* __restrict__ gb, float* out, int reps,
+                                                         int nmat) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4;
+  f32x4 x[16][R];
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const float v = (float)((lane * 7 + g * 3 + rt + blockIdx.x) % 13) * 0.05f - 0.3f;
+      x[g][rt] = f32x4{v, v + 0.01f, v - 0.02f, v + 0.03f};
+    }
+  const f32x4* wp = reinterpret_cast<const f32x4*>(W) + (UNI ? 0 : lane);
+  int m = __builtin_amdgcn_readfirstlane((blockIdx.x + wave) % nmat);
+  if (DESYNC && (blockIdx.x & 256)) {  // every other co-resident workgroup starts half a layer late
+    f32x4 y[8][R];
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) y[ft][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_chain<16, 8, R, DEPTH, NF, MODE>(y, x, wp);
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) x[ft][rt] = x[ft][rt] + y[ft][rt] * 1e-6f;
+  }
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      f32x4 y[16][R];
+#pragma unroll
+      for (int ft = 0; ft < 16; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) y[ft][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gemm_chain<16, 16, R, DEPTH, NF, MODE>(y, x, wp + (size_t)m * 16384, UNI ? (unsigned)lane : 0u);
+      if (LN) {
+        const float* gbp = gb;
+        asm volatile("" : "+s"(gbp));  // defeat LICM of the affine-parameter loads out of the rep loop
+        ln_relu<16, R>(y, gbp, gbp + 256, q);
+      }
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) x[g][rt] = y[g][rt];
+      m = (m + 1 == nmat) ? 0 : m + 1;
+    }
+  }
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) s = s + x[g][rt];
+  out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int R, int DEPTH, int WPS, int NL, bool LN, int NF = 2, int MODE = 0, bool DESYNC = false, bool UNI = false>
+void run(const float* W, const float* gb, float* out, int nmat, int same_start) {
+  auto kern = chain_kernel<R, DEPTH, WPS, NL, LN, NF, MODE, DESYNC, UNI>;
+  const int reps = 24 / NL * (R == 1 ? 2 : 1), grid = 256 * WPS * 3;
+  hipFuncAttributes fa;
+  hipFuncGetAttributes(&fa, (const void*)kern);
+  int occ = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, 0);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  const size_t lds = WPS == 1 ? 100000 : 0;  // pad so that exactly one workgroup fits per CU
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+  for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int it = 0; it < 5; ++it) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    best = ms < best ? ms : best;
+  }
+  const double flop = (double)grid * 4 * reps * NL * 2.0 * 256 * 256 * 16 * R;
+  printf("R=%d depth=%d wps=%d occ=%d NL=%d LN=%d NF=%d MODE=%d DESYNC=%d UNI=%d nmat=%d vgpr=%d : %.3f ms  %.1f TFLOP/s (%.3f of 157.3)\n", R, DEPTH, WPS,
+         occ, NL, (int)LN, NF, MODE, (int)DESYNC, (int)UNI, nmat, fa.numRegs, best, flop / best / 1e9, flop / best / 1e9 / 157.3);
+  fflush(stdout);
+}
+
+// MODE 4: LayerNorm folded into the GEMMs of a one-wave-per-SIMD row owner.
+//   x      : RAW (pre-LN) output of the previous layer, normalised lazily (group g+1 while the MFMAs of step (0,g) run)
+//   mean,rstd : its row statistics
+//   y      : raw output; its statistics are accumulated pair by pair (shifted one-pass: K = mean of the first 32 features)
+template <int R, int DEPTH>
+__device__ __forceinline__ void gemm_chain_ln(f32x4 (&y)[16][R], f32x4 (&x)[16][R], float (&mean)[R], float (&rstd)[R],
+                                              const f32x4* __restrict__ w, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int q) {
+  constexpr int KG = 16, NP = 8 * KG;
+  f32x4 ring[DEPTH][2];
+#pragma unroll
+  for (int p = 0; p < DEPTH; ++p) {
+    ring[p][0] = w[(size_t)(2 * p) * 64];
+    ring[p][1] = w[(size_t)(2 * p + 1) * 64];
+  }
+  f32x4 gmn, btn;  // affine parameters of the next group to normalise, fetched one step ahead
+  auto fetch = [&](int g) {
+    gmn = *reinterpret_cast<const f32x4*>(gamma + 16 * g + 4 * q);
+    btn = *reinterpret_cast<const f32x4*>(beta + 16 * g + 4 * q);
+  };
+  auto apply = [&](int g) {
+    const f32x4 gm = gmn, bt = btn;
+    if (g + 1 < 16) fetch(g + 1);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[g][rt][r] = fmaxf((x[g][rt][r] - mean[rt]) * rstd[rt] * gm[r] + bt[r], 0.f);
+  };
+  fetch(0);
+  float K[R], s1[R], s2[R];
+  apply(0);
+  static_for<0, NP>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    constexpr int ftp = p / KG, g = p % KG;
+    const f32x4 a0 = ring[p % DEPTH][0], a1 = ring[p % DEPTH][1];
+    if constexpr (p + DEPTH < NP) {
+      ring[p % DEPTH][0] = w[(size_t)(2 * (p + DEPTH)) * 64];
+      ring[p % DEPTH][1] = w[(size_t)(2 * (p + DEPTH) + 1) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int nvalu = 0;
+    if constexpr (ftp == 0 && g + 1 < KG) {
+      apply(g + 1);
+      nvalu = 4 * 4 * R;
+    }
+    if constexpr (ftp >= 1 && g == 0) {  // statistics of the pair finished in the previous step
+      const int f = 2 * (ftp - 1);
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        if constexpr (ftp == 1) {
+          const float t = ((y[0][rt][0] + y[0][rt][1]) + (y[0][rt][2] + y[0][rt][3])) + ((y[1][rt][0] + y[1][rt][1]) + (y[1][rt][2] + y[1][rt][3]));
+          K[rt] = red_q(t) * (1.0f / 32.0f);
+          s1[rt] = 0.f;
+          s2[rt] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = y[f + j][rt][r] - K[rt];
+            s1[rt] += d;
+            s2[rt] = fmaf(d, d, s2[rt]);
+          }
+      }
+      nvalu = 3 * 8 * R + (ftp == 1 ? 12 * R : 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        y[2 * ftp][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], x[g][rt][s], y[2 * ftp][rt], 0, 0, 0);
+        y[2 * ftp + 1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], x[g][rt][s], y[2 * ftp + 1][rt], 0, 0, 0);
+      }
+    constexpr int NM = 8 * R;
+    (void)nvalu;
+    if constexpr (ftp == 0 && g + 1 < KG) {  // interleave: 1 MFMA, then a slice of the side work
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    } else if constexpr (ftp >= 1 && g == 0) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  // last pair + finalisation (exposed)
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = y[14 + j][rt][r] - K[rt];
+        s1[rt] += d;
+        s2[rt] = fmaf(d, d, s2[rt]);
+      }
+    const float m1 = red_q(s1[rt]) * (1.0f / 256.0f), m2 = red_q(s2[rt]) * (1.0f / 256.0f);
+    mean[rt] = K[rt] + m1;
+    rstd[rt] = 1.0f / sqrtf(fmaxf(m2 - m1 * m1, 0.f) + 1e-5f);
+  }
+}
+
+template <int R, int DEPTH, int WPS>
+__global__ __launch_bounds__(256, WPS) void chain_ln_kernel(const float* __restrict__ W, const float* __restrict__ gb, float* out, int reps,
+                                                            int nmat) {
+  extern __shared__ float pad_[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4;
+  f32x4 x[16][R];
+  float mean[R], rstd[R];
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) mean[rt] = 0.01f * rt, rstd[rt] = 1.0f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const float v = (float)((lane * 7 + g * 3 + rt + blockIdx.x) % 13) * 0.05f - 0.3f;
+      x[g][rt] = f32x4{v, v + 0.01f, v - 0.02f, v + 0.03f};
+    }
+  const f32x4* wp = reinterpret_cast<const f32x4*>(W) + lane;
+  int m = __builtin_amdgcn_readfirstlane((blockIdx.x + wave) % nmat);
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) {
+    f32x4 y[16][R];
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft)
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) y[ft][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* gbp = gb;
+    asm volatile("" : "+s"(gbp));
+    gemm_chain_ln<R, DEPTH>(y, x, mean, rstd, wp + (size_t)m * 16384, gbp, gbp + 256, q);
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) x[g][rt] = y[g][rt];
+    m = (m + 1 == nmat) ? 0 : m + 1;
+  }
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) s = s + x[g][rt];
+  out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3] + mean[0] + rstd[0];
+}
+
+template <int R, int DEPTH, int WPS>
+void run_ln(const float* W, const float* gb, float* out, int nmat) {
+  auto kern = chain_ln_kernel<R, DEPTH, WPS>;
+  const int reps = 24 * (R == 1 ? 2 : 1), grid = 256 * WPS * 3;
+  hipFuncAttributes fa;
+  hipFuncGetAttributes(&fa, (const void*)kern);
+  const size_t lds = WPS == 1 ? 100000 : 0;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int it = 0; it < 5; ++it) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    best = ms < best ? ms : best;
+  }
+  const double flop = (double)grid * 4 * reps * 2.0 * 256 * 256 * 16 * R;
+  printf("LN-folded R=%d depth=%d wps=%d vgpr=%d : %.3f ms  %.1f TFLOP/s (%.3f of 157.3)\n", R, DEPTH, WPS, fa.numRegs, best,
+         flop / best / 1e9, flop / best / 1e9 / 157.3);
+  fflush(stdout);
+}
+
+int main() {
+  const int nmat_max = 20;
+  std::vector<float> h((size_t)nmat_max * 65536);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = ((float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f) * 0.12f;
+  std::vector<float> gbh(512);
+  for (int i = 0; i < 256; ++i) gbh[i] = 1.0f + 0.01f * (i % 7), gbh[256 + i] = 0.05f * (i % 5);
+  float *W, *gb, *out;
+  hipMalloc(&W, h.size() * 4);
+  hipMalloc(&gb, 512 * 4);
+  hipMalloc(&out, (size_t)256 * 3 * 3 * 256 * 4);
+  hipMemcpy(W, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(gb, gbh.data(), 512 * 4, hipMemcpyHostToDevice);
+  run<2, 2, 1, 1, false, 2, 0>(W, gb, out, 5, 0);
+  run<2, 2, 1, 1, true, 2, 0>(W, gb, out, 5, 0);
+  run_ln<2, 2, 1>(W, gb, out, 5);
+  run_ln<2, 3, 1>(W, gb, out, 5);
+  run_ln<1, 4, 1>(W, gb, out, 5);
+  run_ln<1, 4, 2>(W, gb, out, 5);
+  return 0;
+}
