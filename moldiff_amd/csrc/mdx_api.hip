@@ -124,7 +124,7 @@ struct PackCtx {
   // F is padded to a multiple of 32 with zero rows, plus MDX_RING steps of zero tail so a ring may over-fetch
   void pack_stream(const float** slot, const std::vector<float>& W, int F, int ldw, int col0, int K) {
     const int FTP = (F + 31) / 32, KG = K / 16;
-    size_t off = pk.reserve((size_t)FTP * KG * 512 + 2 * 512);
+    size_t off = pk.reserve((size_t)FTP * KG * 512 + 4 * 512);  // + MDX_RING_PAD zero steps
     float* o = pk.host.data() + off;
     for (int ftp = 0; ftp < FTP; ++ftp)
       for (int g = 0; g < KG; ++g)

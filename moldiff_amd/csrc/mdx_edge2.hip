@@ -9,6 +9,29 @@
 // LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (32 KiB per wave).
 #include "mdx_kernels.h"
 #include "mdx_row.h"
+#include <algorithm>
+
+// Phase trace (tools/trace_edge2.py; build with EXTRA=-DMDX_TRACE2): lane 0 of every wave stamps the shader clock at each
+// phase boundary into a 48-slot record per unit (slot 46/47: 100 MHz wall clock at entry/exit).  Compiled out of the library.
+#ifdef MDX_TRACE2
+__device__ unsigned long long* mdx_trace2_buf = nullptr;
+__device__ int mdx_trace2_sel = 0;  // 0: edge_a2, 1: edge_b2
+extern "C" int mdx_debug_set_trace2(void* p, int which) {
+  hipMemcpyToSymbol(HIP_SYMBOL(mdx_trace2_sel), &which, sizeof(which));
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdx_trace2_buf), &p, sizeof(p));
+}
+#define STAMP_K(k, i)                                                                                       \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (lane == 0 && mdx_trace2_buf && mdx_trace2_sel == (k))                                               \
+      mdx_trace2_buf[(size_t)unit * 48 + (i)] = ((i) >= 46) ? wall_clock64() : clock64();                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+  } while (0)
+#else
+#define STAMP_K(k, i) ((void)0)
+#endif
+#define STAMP(i) STAMP_K(0, i)
+#define STAMPB(i) STAMP_K(1, i)
 
 namespace {
 
@@ -45,266 +68,430 @@ __device__ __forceinline__ void mul_inplace(f32x4 (&y)[FT][RR], const f32x4 (&v)
     for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * v[ft][rt];
 }
 
+// Small per-layer vectors (biases, LayerNorm affine parameters, time columns) are copied once per workgroup into LDS: a
+// lone wave per SIMD has nobody to hide the L2 latency of these loads, a ds_read is an order of magnitude closer.
+template <int OFF, int N>
+__device__ __forceinline__ const float* lds_put(float* base, const float* __restrict__ src, int tid) {
+  static_assert(OFF % 4 == 0 && N % 4 == 0 && N <= 4 * MDX_WG, "constant vector layout");
+  if (4 * tid < N) sts4(base + OFF + 4 * tid, ldg4(src + 4 * tid));
+  return base + OFF;
+}
+constexpr int EA_CONST_FLOATS = 96 + 2560 + 2 * 640;
+constexpr int EB_CONST_FLOATS = 4 * 64 + 5 * 32 + 4 * 256;
+
+// rows of the He tile + edge length of one unit: loaded one unit ahead by the persistent loop
+struct Prolog {
+  RowTile t;
+  f32x4 x[4][RR];
+  float d[RR];
+};
+
+__device__ __forceinline__ void prolog_rows(Prolog& p, const EdgeAArgs& a, int q) {
+  row_gather<4, RR>(p.x, a.He_in, p.t.row, 64, q);
+  if (a.flags & EA_EMB) {
+#pragma unroll
+    for (int rt = 0; rt < RR; ++rt) {
+      if (a.dist_in) {
+        p.d[rt] = a.dist_in[p.t.row[rt]];
+      } else {
+        const float dx = a.pos[3 * p.t.li[rt] + 0] - a.pos[3 * p.t.ri[rt] + 0];
+        const float dy = a.pos[3 * p.t.li[rt] + 1] - a.pos[3 * p.t.ri[rt] + 1];
+        const float dz = a.pos[3 * p.t.li[rt] + 2] - a.pos[3 * p.t.ri[rt] + 2];
+        p.d[rt] = sqrtf(dx * dx + dy * dy + dz * dz);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, const int nunits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
-  const int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  if (unit >= nunits) return;  // no barrier anywhere below: a wave may leave on its own
   const int E = a.E;
-  const RowTile t = load_tile(a.l, a.r, a.te, unit * ROWS, E, c);
-  const bool do_node = a.flags & EA_NODE, do_ffn = a.flags & EA_FFN;
+  const bool do_emb = a.flags & EA_EMB, do_node = a.flags & EA_NODE, do_ffn = a.flags & EA_FFN;
   f32x4* park = reinterpret_cast<f32x4*>(smem + (size_t)wave * PARK_FLOATS) + lane;
-  auto W = [&](const float* p) { return reinterpret_cast<const f32x4*>(p) + lane; };
-  WRing ring;
+  // (the asm keeps the address arithmetic of a stream next to its loads: hoisted out of the persistent loop it would pin
+  // hundreds of 64-bit lane addresses in registers)
+  auto W = [&](const float* p) {
+    int z = 0;
+    asm volatile("" : "+s"(z));  // opaque zero: the pointer keeps its global address space, the sum cannot be hoisted
+    return reinterpret_cast<const f32x4*>(p + z) + lane;
+  };
 
-  // ---- He' = edge_embs([He | smear(d)]) -------------------------------------------------------
-  f32x4 hep[4][RR];
-  if (a.flags & EA_EMB) {
-    ring_prime(ring, W(a.w.s.Wemb));
-    f32x4 x[5][RR];
-#pragma unroll
-    for (int rt = 0; rt < RR; ++rt) {
-      const float* p = a.He_in + (size_t)t.row[rt] * 64 + 4 * q;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) x[g][rt] = ldg4(p + 16 * g);
-    }
-    const f32x4 off = ldg4(a.soff + 4 * q), coef = ldg4(a.scoef + 4 * q);
-#pragma unroll
-    for (int rt = 0; rt < RR; ++rt) {
-      float d;
-      if (a.dist_in) {
-        d = a.dist_in[t.row[rt]];
-      } else {
-        const float dx = a.pos[3 * t.li[rt] + 0] - a.pos[3 * t.ri[rt] + 0];
-        const float dy = a.pos[3 * t.li[rt] + 1] - a.pos[3 * t.ri[rt] + 1];
-        const float dz = a.pos[3 * t.li[rt] + 2] - a.pos[3 * t.ri[rt] + 2];
-        d = sqrtf(dx * dx + dy * dy + dz * dz);
-      }
-      const float u0 = fminf(fmaxf(d, 0.f), a.cutoff);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float u = u0 - off[s];
-        x[4][rt][s] = expf(coef[s] * (u * u));
-      }
-    }
-    row_bias<4, RR>(hep, a.w.bemb, q);
-    rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring);
-    row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
-  } else {
-    row_gather<4, RR>(hep, a.He_in, t.row, 64, q);
-  }
-
-  // ---- NodeBlock message path: M = msg_net(edge_net(He') * h[r]) * sigmoid(gate([He' | x[r] | t])) --------
+  // fixed LDS layout (offsets in floats) so every constant address is cbase + immediate
+  float* cb = smem + 4 * PARK_FLOATS;
+  const float* c_soff = lds_put<0, 16>(cb, a.soff, tid);
+  const float* c_scoef = lds_put<16, 16>(cb, a.scoef, tid);
+  const float* c_bemb = cb + 32;
+  if (do_emb) lds_put<32, 64>(cb, a.w.bemb, tid);
+  const float *c_bg1 = cb + 96, *c_wtg1 = c_bg1 + 256, *c_gg = c_bg1 + 512, *c_gb = c_bg1 + 768, *c_bg2 = c_bg1 + 1024,
+              *c_eb1 = c_bg1 + 1280, *c_eg = c_bg1 + 1536, *c_ebe = c_bg1 + 1792, *c_eb2 = c_bg1 + 2048, *c_bm = c_bg1 + 2304;
   if (do_node) {
-    ring_prime(ring, W(a.w.s.Wg1e));
-    f32x4 y[16][RR], z[16][RR];
-    {  // gate layer 1: accumulator starts at b + gx[r] + t*wt (the hoisted node part and the time column)
-      row_gather<16, RR>(y, a.NT + MDX_NT_GX, t.ri, MDX_NTW, q);
-      float tg[RR];
+    lds_put<96, 256>(cb, a.w.bg1, tid); lds_put<96 + 256, 256>(cb, a.w.wtg1, tid); lds_put<96 + 512, 256>(cb, a.w.gg, tid);
+    lds_put<96 + 768, 256>(cb, a.w.gb, tid); lds_put<96 + 1024, 256>(cb, a.w.bg2, tid); lds_put<96 + 1280, 256>(cb, a.w.en.b1, tid);
+    lds_put<96 + 1536, 256>(cb, a.w.en.g, tid); lds_put<96 + 1792, 256>(cb, a.w.en.be, tid);
+    lds_put<96 + 2048, 256>(cb, a.w.en.b2, tid); lds_put<96 + 2304, 256>(cb, a.w.bm, tid);
+  }
+  constexpr int FO = 96 + 2560, FS = 640;  // per BondFFN: bg1 32 | wtg1 32 | gg 32 | gb 32 | ib1 128 | ig 128 | ibe 128 | ib2 64 | bg2 64
+  const float *f_bg1[2], *f_wtg1[2], *f_gg[2], *f_gb[2], *f_ib1[2], *f_ig[2], *f_ibe[2], *f_ib2[2], *f_bg2[2];
 #pragma unroll
-      for (int rt = 0; rt < RR; ++rt) tg[rt] = a.tn_r ? a.tn_r[t.row[rt]] : t.tt[rt];  // the NodeBlock gate sees node_time[col]
-#pragma unroll
-      for (int ft = 0; ft < 16; ++ft) {
-        const f32x4 b = ldg4(a.w.bg1 + 16 * ft + 4 * q), wt = ldg4(a.w.wtg1 + 16 * ft + 4 * q);
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) y[ft][rt] = (b + y[ft][rt]) + splat4(tg[rt]) * wt;
-      }
-    }
-    rgemm<4, 16, RR>(y, hep, W(a.w.s.Wg1e), ring);
-    ring_prime(ring, W(a.w.s.Wg2));
-    row_layernorm<16, RR>(y, a.w.gg, a.w.gb, q);
-    row_bias<16, RR>(z, a.w.bg2, q);
-    rgemm<16, 16, RR>(z, y, W(a.w.s.Wg2), ring);
-    ring_prime(ring, W(a.w.s.W1));
-#pragma unroll
-    for (int ft = 0; ft < 16; ++ft)
+  for (int s = 0; s < 2; ++s) {
+    const float* fb = cb + FO + FS * s;
+    f_bg1[s] = fb; f_wtg1[s] = fb + 32; f_gg[s] = fb + 64; f_gb[s] = fb + 96; f_ib1[s] = fb + 128; f_ig[s] = fb + 256;
+    f_ibe[s] = fb + 384; f_ib2[s] = fb + 512; f_bg2[s] = fb + 576;
+  }
+  if (do_ffn) {
+    const FfnW& w0 = a.w.ffn[0];
+    const FfnW& w1 = a.w.ffn[1];
+    lds_put<FO, 32>(cb, w0.bg1, tid); lds_put<FO + 32, 32>(cb, w0.wtg1, tid); lds_put<FO + 64, 32>(cb, w0.gg, tid);
+    lds_put<FO + 96, 32>(cb, w0.gb, tid); lds_put<FO + 128, 128>(cb, w0.inter.b1, tid); lds_put<FO + 256, 128>(cb, w0.inter.g, tid);
+    lds_put<FO + 384, 128>(cb, w0.inter.be, tid); lds_put<FO + 512, 64>(cb, w0.inter.b2, tid); lds_put<FO + 576, 64>(cb, w0.bg2, tid);
+    lds_put<FO + FS, 32>(cb, w1.bg1, tid); lds_put<FO + FS + 32, 32>(cb, w1.wtg1, tid); lds_put<FO + FS + 64, 32>(cb, w1.gg, tid);
+    lds_put<FO + FS + 96, 32>(cb, w1.gb, tid); lds_put<FO + FS + 128, 128>(cb, w1.inter.b1, tid);
+    lds_put<FO + FS + 256, 128>(cb, w1.inter.g, tid); lds_put<FO + FS + 384, 128>(cb, w1.inter.be, tid);
+    lds_put<FO + FS + 512, 64>(cb, w1.inter.b2, tid); lds_put<FO + FS + 576, 64>(cb, w1.bg2, tid);
+  }
+  __syncthreads();  // the only barrier of the kernel: constants visible to every wave
+
+  // persistent wave: units slot, slot + nslots, ...   (XCD-contiguous: neighbouring units share node rows in one L2)
+  const int nslots = gridDim.x * 4;
+  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  // contiguous range of units per slot keeps a wave inside one molecule's node rows
+  const int per = (nunits + nslots - 1) / nslots;
+  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
+  if (ubeg >= uend) return;
+
+  // first stream of a unit (the tail of every unit primes it again for the next one)
+  const f32x4* wfirst = do_emb ? W(a.w.s.Wemb) : do_node ? W(a.w.s.Wg1e) : W(a.w.s.ffn[0].Wbl);
+  WRing ring;
+  ring_prime(ring, wfirst);
+  Prolog pr;
+  pr.t = load_tile(a.l, a.r, a.te, ubeg * ROWS, E, c);
+  prolog_rows(pr, a, q);
+
+#pragma unroll 1
+  for (int unit = ubeg; unit < uend; ++unit) {
+    const RowTile t = pr.t;
+    const int unext = min(unit + 1, uend - 1);
+    STAMP(46);
+    STAMP(0);
+    // ---- He' = edge_embs([He | smear(d)]) -------------------------------------------------------
+    f32x4 hep[4][RR];
+    if (do_emb) {
+      f32x4 x[5][RR];
+      const f32x4 off = lds4(c_soff + 4 * q), coef = lds4(c_scoef + 4 * q);
 #pragma unroll
       for (int rt = 0; rt < RR; ++rt) {
-        const f32x4 sg = sigmoid4(z[ft][rt]);
-        if (a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
-        park[(ft * RR + rt) * 64] = sg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x[g][rt] = pr.x[g][rt];
+        const float u0 = fminf(fmaxf(pr.d[rt], 0.f), a.cutoff);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float u = u0 - off[s];
+          x[4][rt][s] = expf(coef[s] * (u * u));
+        }
       }
-    // edge_net
-    row_bias<16, RR>(y, a.w.en.b1, q);
-    rgemm<4, 16, RR>(y, hep, W(a.w.s.W1), ring);
-    ring_prime(ring, W(a.w.s.W2));
-    row_layernorm<16, RR>(y, a.w.en.g, a.w.en.be, q);
-    row_bias<16, RR>(z, a.w.en.b2, q);
-    rgemm<16, 16, RR>(z, y, W(a.w.s.W2), ring);
-    ring_prime(ring, W(a.w.s.Wm));
-    if (a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
-    row_gather<16, RR>(y, a.H, t.ri, MDX_ND, q);
-    mul_inplace<16>(z, y);
-    // msg_net, gated
-    row_bias<16, RR>(y, a.w.bm, q);
-    rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring);
+      row_bias<4, RR>(hep, c_bemb, q);
+      STAMP(1);
+      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, do_node ? W(a.w.s.Wg1e) : do_ffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
+      STAMP(2);
+      row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
+    } else {
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft)
+      for (int rt = 0; rt < RR; ++rt)
 #pragma unroll
-      for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * park[(ft * RR + rt) * 64];
-    row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
-  }
-
-  // ---- EdgeBlock BondFFNs: F_s = inter_s((W_bl He') * nl_s[idx_s]) * sigmoid(gate_s([He' | x[idx_s] | t])) ----
-  if (do_ffn) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const FfnW& w = a.w.ffn[s];
-      const FfnS& ws = a.w.s.ffn[s];
-      int idx[RR];
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) idx[rt] = s ? t.ri[rt] : t.li[rt];
-      ring_prime(ring, W(ws.Wbl));
-      f32x4 bl[8][RR], nl[8][RR], g1[2][RR];
-      row_gather<8, RR>(nl, a.NT + (s ? MDX_NT_NLR : MDX_NT_NLL), idx, MDX_NTW, q);
-      row_gather<2, RR>(g1, a.NT + (s ? MDX_NT_GXR : MDX_NT_GXL), idx, MDX_NTW, q);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
-        const f32x4 b = ldg4(w.bg1 + 16 * ft + 4 * q), wt = ldg4(w.wtg1 + 16 * ft + 4 * q);
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) g1[ft][rt] = (b + g1[ft][rt]) + splat4(t.tt[rt]) * wt;
-      }
-      row_bias<8, RR>(bl, nullptr, q);
-      rgemm<4, 8, RR>(bl, hep, W(ws.Wbl), ring);
-      ring_prime(ring, W(ws.Wg1e));
-      mul_inplace<8>(bl, nl);
-      rgemm<4, 2, RR>(g1, hep, W(ws.Wg1e), ring);
-      ring_prime(ring, W(ws.W1));
-      row_layernorm<2, RR>(g1, w.gg, w.gb, q);
-      f32x4 h[8][RR];
-      row_bias<8, RR>(h, w.inter.b1, q);
-      rgemm<8, 8, RR>(h, bl, W(ws.W1), ring);
-      ring_prime(ring, W(ws.W2));
-      row_layernorm<8, RR>(h, w.inter.g, w.inter.be, q);
-      f32x4 o[4][RR], g2[4][RR];
-      row_bias<4, RR>(o, w.inter.b2, q);
-      rgemm<8, 4, RR>(o, h, W(ws.W2), ring);
-      ring_prime(ring, W(ws.Wg2));
-      row_bias<4, RR>(g2, w.bg2, q);
-      rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) o[ft][rt] = o[ft][rt] * sigmoid4(g2[ft][rt]);
-      row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
+        for (int g = 0; g < 4; ++g) hep[g][rt] = pr.x[g][rt];
     }
+
+    // ---- NodeBlock message path: M = msg_net(edge_net(He') * h[r]) * sigmoid(gate([He' | x[r] | t])) --------
+    if (do_node) {
+      f32x4 y[16][RR], z[16][RR];
+      {  // gate layer 1: accumulator starts at b + gx[r] + t*wt (the hoisted node part and the time column)
+        row_gather<16, RR>(y, a.NT + MDX_NT_GX, t.ri, MDX_NTW, q);
+        float tg[RR];
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) tg[rt] = a.tn_r ? a.tn_r[t.row[rt]] : t.tt[rt];  // the NodeBlock gate sees node_time[col]
+#pragma unroll
+        for (int ft = 0; ft < 16; ++ft) {
+          const f32x4 b = lds4(c_bg1 + 16 * ft + 4 * q), wt = lds4(c_wtg1 + 16 * ft + 4 * q);
+#pragma unroll
+          for (int rt = 0; rt < RR; ++rt) y[ft][rt] = (b + y[ft][rt]) + splat4(tg[rt]) * wt;
+        }
+      }
+      STAMP(3);
+      rgemm<4, 16, RR>(y, hep, W(a.w.s.Wg1e), ring, W(a.w.s.Wg2));
+      STAMP(4);
+      row_layernorm<16, RR>(y, c_gg, c_gb, q);
+      row_bias<16, RR>(z, c_bg2, q);
+      STAMP(5);
+      rgemm<16, 16, RR>(z, y, W(a.w.s.Wg2), ring, W(a.w.s.W1));
+      STAMP(6);
+#pragma unroll
+      for (int ft = 0; ft < 16; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) {
+          const f32x4 sg = row_sigmoid4(z[ft][rt]);
+          if (a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
+          park[(ft * RR + rt) * 64] = sg;
+        }
+      // edge_net
+      row_bias<16, RR>(y, c_eb1, q);
+      STAMP(7);
+      rgemm<4, 16, RR>(y, hep, W(a.w.s.W1), ring, W(a.w.s.W2));
+      STAMP(8);
+      row_layernorm<16, RR>(y, c_eg, c_ebe, q);
+      row_bias<16, RR>(z, c_eb2, q);
+      STAMP(9);
+      rgemm<16, 16, RR>(z, y, W(a.w.s.W2), ring, W(a.w.s.Wm));
+      STAMP(10);
+      if (a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
+      row_gather<16, RR>(y, a.H, t.ri, MDX_ND, q);
+      mul_inplace<16>(z, y);
+      // msg_net, gated
+      row_bias<16, RR>(y, c_bm, q);
+      STAMP(11);
+      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, do_ffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
+      STAMP(12);
+#pragma unroll
+      for (int ft = 0; ft < 16; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * park[(ft * RR + rt) * 64];
+      row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
+      STAMP(13);
+    }
+    if (!do_ffn) {  // next unit's tile (the FFN section does this under its own GEMMs)
+      pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);
+      prolog_rows(pr, a, q);
+    }
+
+    // ---- EdgeBlock BondFFNs: F_s = inter_s((W_bl He') * nl_s[idx_s]) * sigmoid(gate_s([He' | x[idx_s] | t])) ----
+    if (do_ffn) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const FfnS& ws = a.w.s.ffn[s];
+        int idx[RR];
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) idx[rt] = s ? t.ri[rt] : t.li[rt];
+        f32x4 bl[8][RR], nl[8][RR], g1[2][RR];
+        row_gather<8, RR>(nl, a.NT + (s ? MDX_NT_NLR : MDX_NT_NLL), idx, MDX_NTW, q);
+        row_gather<2, RR>(g1, a.NT + (s ? MDX_NT_GXR : MDX_NT_GXL), idx, MDX_NTW, q);
+        if (s == 1) pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);  // next unit's indices, a few GEMMs ahead of their use
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const f32x4 b = lds4(f_bg1[s] + 16 * ft + 4 * q), wt = lds4(f_wtg1[s] + 16 * ft + 4 * q);
+#pragma unroll
+          for (int rt = 0; rt < RR; ++rt) g1[ft][rt] = (b + g1[ft][rt]) + splat4(t.tt[rt]) * wt;
+        }
+        row_bias<8, RR>(bl, nullptr, q);
+        STAMP(14 + 10 * s);
+        rgemm<4, 8, RR>(bl, hep, W(ws.Wbl), ring, W(ws.Wg1e));
+        STAMP(15 + 10 * s);
+        mul_inplace<8>(bl, nl);
+        rgemm<4, 2, RR>(g1, hep, W(ws.Wg1e), ring, W(ws.W1));
+        STAMP(16 + 10 * s);
+        row_layernorm<2, RR>(g1, f_gg[s], f_gb[s], q);
+        f32x4 h[8][RR];
+        row_bias<8, RR>(h, f_ib1[s], q);
+        STAMP(17 + 10 * s);
+        rgemm<8, 8, RR>(h, bl, W(ws.W1), ring, W(ws.W2));
+        STAMP(18 + 10 * s);
+        row_layernorm<8, RR>(h, f_ig[s], f_ibe[s], q);
+        f32x4 o[4][RR], g2[4][RR];
+        row_bias<4, RR>(o, f_ib2[s], q);
+        if (s == 1) prolog_rows(pr, a, q);  // next unit's He rows + edge lengths travel under the last two GEMMs
+        STAMP(19 + 10 * s);
+        rgemm<8, 4, RR>(o, h, W(ws.W2), ring, W(ws.Wg2));
+        STAMP(20 + 10 * s);
+        row_bias<4, RR>(g2, f_bg2[s], q);
+        rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, s == 0 ? W(a.w.s.ffn[1].Wbl) : wfirst);
+        STAMP(21 + 10 * s);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+          for (int rt = 0; rt < RR; ++rt) o[ft][rt] = o[ft][rt] * row_sigmoid4(g2[ft][rt]);
+        row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
+        STAMP(22 + 10 * s);
+      }
+    }
+    STAMP(40);
+    STAMP(47);
   }
 }
 
+struct PrologB {
+  RowTile t;
+  f32x4 he[4][RR];
+};
+
 __global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, const int nunits) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
-  const int unit = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  if (unit >= nunits) return;
   const int E = a.E;
-  const RowTile t = load_tile(a.l, a.r, a.te, unit * ROWS, E, c);
   const bool do_edge = a.flags & EB_EDGE, do_pos = a.flags & EB_POS;
-  auto W = [&](const float* p) { return reinterpret_cast<const f32x4*>(p) + lane; };
-  WRing ring;
+  // (the asm keeps the address arithmetic of a stream next to its loads: hoisted out of the persistent loop it would pin
+  // hundreds of 64-bit lane addresses in registers)
+  auto W = [&](const float* p) {
+    int z = 0;
+    asm volatile("" : "+s"(z));  // opaque zero: the pointer keeps its global address space, the sum cannot be hoisted
+    return reinterpret_cast<const f32x4*>(p + z) + lane;
+  };
 
-  f32x4 he[4][RR];  // He' on entry, He'' after the EdgeBlock tail
-  row_gather<4, RR>(he, a.Hep, t.row, 64, q);
-
-  // ---- EdgeBlock tail: He'' = He' + out_transform(relu(LN(SL[l] + SR[r] + nfl[l] + nfr[r] + self_ffn(He')))) ----
+  float* cb = smem;
+  const float *c_bself = cb, *c_lng = cb + 64, *c_lnb = cb + 128, *c_bout = cb + 192;
   if (do_edge) {
-    ring_prime(ring, W(a.w.s.Wself));
-    f32x4 u[4][RR], v[4][RR];
-    row_gather<4, RR>(u, a.SL, t.li, 64, q);
-    row_gather<4, RR>(v, a.SR, t.ri, 64, q);
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) u[ft][rt] = u[ft][rt] + v[ft][rt];
-    row_gather<4, RR>(v, a.NT + MDX_NT_NFL, t.li, MDX_NTW, q);
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) u[ft][rt] = u[ft][rt] + v[ft][rt];
-    row_gather<4, RR>(v, a.NT + MDX_NT_NFR, t.ri, MDX_NTW, q);
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
-      const f32x4 bs = ldg4(a.w.bself + 16 * ft + 4 * q);
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) u[ft][rt] = (u[ft][rt] + v[ft][rt]) + bs;
-    }
-    rgemm<4, 4, RR>(u, he, W(a.w.s.Wself), ring);
-    ring_prime(ring, W(a.w.s.Wout));
-    row_layernorm<4, RR>(u, a.w.lng, a.w.lnb, q);
-    row_bias<4, RR>(v, a.w.bout, q);
-    rgemm<4, 4, RR>(v, u, W(a.w.s.Wout), ring);
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) {
-        if (!(a.flags & EB_DELTA)) v[ft][rt] = v[ft][rt] + he[ft][rt];
-        he[ft][rt] = v[ft][rt];
-      }
-    row_store<4, RR>(he, a.He_out, t.row, t.valid, 64, q);
+    lds_put<0, 64>(cb, a.w.bself, tid); lds_put<64, 64>(cb, a.w.lng, tid); lds_put<128, 64>(cb, a.w.lnb, tid);
+    lds_put<192, 64>(cb, a.w.bout, tid);
   }
-
-  // ---- PosUpdate: w = inter((W_bl He'') * (W_nl a)) * sigmoid(gate([He'' | a | t])), a = Lf[l] * Rf[r]; Fe = w rel / d / (d+1) ----
+  const float *c_bg1 = cb + 256, *c_wtg1 = cb + 288, *c_gg = cb + 320, *c_gb = cb + 352, *c_wg2 = cb + 384, *c_bi1 = cb + 416,
+              *c_ig = cb + 672, *c_ib = cb + 928, *c_wi2 = cb + 1184;
   if (do_pos) {
-    ring_prime(ring, W(a.w.s.Wbl));
+    lds_put<256, 32>(cb, a.w.bg1, tid); lds_put<288, 32>(cb, a.w.wtg1, tid); lds_put<320, 32>(cb, a.w.gg, tid);
+    lds_put<352, 32>(cb, a.w.gb, tid); lds_put<384, 32>(cb, a.w.wg2, tid); lds_put<416, 256>(cb, a.w.bi1, tid);
+    lds_put<672, 256>(cb, a.w.ig, tid); lds_put<928, 256>(cb, a.w.ib, tid); lds_put<1184, 256>(cb, a.w.wi2, tid);
+  }
+  __syncthreads();
+
+  const int nslots = gridDim.x * 4;
+  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  const int per = (nunits + nslots - 1) / nslots;
+  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
+  if (ubeg >= uend) return;
+
+  const f32x4* wfirst = do_edge ? W(a.w.s.Wself) : W(a.w.s.Wbl);
+  WRing ring;
+  ring_prime(ring, wfirst);
+  PrologB pr;
+  pr.t = load_tile(a.l, a.r, a.te, ubeg * ROWS, E, c);
+  row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);
+
+#pragma unroll 1
+  for (int unit = ubeg; unit < uend; ++unit) {
+    const RowTile t = pr.t;
+    const int unext = min(unit + 1, uend - 1);
+    STAMPB(46);
+    STAMPB(0);
+    f32x4 he[4][RR];  // He' on entry, He'' after the EdgeBlock tail
+#pragma unroll
+    for (int rt = 0; rt < RR; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) he[g][rt] = pr.he[g][rt];
+
+    // PosUpdate inputs that only depend on the tile's indices: requested first, consumed after the EdgeBlock tail
     f32x4 aa[4][RR], bb[4][RR];
-    row_gather<4, RR>(aa, a.Lf, t.li, 64, q);
-    row_gather<4, RR>(bb, a.Rf, t.ri, 64, q);
-    mul_inplace<4>(aa, bb);
     float rx[RR], ry[RR], rz[RR], dd[RR];
-#pragma unroll
-    for (int rt = 0; rt < RR; ++rt) {
-      if (a.rel_in) {
-        rx[rt] = a.rel_in[3 * (size_t)t.row[rt] + 0]; ry[rt] = a.rel_in[3 * (size_t)t.row[rt] + 1]; rz[rt] = a.rel_in[3 * (size_t)t.row[rt] + 2];
-        dd[rt] = a.dist_in[t.row[rt]];
-      } else {
-        rx[rt] = a.pos[3 * t.li[rt] + 0] - a.pos[3 * t.ri[rt] + 0];
-        ry[rt] = a.pos[3 * t.li[rt] + 1] - a.pos[3 * t.ri[rt] + 1];
-        rz[rt] = a.pos[3 * t.li[rt] + 2] - a.pos[3 * t.ri[rt] + 2];
-        dd[rt] = sqrtf(rx[rt] * rx[rt] + ry[rt] * ry[rt] + rz[rt] * rz[rt]);
-      }
-    }
-    f32x4 x[16][RR], h[16][RR], g1[2][RR];
-    row_bias<16, RR>(x, nullptr, q);
-    rgemm<4, 16, RR>(x, he, W(a.w.s.Wbl), ring);
-    ring_prime(ring, W(a.w.s.Wnl));
-    row_bias<16, RR>(h, nullptr, q);
-    rgemm<4, 16, RR>(h, aa, W(a.w.s.Wnl), ring);
-    ring_prime(ring, W(a.w.s.Wg1h));
-    mul_inplace<16>(x, h);
-    // gate: ((b + t wt) + W_h He'') + W_a a, LN(32), ReLU, 32 -> 1
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      const f32x4 b = ldg4(a.w.bg1 + 16 * ft + 4 * q), wt = ldg4(a.w.wtg1 + 16 * ft + 4 * q);
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) g1[ft][rt] = b + splat4(t.tt[rt]) * wt;
-    }
-    rgemm<4, 2, RR>(g1, he, W(a.w.s.Wg1h), ring);
-    ring_prime(ring, W(a.w.s.Wg1a));
-    rgemm<4, 2, RR>(g1, aa, W(a.w.s.Wg1a), ring);
-    ring_prime(ring, W(a.w.s.Wi1));
-    row_layernorm<2, RR>(g1, a.w.gg, a.w.gb, q);
-    float gate[RR], wd[RR];
-    row_dot<2, RR>(g1, a.w.wg2, q, gate);
-    row_bias<16, RR>(h, a.w.bi1, q);
-    rgemm<16, 16, RR>(h, x, W(a.w.s.Wi1), ring);
-    row_layernorm<16, RR>(h, a.w.ig, a.w.ib, q);
-    row_dot<16, RR>(h, a.w.wi2, q, wd);
-    if (q == 0) {
+    if (do_pos) {
+      row_gather<4, RR>(aa, a.Lf, t.li, 64, q);
+      row_gather<4, RR>(bb, a.Rf, t.ri, 64, q);
 #pragma unroll
       for (int rt = 0; rt < RR; ++rt) {
-        if (!t.valid[rt]) continue;
-        const float w = (wd[rt] + a.w.bi2) * sigmoidf_(gate[rt] + a.w.bg2);
-        const float d = dd[rt], dp = d + 1.0f;
-        float* fe = a.Fe + 3 * (size_t)t.row[rt];
-        fe[0] = w * rx[rt] / d / dp;
-        fe[1] = w * ry[rt] / d / dp;
-        fe[2] = w * rz[rt] / d / dp;
+        if (a.rel_in) {
+          rx[rt] = a.rel_in[3 * (size_t)t.row[rt] + 0]; ry[rt] = a.rel_in[3 * (size_t)t.row[rt] + 1]; rz[rt] = a.rel_in[3 * (size_t)t.row[rt] + 2];
+          dd[rt] = a.dist_in[t.row[rt]];
+        } else {
+          rx[rt] = a.pos[3 * t.li[rt] + 0] - a.pos[3 * t.ri[rt] + 0];
+          ry[rt] = a.pos[3 * t.li[rt] + 1] - a.pos[3 * t.ri[rt] + 1];
+          rz[rt] = a.pos[3 * t.li[rt] + 2] - a.pos[3 * t.ri[rt] + 2];
+          dd[rt] = sqrtf(rx[rt] * rx[rt] + ry[rt] * ry[rt] + rz[rt] * rz[rt]);
+        }
       }
     }
+
+    // ---- EdgeBlock tail: He'' = He' + out_transform(relu(LN(SL[l] + SR[r] + nfl[l] + nfr[r] + self_ffn(He')))) ----
+    if (do_edge) {
+      f32x4 u[4][RR], v[4][RR], v2[4][RR], v3[4][RR];
+      row_gather<4, RR>(u, a.SL, t.li, 64, q);
+      row_gather<4, RR>(v, a.SR, t.ri, 64, q);
+      row_gather<4, RR>(v2, a.NT + MDX_NT_NFL, t.li, MDX_NTW, q);
+      row_gather<4, RR>(v3, a.NT + MDX_NT_NFR, t.ri, MDX_NTW, q);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 bs = lds4(c_bself + 16 * ft + 4 * q);
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) u[ft][rt] = (((u[ft][rt] + v[ft][rt]) + v2[ft][rt]) + v3[ft][rt]) + bs;
+      }
+      STAMPB(1);
+      rgemm<4, 4, RR>(u, he, W(a.w.s.Wself), ring, W(a.w.s.Wout));
+      STAMPB(2);
+      row_layernorm<4, RR>(u, c_lng, c_lnb, q);
+      row_bias<4, RR>(v, c_bout, q);
+      STAMPB(3);
+      rgemm<4, 4, RR>(v, u, W(a.w.s.Wout), ring, do_pos ? W(a.w.s.Wbl) : wfirst);
+      STAMPB(4);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) {
+          if (!(a.flags & EB_DELTA)) v[ft][rt] = v[ft][rt] + he[ft][rt];
+          he[ft][rt] = v[ft][rt];
+        }
+      row_store<4, RR>(he, a.He_out, t.row, t.valid, 64, q);
+    }
+    pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);  // next unit's indices travel under the PosUpdate GEMMs
+
+    // ---- PosUpdate: w = inter((W_bl He'') * (W_nl a)) * sigmoid(gate([He'' | a | t])), a = Lf[l] * Rf[r]; Fe = w rel / d / (d+1) ----
+    if (do_pos) {
+      mul_inplace<4>(aa, bb);
+      f32x4 x[16][RR], h[16][RR], g1[2][RR];
+      row_bias<16, RR>(x, nullptr, q);
+      STAMPB(5);
+      rgemm<4, 16, RR>(x, he, W(a.w.s.Wbl), ring, W(a.w.s.Wnl));
+      STAMPB(6);
+      row_bias<16, RR>(h, nullptr, q);
+      rgemm<4, 16, RR>(h, aa, W(a.w.s.Wnl), ring, W(a.w.s.Wg1h));
+      STAMPB(7);
+      mul_inplace<16>(x, h);
+      // gate: ((b + t wt) + W_h He'') + W_a a, LN(32), ReLU, 32 -> 1
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 b = lds4(c_bg1 + 16 * ft + 4 * q), wt = lds4(c_wtg1 + 16 * ft + 4 * q);
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) g1[ft][rt] = b + splat4(t.tt[rt]) * wt;
+      }
+      rgemm<4, 2, RR>(g1, he, W(a.w.s.Wg1h), ring, W(a.w.s.Wg1a));
+      rgemm<4, 2, RR>(g1, aa, W(a.w.s.Wg1a), ring, W(a.w.s.Wi1));
+      STAMPB(8);
+      row_layernorm<2, RR>(g1, c_gg, c_gb, q);
+      float gate[RR], wd[RR];
+      row_dot<2, RR>(g1, c_wg2, q, gate);
+      row_bias<16, RR>(h, c_bi1, q);
+      row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);  // next unit's He' rows under the last GEMM
+      STAMPB(9);
+      rgemm<16, 16, RR>(h, x, W(a.w.s.Wi1), ring, wfirst);
+      STAMPB(10);
+      row_layernorm<16, RR>(h, c_ig, c_ib, q);
+      row_dot<16, RR>(h, c_wi2, q, wd);
+      if (q == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) {
+          if (!t.valid[rt]) continue;
+          const float w = (wd[rt] + a.w.bi2) * sigmoidf_(gate[rt] + a.w.bg2);
+          const float d = dd[rt], dp = d + 1.0f;
+          float* fe = a.Fe + 3 * (size_t)t.row[rt];
+          fe[0] = w * rx[rt] / d / dp;
+          fe[1] = w * ry[rt] / d / dp;
+          fe[2] = w * rz[rt] / d / dp;
+        }
+      }
+    } else {
+      row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);
+    }
+    STAMPB(40);
+    STAMPB(47);
   }
 }
 
 }  // namespace
+
+int mdx_num_cus() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }();
+  return n;
+}
 
 bool mdx_use_rowowner() {
   static const bool v = [] {
@@ -317,17 +504,17 @@ bool mdx_use_rowowner() {
 void launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   static bool attr = false;
-  constexpr int lds = 4 * PARK_FLOATS * 4;
+  constexpr int lds = (4 * PARK_FLOATS + EA_CONST_FLOATS) * 4;
   if (!attr) {
-    hipFuncSetAttribute((const void*)edge_a2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)edge_a2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_a2_kernel, dim3((nunits + 3) / 4), dim3(MDX_WG), lds, s, a, nunits);
+  hipLaunchKernelGGL(edge_a2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus())), dim3(MDX_WG), lds, s, a, nunits);
 }
 
 void launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_b2_kernel, dim3((nunits + 3) / 4), dim3(MDX_WG), 0, s, a, nunits);
+  hipLaunchKernelGGL(edge_b2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus())), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a, nunits);
 }

@@ -241,6 +241,7 @@ void launch_edge_b(const EdgeBArgs& a, hipStream_t s);
 void launch_edge_a2(const EdgeAArgs& a, hipStream_t s);
 void launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
 bool mdx_use_rowowner();
+int mdx_num_cus();
 void launch_node(const NodeArgs& a, hipStream_t s);
 
 // out[v][0..C) (+)= sum_{j in ptr[v]..ptr[v+1]} src[(eids ? eids[j] : j)][0..C)

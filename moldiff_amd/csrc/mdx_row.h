@@ -25,12 +25,18 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-constexpr int MDX_RING = 2;
+#ifndef MDX_ABL
+#define MDX_ABL 0  // timing-only ablations (wrong results): 1 no stores, 2 no row gathers, 4 weight stream served from L1
+#endif
+#ifndef MDX_RING
+#define MDX_RING 2  // steps (2 KiB each) of the weight stream in flight per wave
+#endif
 struct WRing {
   f32x4 a[MDX_RING][2];
 };
 
-// first MDX_RING steps of a stream (w already carries the +lane offset)
+// first MDX_RING steps of a stream (w already carries the +lane offset; every stream pack ends in MDX_RING_PAD zero steps,
+// so priming a stream shorter than the ring stays in bounds)
 __device__ __forceinline__ void ring_prime(WRing& r, const f32x4* __restrict__ w) {
 #pragma unroll
   for (int p = 0; p < MDX_RING; ++p) {
@@ -39,20 +45,49 @@ __device__ __forceinline__ void ring_prime(WRing& r, const f32x4* __restrict__ w
   }
 }
 
-// y[ft][rt] += sum_g W(ft, g) x[g][rt]      (FT even; the ring must have been primed with this stream)
-template <int KG, int FT, int R>
-__device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R], const f32x4* __restrict__ w, WRing& ring) {
+// sigmoid on the hardware transcendentals: 1 / (1 + 2^(-x log2 e)) with v_exp_f32 and v_rcp_f32 (1 ulp each; exact limits
+// 0 and 1 for |x| large).  On this core VALU work does not hide under the f32 MFMAs, and the IEEE expf + division form
+// costs ~27 VALU instructions per value against 5 here (tests/test_gpu_fullsize.py arbitrates the accuracy against fp64).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ f32x4 fast_sigmoid4(f32x4 v) {
+  f32x4 r = {fast_sigmoid(v[0]), fast_sigmoid(v[1]), fast_sigmoid(v[2]), fast_sigmoid(v[3])};
+  return r;
+}
+#ifndef MDX_FAST_SIGMOID
+#define MDX_FAST_SIGMOID 1
+#endif
+__device__ __forceinline__ f32x4 row_sigmoid4(f32x4 v) { return MDX_FAST_SIGMOID ? fast_sigmoid4(v) : sigmoid4(v); }
+
+struct NoHook {
+  template <class P>
+  __device__ __forceinline__ void operator()(P) const {}
+};
+
+// y[ft][rt] += sum_g W(ft, g) x[g][rt]      (FT even; `ring` must hold the first MDX_RING steps of this stream)
+//   wnext : stream of the NEXT GEMM this wave will run (or nullptr): its first steps are requested a few steps before this
+//           GEMM ends and are in `ring` on return, so the L2 latency of a layer's first fragments never sits between layers
+//   hook(integral_constant<int, p>) runs in the load slot of step p (before its MFMAs): the caller's place for row gathers
+//           and other prefetches that should travel under this GEMM
+template <int KG, int FT, int R, class Hook = NoHook>
+__device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R], const f32x4* __restrict__ w, WRing& ring,
+                                      const f32x4* __restrict__ wnext = nullptr, Hook&& hook = Hook{}) {
   static_assert(FT % 2 == 0, "feature tiles come in pairs");
   constexpr int NP = (FT / 2) * KG;
-  static_assert(NP >= MDX_RING, "stream shorter than the ring");
+  constexpr int PRIME_AT = NP > 3 ? NP - 3 : 0;
+  WRing nx;
   static_for<0, NP>([&](auto pc) {
     constexpr int p = decltype(pc)::value;
     constexpr int ftp = p / KG, g = p % KG;
     const f32x4 a0 = ring.a[p % MDX_RING][0], a1 = ring.a[p % MDX_RING][1];
     if constexpr (p + MDX_RING < NP) {
-      ring.a[p % MDX_RING][0] = w[(size_t)(2 * (p + MDX_RING)) * 64];
-      ring.a[p % MDX_RING][1] = w[(size_t)(2 * (p + MDX_RING) + 1) * 64];
+      ring.a[p % MDX_RING][0] = w[(size_t)(2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING)) * 64];
+      ring.a[p % MDX_RING][1] = w[(size_t)(2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING) + 1) * 64];
     }
+    if constexpr (p == PRIME_AT)
+      if (wnext) ring_prime(nx, wnext);
+    hook(pc);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -63,6 +98,7 @@ __device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R]
       }
     __builtin_amdgcn_sched_barrier(0);
   });
+  if (wnext) ring = nx;
 }
 
 // y[ft][rt] = v[16 ft + 4 q ..]   (v may be nullptr -> zeros)
@@ -81,7 +117,7 @@ template <int FT, int R>
 __device__ __forceinline__ void row_gather(f32x4 (&v)[FT][R], const float* __restrict__ base, const int (&idx)[R], int ld, int q) {
 #pragma unroll
   for (int rt = 0; rt < R; ++rt) {
-    const float* p = base + (size_t)idx[rt] * ld + 4 * q;
+    const float* p = base + (size_t)((MDX_ABL & 2) ? 0 : idx[rt]) * ld + 4 * q;
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) v[ft][rt] = ldg4(p + 16 * ft);
   }
@@ -92,7 +128,7 @@ __device__ __forceinline__ void row_store(const f32x4 (&v)[FT][R], float* __rest
                                           const bool (&valid)[R], int ld, int q) {
 #pragma unroll
   for (int rt = 0; rt < R; ++rt) {
-    if (!valid[rt]) continue;
+    if (!valid[rt] || (MDX_ABL & 1)) continue;
     float* p = base + (size_t)row[rt] * ld + 4 * q;
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) stg4(p + 16 * ft, v[ft][rt]);

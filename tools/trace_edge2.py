@@ -1,0 +1,81 @@
+"""Phase-level timing of the row-owner edge kernels on the bench workload (development tool, not product).
+
+    tools/build_variant.sh trace2 -DMDX_TRACE2
+    python tools/trace_edge2.py a          # on the GPU box
+
+Lane 0 of every wave stamps clock64() at the phase boundaries (STAMP in csrc/mdx_edge2.hip) and the 100 MHz wall clock at
+entry and exit.  Printed per phase: mean duration over all 32-edge units next to the time the phase's MFMAs alone need on
+the wave's SIMD (64 flop/clk at the measured shader clock).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import moldiff_amd._lib as _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, 'moldiff_amd', 'libmoldiff_hip_trace2.so')
+import bench  # noqa: E402
+
+ROWS = 32
+PH_A = [('tile load + He + smear', 0, 1, 0), ('emb GEMM 80->64', 1, 2, 2 * 80 * 64), ('He store + gate init gathers', 2, 3, 0),
+        ('gate GEMM1 64->256', 3, 4, 2 * 64 * 256), ('LN + bias', 4, 5, 0), ('gate GEMM2 256->256', 5, 6, 2 * 256 * 256),
+        ('sigmoid + park + bias', 6, 7, 0), ('en GEMM1 64->256', 7, 8, 2 * 64 * 256), ('LN + bias', 8, 9, 0),
+        ('en GEMM2 256->256', 9, 10, 2 * 256 * 256), ('H[r] gather * + bias', 10, 11, 0),
+        ('msg GEMM 256->256', 11, 12, 2 * 256 * 256), ('unpark * + M store', 12, 13, 0)]
+for s in (0, 1):
+    o = 10 * s
+    PH_A += [(f'ffn{s}: gathers', 13 + 9 * s if s == 0 else 22, 14 + o, 0), (f'ffn{s}: bl GEMM 64->128', 14 + o, 15 + o, 2 * 64 * 128),
+             (f'ffn{s}: *nl + gate1 GEMM 64->32', 15 + o, 16 + o, 2 * 64 * 32), (f'ffn{s}: LN32 + bias', 16 + o, 17 + o, 0),
+             (f'ffn{s}: W1 GEMM 128->128', 17 + o, 18 + o, 2 * 128 * 128), (f'ffn{s}: LN128 + bias', 18 + o, 19 + o, 0),
+             (f'ffn{s}: W2 GEMM 128->64', 19 + o, 20 + o, 2 * 128 * 64), (f'ffn{s}: gate2 GEMM 32->64', 20 + o, 21 + o, 2 * 32 * 64),
+             (f'ffn{s}: sigmoid + store', 21 + o, 22 + o, 0)]
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else 'a'
+    phases, last = PH_A, 40
+    dev = torch.device('cuda:0')
+    model, ph, sizes = bench.build_workload(256, 0, dev)
+    model = model.to(dev)
+    L = _lib.lib()
+    sm = model.sampler(256, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023, return_traj=False)
+    sm.init()
+    for i in range(3):
+        sm.step(i)
+    torch.cuda.synchronize()
+    E = 2 * ph['halfedge_index'].shape[1]
+    nunits = (E + ROWS - 1) // ROWS
+    buf = torch.zeros(nunits * 48, dtype=torch.int64, device=dev)
+    assert L.mdx_debug_set_trace2(ctypes.c_void_p(buf.data_ptr()), 0 if which == 'a' else 1) == 0
+    sm.step(3)
+    torch.cuda.synchronize()
+    L.mdx_debug_set_trace2(ctypes.c_void_p(0), 0)
+    tr = buf.cpu().numpy().reshape(nunits, 48).astype(np.int64)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    np.save(os.path.join(ROOT, 'gpurun_out', f'trace_edge2_{which}.npy'), tr)
+    clk, wall0, wall1 = tr[:, :46], tr[:, 46], tr[:, 47]
+    scale = (clk[:, last] - clk[:, 0]).sum() / ((wall1 - wall0).sum() / 100.0)   # shader clocks per us
+    dur = (clk[:, last] - clk[:, 0]) / scale
+    start = (wall0 - wall0.min()) / 100.0
+    end = start + dur
+    print(f'edge_{which}2: units {nunits}; shader clock {scale:.0f} MHz; kernel span {end.max():.1f} us (last of 6 launches); '
+          f'unit duration mean {dur.mean():.1f} median {np.median(dur):.1f} min {dur.min():.1f} max {dur.max():.1f} us; '
+          f'mean resident waves {dur.sum() / end.max():.0f} of 1024')
+    tg = tn = ti = 0.0
+    print(f'{"phase":40s} {"mean us":>8s} {"median":>8s} {"MFMA-only":>10s} {"ratio":>6s}')
+    for name, a, b, fl in phases:
+        d = (clk[:, b] - clk[:, a]) / scale
+        ideal = fl * ROWS / 64.0 / scale
+        ti += ideal
+        tg, tn = (tg + d.mean(), tn) if fl else (tg, tn + d.mean())
+        print(f'{name:40s} {d.mean():8.2f} {np.median(d):8.2f} {ideal:10.2f} {(ideal / d.mean() if fl else 0):6.2f}')
+    print(f'GEMM phases {tg:.1f} us + other phases {tn:.1f} us = {tg + tn:.1f} us per unit; MFMA-only {ti:.1f} us => pipe busy {ti / (tg + tn):.3f}')
+
+
+if __name__ == '__main__':
+    main()

@@ -118,7 +118,13 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict
     }
   const f32x4* wp = reinterpret_cast<const f32x4*>(W) + (UNI ? 0 : lane);
   int m = __builtin_amdgcn_readfirstlane((blockIdx.x + wave) % nmat);
-  if (DESYNC && (blockIdx.x & 256)) {  // every other co-resident workgroup starts half a layer late
+  if (DESYNC) {  // random start delay per wave, up to ~100 us: the waves of a CU (and the chip) lose lock-step
+    unsigned h = (blockIdx.x * 4u + wave) * 2654435761u;
+    h ^= h >> 15;
+    const int n = __builtin_amdgcn_readfirstlane((int)(h % 4000u));
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+  if (false) {  // every other co-resident workgroup starts half a layer late
     f32x4 y[8][R];
 #pragma unroll
     for (int ft = 0; ft < 8; ++ft)
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict
 template <int R, int DEPTH, int WPS, int NL, bool LN, int NF = 2, int MODE = 0, bool DESYNC = false, bool UNI = false>
 void run(const float* W, const float* gb, float* out, int nmat, int same_start) {
   auto kern = chain_kernel<R, DEPTH, WPS, NL, LN, NF, MODE, DESYNC, UNI>;
-  const int reps = 24 / NL * (R == 1 ? 2 : 1), grid = 256 * WPS * 3;
+  const int reps = (NL > 8 ? 48 : 24) / NL * (R == 1 ? 2 : 1), grid = 256 * WPS * 3;
   hipFuncAttributes fa;
   hipFuncGetAttributes(&fa, (const void*)kern);
   int occ = 0;
@@ -385,10 +391,10 @@ int main() {
   hipMemcpy(W, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(gb, gbh.data(), 512 * 4, hipMemcpyHostToDevice);
   run<2, 2, 1, 1, false, 2, 0>(W, gb, out, 5, 0);
-  run<2, 2, 1, 1, true, 2, 0>(W, gb, out, 5, 0);
-  run_ln<2, 2, 1>(W, gb, out, 5);
-  run_ln<2, 3, 1>(W, gb, out, 5);
-  run_ln<1, 4, 1>(W, gb, out, 5);
-  run_ln<1, 4, 2>(W, gb, out, 5);
+  run<2, 2, 1, 1, false, 2, 0, true>(W, gb, out, 5, 0);
+  run<2, 2, 1, 12, false, 2, 0, true>(W, gb, out, 5, 0);
+  run<2, 2, 1, 12, false, 2, 0, false>(W, gb, out, 5, 0);
+  run<2, 2, 1, 12, true, 2, 0, true>(W, gb, out, 5, 0);
+  run<2, 2, 1, 4, false, 2, 0, true>(W, gb, out, 5, 0);
   return 0;
 }
