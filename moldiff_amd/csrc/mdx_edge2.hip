@@ -9,7 +9,9 @@
 // LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (32 KiB per wave).
 #include "mdx_kernels.h"
 #include "mdx_row.h"
+#include "../../include/moldiff_hip.h"
 #include <algorithm>
+int mdx_set_error(int code, const char* msg);
 
 // Phase trace (tools/trace_edge2.py; build with EXTRA=-DMDX_TRACE2): lane 0 of every wave stamps the shader clock at each
 // phase boundary into a 48-slot record per unit (slot 46/47: 100 MHz wall clock at entry/exit).  Compiled out of the library.
@@ -79,6 +81,45 @@ __device__ __forceinline__ const float* lds_put(float* base, const float* __rest
 constexpr int EA_CONST_FLOATS = 96 + 2560 + 2 * 640;
 constexpr int EB_CONST_FLOATS = 4 * 64 + 5 * 32 + 4 * 256;
 
+// Work list of a persistent wave ("slot"): nf full units (a contiguous range), then its share of the last, partial round.
+// When the last round is short and the kernel runs both sections, that round is cut by SECTION instead of by rows (a
+// 16-row MFMA tile cannot be split further): the first `rem` slots run the NodeBlock message path of one unit each, the other
+// slots the BondFFN sections of `m` units each -- 0.76 + 3 x 0.25 of a unit instead of a whole extra round.
+struct EdgePlan {
+  int nslots, nf, rem, split, m;
+};
+__host__ __device__ inline int plan_items(const EdgePlan& p, int slot) {
+  if (!p.split) return p.nf + (slot < p.rem ? 1 : 0);
+  if (slot < p.rem) return p.nf + 1;
+  const int k = slot - p.rem, left = p.rem - k * p.m;
+  return p.nf + (left < 0 ? 0 : left < p.m ? left : p.m);
+}
+// item it of a slot -> unit index; mode bits: 1 message path, 2 BondFFNs, 4 this item owns the He' store
+__device__ __forceinline__ int plan_item(const EdgePlan& p, int slot, int it, int& mode) {
+  if (it < p.nf) {
+    mode = 7;
+    return slot * p.nf + it;
+  }
+  const int base = p.nf * p.nslots;
+  if (!p.split || slot < p.rem) {
+    mode = p.split ? 5 : 7;
+    return base + slot;
+  }
+  mode = 2;
+  return base + (slot - p.rem) * p.m + (it - p.nf);
+}
+inline EdgePlan make_plan(int nunits, int nslots, bool can_split) {
+  EdgePlan p{nslots, nunits / nslots, nunits % nslots, 0, 0};
+  if (can_split && p.rem > 0 && p.rem < nslots) {
+    const int m = (p.rem + (nslots - p.rem) - 1) / (nslots - p.rem);
+    if (0.27f * m < 0.9f) {
+      p.split = 1;
+      p.m = m;
+    }
+  }
+  return p;
+}
+
 // rows of the He tile + edge length of one unit: loaded one unit ahead by the persistent loop
 struct Prolog {
   RowTile t;
@@ -103,12 +144,15 @@ __device__ __forceinline__ void prolog_rows(Prolog& p, const EdgeAArgs& a, int q
   }
 }
 
-__global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, const int nunits) {
+// FLAGS (EA_*) is a template parameter: with run-time section flags every section sits behind a branch and the values that
+// cross it (He', the tile, the weight ring) get spilled around the control flow.
+template <int FLAGS>
+__global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, const EdgePlan plan) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
+  const int c = lane & 15, q0 = lane >> 4;
   const int E = a.E;
-  const bool do_emb = a.flags & EA_EMB, do_node = a.flags & EA_NODE, do_ffn = a.flags & EA_FFN;
+  constexpr bool do_emb = FLAGS & EA_EMB, do_node = FLAGS & EA_NODE, do_ffn = FLAGS & EA_FFN;
   f32x4* park = reinterpret_cast<f32x4*>(smem + (size_t)wave * PARK_FLOATS) + lane;
   // (the asm keeps the address arithmetic of a stream next to its loads: hoisted out of the persistent loop it would pin
   // hundreds of 64-bit lane addresses in registers)
@@ -153,26 +197,29 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
   }
   __syncthreads();  // the only barrier of the kernel: constants visible to every wave
 
-  // persistent wave: units slot, slot + nslots, ...   (XCD-contiguous: neighbouring units share node rows in one L2)
-  const int nslots = gridDim.x * 4;
-  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  // contiguous range of units per slot keeps a wave inside one molecule's node rows
-  const int per = (nunits + nslots - 1) / nslots;
-  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
-  if (ubeg >= uend) return;
+  // persistent wave; slots are XCD-contiguous so that neighbouring units (same molecule -> same node rows) share an L2
+  const int slot = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  const int nitems = plan_items(plan, slot);
+  if (nitems <= 0) return;
 
   // first stream of a unit (the tail of every unit primes it again for the next one)
   const f32x4* wfirst = do_emb ? W(a.w.s.Wemb) : do_node ? W(a.w.s.Wg1e) : W(a.w.s.ffn[0].Wbl);
   WRing ring;
   ring_prime(ring, wfirst);
   Prolog pr;
-  pr.t = load_tile(a.l, a.r, a.te, ubeg * ROWS, E, c);
-  prolog_rows(pr, a, q);
+  int mode, mode_next;
+  int unit = plan_item(plan, slot, 0, mode);
+  pr.t = load_tile(a.l, a.r, a.te, unit * ROWS, E, c);
+  prolog_rows(pr, a, q0);
 
 #pragma unroll 1
-  for (int unit = ubeg; unit < uend; ++unit) {
+  for (int it = 0; it < nitems; ++it) {
+    int q = q0;
+    asm volatile("" : "+v"(q));  // opaque per iteration: lane-dependent address parts stay next to their loads instead of
+                                 // being hoisted out of the persistent loop into (spilled) registers
     const RowTile t = pr.t;
-    const int unext = min(unit + 1, uend - 1);
+    const int unext = plan_item(plan, slot, min(it + 1, nitems - 1), mode_next);
+    const bool inode = do_node && (mode & 1), iffn = do_ffn && (mode & 2);
     STAMP(46);
     STAMP(0);
     // ---- He' = edge_embs([He | smear(d)]) -------------------------------------------------------
@@ -193,9 +240,9 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
       }
       row_bias<4, RR>(hep, c_bemb, q);
       STAMP(1);
-      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, do_node ? W(a.w.s.Wg1e) : do_ffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
+      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, inode ? W(a.w.s.Wg1e) : iffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
       STAMP(2);
-      row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
+      if (mode & 4) row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
     } else {
 #pragma unroll
       for (int rt = 0; rt < RR; ++rt)
@@ -204,7 +251,7 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
     }
 
     // ---- NodeBlock message path: M = msg_net(edge_net(He') * h[r]) * sigmoid(gate([He' | x[r] | t])) --------
-    if (do_node) {
+    if (inode) {
       f32x4 y[16][RR], z[16][RR];
       {  // gate layer 1: accumulator starts at b + gx[r] + t*wt (the hoisted node part and the time column)
         row_gather<16, RR>(y, a.NT + MDX_NT_GX, t.ri, MDX_NTW, q);
@@ -250,7 +297,7 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
       // msg_net, gated
       row_bias<16, RR>(y, c_bm, q);
       STAMP(11);
-      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, do_ffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
+      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, iffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
       STAMP(12);
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft)
@@ -259,13 +306,13 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
       row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
       STAMP(13);
     }
-    if (!do_ffn) {  // next unit's tile (the FFN section does this under its own GEMMs)
+    if (!iffn) {  // next unit's tile (the FFN section does this under its own GEMMs)
       pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);
       prolog_rows(pr, a, q);
     }
 
     // ---- EdgeBlock BondFFNs: F_s = inter_s((W_bl He') * nl_s[idx_s]) * sigmoid(gate_s([He' | x[idx_s] | t])) ----
-    if (do_ffn) {
+    if (iffn) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const FfnS& ws = a.w.s.ffn[s];
@@ -282,7 +329,7 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
 #pragma unroll
           for (int rt = 0; rt < RR; ++rt) g1[ft][rt] = (b + g1[ft][rt]) + splat4(t.tt[rt]) * wt;
         }
-        row_bias<8, RR>(bl, nullptr, q);
+        row_zero<8, RR>(bl);
         STAMP(14 + 10 * s);
         rgemm<4, 8, RR>(bl, hep, W(ws.Wbl), ring, W(ws.Wg1e));
         STAMP(15 + 10 * s);
@@ -315,6 +362,8 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, c
     }
     STAMP(40);
     STAMP(47);
+    unit = unext;
+    mode = mode_next;
   }
 }
 
@@ -323,12 +372,13 @@ struct PrologB {
   f32x4 he[4][RR];
 };
 
+template <int FLAGS>
 __global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, const int nunits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
+  const int c = lane & 15, q0 = lane >> 4;
   const int E = a.E;
-  const bool do_edge = a.flags & EB_EDGE, do_pos = a.flags & EB_POS;
+  constexpr bool do_edge = FLAGS & EB_EDGE, do_pos = FLAGS & EB_POS;
   // (the asm keeps the address arithmetic of a stream next to its loads: hoisted out of the persistent loop it would pin
   // hundreds of 64-bit lane addresses in registers)
   auto W = [&](const float* p) {
@@ -363,10 +413,12 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, c
   ring_prime(ring, wfirst);
   PrologB pr;
   pr.t = load_tile(a.l, a.r, a.te, ubeg * ROWS, E, c);
-  row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);
+  row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q0);
 
 #pragma unroll 1
   for (int unit = ubeg; unit < uend; ++unit) {
+    int q = q0;
+    asm volatile("" : "+v"(q));  // see edge_a2_kernel
     const RowTile t = pr.t;
     const int unext = min(unit + 1, uend - 1);
     STAMPB(46);
@@ -422,7 +474,7 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, c
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int rt = 0; rt < RR; ++rt) {
-          if (!(a.flags & EB_DELTA)) v[ft][rt] = v[ft][rt] + he[ft][rt];
+          if (!(FLAGS & EB_DELTA)) v[ft][rt] = v[ft][rt] + he[ft][rt];
           he[ft][rt] = v[ft][rt];
         }
       row_store<4, RR>(he, a.He_out, t.row, t.valid, 64, q);
@@ -433,14 +485,27 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, c
     if (do_pos) {
       mul_inplace<4>(aa, bb);
       f32x4 x[16][RR], h[16][RR], g1[2][RR];
-      row_bias<16, RR>(x, nullptr, q);
+      // x = (W_bl He'') * (W_nl a): the second product is formed pair by pair in a 2-tile scratch accumulator and multiplied
+      // into x in place, so the two (32 x 256) operands are never both live (128 registers less at the kernel's tightest point)
+      row_zero<16, RR>(x);
       STAMPB(5);
       rgemm<4, 16, RR>(x, he, W(a.w.s.Wbl), ring, W(a.w.s.Wnl));
       STAMPB(6);
-      row_bias<16, RR>(h, nullptr, q);
-      rgemm<4, 16, RR>(h, aa, W(a.w.s.Wnl), ring, W(a.w.s.Wg1h));
+      {
+        const f32x4* wnl = W(a.w.s.Wnl);
+        const f32x4* wg1h = W(a.w.s.Wg1h);
+        static_for<0, 8>([&](auto fc) {
+          constexpr int ftp = decltype(fc)::value;
+          f32x4 tmp[2][RR];
+          row_zero<2, RR>(tmp);
+          rgemm<4, 2, RR>(tmp, aa, wnl + (size_t)ftp * 4 * 2 * 64, ring, ftp < 7 ? wnl + (size_t)(ftp + 1) * 4 * 2 * 64 : wg1h);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RR; ++rt) x[2 * ftp + j][rt] = x[2 * ftp + j][rt] * tmp[j][rt];
+        });
+      }
       STAMPB(7);
-      mul_inplace<16>(x, h);
       // gate: ((b + t wt) + W_h He'') + W_a a, LN(32), ReLU, 32 -> 1
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
@@ -455,10 +520,10 @@ __global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, c
       float gate[RR], wd[RR];
       row_dot<2, RR>(g1, c_wg2, q, gate);
       row_bias<16, RR>(h, c_bi1, q);
-      row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);  // next unit's He' rows under the last GEMM
       STAMPB(9);
       rgemm<16, 16, RR>(h, x, W(a.w.s.Wi1), ring, wfirst);
       STAMPB(10);
+      row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);  // next unit's He' rows: their latency hides under the LayerNorm below
       row_layernorm<16, RR>(h, c_ig, c_ib, q);
       row_dot<16, RR>(h, c_wi2, q, wd);
       if (q == 0) {
@@ -501,20 +566,46 @@ bool mdx_use_rowowner() {
   return v;
 }
 
-void launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
+template <int FLAGS>
+static void launch_a2(const EdgeAArgs& a, hipStream_t s) {
   static bool attr = false;
   constexpr int lds = (4 * PARK_FLOATS + EA_CONST_FLOATS) * 4;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)edge_a2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)edge_a2_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_a2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus())), dim3(MDX_WG), lds, s, a, nunits);
+  const int grid = std::min((nunits + 3) / 4, mdx_num_cus());
+  constexpr bool all = FLAGS == (EA_EMB | EA_NODE | EA_FFN);
+  static const bool nosplit = getenv("MDX_NO_TAIL_SPLIT") != nullptr;
+  const EdgePlan plan = make_plan(nunits, grid * 4, all && !nosplit);
+  hipLaunchKernelGGL(edge_a2_kernel<FLAGS>, dim3(grid), dim3(MDX_WG), lds, s, a, plan);
+}
+
+void launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
+  if (a.E <= 0) return;
+  switch (a.flags) {
+    case EA_EMB | EA_NODE | EA_FFN: return launch_a2<EA_EMB | EA_NODE | EA_FFN>(a, s);  // product path
+    case EA_NODE: return launch_a2<EA_NODE>(a, s);                                    // NodeBlock.forward
+    case EA_FFN: return launch_a2<EA_FFN>(a, s);                                      // EdgeBlock.forward
+    default: mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel A: unsupported section flags");
+  }
+}
+
+template <int FLAGS>
+static void launch_b2(const EdgeBArgs& a, hipStream_t s) {
+  const int nunits = (a.E + ROWS - 1) / ROWS;
+  hipLaunchKernelGGL(edge_b2_kernel<FLAGS>, dim3(std::min((nunits + 3) / 4, mdx_num_cus())), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a,
+                     nunits);
 }
 
 void launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
-  const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_b2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus())), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a, nunits);
+  switch (a.flags) {
+    case EB_EDGE | EB_POS: return launch_b2<EB_EDGE | EB_POS>(a, s);      // MolDiff denoiser
+    case EB_EDGE: return launch_b2<EB_EDGE>(a, s);                        // bond predictor (update_pos = False)
+    case EB_EDGE | EB_DELTA: return launch_b2<EB_EDGE | EB_DELTA>(a, s);  // EdgeBlock.forward
+    case EB_POS: return launch_b2<EB_POS>(a, s);                          // PosUpdate.forward
+    default: mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel B: unsupported section flags");
+  }
 }

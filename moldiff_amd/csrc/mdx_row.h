@@ -101,15 +101,22 @@ __device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R]
   if (wnext) ring = nx;
 }
 
-// y[ft][rt] = v[16 ft + 4 q ..]   (v may be nullptr -> zeros)
+// y[ft][rt] = v[16 ft + 4 q ..]   (v: LDS or global, never null -- a null test here becomes one branch per feature tile)
 template <int FT, int R>
 __device__ __forceinline__ void row_bias(f32x4 (&y)[FT][R], const float* __restrict__ v, int q) {
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft) {
-    const f32x4 b = v ? ldg4(v + 16 * ft + 4 * q) : splat4(0.f);
+    const f32x4 b = ldg4(v + 16 * ft + 4 * q);
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) y[ft][rt] = b;
   }
+}
+template <int FT, int R>
+__device__ __forceinline__ void row_zero(f32x4 (&y)[FT][R]) {
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) y[ft][rt] = splat4(0.f);
 }
 
 // v[ft][rt] = base[idx[rt] * ld + 16 ft + 4 q ..]
