@@ -165,6 +165,42 @@ int mdx_sample_step(mdx_model_t m, mdx_graph_t g, const mdx_tables* tables, cons
                     float* pred_halfedge, const float* eps_pos, const float* u_node, const float* u_halfedge, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* ---- the WHOLE loop body of MolDiff.sample in one call (models/model.py:271-372): per-graph time tensor (:272), noise
+ * draws (transition.py:60, diffusion.py:80), denoiser forward (:274-284), Gaussian posterior (:287-288), categorical
+ * posteriors + Gumbel-max draws (:291-307) and, when `guide` is given, the bond-predictor guidance with the default
+ * 'uncertainty' objective (:309-362: predictor forward at the step's INPUT state, dU/dlogits, hand-written backward
+ * w.r.t. the positions, pos_prev += -scale * grad).  With guide->side_stream set, the guidance chain runs on that stream
+ * concurrently with the denoiser of the same step (both only read the input state); the library orders the two streams
+ * with events and `stream` ends up holding the complete result.  A C caller runs the chain with
+ *     for (i = 0; i < T; ++i) { mdx_sample_step_full(..., T - 1 - i, ..., frames i and i + 1, ...); }
+ *   step        : the diffusion step id (the reference's `step`), identical for every molecule of the batch
+ *   noise       : draw >= 0: Philox draw index (0 = prior, i + 1 = loop iteration i), the buffers receive this step's noise
+ *                 (mdx_noise with `seed`); draw < 0: the buffers already hold it (explicit noise, e.g. parity tests)
+ *   t_buf       : (n_graphs) int64 device scratch that receives `step` (the reference's time_step tensor)
+ *   node_cls / halfedge_cls : optional (N) / (Eh) uint8 outputs = the sampled class ids of `next` (a frame of the compact
+ *                 trajectory: one byte per atom / half-edge instead of a one-hot fp32 row, models/model.py:365-367)
+ *   guide       : NULL = no guidance */
+typedef struct {
+  mdx_model_t predictor;          /* BondPredictor handle (MDX_KIND_BONDPRED) */
+  float scale;                    /* sample.guidance[1] */
+  void* tape;                     /* mdx_bondpred_tape_bytes(N, E, predictor blocks), 256-byte aligned */
+  size_t tape_bytes;
+  void* ws2;                      /* a second workspace of mdx_workspace_bytes(N, E): the predictor's own */
+  size_t ws2_bytes;
+  float *logits, *glogits;        /* (Eh, Kb) scratch: predictor logits and dU/dlogits */
+  float* delta;                   /* (N,3) out: the increment added to next->pos */
+  void* side_stream;              /* NULL = run the guidance chain in line on `stream` */
+} mdx_guidance;
+typedef struct {
+  uint64_t seed;
+  int32_t draw;
+  float *eps_pos, *u_node, *u_halfedge;   /* (N,3), (N,Kn), (Eh,Ke) */
+} mdx_step_noise;
+int mdx_sample_step_full(mdx_model_t m, mdx_graph_t g, const mdx_tables* tables, int32_t step, const int64_t* batch_node,
+                         const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node,
+                         float* pred_pos, float* pred_halfedge, const mdx_step_noise* noise, int64_t* t_buf, uint8_t* node_cls,
+                         uint8_t* halfedge_cls, const mdx_guidance* guide, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- harness consumer of the path's outputs (next-row) ---------------------------------------
  * seperate_outputs (utils/sample.py:4-30) + FeaturizeMol.decode_output (utils/transforms.py:65-122) on the device:
  * arg-max class + soft-max confidence per atom / half-edge, mask-type atoms (class >= num_element) dropped and the

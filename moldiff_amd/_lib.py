@@ -19,7 +19,7 @@ EXPORTS = [
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
-    'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
+    'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
     'mdx_profile_enable', 'mdx_profile_read',
@@ -36,6 +36,16 @@ class MdxTables(ctypes.Structure):   # == struct mdx_tables
 
 class MdxState(ctypes.Structure):    # == struct mdx_state
     _fields_ = [(n, c_void_p) for n in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')]
+
+
+class MdxGuidance(ctypes.Structure):   # == struct mdx_guidance
+    _fields_ = [('predictor', c_void_p), ('scale', c_float), ('tape', c_void_p), ('tape_bytes', c_size_t), ('ws2', c_void_p),
+                ('ws2_bytes', c_size_t), ('logits', c_void_p), ('glogits', c_void_p), ('delta', c_void_p),
+                ('side_stream', c_void_p)]
+
+
+class MdxStepNoise(ctypes.Structure):  # == struct mdx_step_noise
+    _fields_ = [('seed', c_uint64), ('draw', c_int32), ('eps_pos', c_void_p), ('u_node', c_void_p), ('u_halfedge', c_void_p)]
 
 
 class MdxConfig(ctypes.Structure):
@@ -73,6 +83,9 @@ def lib():
         L.mdx_moldiff_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]
         L.mdx_sample_step.argtypes = [c_void_p, c_void_p, POINTER(MdxTables), c_void_p, c_void_p, c_void_p, POINTER(MdxState),
                                       POINTER(MdxState)] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_sample_step_full.argtypes = [c_void_p, c_void_p, POINTER(MdxTables), c_int32, c_void_p, c_void_p, POINTER(MdxState),
+                                           POINTER(MdxState), c_void_p, c_void_p, c_void_p, POINTER(MdxStepNoise), c_void_p,
+                                           c_void_p, c_void_p, POINTER(MdxGuidance), c_void_p, c_size_t, c_void_p]
         L.mdx_bondpred_forward.argtypes = [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
         L.mdx_bondpred_backward.argtypes = [c_void_p] * 4 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                                             c_void_p]

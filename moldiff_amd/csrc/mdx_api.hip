@@ -475,6 +475,7 @@ struct mdx_graph_s {
   int64_t* mol_ids = nullptr;
   const int32_t *left, *right, *int2ref, *ref2int, *row_ptr, *col_ptr, *col_eids, *node_graph, *node_local, *he_graph,
       *he_local, *half_of_int, *node_ptr, *he_ptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr;  // stream hand-offs of mdx_sample_step_full's concurrent guidance chain
 };
 
 namespace {
@@ -611,6 +612,8 @@ extern "C" int mdx_graph_destroy(mdx_graph_t g) {
   if (!g) return MDX_OK;
   if (g->dev) hipFree(g->dev);
   if (g->mol_ids) hipFree(g->mol_ids);
+  if (g->ev_in) hipEventDestroy(g->ev_in);
+  if (g->ev_done) hipEventDestroy(g->ev_done);
   delete g;
   return MDX_OK;
 }
@@ -967,10 +970,11 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
   return MDX_OK;
 }
 
-extern "C" int mdx_sample_step(mdx_model_t m, mdx_graph_t g, const mdx_tables* tb, const int64_t* t, const int64_t* batch_node,
-                               const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node,
-                               float* pred_pos, float* pred_halfedge, const float* eps_pos, const float* u_node,
-                               const float* u_halfedge, void* ws, size_t ws_bytes, void* stream) {
+static int sample_step_core(mdx_model_t m, mdx_graph_t g, const mdx_tables* tb, const int64_t* t, const int64_t* batch_node,
+                            const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node,
+                            float* pred_pos, float* pred_halfedge, const float* eps_pos, const float* u_node,
+                            const float* u_halfedge, uint8_t* node_cls, uint8_t* halfedge_cls, void* ws, size_t ws_bytes,
+                            void* stream) {
   if (!tb || !cur || !next) return fail(MDX_ERR_ARG, "null tables / state");
   if (!m || !g) return fail(MDX_ERR_ARG, "null handle");
   const int N = (int)g->N, Eh = (int)g->Eh;
@@ -986,14 +990,85 @@ extern "C" int mdx_sample_step(mdx_model_t m, mdx_graph_t g, const mdx_tables* t
   launch_pos_posterior(tb->pos_coef_x0, tb->pos_coef_xt, tb->pos_std, cur->pos, pred_pos, eps_pos, t, batch_node, N, next->pos, s);
   launch_cat_posterior(tb->node_q_mats, tb->node_qT_onestep, cf.num_node_types, cf.num_timesteps, pred_node, 1, cur->log_node, t,
                        batch_node, N, next->log_node, s);
-  launch_gumbel_argmax(next->log_node, u_node, cf.num_node_types, N, nullptr, next->h_node, s);
+  launch_gumbel_argmax(next->log_node, u_node, cf.num_node_types, N, nullptr, next->h_node, s, node_cls);
   if (Eh > 0) {
     launch_cat_posterior(tb->edge_q_mats, tb->edge_qT_onestep, cf.num_edge_types, cf.num_timesteps, pred_halfedge, 1,
                          cur->log_halfedge, t, batch_halfedge, Eh, next->log_halfedge, s);
-    launch_gumbel_argmax(next->log_halfedge, u_halfedge, cf.num_edge_types, Eh, nullptr, next->h_halfedge, s);
+    launch_gumbel_argmax(next->log_halfedge, u_halfedge, cf.num_edge_types, Eh, nullptr, next->h_halfedge, s, halfedge_cls);
   }
   HIPCHK(hipGetLastError());
   return MDX_OK;
+}
+
+extern "C" int mdx_sample_step(mdx_model_t m, mdx_graph_t g, const mdx_tables* tb, const int64_t* t, const int64_t* batch_node,
+                               const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node,
+                               float* pred_pos, float* pred_halfedge, const float* eps_pos, const float* u_node,
+                               const float* u_halfedge, void* ws, size_t ws_bytes, void* stream) {
+  return sample_step_core(m, g, tb, t, batch_node, batch_halfedge, cur, next, pred_node, pred_pos, pred_halfedge, eps_pos, u_node,
+                          u_halfedge, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int mdx_sample_step_full(mdx_model_t m, mdx_graph_t g, const mdx_tables* tb, int32_t step, const int64_t* batch_node,
+                                    const int64_t* batch_halfedge, const mdx_state* cur, const mdx_state* next, float* pred_node,
+                                    float* pred_pos, float* pred_halfedge, const mdx_step_noise* noise, int64_t* t_buf,
+                                    uint8_t* node_cls, uint8_t* halfedge_cls, const mdx_guidance* gd, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  if (!m || !g || !tb || !cur || !next || !noise || !t_buf) return fail(MDX_ERR_ARG, "null argument");
+  if (m->cfg.kind != MDX_KIND_MOLDIFF) return fail(MDX_ERR_STATE, "not a MolDiff model handle");
+  if (step < 0 || step >= m->cfg.num_timesteps) return fail(MDX_ERR_ARG, "step %d outside [0, %d)", step, m->cfg.num_timesteps);
+  if (g->N == 0) return MDX_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const mdx_config& cf = m->cfg;
+  launch_fill_i64(t_buf, step, (int)g->B, s);
+  if (noise->draw >= 0) {
+    int rc = mdx_noise(g, noise->seed, noise->draw, cf.num_node_types, cf.num_edge_types, noise->eps_pos, noise->u_node,
+                       noise->u_halfedge, stream);
+    if (rc != MDX_OK) return rc;
+  }
+  hipStream_t gs = s;  // the stream the guidance chain runs on
+  if (gd) {
+    if (!gd->predictor || !gd->tape || !gd->logits || !gd->glogits || !gd->delta) return fail(MDX_ERR_ARG, "incomplete mdx_guidance");
+    if (gd->side_stream) {
+      if (!gd->ws2) return fail(MDX_ERR_ARG, "a concurrent guidance chain needs its own workspace (ws2)");
+      if (!g->ev_in) {
+        HIPCHK(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
+      }
+      gs = (hipStream_t)gd->side_stream;
+      // everything the chain reads (state, t_buf) and the previous step's use of `delta` is ordered before this point
+      HIPCHK(hipEventRecord(g->ev_in, s));
+      HIPCHK(hipStreamWaitEvent(gs, g->ev_in, 0));
+    }
+    void* gws = gd->side_stream ? gd->ws2 : ws;
+    const size_t gwb = gd->side_stream ? gd->ws2_bytes : ws_bytes;
+    auto chain = [&]() -> int {
+      int rc = mdx_bondpred_forward(gd->predictor, g, cur->h_node, cur->pos, t_buf, gd->logits, gws, gwb, gd->tape, gd->tape_bytes, gs);
+      if (rc != MDX_OK) return rc;
+      const int Kb = gd->predictor->cfg.num_edge_types;
+      launch_uncertainty_grad(gd->logits, Kb, (int)g->Eh, gd->glogits, gs);
+      return mdx_bondpred_backward(gd->predictor, g, cur->pos, gd->glogits, -gd->scale, gd->delta, gws, gwb, gd->tape,
+                                   gd->tape_bytes, gs);
+    };
+    if (gd->side_stream) {  // enqueue the chain first: it then runs under the denoiser launched below
+      int rc = chain();
+      if (rc != MDX_OK) return rc;
+      HIPCHK(hipEventRecord(g->ev_done, gs));
+    }
+    int rc = sample_step_core(m, g, tb, t_buf, batch_node, batch_halfedge, cur, next, pred_node, pred_pos, pred_halfedge,
+                              noise->eps_pos, noise->u_node, noise->u_halfedge, node_cls, halfedge_cls, ws, ws_bytes, stream);
+    if (rc != MDX_OK) return rc;
+    if (gd->side_stream) {
+      HIPCHK(hipStreamWaitEvent(s, g->ev_done, 0));
+    } else {  // in line: the predictor reuses the denoiser's workspace after it
+      rc = chain();
+      if (rc != MDX_OK) return rc;
+    }
+    launch_add_inplace(next->pos, gd->delta, 3 * (int)g->N, s);
+    HIPCHK(hipGetLastError());
+    return MDX_OK;
+  }
+  return sample_step_core(m, g, tb, t_buf, batch_node, batch_halfedge, cur, next, pred_node, pred_pos, pred_halfedge, noise->eps_pos,
+                          noise->u_node, noise->u_halfedge, node_cls, halfedge_cls, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -279,7 +279,9 @@ void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, co
                           const float* log_vt, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
 void launch_uncertainty_grad(const float* logits, int K, int n, float* glogits, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, int n, hipStream_t s);
-void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s);
+void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s,
+                          uint8_t* cls8 = nullptr);
+void launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t s);
 void launch_philox_noise(uint64_t seed, int step, const int* node_graph, const int* node_local, const int* he_graph,
                          const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,
                          float* u_node, float* u_half, hipStream_t s);

@@ -83,7 +83,7 @@ __global__ void cat_posterior_kernel(const float* __restrict__ qmats, const floa
 }
 
 __global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const float* __restrict__ u, int K, int n,
-                                     int64_t* __restrict__ cls, float* __restrict__ onehot) {
+                                     int64_t* __restrict__ cls, float* __restrict__ onehot, uint8_t* __restrict__ cls8) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int best = 0;
@@ -97,6 +97,7 @@ __global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const flo
     }
   }
   if (cls) cls[i] = best;
+  if (cls8) cls8[i] = (uint8_t)best;  // compact trajectory frame (one byte per atom / half-edge)
   if (onehot)
     for (int k = 0; k < K; ++k) onehot[(size_t)i * K + k] = (k == best) ? 1.f : 0.f;
 }
@@ -213,9 +214,21 @@ void launch_add_inplace(float* dst, const float* src, int n, hipStream_t s) {
   hipLaunchKernelGGL(add_inplace_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
 }
 
-void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s) {
+void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s,
+                          uint8_t* cls8) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(gumbel_argmax_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, u, K, n, cls, onehot);
+  hipLaunchKernelGGL(gumbel_argmax_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, u, K, n, cls, onehot, cls8);
+}
+
+namespace {
+__global__ void fill_i64_kernel(int64_t* __restrict__ p, int64_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+}  // namespace
+void launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(fill_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
 }
 
 void launch_philox_noise(uint64_t seed, int draw, const int* node_graph, const int* node_local, const int* he_graph,

@@ -214,8 +214,13 @@ class MolDiff(Module):
 
 
 class _Sampler:
-    """One packed batch moving through models/model.py:244-378.  All buffers are allocated once in __init__;
-    a step is: noise draw -> denoiser forward -> 3 posteriors -> 2 Gumbel-max draws, every piece a HIP kernel."""
+    """One packed batch moving through models/model.py:244-378.  All buffers are allocated once in __init__; a step is ONE
+    library call (``mdx_sample_step_full``: time tensor, noise draw, denoiser forward, 3 posteriors, 2 Gumbel-max draws and,
+    with the default 'uncertainty' objective, the bond-predictor guidance on a concurrent stream).
+
+    State layout: the one-hot inputs of the denoiser ping-pong between two frames; the trajectory the reference returns is
+    kept compact -- class ids as one byte per atom / half-edge and frame, positions fp32 -- and expanded lazily at the API
+    edge (``traj.LazyOneHot``): 0.16 GB instead of 2.1 GB at 256 molecules."""
 
     def __init__(self, model, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
                  bond_predictor, guidance):
@@ -246,132 +251,104 @@ class _Sampler:
         N, Eh, Kn, Ke, T = self.N, self.Eh, self.Kn, self.Ke, self.T
         self.eps, self.u_n, self.u_h = torch.empty(N, 3, **f32), torch.empty(N, Kn, **f32), torch.empty(Eh, Ke, **f32)
         nT = T + 1 if return_traj else 2
-        self.node_traj = torch.zeros(nT, N, Kn, **f32)
+        self.h_node = torch.zeros(2, N, Kn, **f32)        # one-hot state, frames ping-pong
+        self.h_half = torch.zeros(2, Eh, Ke, **f32)
         self.pos_traj = torch.zeros(nT, N, 3, **f32)
-        self.halfedge_traj = torch.zeros(nT, Eh, Ke, **f32)
-        self.t = torch.empty(n_graphs, dtype=torch.int64, device=dev)
+        self.node_ids = torch.zeros(nT, N, dtype=torch.uint8, device=dev)     # compact trajectory
+        self.half_ids = torch.zeros(nT, Eh, dtype=torch.uint8, device=dev)
+        self.t = torch.empty(max(n_graphs, 1), dtype=torch.int64, device=dev)
         self.bn, self.bh = _lib.i64c(batch_node), _lib.i64c(batch_halfedge)
         self.preds = (torch.empty(N, Kn, **f32), torch.empty(N, 3, **f32), torch.empty(Eh, Ke, **f32))
         self.log_node = [torch.empty(N, Kn, **f32), torch.empty(N, Kn, **f32)]
         self.log_half = [torch.empty(Eh, Ke, **f32), torch.empty(Eh, Ke, **f32)]
+        self.gd = None
         if self.guidance is not None:
             Kb = self.bp.num_edge_types
             self.bp_logits, self.bp_glogits = torch.empty(Eh, Kb, **f32), torch.empty(Eh, Kb, **f32)
             self.delta = torch.empty(N, 3, **f32)
             self.edge_index = edge_index
             self.batch_edge = torch.cat([self.bh, self.bh], dim=0)
-            # the default objective runs on a side stream with its own workspace, concurrently with the denoiser's forward
-            # of the same step (both only read the step's input state); kernels of the two chains fill each other's tails
-            self.side = torch.cuda.Stream(device=dev) if self.guidance[0] == 'uncertainty' else None
-            if self.side is not None:
+            if self.guidance[0] == 'uncertainty':
+                # the default objective is part of the library call; it runs on a side stream with its own workspace,
+                # concurrently with the denoiser's forward of the same step (both only read the step's input state)
+                self.side = torch.cuda.Stream(device=dev)
                 nbytes = _lib.lib().mdx_workspace_bytes(self.N, 2 * self.Eh)
                 self._ws2 = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-                self._ev_in, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
+                off = (-self._ws2.data_ptr()) % 256
+                _, tptr, tbytes = self.g.tape(dev, self.bp.encoder.num_blocks)
+                self.gd = _lib.MdxGuidance(self.bp_eng.h, self.guidance[1], tptr, tbytes.value,
+                                           ctypes.c_void_p(self._ws2.data_ptr() + off), self._ws2.numel() - off,
+                                           _lib.ptr(self.bp_logits), _lib.ptr(self.bp_glogits), _lib.ptr(self.delta),
+                                           ctypes.c_void_p(self.side.cuda_stream))
         pt, ntr, etr = m.pos_transition, m.node_transition, m.edge_transition
         self.tables = _lib.MdxTables(*(_lib.ptr(x) for x in (pt.coef_x0, pt.coef_xt, pt.std, ntr.q_mats, ntr.transpopse_q_onestep_mats,
                                                              etr.q_mats, etr.transpopse_q_onestep_mats)))
-        self.cur = 0  # frame holding the current state
+        self.cur, self.lcur, self.pcur = 0, 0, 0  # one-hot frame / log-prob frame / position (and id) frame of the current state
 
-    def _frame(self, j):
+    def _pframe(self, j):
         return j if self.return_traj else j % 2
-
-    def _draw(self, i):
-        if self.noise is not None:
-            e, a, b = self.noise(i)
-            self.eps.copy_(e); self.u_n.copy_(a); self.u_h.copy_(b)
-        else:
-            _lib.check(_lib.lib().mdx_noise(self.g.h, ctypes.c_uint64(self.seed), i, self.Kn, self.Ke, _lib.ptr(self.eps),
-                                            _lib.ptr(self.u_n), _lib.ptr(self.u_h), _lib.stream()))
 
     @torch.no_grad()
     def init(self):
         """Prior draw (models/model.py:244-263): classes ~ init_prob by Gumbel-max, positions ~ N(0, I)."""
         m, L, dev = self.m, _lib.lib(), self.dev
-        self._draw(0)
-        for tr, n, K, u, traj, logs in ((m.node_transition, self.N, self.Kn, self.u_n, self.node_traj, self.log_node),
-                                        (m.edge_transition, self.Eh, self.Ke, self.u_h, self.halfedge_traj, self.log_half)):
+        if self.noise is not None:
+            e, a, b = self.noise(0)
+            self.eps.copy_(e); self.u_n.copy_(a); self.u_h.copy_(b)
+        else:
+            _lib.check(L.mdx_noise(self.g.h, ctypes.c_uint64(self.seed), 0, self.Kn, self.Ke, _lib.ptr(self.eps),
+                                   _lib.ptr(self.u_n), _lib.ptr(self.u_h), _lib.stream()))
+        for tr, n, K, u, oh, ids, logs in ((m.node_transition, self.N, self.Kn, self.u_n, self.h_node, self.node_ids, self.log_node),
+                                           (m.edge_transition, self.Eh, self.Ke, self.u_h, self.h_half, self.half_ids, self.log_half)):
             logit = torch.log(torch.from_numpy(tr.init_prob).float() + 1e-30).clamp_min(-32.).to(dev)
             logit = logit.unsqueeze(0).repeat(n, 1).contiguous()
-            _lib.check(L.mdx_gumbel_argmax(_lib.ptr(logit), _lib.ptr(u), K, n, None, _lib.ptr(traj[0]), _lib.stream()))
-            torch.log(traj[0].clamp(min=1e-30), out=logs[0])
+            cls = torch.empty(n, dtype=torch.int64, device=dev)
+            _lib.check(L.mdx_gumbel_argmax(_lib.ptr(logit), _lib.ptr(u), K, n, _lib.ptr(cls), _lib.ptr(oh[0]), _lib.stream()))
+            ids[0].copy_(cls)
+            torch.log(oh[0].clamp(min=1e-30), out=logs[0])
         self.pos_traj[0].copy_(self.eps)
-        self.cur, self.lcur = 0, 0
+        self.cur, self.lcur, self.pcur = 0, 0, 0
 
     @torch.no_grad()
     def step(self, i):
-        """Loop iteration i (diffusion step T-1-i), models/model.py:272-372."""
-        m, L, T, N, Eh, Kn, Ke = self.m, _lib.lib(), self.T, self.N, self.Eh, self.Kn, self.Ke
-        step = T - 1 - i
-        self.t.fill_(step)
-        self._draw(i + 1)
-        c, n = self._frame(i), self._frame(i + 1)
-        h_node, pos, h_half = self.node_traj[c], self.pos_traj[c], self.halfedge_traj[c]
+        """Loop iteration i (diffusion step T-1-i), models/model.py:272-372: one library call."""
+        L, T = _lib.lib(), self.T
+        draw = i + 1
+        if self.noise is not None:
+            e, a, b = self.noise(draw)
+            self.eps.copy_(e); self.u_n.copy_(a); self.u_h.copy_(b)
+            draw = -1
+        c, n = self.cur, 1 - self.cur
         lc, ln = self.lcur, 1 - self.lcur
+        pc, pn = self.pcur, self._pframe(i + 1)
         P = _lib.ptr
-        cur = _lib.MdxState(P(h_node), P(pos), P(h_half), P(self.log_node[lc]), P(self.log_half[lc]))
-        nxt = _lib.MdxState(P(self.node_traj[n]), P(self.pos_traj[n]), P(self.halfedge_traj[n]), P(self.log_node[ln]),
-                            P(self.log_half[ln]))
-        overlapped = self.guidance is not None and self.side is not None
-        if overlapped:
-            self._launch_guidance_on_side_stream(h_node, pos)
+        cur = _lib.MdxState(P(self.h_node[c]), P(self.pos_traj[pc]), P(self.h_half[c]), P(self.log_node[lc]), P(self.log_half[lc]))
+        nxt = _lib.MdxState(P(self.h_node[n]), P(self.pos_traj[pn]), P(self.h_half[n]), P(self.log_node[ln]), P(self.log_half[ln]))
+        nz = _lib.MdxStepNoise(self.seed, draw, P(self.eps), P(self.u_n), P(self.u_h))
         ws, nb = self.g.workspace(self.dev)
-        _lib.check(L.mdx_sample_step(self.eng.h, self.g.h, ctypes.byref(self.tables), P(self.t), P(self.bn), P(self.bh),
-                                     ctypes.byref(cur), ctypes.byref(nxt), P(self.preds[0]), P(self.preds[1]), P(self.preds[2]),
-                                     P(self.eps), P(self.u_n), P(self.u_h), ws, nb, _lib.stream()))
-        if overlapped:
-            torch.cuda.current_stream().wait_event(self._ev_done)
-            _lib.check(L.mdx_add_inplace(_lib.ptr(self.pos_traj[n]), _lib.ptr(self.delta), 3 * self.N, _lib.stream()))
-        elif self.guidance is not None:
-            self._guide(h_node, pos, self.pos_traj[n], self.halfedge_traj[n], self.log_half[ln])
-        self.cur, self.lcur = n, ln
-
-    def _launch_guidance_on_side_stream(self, h_node, pos):
-        """'uncertainty' guidance of this step (predictor forward with tape -> dU/dlogits -> hand-written backward -> delta)
-        enqueued on the side stream; the main stream adds `delta` after its own posteriors."""
-        L, g = _lib.lib(), self.g
-        main = torch.cuda.current_stream()
-        self._ev_in.record(main)               # state, t and (last step's) delta consumption are ordered before this point
-        self.side.wait_event(self._ev_in)
-        off = (-self._ws2.data_ptr()) % 256
-        ws, nb = ctypes.c_void_p(self._ws2.data_ptr() + off), ctypes.c_size_t(self._ws2.numel() - off)
-        _, tptr, tbytes = g.tape(self.dev, self.bp.encoder.num_blocks)
-        with torch.cuda.stream(self.side):
-            st = _lib.stream()
-            _lib.check(L.mdx_bondpred_forward(self.bp_eng.h, g.h, _lib.ptr(h_node), _lib.ptr(pos), _lib.ptr(self.t),
-                                              _lib.ptr(self.bp_logits), ws, nb, tptr, tbytes, st))
-            _lib.check(L.mdx_guidance_uncertainty_grad(_lib.ptr(self.bp_logits), self.bp.num_edge_types, self.Eh,
-                                                       _lib.ptr(self.bp_glogits), st))
-            _lib.check(L.mdx_bondpred_backward(self.bp_eng.h, g.h, _lib.ptr(pos), _lib.ptr(self.bp_glogits), -self.guidance[1],
-                                               _lib.ptr(self.delta), ws, nb, tptr, tbytes, st))
-            self._ev_done.record(self.side)
+        _lib.check(L.mdx_sample_step_full(self.eng.h, self.g.h, ctypes.byref(self.tables), T - 1 - i, P(self.bn), P(self.bh),
+                                          ctypes.byref(cur), ctypes.byref(nxt), P(self.preds[0]), P(self.preds[1]), P(self.preds[2]),
+                                          ctypes.byref(nz), P(self.t), P(self.node_ids[pn]), P(self.half_ids[pn]),
+                                          ctypes.byref(self.gd) if self.gd is not None else None, ws, nb, _lib.stream()))
+        if self.guidance is not None and self.gd is None:  # the seven objectives that are torch expressions on the logits
+            self._guide(self.h_node[c], self.pos_traj[pc], self.pos_traj[pn], self.h_half[n], self.log_half[ln])
+        self.cur, self.lcur, self.pcur = n, ln, pn
 
     def _guide(self, h_node, pos, pos_prev, h_half_prev, log_half):
-        """models/model.py:309-362: pos_prev += delta, delta = -+scale * d f(bond logits) / d pos evaluated at the
-        step's INPUT state (h_node_pert, pos_pert).  The default 'uncertainty' objective runs entirely in HIP
-        (predictor forward with tape -> dU/dlogits -> hand-written backward); the other seven objectives are the
-        reference's torch expressions on the (Eh,5) logits, differentiated through the same HIP backward."""
-        L, g = _lib.lib(), self.g
+        """models/model.py:309-362 for the non-default objectives: pos_prev += delta, delta = -+scale * d f(bond logits) / d pos
+        evaluated at the step's INPUT state; the reference's torch expression on the (Eh,5) logits, differentiated through
+        the HIP backward of the predictor.  (The default 'uncertainty' objective lives inside mdx_sample_step_full.)"""
+        g = self.g
         gui_type, scale = self.guidance
-        if gui_type == 'uncertainty':
-            dev = self.dev
-            ws, nb = g.workspace(dev)
-            _, tptr, tbytes = g.tape(dev, self.bp.encoder.num_blocks)
-            st = _lib.stream()
-            _lib.check(L.mdx_bondpred_forward(self.bp_eng.h, g.h, _lib.ptr(h_node), _lib.ptr(pos), _lib.ptr(self.t),
-                                              _lib.ptr(self.bp_logits), ws, nb, tptr, tbytes, st))
-            _lib.check(L.mdx_guidance_uncertainty_grad(_lib.ptr(self.bp_logits), self.bp.num_edge_types, self.Eh,
-                                                       _lib.ptr(self.bp_glogits), st))
-            _lib.check(L.mdx_bondpred_backward(self.bp_eng.h, g.h, _lib.ptr(pos), _lib.ptr(self.bp_glogits), -scale,
-                                               _lib.ptr(self.delta), ws, nb, tptr, tbytes, st))
-            _lib.check(L.mdx_add_inplace(_lib.ptr(pos_prev), _lib.ptr(self.delta), 3 * self.N, st))
-            return
         with torch.enable_grad():
             pos_in = pos.detach().clone().requires_grad_(True)
-            pred = self.bp(h_node.detach(), pos_in, self.bn, self.edge_index, self.batch_edge, self.t, _graph=g)
+            pred = self.bp(h_node.detach(), pos_in, self.bn, self.edge_index, self.batch_edge, self.t[:self.n_graphs], _graph=g)
             sign = -1.0
             if gui_type == 'entropy':
                 p = torch.softmax(pred, dim=-1)
                 obj = (-torch.sum(p * torch.log(p + 1e-12), dim=-1)).log().sum()
+            elif gui_type == 'uncertainty':
+                obj = torch.sigmoid(-torch.logsumexp(pred, dim=-1)).log().sum()
             elif gui_type == 'uncertainty_bond':
                 p = torch.softmax(pred, dim=-1)
                 u = torch.sigmoid(-torch.logsumexp(pred, dim=-1)).log()
@@ -394,21 +371,23 @@ class _Sampler:
         pos_prev.add_(delta)
 
     def state(self):
-        c = self.cur
-        return {'h_node': self.node_traj[c], 'pos': self.pos_traj[c], 'h_halfedge': self.halfedge_traj[c],
+        return {'h_node': self.h_node[self.cur], 'pos': self.pos_traj[self.pcur], 'h_halfedge': self.h_half[self.cur],
                 'log_node': self.log_node[self.lcur], 'log_halfedge': self.log_half[self.lcur]}
 
     def set_state(self, h_node, pos, h_halfedge, log_node, log_halfedge, frame=0):
-        """Teacher-forcing hook for the parity tests."""
-        frame = self._frame(frame)
-        self.node_traj[frame].copy_(h_node); self.pos_traj[frame].copy_(pos); self.halfedge_traj[frame].copy_(h_halfedge)
+        """Teacher-forcing hook for the parity tests: the state becomes trajectory frame `frame`."""
+        pf = self._pframe(frame)
+        self.h_node[0].copy_(h_node); self.pos_traj[pf].copy_(pos); self.h_half[0].copy_(h_halfedge)
+        self.node_ids[pf].copy_(h_node.argmax(-1)); self.half_ids[pf].copy_(h_halfedge.argmax(-1))
         self.log_node[0].copy_(log_node); self.log_half[0].copy_(log_halfedge)
-        self.cur, self.lcur = frame, 0
+        self.cur, self.lcur, self.pcur = 0, 0, pf
 
     def result(self):
+        from .traj import LazyOneHot
         if self.return_traj:
-            traj = [self.node_traj, self.pos_traj, self.halfedge_traj]
+            node_ids, pos, half_ids = self.node_ids, self.pos_traj, self.half_ids
         else:
-            c = self.cur
-            traj = [self.node_traj[c:c + 1], self.pos_traj[c:c + 1], self.halfedge_traj[c:c + 1]]
+            p = self.pcur
+            node_ids, pos, half_ids = self.node_ids[p:p + 1], self.pos_traj[p:p + 1], self.half_ids[p:p + 1]
+        traj = [LazyOneHot(node_ids, self.Kn), pos, LazyOneHot(half_ids, self.Ke)]
         return {'pred': [self.preds[0], self.preds[1], self.preds[2]], 'traj': traj}

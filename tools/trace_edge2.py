@@ -27,6 +27,10 @@ PH_A = [('tile load + He + smear', 0, 1, 0), ('emb GEMM 80->64', 1, 2, 2 * 80 * 
         ('sigmoid + park + bias', 6, 7, 0), ('en GEMM1 64->256', 7, 8, 2 * 64 * 256), ('LN + bias', 8, 9, 0),
         ('en GEMM2 256->256', 9, 10, 2 * 256 * 256), ('H[r] gather * + bias', 10, 11, 0),
         ('msg GEMM 256->256', 11, 12, 2 * 256 * 256), ('unpark * + M store', 12, 13, 0)]
+PH_B = [('gathers SL,SR,nfl,nfr,Lf,Rf + sum', 0, 1, 0), ('self_ffn GEMM 64->64', 1, 2, 2 * 64 * 64), ('LN64 + bias', 2, 3, 0),
+        ('out GEMM 64->64', 3, 4, 2 * 64 * 64), ('He store + next tile + a=Lf*Rf', 4, 5, 0), ('Wbl GEMM 64->256', 5, 6, 2 * 64 * 256),
+        ('Wnl GEMM 64->256 pairwise *', 6, 7, 2 * 64 * 256), ('gate GEMMs 2x(64->32)', 7, 8, 2 * 2 * 64 * 32),
+        ('gate LN32 + dot + bias', 8, 9, 0), ('inter GEMM 256->256', 9, 10, 2 * 256 * 256), ('LN256 + dot + force + store', 10, 40, 0)]
 for s in (0, 1):
     o = 10 * s
     PH_A += [(f'ffn{s}: gathers', 13 + 9 * s if s == 0 else 22, 14 + o, 0), (f'ffn{s}: bl GEMM 64->128', 14 + o, 15 + o, 2 * 64 * 128),
@@ -38,7 +42,7 @@ for s in (0, 1):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'a'
-    phases, last = PH_A, 40
+    phases, last = (PH_A, 40) if which == 'a' else (PH_B, 40)
     dev = torch.device('cuda:0')
     model, ph, sizes = bench.build_workload(256, 0, dev)
     model = model.to(dev)
