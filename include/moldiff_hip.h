@@ -93,6 +93,13 @@ int mdx_node_block(mdx_model_t m, mdx_graph_t g, int32_t i, const float* x, cons
 /* EdgeBlock.forward, graph.py:268-295: out (E,64) reference order (no residual). */
 int mdx_edge_block(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_bond, const float* h_node,
                    const float* bond_time, float* out, void* ws, size_t ws_bytes, void* stream);
+/* BondFFN.forward of an EdgeBlock (models/graph.py:133-141) on its own:
+ *   out[e] = inter_module((W_bl bond[e]) * (W_nl node[e])) * sigmoid(gate([bond[e] | node[e] | time[e]]))
+ * side 0 = edge_blocks[i].bond_ffn_left, 1 = bond_ffn_right.  node_feat holds one ALREADY GATHERED row per edge (the
+ * reference calls it with h_node[left] / h_node[right]), so `g` must be the identity graph of E nodes and E edges
+ * (edge e = (e, e)); bond_feat (E,64), node_feat (E,256), time (E), out (E,64). */
+int mdx_bond_ffn(mdx_model_t m, mdx_graph_t g, int32_t i, int32_t side, const float* bond_feat, const float* node_feat,
+                 const float* time, float* out, void* ws, size_t ws_bytes, void* stream);
 /* PosUpdate.forward, graph.py:384-396: rel (E,3), dist (E) reference order; out (N,3) = delta_pos. */
 int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_node, const float* h_edge,
                    const float* rel, const float* dist, const float* edge_time, float* out, void* ws,

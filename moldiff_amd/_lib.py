@@ -18,7 +18,7 @@ EXPORTS = [
     'mdx_last_error', 'mdx_version', 'mdx_device_count',
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
-    'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_pos_update', 'mdx_segment_sum',
+    'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_bond_ffn', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
@@ -78,6 +78,7 @@ def lib():
         L.mdx_net_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]
         L.mdx_node_block.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 4 + [c_void_p, c_size_t, c_void_p]
         L.mdx_edge_block.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 4 + [c_void_p, c_size_t, c_void_p]
+        L.mdx_bond_ffn.argtypes = [c_void_p, c_void_p, c_int32, c_int32] + [c_void_p] * 4 + [c_void_p, c_size_t, c_void_p]
         L.mdx_pos_update.argtypes = [c_void_p, c_void_p, c_int32] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]
         L.mdx_segment_sum.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]
         L.mdx_moldiff_forward.argtypes = [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p]

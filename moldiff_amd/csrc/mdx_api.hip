@@ -884,6 +884,26 @@ extern "C" int mdx_edge_block(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   return MDX_OK;
 }
 
+extern "C" int mdx_bond_ffn(mdx_model_t m, mdx_graph_t g, int32_t i, int32_t side, const float* bond_feat, const float* node_feat,
+                            const float* time, float* out, void* ws, size_t ws_bytes, void* stream) {
+  CHECK_READY(m, g, ws, ws_bytes);
+  if (i < 0 || i >= m->cfg.num_blocks || side < 0 || side > 1 || !bond_feat || !node_feat || !time || !out)
+    return fail(MDX_ERR_ARG, "bad argument");
+  if (g->N != g->E) return fail(MDX_ERR_ARG, "mdx_bond_ffn expects the identity graph (edge e joins node e to itself)");
+  hipStream_t s = (hipStream_t)stream;
+  Ws w;
+  ws_layout(g->N, g->E, (char*)ws, &w);
+  // every edge is its own node: the hoisted node_linear / gate node parts become per-edge rows of the node table
+  HIPCHK(hipMemcpyAsync(w.Hn, node_feat, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
+  gather_rows(bond_feat, g->int2ref, w.HeA, g->E, 64, s);
+  gather_rows(time, g->int2ref, w.te, g->E, 1, s);
+  launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
+  launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s);
+  gather_rows(side ? w.FR : w.FL, g->ref2int, out, g->E, 64, s);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
 extern "C" int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_node, const float* h_edge,
                               const float* rel, const float* dist, const float* edge_time, float* out, void* ws,
                               size_t ws_bytes, void* stream) {

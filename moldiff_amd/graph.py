@@ -75,8 +75,26 @@ class BondFFN(_Block):
         self.inter_module = MLP(inter_dim, out_dim, inter_dim)
         self.gate = MLP(bond_dim + node_dim + 1, out_dim, 32)  # +1: time
 
+    _side = -1  # 0 / 1 = bond_ffn_left / bond_ffn_right of an EdgeBlock (set by the owning NodeEdgeNet)
+
     def forward(self, bond_feat_input, node_feat_input, time):
-        no_device_math('BondFFN')
+        """bond (E,He), node (E,H) -- one gathered node row per edge --, time (E,1) -> (E,He)  (models/graph.py:133-141)."""
+        if self._side < 0:
+            raise NotImplementedError('standalone BondFFN.forward is built for the EdgeBlock FFNs (bond_ffn_left / _right); '
+                                      "PosUpdate.edge_lin only runs fused inside PosUpdate.forward")
+        net = self._net()
+        _lib._need_gpu(bond_feat_input, node_feat_input, time)
+        eng = net._engine()
+        E, dev = bond_feat_input.shape[0], bond_feat_input.device
+        ident = torch.arange(E, dtype=torch.int64).unsqueeze(0).repeat(2, 1)
+        g = _lib.Graph(ident, torch.zeros(E, dtype=torch.int64), 1)
+        bond, node, tt = _lib.f32c(bond_feat_input), _lib.f32c(node_feat_input), _lib.f32c(time).view(-1)
+        out = torch.empty(E, bond.shape[1], dtype=torch.float32, device=dev)
+        ws, nb = g.workspace(dev)
+        _lib.check(_lib.lib().mdx_bond_ffn(eng.h, g.h, self._index, self._side, _lib.ptr(bond), _lib.ptr(node), _lib.ptr(tt),
+                                           _lib.ptr(out), ws, nb, _lib.stream()))
+        torch.cuda.current_stream().synchronize()  # `g` and its workspace die with this frame
+        return out
 
 
 class EdgeBlock(_Block):
@@ -166,6 +184,9 @@ class NodeEdgeNet(Module):
         for lst in (self.node_blocks_with_edge, self.edge_blocks, self.pos_blocks):
             for i, blk in enumerate(lst):
                 blk._owner, blk._index = ref, i
+        for i, blk in enumerate(self.edge_blocks):
+            for side, ffn in enumerate((blk.bond_ffn_left, blk.bond_ffn_right)):
+                ffn._owner, ffn._index, ffn._side = ref, i, side
         self._eng = None
         self._eng_sig = None
 

@@ -231,8 +231,10 @@ def moldiff_forward(P, cfg, h_node_pert, pos_pert, batch_node, h_edge_pert, edge
     """cfg: dict(num_timesteps, num_blocks, cutoff).  model.py:204-234."""
     T = cfg['num_timesteps']
     toff, tco = P['time_emb.0.offset'], P['time_emb.0.coeff']
-    tn = t.index_select(0, batch_node)
-    te = t.index_select(0, batch_edge)
+    # (cast to the parameter dtype: a no-op for the fp32 restatement -- long -> float32 is what the clamp / division below
+    # promote to anyway -- and what lets tests evaluate the same function in float64 as the arbiter of fp32 differences)
+    tn = t.index_select(0, batch_node).to(toff.dtype)
+    te = t.index_select(0, batch_edge).to(toff.dtype)
     hn = torch.cat([F.linear(h_node_pert, P['node_embedder.weight']), smear(tn, toff, tco, 0.0, T)], -1)
     he = torch.cat([F.linear(h_edge_pert, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
     hn, pos, he = node_edge_net(P, 'denoiser', hn, pos_pert, he, edge_index,
@@ -249,8 +251,8 @@ def bondpred_forward(P, cfg, h_node, pos, batch_node, edge_index, batch_edge, t)
     T = cfg['num_timesteps']
     toff, tco = P['time_emb.offset'], P['time_emb.coeff']
     he = torch.cat([h_node[edge_index[0]], h_node[edge_index[1]]], -1)
-    tn = t.index_select(0, batch_node)
-    te = t.index_select(0, batch_edge)
+    tn = t.index_select(0, batch_node).to(toff.dtype)
+    te = t.index_select(0, batch_edge).to(toff.dtype)
     hn = torch.cat([F.linear(h_node, P['node_embedder.weight']), smear(tn, toff, tco, 0.0, T)], -1)
     he = torch.cat([F.linear(he, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
     hn, _, he = node_edge_net(P, 'encoder', hn, pos, he, edge_index, tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,

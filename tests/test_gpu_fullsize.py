@@ -1,11 +1,14 @@
 """Parity at BASELINE.json's full size (configs[1]/[2]: 256 molecules per GPU, N ~ 6.3k atoms, E ~ 155k directed edges).
 
 The golden files hold small cases only, so at full size the HIP path is checked (a) directly against the CPU oracle on
-ONE teacher-forced denoising step (the oracle needs ~10-20 s for it), and (b) through properties that do not depend on
+ONE teacher-forced denoising step of config #2 and ONE of config #3 (the oracle needs ~10-40 s for each; differences are
+arbitrated by an fp64 evaluation of the same oracle), and (b) through properties that do not depend on
 size: E(3) equivariance of the denoiser (models/graph.py builds every position update from relative vectors and
 distances), independence of a molecule from the rest of its batch (disjoint graphs), and exactness of the segmented
 reductions.  Tolerances are stated next to each assertion.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,10 +39,66 @@ def _state(ph, seed, pos_scale=2.0):
             'log_halfedge': torch.log(F.one_hot(ht, 6).float().clamp(min=1e-30))}
 
 
+def _f64(d):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+
+
+def _oracle_step(P, cfg, st, graph, step, noise, double=False, **guide):
+    """The oracle's sample_step in fp32 (the reference's arithmetic) or fp64 (the arbiter of fp32 differences)."""
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        if double:
+            P, st, noise = _f64(P), _f64(st), _f64(noise)
+            if 'Pb' in guide:
+                guide = dict(guide, Pb=_f64(guide['Pb']))
+        tabs = U.tables(P)
+        with torch.no_grad():
+            return O.sample_step(P, cfg, tabs, st, graph, step, noise, **guide)
+    finally:
+        torch.set_num_threads(nthreads)
+
+
+def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, pos_keys_extra=()):
+    """SURVEY 8(c) tolerances, arbitrated in fp64.
+
+    The contract: positions 1e-4, logits 2e-5 (pre-softmax network outputs), log-posteriors 1e-4, class ids bit-exact
+    outside a 1e-4 Gumbel margin.  At 256 molecules, random states put atom pairs ~0.1 apart where w*rel/d/(d+1) (graph.py:393)
+    amplifies fp32 rounding, so the reference's own fp32 result deviates from exact arithmetic by more than the contract on
+    a few rows.  Each quantity therefore has to satisfy  |HIP - fp64| <= max(contract, 1.5 * |oracle_fp32 - fp64|):  within
+    the contract, or as close to exact arithmetic as the reference's fp32 is (1.5x covers the different, equally valid,
+    summation orders of the two fp32 evaluations)."""
+    report = {}
+    for name, hip, r32, r64, tol in (
+            ('pred_pos', gp[1], preds32['pred_pos'], preds64['pred_pos'], 1e-4),
+            ('pred_node', gp[0], preds32['pred_node'], preds64['pred_node'], 2e-5),
+            ('pred_halfedge', gp[2], preds32['pred_halfedge'], preds64['pred_halfedge'], 2e-5),
+            ('pos', got['pos'], want32['pos'], want64['pos'], 1e-4),
+            ('log_node', got['log_node'], want32['log_node'], want64['log_node'], 1e-4),
+            ('log_halfedge', got['log_halfedge'], want32['log_halfedge'], want64['log_halfedge'], 1e-4)):
+        e_hip, e_ref = U.maxdiff(hip, r64), U.maxdiff(r32, r64)
+        report[name] = (e_hip, e_ref, U.maxdiff(hip, r32))
+        assert e_hip <= max(tol, 1.5 * e_ref), f'{name}: |HIP-fp64| = {e_hip:.3e}, |oracle_fp32-fp64| = {e_ref:.3e}, contract {tol}'
+    print('\n[fp64 arbitration] quantity: |HIP-fp64|  |oracle32-fp64|  |HIP-oracle32|')
+    for k, v in report.items():
+        print(f'    {k:14s} {v[0]:.3e}  {v[1]:.3e}  {v[2]:.3e}')
+    # class ids: bit-exact wherever the exact (fp64) Gumbel-max margin exceeds the contract's 1e-4
+    for part, log_p, u, cls in (('node', want64['log_node'], noise['u_node'].double(), got['h_node'].argmax(-1)),
+                                ('halfedge', want64['log_halfedge'], noise['u_halfedge'].double(), got['h_halfedge'].argmax(-1))):
+        z = log_p - torch.log(-torch.log(u + 1e-30) + 1e-30)
+        top = z.topk(2, dim=-1).values
+        clear = (top[:, 0] - top[:, 1]) > 1e-4
+        n_close = int((~clear).sum())
+        print(f'    {part}: {n_close} of {clear.numel()} rows within the 1e-4 Gumbel margin (excused), '
+              f'{int((cls[clear] != z.argmax(-1)[clear]).sum())} mismatches outside it')
+        assert n_close <= 2e-4 * clear.numel() + 2
+        assert torch.equal(cls[clear], z.argmax(-1)[clear])
+    return report
+
+
 def test_one_full_size_step_matches_oracle():
-    """256 molecules, step t = 600, explicit noise: positions within 2e-4 (see test_gpu_sampling for why not 1e-4 when
-    atoms sit closer than ~0.2), log-posteriors within 1e-4, class ids bit-exact wherever the oracle's own Gumbel-max
-    margin exceeds 1e-3 (fewer than 0.2 % of the rows are that close to a tie)."""
+    """Config #2 at full size: 256 molecules, step t = 600, explicit noise, one teacher-forced step against the oracle in fp32
+    and fp64 (see _check_against_oracle for the tolerances)."""
     ph, sizes = _workload()
     m = U.moldiff('MolDiff_simple', DEV)
     P = U.params(U.moldiff('MolDiff_simple'))
@@ -54,28 +113,54 @@ def test_one_full_size_step_matches_oracle():
     sm.set_state(*(st[k].to(DEV) for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')), frame=999 - step)
     sm.step(999 - step)
     got = {k: v.cpu() for k, v in sm.state().items()}
-    nthreads = torch.get_num_threads()
-    torch.set_num_threads(min(16, nthreads))
-    try:
-        graph = {'batch_node': ph['batch_node'], 'halfedge_index': ph['halfedge_index'], 'batch_halfedge': ph['batch_halfedge'],
-                 'n_graphs': B}
-        with torch.no_grad():
-            want, preds = O.sample_step(P, U.CFG, U.tables(P), st, graph, step, noise)
-    finally:
-        torch.set_num_threads(nthreads)
-    assert U.maxdiff(sm.preds[1], preds['pred_pos']) < 2e-4
-    assert U.maxdiff(sm.preds[0], preds['pred_node']) < 5e-5
-    assert U.maxdiff(sm.preds[2], preds['pred_halfedge']) < 5e-5
-    assert U.maxdiff(got['pos'], want['pos']) < 2e-4
-    assert U.maxdiff(got['log_node'], want['log_node']) < 1e-4
-    assert U.maxdiff(got['log_halfedge'], want['log_halfedge']) < 1e-4
-    for log_p, u, cls in ((want['log_node'], noise['u_node'], got['h_node'].argmax(-1)),
-                          (want['log_halfedge'], noise['u_halfedge'], got['h_halfedge'].argmax(-1))):
-        z = log_p - torch.log(-torch.log(u + 1e-30) + 1e-30)
-        top = z.topk(2, dim=-1).values
-        clear = (top[:, 0] - top[:, 1]) > 1e-3
-        assert clear.float().mean() > 0.998
-        assert torch.equal(cls[clear], z.argmax(-1)[clear])
+    gp = [p.cpu() for p in sm.preds]
+    graph = {'batch_node': ph['batch_node'], 'halfedge_index': ph['halfedge_index'], 'batch_halfedge': ph['batch_halfedge'],
+             'n_graphs': B}
+    want32, preds32 = _oracle_step(P, U.CFG, st, graph, step, noise)
+    want64, preds64 = _oracle_step(P, U.CFG, st, graph, step, noise, double=True)
+    _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64)
+
+
+def test_one_full_size_guided_step_matches_oracle():
+    """Config #3 at full size (full model, segment bond schedule, ['uncertainty', 1e-4] guidance through the 8-block bond
+    predictor and its hand-written backward): one teacher-forced step at t = 500 against the oracle's autograd, in fp32 and
+    arbitrated in fp64.  The guidance increment itself is also compared: within 1e-3 of its own scale."""
+    ph, sizes = _workload('MolDiff')
+    m, bp = U.moldiff('MolDiff', DEV), U.bondpred(DEV)
+    P, Pb = U.params(U.moldiff('MolDiff')), U.params(U.bondpred())
+    st = _state(ph, 61)
+    N, Eh = st['pos'].shape[0], st['h_halfedge'].shape[0]
+    g = U.rng(62)
+    noise = {'eps_pos': U.t32(g.standard_normal((N, 3))), 'u_node': U.t32(g.random((N, 8))), 'u_halfedge': U.t32(g.random((Eh, 6)))}
+    step = 500
+    sm = m.sampler(B, ph['batch_node'].to(DEV), ph['halfedge_index'].to(DEV), ph['batch_halfedge'].to(DEV), return_traj=False,
+                   bond_predictor=bp, guidance=['uncertainty', 1e-4],
+                   noise=lambda i: tuple(noise[k].to(DEV) for k in ('eps_pos', 'u_node', 'u_halfedge')))
+    sm.set_state(*(st[k].to(DEV) for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')), frame=999 - step)
+    sm.step(999 - step)
+    got = {k: v.cpu() for k, v in sm.state().items()}
+    gp = [p.cpu() for p in sm.preds]
+    delta = sm.delta.cpu()
+    graph = {'batch_node': ph['batch_node'], 'halfedge_index': ph['halfedge_index'], 'batch_halfedge': ph['batch_halfedge'],
+             'n_graphs': B}
+    gd = dict(Pb=Pb, cfgb=U.CFGB, guidance=['uncertainty', 1e-4])
+    want32, preds32 = _oracle_step(P, U.CFG, st, graph, step, noise, **gd)
+    want64, preds64 = _oracle_step(P, U.CFG, st, graph, step, noise, double=True, **gd)
+    _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64)
+    # the increment alone (oracle: new pos minus the unguided posterior mean + noise, evaluated in fp64)
+    bn, hei, bh = graph['batch_node'], graph['halfedge_index'], graph['batch_halfedge']
+    ei, be = torch.cat([hei, hei.flip(0)], 1), torch.cat([bh, bh])
+    t = torch.full((B,), step, dtype=torch.long)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    d64, _ = O.guidance_delta(_f64(Pb), U.CFGB, st['h_node'].double(), st['pos'].double(), bn, ei, be, t, 1e-4)
+    d32, _ = O.guidance_delta(Pb, U.CFGB, st['h_node'], st['pos'], bn, ei, be, t, 1e-4)
+    scale = float(d64.abs().max())
+    assert scale > 0
+    e_hip, e_ref = U.maxdiff(delta, d64), U.maxdiff(d32, d64)
+    print(f'    guidance delta: max |delta| {scale:.3e}, |HIP-fp64| {e_hip:.3e}, |oracle32-fp64| {e_ref:.3e}')
+    # a gradient through 8 blocks in a different (equally valid) summation order: within 2x the reference's own fp32 error,
+    # and two orders of magnitude inside the 1e-4 position contract it feeds
+    assert e_hip <= max(1e-3 * scale, 2.0 * e_ref) and e_hip <= 2e-6
 
 
 def _rotation(seed):

@@ -24,6 +24,8 @@ def _replay(kind, tag, window, guided=False):
     extra = dict(bond_predictor=U.bondpred(DEV), guidance=['uncertainty', 1e-4]) if guided else {}
     pre = f'{tag}_{window}'
     steps = g[pre + '_steps']
+    P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in U.params(U.moldiff(kind)).items()}
+    Pb64 = {k: (v.double() if v.is_floating_point() else v) for k, v in U.params(U.bondpred()).items()} if guided else None
     st = {'h_node': F.one_hot(torch.from_numpy(g[pre + '_init_node_type']), 8).float(),
           'pos': U.t32(g[pre + '_init_pos']),
           'h_halfedge': F.one_hot(torch.from_numpy(g[pre + '_init_halfedge_type']), 6).float(),
@@ -43,13 +45,21 @@ def _replay(kind, tag, window, guided=False):
         sm.step(i)
         got = sm.state()
         assert float(g[f"{pre}_{j}_node_margin_min"]) > 1e-4 and float(g[f"{pre}_{j}_halfedge_margin_min"]) > 1e-4
-        # 'hi' window: random positions at unit scale put atom pairs 0.15 apart, and w*rel/d/(d+1) amplifies fp32
-        # rounding: the reference's own fp32 CPU result is 7.2e-5 away from an fp64 evaluation there (the HIP result
-        # 5.5e-5), so the position tolerance for that window is 2e-4; 'lo' (min distance 0.46) keeps 1e-4.
-        ptol = 2e-4 if window == 'hi' else 1e-4
-        assert U.maxdiff(sm.preds[1], g[f'{pre}_{j}_pred_pos']) < ptol
+        # Contract: positions 1e-4.  In the 'hi' window random unit-scale positions put atom pairs 0.15 apart
+        # and w*rel/d/(d+1) amplifies fp32 rounding: the reference's own fp32 result (the golden) is then ~7e-5 from exact
+        # arithmetic, so |HIP - golden| may exceed 1e-4 although HIP is no further from the truth than the reference is.
+        # Arbitrated in fp64: |HIP - fp64| <= max(1e-4, 1.5 |golden - fp64|).
+        with torch.no_grad():
+            graph = {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': 4}
+            nz = {'eps_pos': cur['eps'].cpu().double(), 'u_node': cur['un'].cpu().double(), 'u_halfedge': cur['uh'].cpu().double()}
+            st64 = {k: v.double() for k, v in st.items()}
+            w64, p64 = O.sample_step(P64, U.CFG, U.tables(P64), st64, graph, int(s), nz,
+                                     **(dict(Pb=Pb64, cfgb=U.CFGB, guidance=['uncertainty', 1e-4]) if guided else {}))
+        for hip, gold_, r64 in ((sm.preds[1], g[f'{pre}_{j}_pred_pos'], p64['pred_pos']), (got['pos'], g[f'{pre}_{j}_pos'], w64['pos'])):
+            assert U.maxdiff(hip, r64) <= max(1e-4, 1.5 * U.maxdiff(gold_, r64))
+        if window == 'lo':  # well-conditioned window: the contract holds directly against the reference's fp32 golden
+            assert U.maxdiff(sm.preds[1], g[f'{pre}_{j}_pred_pos']) < 1e-4 and U.maxdiff(got['pos'], g[f'{pre}_{j}_pos']) < 1e-4
         assert U.maxdiff(sm.preds[0], g[f'{pre}_{j}_pred_node']) < 2e-5
-        assert U.maxdiff(got['pos'], g[f'{pre}_{j}_pos']) < ptol
         assert U.maxdiff(got['log_node'], g[f'{pre}_{j}_log_node']) < 1e-4
         assert U.maxdiff(got['log_halfedge'], g[f'{pre}_{j}_log_halfedge']) < 1e-4
         assert np.array_equal(got['h_node'].argmax(-1).cpu().numpy(), g[f'{pre}_{j}_node_type'])
