@@ -13,8 +13,13 @@ give-up rule (:106-108).  What differs, deliberately:
   * RDKit reconstruction (utils/reconstruct.py, CPU chemistry) is out of scope: a molecule counts as
     finished when its decoded bond graph is connected (the reference's test is "no '.' in the SMILES");
     molecules are written as V2000 mol blocks (bond order 4 = aromatic) and collected in ``samples_all.pt``;
-  * with WORLD_SIZE > 1 every rank samples a contiguous slice of each batch (noise keyed by global molecule
-    id) and rank 0 gathers the decoded molecules -- the only collective of the run.
+  * ``sample.save_traj_prob``: the trajectory is kept compact on the device (class ids, one byte per atom / half-edge and
+    frame) and only the drawn molecules' frames are decoded (``traj_mol<id>.sdf``, one mol block per frame); the draw is a
+    function of (seed, global molecule id) instead of the position in numpy's global stream, so it does not depend on the
+    number of GPUs;
+  * with WORLD_SIZE > 1 every rank samples a contiguous slice of each batch's cost-balanced molecule order (noise keyed by
+    global molecule id); per batch the last-step predictions travel to rank 0 as tensors (``distributed.gather_pred``:
+    one size all_gather + one padded all_gather each) and one 2-element all-reduce carries the loop condition.
 No pretrained checkpoint ships with the reference (Google-Drive download); ``--recipe-weights`` substitutes the
 deterministic synthetic weights used by the tests so the entry point can be exercised end to end.
 """
@@ -26,8 +31,8 @@ import time
 import numpy as np
 import torch
 
-from . import BondPredictor, MolDiff
-from .distributed import shard_bounds
+from . import BondPredictor, MolDiff, _lib
+from .distributed import balanced_order, gather_pred, shard_bounds
 from .harness import default_config, load_config, placeholder_from_sizes, recipe_state_dict, seed_all
 from .harness import GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
 from .postprocess import FeaturizeMol
@@ -100,6 +105,26 @@ def build_models(config, device, recipe):
     return model, bond_predictor, guidance
 
 
+def traj_blocks(featurizer, traj, sel, sizes, device):
+    """Trajectories of the molecules `sel` (batch-local indices) as lists of decode_output dicts, one per frame
+    (scripts/sample_drug3d.py:157-163).  The frames are cut out of the compact trajectory (class ids, one byte each),
+    re-packed as a small batch of their own and decoded on the device frame by frame with ``decode_batch``."""
+    node_traj, pos_traj, half_traj = traj
+    sizes = np.asarray(sizes, dtype=np.int64)
+    node_off = np.concatenate([[0], np.cumsum(sizes)])
+    half_off = np.concatenate([[0], np.cumsum(sizes * (sizes - 1) // 2)])
+    nidx = torch.as_tensor(np.concatenate([np.arange(node_off[m], node_off[m + 1]) for m in sel]), device=device)
+    hidx = torch.as_tensor(np.concatenate([np.arange(half_off[m], half_off[m + 1]) for m in sel]), device=device)
+    sub = placeholder_from_sizes(sizes[list(sel)], device)
+    graph = _lib.Graph(torch.cat([sub['halfedge_index'], sub['halfedge_index'].flip(0)], dim=1), sub['batch_node'], len(sel))
+    nt, pt, ht = node_traj[:, nidx], pos_traj[:, nidx], half_traj[:, hidx]   # still compact
+    frames = []
+    for t in range(pt.shape[0]):
+        frames.append(featurizer.decode_batch([nt[t].dense(), pt[t].contiguous(), ht[t].dense()], sub['batch_node'],
+                                              sub['halfedge_index'], sub['batch_halfedge'], len(sel), graph=graph))
+    return {m: [frames[t][j] for t in range(len(frames))] for j, m in enumerate(sel)}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', type=str, required=True)
@@ -119,51 +144,85 @@ def main(argv=None):
         backend = os.environ.get('MDX_DIST_BACKEND', 'nccl')
         lr = int(os.environ.get('LOCAL_RANK', '0'))
         args.device = f"cuda:{lr if backend == 'nccl' else lr % torch.cuda.device_count()}"
-        torch.cuda.set_device(torch.device(args.device))
+    device = torch.device(args.device)
+    # the library allocates and launches on the CURRENT HIP device: make it the one the tensors live on (the reference's
+    # default is --device cuda:7) before any handle is created
+    torch.cuda.set_device(device)
+    if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device(args.device))
+            dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(backend)
-    device = torch.device(args.device)
+    comm_dev = device if (world > 1 and backend == 'nccl') else torch.device('cpu')
 
     config = load_config(args.config)
     config_name = os.path.basename(args.config).rsplit('.', 1)[0]
     seed = int(config.sample.seed + np.sum([ord(s) for s in args.outdir]))
     seed_all(seed)
     log_dir = os.path.join(args.outdir, config_name + '_' + time.strftime('%Y%m%d_%H%M%S'))
+    if world > 1:  # every rank writes trajectories of its own molecules: agree on rank 0's directory name
+        name = [log_dir]
+        dist.broadcast_object_list(name, src=0)   # once per run, not per batch
+        log_dir = name[0]
     if rank == 0:
         os.makedirs(log_dir, exist_ok=True)
-        os.makedirs(log_dir + '_SDF', exist_ok=True)
         shutil.copyfile(args.config, os.path.join(log_dir, os.path.basename(args.config)))
+    os.makedirs(log_dir + '_SDF', exist_ok=True)
     featurizer = FeaturizeMol([6, 7, 8, 9, 15, 16, 17], [1, 2, 3, 4], use_mask_node=True, use_mask_edge=True)
     model, bond_predictor, guidance = build_models(config, device, args.recipe_weights)
     num_mols = args.num_mols or config.sample.num_mols
     batch_size = args.batch_size if args.batch_size > 0 else config.sample.batch_size
+    save_traj_prob = float(getattr(config.sample, 'save_traj_prob', 0.0) or 0.0)
     pool = {'finished': [], 'failed': []}
+    n_finished, n_failed = 0, 0
     next_id, i_batch = 0, 0
-    while len(pool['finished']) < num_mols:
-        if len(pool['failed']) > 3 * num_mols:
-            print('Too many failed molecules. Stop sampling.')
+    while n_finished < num_mols:
+        if n_failed > 3 * num_mols:
+            if rank == 0:
+                print('Too many failed molecules. Stop sampling.')
             break
-        n_graphs = min(batch_size, (num_mols - len(pool['finished'])) * 2)
-        # every rank draws the same sizes (same numpy stream), then takes its slice
+        n_graphs = min(batch_size, (num_mols - n_finished) * 2)
+        # every rank draws the same sizes (same numpy stream) and takes a contiguous slice of the cost-balanced order
         sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=n_graphs).astype('int64')
         sizes = np.maximum(sizes, 2)  # the reference's harness cannot handle molecules without half-edges
+        order = balanced_order(sizes, world) if world > 1 else np.arange(n_graphs)
         lo, hi = shard_bounds(n_graphs, world, rank)
-        ph = placeholder_from_sizes(sizes[lo:hi], device)
-        ids = np.arange(next_id + lo, next_id + hi, dtype=np.int64)
-        next_id += n_graphs
+        mine = order[lo:hi]
+        ph = placeholder_from_sizes(sizes[mine], device)
+        ids = next_id + mine.astype(np.int64)
         out = model.sample(hi - lo, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], bond_predictor, guidance,
-                           seed=seed + i_batch, mol_ids=ids, return_traj=False)
-        mols = featurizer.decode_batch(out['pred'], ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], hi - lo)
+                           seed=seed + i_batch, mol_ids=ids, return_traj=save_traj_prob > 0)
+        # trajectories stay rank-local (scripts/sample_drug3d.py:155 looks at ~2 % of them): the owner decodes and writes
+        # them, named by global molecule id; whether a molecule is drawn depends only on (seed, id), not on the sharding
+        traj_of = {}
+        if save_traj_prob > 0:
+            local = featurizer.decode_batch(out['pred'], ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], hi - lo)
+            sel = [j for j, info in enumerate(local)
+                   if is_connected(len(info['element']), info['bond_index'])
+                   and np.random.default_rng([seed, int(ids[j])]).random() < save_traj_prob]
+            if sel:
+                for j, frames in traj_blocks(featurizer, out['traj'], sel, sizes[mine], device).items():
+                    path = os.path.join(log_dir + '_SDF', 'traj_mol%d.sdf' % int(ids[j]))
+                    with open(path, 'w') as f:
+                        for info in frames:
+                            f.write(mol_block(info) + '$$$$\n')
+                    traj_of[int(ids[j])] = os.path.basename(path)
+        # the only data-path collective: this batch's last-step predictions to rank 0 (one size all_gather + one padded
+        # all_gather per tensor, RCCL over xGMI; about 2 MB per rank at 256 molecules)
+        pred = out['pred']
         if dist is not None:
-            gathered = [None] * world if rank == 0 else None
-            dist.gather_object(mols, gathered, dst=0)
-            mols = [m for part in gathered for m in part] if rank == 0 else []
+            pred = gather_pred([p.to(comm_dev) for p in pred], dst=0)
+        counts = torch.zeros(2, dtype=torch.int64, device=comm_dev)
         if rank == 0:
+            full = placeholder_from_sizes(sizes[order], device)
+            mols = featurizer.decode_batch([p.to(device) for p in pred], full['batch_node'], full['halfedge_index'],
+                                           full['batch_halfedge'], n_graphs)
+            inv = np.argsort(order)                       # back to the batch's original molecule order
+            mols = [mols[inv[k]] for k in range(n_graphs)]
             gen = []
-            for info in mols:
+            for k, info in enumerate(mols):
+                info['mol_id'] = next_id + k
                 if is_connected(len(info['element']), info['bond_index']):
                     gen.append(info)
                 else:
@@ -171,17 +230,20 @@ def main(argv=None):
             for i, info in enumerate(gen):
                 with open(os.path.join(log_dir + '_SDF', '%d.sdf' % (i + len(pool['finished']))), 'w') as f:
                     f.write(mol_block(info) + '$$$$\n')
+                if info['mol_id'] in traj_of:
+                    info['traj_file'] = traj_of[info['mol_id']]
             pool['finished'].extend(gen)
             print('[Pool] Finished %d | Failed %d' % (len(pool['finished']), len(pool['failed'])))
-        if dist is not None:  # keep the loop condition identical on every rank
-            counts = [len(pool['finished']), len(pool['failed'])]
-            dist.broadcast_object_list(counts, src=0)
-            if rank != 0:
-                pool['finished'], pool['failed'] = [None] * counts[0], [None] * counts[1]
+            counts[0], counts[1] = len(pool['finished']), len(pool['failed'])
+        if dist is not None:  # one small all-reduce keeps the loop condition identical on every rank
+            dist.all_reduce(counts)
+        n_finished, n_failed = int(counts[0]), int(counts[1])
+        next_id += n_graphs
         i_batch += 1
     if rank == 0:
         torch.save(pool, os.path.join(log_dir, 'samples_all.pt'))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     return log_dir
 
