@@ -41,6 +41,9 @@ sys.path.insert(0, ROOT)
 
 T_STEPS = 1000
 FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIGN.md / SURVEY Appendix D)
+FLOP_EDGE_BWD = 829440      # per directed edge per launch of the guidance backward's edge kernel
+EDGE_A_NAME = 'edge_a2_kernel (row-owner fused per-edge MLP chain, v_mfma_f32_16x16x4_f32)'
+REFERENCE_CPU_MOL_S = 0.097  # the REAL reference on 8 CPU cores, config #2 (2.64 s/step at 256 molecules)
 PEAK_FP32_MFMA = 157.3      # TFLOP/s (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0           # GB/s
 
@@ -68,9 +71,12 @@ def build_workload(batch, rank, device, kind='MolDiff_simple'):
 
 
 def cpu_baseline(model, ph_cpu, batch, budget_s=20.0, bond_predictor=None):
-    """Time the CPU oracle on the same workload (bounded sample)."""
-    from oracle import moldiff_oracle as O
+    """Time the CPU oracle on a bounded sample of the same workload: the first `nmol` molecules of the batch (per-step cost is
+    proportional to the directed edges, so the result is scaled by the edge ratio), thread count chosen by a ladder on that
+    same sample, 1 warm-up + >= 3 timed consecutive steps."""
     import torch.nn.functional as F
+    from oracle import moldiff_oracle as O
+    from moldiff_amd.harness import placeholder_from_sizes
     gkw = {}
     if bond_predictor is not None:
         gkw = dict(Pb={k: v.detach().cpu() for k, v in bond_predictor.state_dict().items()},
@@ -80,66 +86,74 @@ def cpu_baseline(model, ph_cpu, batch, budget_s=20.0, bond_predictor=None):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
     P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     tabs = {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std')},
             'node': {k: P['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
             'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
     cfg = dict(num_timesteps=1000, num_blocks=6, cutoff=15)
-    bn, hei, bh = ph_cpu['batch_node'], ph_cpu['halfedge_index'], ph_cpu['batch_halfedge']
-    N, Eh = len(bn), len(bh)
+    sizes = torch.bincount(ph_cpu['batch_node'], minlength=batch).numpy()
+    e_all = int((sizes * (sizes - 1)).sum())
     g = torch.Generator().manual_seed(0)
-    st = {'h_node': F.one_hot(torch.randint(0, 8, (N,), generator=g), 8).float(), 'pos': torch.randn(N, 3, generator=g),
-          'h_halfedge': F.one_hot(torch.randint(0, 6, (Eh,), generator=g), 6).float()}
-    st['log_node'] = torch.log(st['h_node'].clamp(min=1e-30))
-    st['log_halfedge'] = torch.log(st['h_halfedge'].clamp(min=1e-30))
-    graph = {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': batch}
 
-    def one(step, st):
+    def make(nmol):
+        ph = placeholder_from_sizes(sizes[:nmol])
+        N, Eh = len(ph['batch_node']), len(ph['batch_halfedge'])
+        st = {'h_node': F.one_hot(torch.randint(0, 8, (N,), generator=g), 8).float(), 'pos': torch.randn(N, 3, generator=g),
+              'h_halfedge': F.one_hot(torch.randint(0, 6, (Eh,), generator=g), 6).float()}
+        st['log_node'] = torch.log(st['h_node'].clamp(min=1e-30))
+        st['log_halfedge'] = torch.log(st['h_halfedge'].clamp(min=1e-30))
+        return dict(ph, n_graphs=nmol), st, N, Eh
+
+    def one(graph, st, N, Eh, step):
         noise = {'eps_pos': torch.randn(N, 3, generator=g), 'u_node': torch.rand(N, 8, generator=g),
                  'u_halfedge': torch.rand(Eh, 6, generator=g)}
         with torch.no_grad():
             new, _ = O.sample_step(P, cfg, tabs, st, graph, step, noise, **gkw)
         return {k: new[k] for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')}
 
-    # thread-count calibration on a 64-molecule slice (many-core hosts are far slower with one thread per logical
-    # CPU than with a moderate count; the baseline gets the best of a small ladder, which is stated in `cores`)
-    from moldiff_amd.harness import placeholder_from_sizes
-    sizes = torch.bincount(bn, minlength=batch).numpy()
-    small = placeholder_from_sizes(sizes[:64])
-    sN, sEh = len(small['batch_node']), len(small['batch_halfedge'])
-    sst = {'h_node': st['h_node'][:sN], 'pos': st['pos'][:sN], 'h_halfedge': st['h_halfedge'][:sEh],
-           'log_node': st['log_node'][:sN], 'log_halfedge': st['log_halfedge'][:sEh]}
-    sgraph = dict(small, n_graphs=64)
-    snoise = {'eps_pos': torch.randn(sN, 3, generator=g), 'u_node': torch.rand(sN, 8, generator=g),
-              'u_halfedge': torch.rand(sEh, 6, generator=g)}
+    # 1. size of the sample: one probe step on 32 molecules at 16 threads -> molecules that fit 4 steps into the budget
+    torch.set_num_threads(min(16, cores))
+    graph, st, N, Eh = make(min(32, batch))
+    one(graph, st, N, Eh, 999)
+    t0 = time.perf_counter()
+    one(graph, st, N, Eh, 998)
+    probe = time.perf_counter() - t0
+    e_probe = int((sizes[:min(32, batch)] * (sizes[:min(32, batch)] - 1)).sum())
+    nmol = int(max(min(32, batch), min(batch, (budget_s / 7.0) / max(probe, 1e-4) * min(32, batch))))   # ~budget/7 per step
+    graph, st, N, Eh = make(nmol)
+    e_sub = int((sizes[:nmol] * (sizes[:nmol] - 1)).sum())
+    # 2. thread ladder on that sample (many-core hosts are far slower with one thread per logical CPU)
     best = (float('inf'), 1)
-    for th in sorted({c for c in (8, 16, 32, 64, 128) if c <= cores} | {min(cores, 8)}):
+    ladder = []
+    for th in sorted({c for c in (16, 32, 64) if c <= cores} | {min(cores, 16)}):
         torch.set_num_threads(th)
-        with torch.no_grad():
-            O.sample_step(P, cfg, tabs, sst, sgraph, 500, snoise, **gkw)
-            t0 = time.perf_counter()
-            O.sample_step(P, cfg, tabs, sst, sgraph, 500, snoise, **gkw)
-            dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        one(graph, st, N, Eh, 997)
+        dt = time.perf_counter() - t0
+        ladder.append((th, round(dt, 3)))
         if dt < best[0]:
             best = (dt, th)
-        if dt > 4 * best[0]:
+        if dt > 1.15 * best[0]:
             break
     threads = best[1]
     torch.set_num_threads(threads)
-    t0 = time.perf_counter()
-    st = one(999, st)  # warm-up (also gives a first estimate of the per-step cost)
-    est = time.perf_counter() - t0
-    nsteps = int(max(1, min(20, budget_s / max(est, 1e-3))))
+    # 3. warm-up + >= 3 timed consecutive steps
+    st = one(graph, st, N, Eh, 996)
+    nsteps = int(max(3, min(10, (budget_s * 0.45) / max(best[0], 1e-3))))
     t0 = time.perf_counter()
     for j in range(nsteps):
-        st = one(998 - j, st)
-    per_step = (time.perf_counter() - t0) / nsteps
-    return {'value': batch / (per_step * T_STEPS), 'unit': 'molecules/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{nsteps} consecutive denoising steps (after 1 warm-up) of the same {batch}-molecule batch with the '
-                      f'torch-CPU oracle, fp32, {threads} threads (best of a ladder up to {cores} logical CPUs, calibrated on a '
-                      f'64-molecule slice); scaled to T=1000 (per-step cost is step-independent)',
-            'ms_per_step': per_step * 1e3, 'host_logical_cpus': cores}
+        st = one(graph, st, N, Eh, 995 - j)
+    per_step = (time.perf_counter() - t0) / nsteps * e_all / e_sub
+    value = batch / (per_step * T_STEPS)
+    return {'value': value, 'unit': 'molecules/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{nsteps} consecutive denoising steps (after 1 warm-up) of the first {nmol} of the {batch} molecules '
+                      f'({e_sub} of {e_all} directed edges; cost scaled by that ratio) with the torch-CPU oracle, fp32, {threads} '
+                      f'threads = best of the ladder {ladder} (threads, s/step) on the same sample, host has {cores} logical CPUs; '
+                      f'scaled to T=1000 (per-step cost is step-independent)',
+            'ms_per_step': per_step * 1e3, 'host_logical_cpus': cores, 'timed_steps': nsteps, 'sample_molecules': nmol,
+            'reference_cpu_mol_s': REFERENCE_CPU_MOL_S if bond_predictor is None else None,
+            'reference_cpu_note': 'BASELINE.md: the real reference (PyTorch CPU), config #2, 8 cores: 2.64 s/step at 256 molecules'
+                                  if bond_predictor is None else 'BASELINE.md has no measured CPU number for config #3'}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -289,6 +303,54 @@ def main_train():
 
 
 
+def _profile(L, k):
+    c, ms = ctypes.c_int64(), ctypes.c_double()
+    from moldiff_amd import _lib
+    _lib.check(L.mdx_profile_read(k, ctypes.byref(c), ctypes.byref(ms)))
+    return c.value, ms.value
+
+
+def run_chain(sm, steps, warmup, barrier, start=0):
+    """`warmup` untimed + `steps` timed iterations of the reverse chain; hipEvent kernel timing on during the timed region.
+    Returns (elapsed seconds, {kernel: (launches, total ms)})."""
+    from moldiff_amd import _lib
+    L = _lib.lib()
+    i = start
+    for _ in range(warmup):
+        sm.step(i % T_STEPS)
+        i += 1
+    barrier()
+    L.mdx_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sm.step(i % T_STEPS)
+        i += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.mdx_profile_enable(0)
+    return elapsed, {n: _profile(L, k) for n, k in (('edge_a', 0), ('edge_b', 1), ('node', 2), ('aggregate', 3), ('edge_bwd', 4))}
+
+
+def roofline_mfma(name, kernel, flop_per_edge, E, prof):
+    c, ms = prof[name]
+    avg = ms / max(c, 1)
+    ach = flop_per_edge * E / (avg * 1e-3) / 1e12 if c else None
+    return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s',
+            'frac': (ach / PEAK_FP32_MFMA) if ach else None, 'traffic': None, 'launches': c, 'avg_ms': avg,
+            'flops_per_launch': flop_per_edge * E, 'flops_per_edge': flop_per_edge}
+
+
+def aggregation_line(N, E, prof):
+    c, ms = prof['aggregate']
+    avg = ms / max(c, 1)
+    nbytes = 1024.0 * (E + N)
+    agg = nbytes / (avg * 1e-3) / 1e9 if c else None
+    return {'bound': 'hbm', 'kernel': 'seg_reduce_kernel<256> (E,256)->(N,256)', 'achieved': agg, 'peak': PEAK_HBM,
+            'unit': 'GB/s (HBM or Infinity Cache: the (E,256) operand was written by the preceding kernel and is smaller than '
+                    'the 256 MiB MALL when E*1 KiB < 256 MiB)', 'frac': (agg / PEAK_HBM) if agg else None,
+            'bytes_per_launch': nbytes, 'launches': c, 'avg_ms': avg, 'operand_mib': E * 1024.0 / 2 ** 20}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -298,7 +360,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     ap.add_argument('--guided', action='store_true',
-                    help="BASELINE config #3: full model + bond-predictor 'uncertainty' guidance (default: config #2, simple)")
+                    help="make BASELINE config #3 (full model + bond-predictor 'uncertainty' guidance) the headline instead of "
+                         "config #2; by default config #3 is reported under configs.guided of the same line")
+    ap.add_argument('--headline-only', action='store_true', help='skip the extra single-GPU measurements (configs, sample(), B=2048)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -327,40 +391,41 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from moldiff_amd import _lib
-    model, ph_cpu, sizes = build_workload(args.batch, rank, None, 'MolDiff' if args.guided else 'MolDiff_simple')
-    model = model.to(dev)
-    gkw = {}
-    if args.guided:
-        gkw = dict(bond_predictor=build_bond_predictor().to(dev), guidance=['uncertainty', 1e-4])
-    ph = {k: v.to(dev) for k, v in ph_cpu.items()}
-    N, Eh = int(ph['batch_node'].numel()), int(ph['batch_halfedge'].numel())
-    E = 2 * Eh
-    mol_ids = np.arange(args.batch * rank, args.batch * (rank + 1), dtype=np.int64)
-    sm = model.sampler(args.batch, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023,
-                       mol_ids=mol_ids, return_traj=False, **gkw)
-    sm.init()
-    L = _lib.lib()
-    i = 0
-    for _ in range(args.warmup):
-        sm.step(i % T_STEPS)
-        i += 1
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    barrier()
-    L.mdx_profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sm.step(i % T_STEPS)
-        i += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    L.mdx_profile_enable(0)
+    def sampler_for(kind, batch, rk, **kw):
+        model, ph_cpu, sizes = build_workload(batch, rk, None, kind)
+        model = model.to(dev)
+        gkw = {}
+        if kind == 'MolDiff':
+            gkw = dict(bond_predictor=build_bond_predictor().to(dev), guidance=['uncertainty', 1e-4])
+        ph = {k: v.to(dev) for k, v in ph_cpu.items()}
+        mol_ids = np.arange(batch * rk, batch * (rk + 1), dtype=np.int64)
+        sm = model.sampler(batch, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023, mol_ids=mol_ids,
+                           return_traj=False, **gkw, **kw)
+        sm.init()
+        return sm, model, ph, ph_cpu, gkw
+
+    def config_line(kind, sm, steps, warmup, elapsed, prof, nranks):
+        N, E = sm.N, 2 * sm.Eh
+        ms = elapsed / steps * 1e3
+        line = {'ms_per_step': ms, 'value': args.batch * nranks / (ms * T_STEPS / 1e3), 'unit': 'molecules/sec', 'steps': steps,
+                'warmup': warmup,
+                'workload': ('sample_MolDiff.yml: full model + bond_predictor guidance [uncertainty, 1e-4], ' if kind == 'MolDiff'
+                             else 'sample_MolDiff_simple.yml: no bond guidance, ') +
+                            'batch_size=%d molecules/GPU, T=1000 steps; sizes ~ reference recipe seed 2920 (rank 0: N=%d atoms, '
+                            'E=%d directed edges); recipe weights' % (args.batch, N, E),
+                'kernel_ms_per_step': {k: v[1] / steps for k, v in prof.items() if v[0]}}
+        return line
+
+    head_kind = 'MolDiff' if args.guided else 'MolDiff_simple'
+    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank)
+    N, E = sm.N, 2 * sm.Eh
+    elapsed, prof = run_chain(sm, args.steps, args.warmup, barrier)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -368,57 +433,116 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world / (ms_per_step * T_STEPS / 1e3)
 
-    def prof(k):
-        c, ms = ctypes.c_int64(), ctypes.c_double()
-        _lib.check(L.mdx_profile_read(k, ctypes.byref(c), ctypes.byref(ms)))
-        return c.value, ms.value
-
     out = None
     if rank == 0:
-        ca, ma = prof(0)
-        cb, mb = prof(1)
-        cn, mn = prof(2)
-        cg, mg = prof(3)
-        avg_a = ma / max(ca, 1)
-        ach = FLOP_EDGE_A * E / (avg_a * 1e-3) / 1e12 if ca else None
-        avg_g = mg / max(cg, 1)
-        agg_bytes = 1024.0 * (E + N)
-        agg = agg_bytes / (avg_g * 1e-3) / 1e9 if cg else None
+        head = config_line(head_kind, sm, args.steps, args.warmup, elapsed, prof, world)
         out = {
             'metric': 'molecules/sec (1000-step GEOM-Drugs sampling)', 'value': value, 'unit': 'molecules/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('sample_MolDiff.yml: full model + bond_predictor guidance [uncertainty, 1e-4], '
-                                    if args.guided else 'sample_MolDiff_simple.yml: no bond guidance, ') +
-                                   'batch_size=%d molecules/GPU, T=1000 steps; sizes ~ reference recipe seed 2920 '
-                                   '(rank 0: N=%d atoms, E=%d directed edges); recipe weights' % (args.batch, N, E),
-                       'molecules_per_gpu': args.batch, 'num_timesteps': T_STEPS, 'parallelism': f'independent streams x{world}',
-                       'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
-            'roofline': {'bound': 'mfma', 'kernel': 'edge_a_kernel (fused per-edge MLP chain, v_mfma_f32_16x16x4_f32)',
-                         'achieved': ach, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s', 'frac': (ach / PEAK_FP32_MFMA) if ach else None,
-                         'traffic': None, 'launches': ca, 'avg_ms': avg_a, 'flops_per_launch': FLOP_EDGE_A * E},
-            'aggregation': {'bound': 'hbm', 'kernel': 'seg_reduce_kernel<256> (E,256)->(N,256)', 'achieved': agg, 'peak': PEAK_HBM,
-                            'unit': 'GB/s', 'frac': (agg / PEAK_HBM) if agg else None, 'bytes_per_launch': agg_bytes,
-                            'launches': cg, 'avg_ms': avg_g},
-            'kernel_ms_per_step': {'edge_a': ma / args.steps, 'edge_b': mb / args.steps, 'node': mn / args.steps,
-                                   'aggregate': mg / args.steps},
+            'config': {'workload': head['workload'], 'molecules_per_gpu': args.batch, 'num_timesteps': T_STEPS,
+                       'parallelism': f'independent streams x{world}', 'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
+            'roofline': roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, E, prof),
+            'aggregation': aggregation_line(N, E, prof),
+            'kernel_ms_per_step': head['kernel_ms_per_step'],
         }
         # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
-        # gfx950 correction applied) committed under profiles/; bench.py cannot collect PMCs itself.
+        # gfx950 correction applied) committed under profiles/; a Python process cannot collect PMCs on itself.
         try:
             import glob
             pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
             if pm and args.batch == 256 and not args.guided:
                 ks = json.load(open(pm[-1]))['kernels']
-                out['roofline']['traffic'] = ks['edge_a_kernel']['hbm_bytes_per_launch']
-                out['roofline']['traffic_source'] = os.path.relpath(pm[-1], ROOT)
-                out['aggregation']['traffic'] = ks['seg_reduce_kernel<256>']['hbm_bytes_per_launch']
+                ka = next((v for k, v in ks.items() if k.startswith('edge_a')), None)
+                if ka:
+                    out['roofline']['traffic'] = ka['hbm_bytes_per_launch']
+                    out['roofline']['traffic_source'] = os.path.relpath(pm[-1], ROOT) + ' (PMC passes of the same command; not measured in this run)'
+                kg = ks.get('seg_reduce_kernel<256>')
+                if kg:
+                    out['aggregation']['traffic'] = kg['hbm_bytes_per_launch']
         except Exception:
             pass
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(model.cpu(), ph_cpu, args.batch, args.cpu_budget,
-                                               gkw['bond_predictor'].cpu() if args.guided else None)
-            out['speedup_vs_cpu_baseline'] = value / world / out['cpu_baseline']['value'] if world == 1 else None
+
+    # ---- single-GPU extras, all OUTSIDE the headline's timed region --------------------------------------------------
+    if world == 1 and not args.headline_only:
+        configs = {'guided' if args.guided else 'simple': dict(head, roofline=out['roofline'])}
+        other_kind = 'MolDiff_simple' if args.guided else 'MolDiff'
+        del sm
+        torch.cuda.empty_cache()
+        # the other configuration: overlapped run for the step time, then a short NON-overlapped run for kernel durations
+        # (hipEvent brackets on one stream include time the other stream's kernels steal when the two chains overlap)
+        osteps, owarm = max(10, min(args.steps, 200)), min(args.warmup, 10)
+        sm2, model2, ph2, ph_cpu2, gkw2 = sampler_for(other_kind, args.batch, 0)
+        el2, prof2 = run_chain(sm2, osteps, owarm, barrier)
+        line2 = config_line(other_kind, sm2, osteps, owarm, el2, prof2, 1)
+        guided_sm_kind = 'MolDiff'
+        if other_kind == 'MolDiff':
+            del sm2
+            torch.cuda.empty_cache()
+            sm3, *_ = sampler_for('MolDiff', args.batch, 0, overlap_guidance=False)
+            el3, prof3 = run_chain(sm3, 20, 3, barrier)
+            ra = roofline_mfma('edge_a', EDGE_A_NAME + ' (14 launches per guided step: 6 denoiser + 8 predictor blocks)', FLOP_EDGE_A,
+                               2 * sm3.Eh, prof3)
+            rb = roofline_mfma('edge_bwd', 'edge_bwd_kernel (guidance backward: residual recompute + dgrad chain, '
+                               'v_mfma_f32_16x16x4_f32)', FLOP_EDGE_BWD, 2 * sm3.Eh, prof3)
+            tot_a, tot_b = prof3['edge_a'][1], prof3['edge_bwd'][1]
+            line2['roofline'] = dict(ra if tot_a >= tot_b else rb,
+                                     note='kernel durations from a 20-step run with the guidance chain in line on one stream '
+                                          '(%.2f ms/step); ms_per_step is the overlapped two-stream run' % (el3 / 20 * 1e3))
+            line2['roofline_other'] = rb if tot_a >= tot_b else ra
+            line2['kernel_ms_per_step_inline'] = {k: v[1] / 20 for k, v in prof3.items() if v[0]}
+            del sm3
+        else:
+            line2['roofline'] = roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, 2 * sm2.Eh, prof2)
+            del sm2
+        torch.cuda.empty_cache()
+        configs['simple' if args.guided else 'guided'] = line2
+        # the stated metric: wall time of one real model.sample() call with default arguments (prior draw + 1000 steps +
+        # trajectory, synchronised at the end), scripts/sample_drug3d.py:117-125
+        m_s, ph_s, _ = build_workload(args.batch, 0, None, 'MolDiff_simple')
+        m_s = m_s.to(dev)
+        ph_s = {k: v.to(dev) for k, v in ph_s.items()}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = m_s.sample(n_graphs=args.batch, batch_node=ph_s['batch_node'], halfedge_index=ph_s['halfedge_index'],
+                         batch_halfedge=ph_s['batch_halfedge'])
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        traj_bytes = sum(int(t.ids.numel()) if hasattr(t, 'ids') else int(t.numel()) * 4 for t in res['traj'])
+        out['sample_wall_s'] = {'value': wall, 'molecules_per_sec': args.batch / wall,
+                                'what': 'one model.sample(n_graphs=%d, ...) call with default arguments on config #2: graph plan, '
+                                        'prior draw, 1000 steps, compact trajectory (%.0f MB on the device; the reference layout '
+                                        'is expanded lazily), synchronised at the end' % (args.batch, traj_bytes / 1e6)}
+        del res, m_s
+        torch.cuda.empty_cache()
+        # the aggregation pass with an operand that cannot sit in the Infinity Cache: 2048 molecules, M = 1.2 GiB
+        try:
+            big = 2048
+            mb, phb, _ = build_workload(big, 0, None, 'MolDiff_simple')
+            mb = mb.to(dev)
+            phb = {k: v.to(dev) for k, v in phb.items()}
+            smb = mb.sampler(big, phb['batch_node'], phb['halfedge_index'], phb['batch_halfedge'], seed=5, return_traj=False)
+            smb.init()
+            elb, profb = run_chain(smb, 5, 2, barrier)
+            out['aggregation_large'] = dict(aggregation_line(smb.N, 2 * smb.Eh, profb), molecules=big,
+                                            ms_per_step=elb / 5 * 1e3, molecules_per_sec=big / (elb / 5 * T_STEPS))
+            out['aggregation_large']['roofline_edge_a'] = roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, 2 * smb.Eh, profb)['frac']
+            del smb, mb
+            torch.cuda.empty_cache()
+        except Exception as e:  # measurement extra: never fail the headline line
+            out['aggregation_large'] = {'error': repr(e)}
+        out['configs'] = configs
+        if not args.no_cpu_baseline:
+            for name, kind in (('simple', 'MolDiff_simple'), ('guided', 'MolDiff')):
+                mc, phc, _ = build_workload(args.batch, 0, None, kind)
+                cb = cpu_baseline(mc, phc, args.batch, args.cpu_budget, build_bond_predictor() if kind == 'MolDiff' else None)
+                configs[name]['cpu_baseline'] = cb
+                configs[name]['speedup_vs_cpu_baseline'] = configs[name]['value'] / cb['value']
+            hk = 'guided' if args.guided else 'simple'
+            out['cpu_baseline'] = configs[hk]['cpu_baseline']
+            out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+            if not args.guided:
+                out['speedup_vs_reference_cpu'] = value / REFERENCE_CPU_MOL_S
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -293,7 +293,8 @@ int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 
 /* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
  * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
- * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass).  read() drains pending events. */
+ * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass), 4 = the guidance backward's fused edge kernel
+ * (edge_bwd_kernel, MFMA).  read() drains pending events. */
 int mdx_profile_enable(int32_t on);
 int mdx_profile_read(int32_t kernel, int64_t* count, double* total_ms);
 

@@ -206,22 +206,47 @@ class Graph:
             pass
 
 
-_graph_cache = {}
+_graph_cache = {}     # identity-keyed, least recently used first; each Graph owns a workspace (hundreds of MB at 256 molecules)
+_GRAPH_CACHE_MAX = 3
+
+
+def _cache_get(key):
+    g = _graph_cache.pop(key, None)
+    if g is not None:
+        _graph_cache[key] = g   # most recently used last
+    return g
+
+
+def _cache_put(key, g):
+    _graph_cache[key] = g
+    while len(_graph_cache) > _GRAPH_CACHE_MAX:
+        _graph_cache.pop(next(iter(_graph_cache)))
 
 
 def graph_for(edge_index, batch_node, n_graphs=None, mol_ids=None):
-    """Small identity-keyed cache so repeated forward() calls on the same index tensors reuse the plan."""
+    """Small identity-keyed LRU so repeated forward() calls on the same index tensors reuse the plan."""
     key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, batch_node.data_ptr(),
            batch_node._version, int(batch_node.numel()), n_graphs)
-    g = _graph_cache.get(key)
+    g = _cache_get(key)
     if g is None:
         if n_graphs is None:
             n_graphs = int(batch_node.max().item()) + 1 if batch_node.numel() else 0
         g = Graph(edge_index, batch_node, n_graphs, mol_ids)
         g._keepalive = (edge_index, batch_node)
-        if len(_graph_cache) > 8:
-            _graph_cache.clear()
-        _graph_cache[key] = g
+        _cache_put(key, g)
+    return g
+
+
+def graph_for_halfedges(halfedge_index, batch_node, n_graphs):
+    """Plan of edge_index = cat[halfedge_index, flip(halfedge_index)] keyed on the HALF-edge tensor: callers that rebuild the
+    directed list with torch.cat on every call (get_loss, decode_batch) still hit the cache."""
+    key = ('half', halfedge_index.data_ptr(), tuple(halfedge_index.shape), halfedge_index._version, batch_node.data_ptr(),
+           batch_node._version, int(batch_node.numel()), n_graphs)
+    g = _cache_get(key)
+    if g is None:
+        g = Graph(torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1), batch_node, n_graphs)
+        g._keepalive = (halfedge_index, batch_node)
+        _cache_put(key, g)
     return g
 
 
@@ -258,19 +283,21 @@ class Model:
 
 def pos_posterior(c0, ct, sd, x_t, x_recon, eps, t, batch):
     _need_gpu(x_t, x_recon, eps, t, batch, c0)
-    x_t, x_recon, eps = f32c(x_t), f32c(x_recon), f32c(eps)
+    # converted copies are bound to names that live until the launch: a temporary handed straight to ptr() goes back to the
+    # caching allocator at once and the next conversion in the same argument list may reuse its block
+    x_t, x_recon, eps, t, batch = f32c(x_t), f32c(x_recon), f32c(eps), i64c(t), i64c(batch)
     out = torch.empty_like(x_t)
-    check(lib().mdx_pos_posterior(ptr(c0), ptr(ct), ptr(sd), ptr(x_t), ptr(x_recon), ptr(eps), ptr(i64c(t)),
-                                  ptr(i64c(batch)), x_t.shape[0], ptr(out), stream()))
+    check(lib().mdx_pos_posterior(ptr(c0), ptr(ct), ptr(sd), ptr(x_t), ptr(x_recon), ptr(eps), ptr(t),
+                                  ptr(batch), x_t.shape[0], ptr(out), stream()))
     return out
 
 
 def cat_posterior(q_mats, qT, in0, log_vt, t, batch, is_logits=False):
     _need_gpu(in0, log_vt, t, batch, q_mats)
-    in0, log_vt = f32c(in0), f32c(log_vt)
+    in0, log_vt, t, batch = f32c(in0), f32c(log_vt), i64c(t), i64c(batch)
     out = torch.empty_like(in0)
     check(lib().mdx_cat_posterior(ptr(q_mats), ptr(qT), in0.shape[1], q_mats.shape[0], ptr(in0), int(is_logits),
-                                  ptr(log_vt), ptr(i64c(t)), ptr(i64c(batch)), in0.shape[0], ptr(out), stream()))
+                                  ptr(log_vt), ptr(t), ptr(batch), in0.shape[0], ptr(out), stream()))
     return out
 
 

@@ -34,6 +34,9 @@ class _BondLogits(torch.autograd.Function):
         need_grad = pos.requires_grad
         if need_grad:
             tape, tptr, tbytes = g.tape(dev, num_blocks)
+            # one tape per graph: a second forward before this one's backward overwrites it -> detected in backward
+            g._tape_version = getattr(g, '_tape_version', 0) + 1
+            ctx.tape_version = g._tape_version
         _lib.check(_lib.lib().mdx_bondpred_forward(eng.h, g.h, _lib.ptr(h_c), _lib.ptr(pos_c), _lib.ptr(t_c), _lib.ptr(logits),
                                                    ws, nb, tptr, tbytes, _lib.stream()))
         ctx.eng, ctx.g, ctx.num_blocks = eng, g, num_blocks
@@ -47,8 +50,12 @@ class _BondLogits(torch.autograd.Function):
         dev = pos_c.device
         gpos = torch.empty_like(pos_c)
         ws, nb = g.workspace(dev)
+        if getattr(ctx, 'tape_version', None) != getattr(g, '_tape_version', None):
+            raise RuntimeError('BondPredictor backward: the per-graph tape was overwritten by a later forward on the same graph '
+                               '(run forward -> backward pairs one at a time, or use separate graphs)')
         _, tptr, tbytes = g.tape(dev, ctx.num_blocks)
-        _lib.check(_lib.lib().mdx_bondpred_backward(eng.h, g.h, _lib.ptr(pos_c), _lib.ptr(_lib.f32c(glogits)), 1.0,
+        gl = _lib.f32c(glogits)
+        _lib.check(_lib.lib().mdx_bondpred_backward(eng.h, g.h, _lib.ptr(pos_c), _lib.ptr(gl), 1.0,
                                                     _lib.ptr(gpos), ws, nb, tptr, tbytes, _lib.stream()))
         return gpos, None, None, None, None, None, None
 
@@ -133,7 +140,8 @@ class BondPredictor(Module):
                 from . import train_graph
                 pred_halfedge = train_graph.bondpred_forward(self, h_node, pos, batch_node, edge_index, batch_edge, t)
             else:
-                pred_halfedge = self(h_node, pos, batch_node, edge_index, batch_edge, t)
+                pred_halfedge = self(h_node, pos, batch_node, edge_index, batch_edge, t,
+                                     _graph=_lib.graph_for_halfedges(halfedge_index, batch_node, int(t.numel())))
             loss_edge = self.ce_loss(pred_halfedge, halfedge_type)
         return {'loss': loss_edge, 'loss_edge': loss_edge}
 

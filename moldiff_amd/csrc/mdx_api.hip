@@ -682,7 +682,7 @@ __global__ void expand_halfedge_kernel(const float* __restrict__ xh, const int* 
 // live kernel timing (hipEvents on the launch stream) -- used by bench.py for the roofline numbers
 // ------------------------------------------------------------------------------------------------
 namespace {
-enum { PK_EDGE_A = 0, PK_EDGE_B = 1, PK_NODE = 2, PK_AGGR = 3, PK_COUNT = 4 };
+enum { PK_EDGE_A = 0, PK_EDGE_B = 1, PK_NODE = 2, PK_AGGR = 3, PK_EDGE_BWD = 4, PK_COUNT = 5 };
 constexpr int PROF_RING = 1024;
 struct ProfSlot {
   hipEvent_t a[PROF_RING], b[PROF_RING];
@@ -1176,7 +1176,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
         ea_args.tSG = tp.b[i].SG;
         ea_args.tHE = tp.b[i].HE;
       }
-      launch_edge_a(ea_args, s);
+      { ProfScope ps(PK_EDGE_A, s); launch_edge_a(ea_args, s); }
     }
     launch_seg_reduce(wi.M, g->row_ptr, nullptr, wi.aggr, nullptr, (int)g->N, 256, s);
     launch_seg_reduce(wi.FL, g->col_ptr, g->col_eids, wi.SL, nullptr, (int)g->N, 64, s);
@@ -1246,7 +1246,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i];
-    launch_edge_bwd(eb, s);
+    { ProfScope ps(PK_EDGE_BWD, s); launch_edge_bwd(eb, s); }
     launch_seg_reduce_ld(GH, g->col_ptr, g->col_eids, gH, MDX_ND, N, 256, s);
     launch_seg_reduce_ld(tp.GGX, g->col_ptr, g->col_eids, GNT + MDX_NT_GX, MDX_NTW, N, 256, s);
     launch_seg_reduce_ld(tp.GNL0, g->row_ptr, nullptr, GNT + MDX_NT_NLL, MDX_NTW, N, 128, s);

@@ -909,7 +909,12 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float gs = 1.0f;
-  if (gnorm2) gs = fminf(max_norm / (sqrtf(gnorm2[0]) + 1e-6f), 1.0f);
+  if (gnorm2) {
+    // a non-finite gradient norm skips the whole update, like GradScaler / the reference's try-except around the
+    // iteration (scripts/train_drug3d.py:93-119): fminf(NaN, 1) would be 1 and write NaNs into p, m and v for good
+    if (!isfinite(gnorm2[0])) return;
+    gs = fminf(max_norm / (sqrtf(gnorm2[0]) + 1e-6f), 1.0f);
+  }
   const float gi = g[i] * gs;
   float pi = p[i] * (1.0f - lr * wd);
   const float mi = b1 * m[i] + (1.0f - b1) * gi;

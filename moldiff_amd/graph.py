@@ -58,8 +58,9 @@ class NodeBlock(_Block):
         g = net._graph(edge_index, x.shape[0])
         out = torch.empty(x.shape[0], self.node_dim, dtype=torch.float32, device=x.device)
         ws, nb = g.workspace(x.device)
-        _lib.check(_lib.lib().mdx_node_block(eng.h, g.h, self._index, _lib.ptr(_lib.f32c(x)), _lib.ptr(_lib.f32c(edge_attr)),
-                                             _lib.ptr(_lib.f32c(node_time).view(-1)), _lib.ptr(out), ws, nb, _lib.stream()))
+        xc, ec, tc = _lib.f32c(x), _lib.f32c(edge_attr), _lib.f32c(node_time).view(-1)   # alive until the launch
+        _lib.check(_lib.lib().mdx_node_block(eng.h, g.h, self._index, _lib.ptr(xc), _lib.ptr(ec), _lib.ptr(tc), _lib.ptr(out),
+                                             ws, nb, _lib.stream()))
         return out
 
 
@@ -120,8 +121,9 @@ class EdgeBlock(_Block):
         g = net._graph(bond_index, h_node.shape[0])
         out = torch.empty(h_bond.shape[0], self.edge_dim, dtype=torch.float32, device=h_bond.device)
         ws, nb = g.workspace(h_bond.device)
-        _lib.check(_lib.lib().mdx_edge_block(eng.h, g.h, self._index, _lib.ptr(_lib.f32c(h_bond)), _lib.ptr(_lib.f32c(h_node)),
-                                             _lib.ptr(_lib.f32c(bond_time).view(-1)), _lib.ptr(out), ws, nb, _lib.stream()))
+        bc, nc, tc = _lib.f32c(h_bond), _lib.f32c(h_node), _lib.f32c(bond_time).view(-1)   # alive until the launch
+        _lib.check(_lib.lib().mdx_edge_block(eng.h, g.h, self._index, _lib.ptr(bc), _lib.ptr(nc), _lib.ptr(tc), _lib.ptr(out), ws,
+                                             nb, _lib.stream()))
         return out
 
 
@@ -140,9 +142,10 @@ class PosUpdate(_Block):
         g = net._graph(edge_index, h_node.shape[0])
         out = torch.empty(h_node.shape[0], 3, dtype=torch.float32, device=h_node.device)
         ws, nb = g.workspace(h_node.device)
-        _lib.check(_lib.lib().mdx_pos_update(eng.h, g.h, self._index, _lib.ptr(_lib.f32c(h_node)), _lib.ptr(_lib.f32c(h_edge)),
-                                             _lib.ptr(_lib.f32c(relative_vec)), _lib.ptr(_lib.f32c(distance).view(-1)),
-                                             _lib.ptr(_lib.f32c(edge_time).view(-1)), _lib.ptr(out), ws, nb, _lib.stream()))
+        nc, ec, rc = _lib.f32c(h_node), _lib.f32c(h_edge), _lib.f32c(relative_vec)   # alive until the launch
+        dc, tc = _lib.f32c(distance).view(-1), _lib.f32c(edge_time).view(-1)
+        _lib.check(_lib.lib().mdx_pos_update(eng.h, g.h, self._index, _lib.ptr(nc), _lib.ptr(ec), _lib.ptr(rc), _lib.ptr(dc),
+                                             _lib.ptr(tc), _lib.ptr(out), ws, nb, _lib.stream()))
         return out
 
 
@@ -205,13 +208,11 @@ class NodeEdgeNet(Module):
     def _graph(edge_index, n_nodes):
         bn = torch.zeros(n_nodes, dtype=torch.int64)
         key = ('net', edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, n_nodes)
-        g = _lib._graph_cache.get(key)
+        g = _lib._cache_get(key)
         if g is None:
             g = _lib.Graph(edge_index, bn, 1)
             g._keepalive = edge_index
-            if len(_lib._graph_cache) > 8:
-                _lib._graph_cache.clear()
-            _lib._graph_cache[key] = g
+            _lib._cache_put(key, g)
         return g
 
     def forward(self, h_node, pos_node, h_edge, edge_index, node_time, edge_time):
@@ -223,8 +224,8 @@ class NodeEdgeNet(Module):
         po = torch.empty(h_node.shape[0], 3, dtype=torch.float32, device=dev)
         he = torch.empty(h_edge.shape[0], self.edge_dim, dtype=torch.float32, device=dev)
         ws, nb = g.workspace(dev)
-        _lib.check(_lib.lib().mdx_net_forward(eng.h, g.h, _lib.ptr(_lib.f32c(h_node)), _lib.ptr(_lib.f32c(pos_node)),
-                                              _lib.ptr(_lib.f32c(h_edge)), _lib.ptr(_lib.f32c(node_time).view(-1)),
-                                              _lib.ptr(_lib.f32c(edge_time).view(-1)), _lib.ptr(hn), _lib.ptr(po),
-                                              _lib.ptr(he), ws, nb, _lib.stream()))
+        a, b, c = _lib.f32c(h_node), _lib.f32c(pos_node), _lib.f32c(h_edge)   # alive until the launch
+        tn, te = _lib.f32c(node_time).view(-1), _lib.f32c(edge_time).view(-1)
+        _lib.check(_lib.lib().mdx_net_forward(eng.h, g.h, _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(tn), _lib.ptr(te),
+                                              _lib.ptr(hn), _lib.ptr(po), _lib.ptr(he), ws, nb, _lib.stream()))
         return hn, po, he

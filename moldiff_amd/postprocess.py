@@ -67,8 +67,7 @@ class FeaturizeMol(object):
         _lib._need_gpu(pn, pp, ph, batch_node, halfedge_index)
         dev = pn.device
         if graph is None:
-            ei = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
-            graph = _lib.graph_for(ei, batch_node, n_graphs)
+            graph = _lib.graph_for_halfedges(halfedge_index, batch_node, n_graphs)
         N, Eh, B = graph.N, graph.Eh, graph.B
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)

@@ -65,8 +65,7 @@ def main(argv=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    seed_all(config.train.seed + rank)
-    is_bond = config.model.name == 'bond_predictor'
+XX
     if is_bond:
         model = BondPredictor(config.model, 8, 5)
     else:
@@ -78,7 +77,10 @@ def main(argv=None):
     oc = config.train.optimizer
     if oc.type != 'adamw':
         raise NotImplementedError('Optimizer not supported: %s' % oc.type)
+    # ... and Trainer broadcasts rank 0's flat parameter buffer on top of that (sync_replicas), so the replicas agree even if a
+    # module draws its initial values from somewhere else
     trainer = Trainer(model, lr=oc.lr, betas=(oc.beta1, oc.beta2), weight_decay=oc.weight_decay, max_grad_norm=config.train.max_grad_norm)
+    seed_all(config.train.seed + rank)   # from here on: per-rank streams (position perturbation, time steps, noise)
     sc = config.train.scheduler
     if sc.type != 'plateau':
         raise NotImplementedError('Scheduler not supported: %s' % sc.type)

@@ -58,6 +58,16 @@ def allreduce_mean_(flat_grad, group=None):
     return world
 
 
+def broadcast_replicas_(buffers, src=0, group=None):
+    """Make every data-parallel rank hold rank `src`'s copy of the given flat buffers (no-op for a single process)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return 1
+    for buf in buffers:
+        dist.broadcast(buf, src, group=group)
+    return dist.get_world_size(group)
+
+
 class PlateauScheduler:
     """torch.optim.lr_scheduler.ReduceLROnPlateau (mode='min', rel. threshold 1e-4) as host logic on a Trainer's lr
     (utils/train.py get_scheduler 'plateau': factor, patience, min_lr)."""
@@ -95,6 +105,12 @@ class Trainer:
         self.norm2 = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
         self.steps = 0
+        self.sync_replicas()
+
+    def sync_replicas(self, src=0):
+        """Data-parallel replicas must start from ONE set of weights: broadcast rank `src`'s flat parameter buffer (nn.Linear /
+        LayerNorm default initialisation draws from each process's own torch RNG stream) and the optimizer moments."""
+        broadcast_replicas_((self.flat.data, self.m, self.v), src, self.group)
         self._stale()
 
     def _stale(self):
@@ -116,10 +132,12 @@ class Trainer:
         f = self.flat
         _lib.check(L.mdx_op_sumsq(_lib.ptr(f.grad), f.numel, _lib.ptr(self.norm2), _lib.ptr(self.ws), _lib.stream()))
         self.steps += 1
-        clip = self.max_grad_norm is not None
+        # the squared norm always travels to the kernel: it is also the guard that skips the update when the gradient is not
+        # finite (max_norm = inf disables the clipping itself)
+        max_norm = float(self.max_grad_norm) if self.max_grad_norm is not None else float('inf')
         _lib.check(L.mdx_op_adamw(_lib.ptr(f.data), _lib.ptr(f.grad), _lib.ptr(self.m), _lib.ptr(self.v), f.numel, self.lr,
                                   self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
-                                  _lib.ptr(self.norm2) if clip else None, float(self.max_grad_norm or 0.0), _lib.stream()))
+                                  _lib.ptr(self.norm2), max_norm, _lib.stream()))
         self._stale()
         return self.norm2.sqrt()[0]
 

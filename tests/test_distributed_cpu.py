@@ -117,3 +117,40 @@ def test_two_rank_gradient_average_over_the_flat_buffer():
     assert np.array_equal(a0, a1)                                      # every rank ends with the same gradient
     assert np.allclose(a0, 0.5 * (l0 + l1), rtol=1e-6, atol=1e-6)      # ... the mean of the per-rank gradients
     assert off0 == off1 and off0[0] == 0 and all(b > a for a, b in zip(off0, off0[1:]))   # .grad are views, in order
+
+
+def _init_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from moldiff_amd.trainer import FlatParams, broadcast_replicas_
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)              # every rank initialises its nn.Linear / LayerNorm from a DIFFERENT stream
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 2))
+    flat = FlatParams(net)
+    before = flat.data.clone()
+    w = broadcast_replicas_((flat.data,), 0)
+    q.put((rank, w, before.numpy(), flat.data.numpy().copy(), net[0].weight.detach().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank0_weights_even_with_different_init_streams():
+    """without a broadcast, default-initialised replicas differ and the averaged gradient is applied to N
+    different models.  Trainer.sync_replicas = broadcast_replicas_ over the flat parameter buffer."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, w0, b0, a0, lin0), (_, w1, b1, a1, lin1) = res
+    assert w0 == w1 == 2
+    assert np.abs(b0 - b1).max() > 0            # the default initialisations really differed
+    assert np.array_equal(a0, b0)               # rank 0 keeps its weights
+    assert np.array_equal(a1, a0)               # rank 1 now holds them too ...
+    assert np.array_equal(lin1, lin0)           # ... and the module's parameters are views of the synced buffer
