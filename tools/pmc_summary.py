@@ -2,7 +2,7 @@
 
     python tools/pmc_summary.py profiles/r1_c_pmc_summary.json
 
-Three separate rocprofv3 --pmc passes over `bench.py --steps 6 --warmup 2 --no-cpu-baseline` (never combined with a trace
+Three separate rocprofv3 --pmc passes over `bench.py --steps 6 --warmup 2 --headline-only [extra args, e.g. --guided]` (never combined with a trace
 domain), exactly as MI355X_MICROARCH.md prescribes: (1) SQ / GRBM counters, (2) FETCH_SIZE, (3) WRITE_SIZE.  Per-kernel,
 per-launch averages are written as JSON.  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE under-reports wide
 (16 B/lane) coalesced reads by 2x, so hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (checked on the pure streaming
@@ -18,8 +18,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [['SQ_WAVE_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_ANY', 'GRBM_GUI_ACTIVE'], ['FETCH_SIZE'], ['WRITE_SIZE']]
-KERNELS = {'edge_a_kernel': 'edge_a_kernel', 'edge_b_kernel': 'edge_b_kernel', 'node_kernel(': 'node_kernel',
-           'seg_reduce_kernel<256>': 'seg_reduce_kernel<256>'}
+KERNELS = {'edge_a2_kernel': 'edge_a2_kernel', 'edge_b2_kernel': 'edge_b2_kernel', 'edge_a_kernel': 'edge_a_kernel',
+           'edge_b_kernel': 'edge_b_kernel', 'node_kernel(': 'node_kernel', 'seg_reduce_kernel<256>': 'seg_reduce_kernel<256>',
+           'edge_bwd_kernel': 'edge_bwd_kernel'}
 
 
 def main():
@@ -30,7 +31,7 @@ def main():
     for i, ctrs in enumerate(PASSES):
         d = os.path.join(work, f'pass{i}')
         cmd = ['rocprofv3', '--pmc'] + ctrs + ['--output-format', 'csv', '-d', d, '--', sys.executable, os.path.join(ROOT, 'bench.py'),
-                                               '--steps', '6', '--warmup', '2', '--no-cpu-baseline']
+                                               '--steps', '6', '--warmup', '2', '--headline-only'] + sys.argv[2:]
         subprocess.run(cmd, cwd='/tmp', env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
             for row in csv.DictReader(open(f)):
