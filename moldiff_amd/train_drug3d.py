@@ -65,7 +65,8 @@ def main(argv=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-XX
+    seed_all(config.train.seed)      # the SAME seed on every rank while the parameters are created ...
+    is_bond = config.model.name == 'bond_predictor'
     if is_bond:
         model = BondPredictor(config.model, 8, 5)
     else:
