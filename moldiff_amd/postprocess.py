@@ -6,7 +6,7 @@
   (``mdx_decode_output``) arg-maxes, drops mask-type atoms, re-indexes and compacts atoms/bonds for the whole
   packed batch on the device, so only the compact arrays travel.
 * ``seperate_outputs`` / ``seperate_outputs_no_traj`` -- utils/sample.py:4-55 (same spelling as the reference).
-The training-side ``FeaturizeMol.__call__`` (dataset featurisation) is out of scope and raises.
+``FeaturizeMol.__call__`` (training-side featurisation of a processed record) lives in ``moldiff_amd/data.py``.
 """
 import ctypes
 
@@ -33,8 +33,12 @@ class FeaturizeMol(object):
         self.ele_to_nodetype = {ele: i for i, ele in enumerate(atomic_numbers)}
         self.nodetype_to_ele = {i: ele for i, ele in enumerate(atomic_numbers)}
 
+    follow_batch = ['node_type', 'halfedge_type']
+
     def __call__(self, data):
-        raise NotImplementedError('dataset featurisation belongs to the training path (out of scope)')
+        """Training-side featurisation of one processed record (utils/transforms.py:35-62): see ``moldiff_amd.data.featurize``."""
+        from .data import featurize
+        return featurize(data, self)
 
     def decode_output(self, pred_node, pred_pos, pred_halfedge, halfedge_index):
         """One molecule, numpy arrays in, dict out (element, atom_pos, bond_type, bond_index, atom_prob, bond_prob)."""

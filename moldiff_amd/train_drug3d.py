@@ -10,10 +10,11 @@ iteration}`` under ``<logdir>/checkpoints/<it>.pt`` that ``sample_drug3d`` loads
   * forward/backward run on the HIP layer operators, the optimizer on flat buffers (``trainer.Trainer``), fp32 (no AMP);
   * data parallelism is one process per GPU with one gradient all-reduce per step (torch.distributed / RCCL); every rank
     draws its own batches (seed + rank), rank 0 validates, logs and checkpoints;
-  * the GEOM-Drugs pipeline (SDF parsing, RDKit featurisation, LMDB: utils/dataset.py, utils/transforms.py) is CPU
-    chemistry outside this path.  The loader seam is ``batches(it)`` below: anything yielding the seven fields
-    (node_type (N), node_pos (N,3), batch_node (N), halfedge_type (Eh), halfedge_index (2,Eh), batch_halfedge (Eh),
-    num_graphs) of the reference's collated ``Drug3DData`` batch can replace the built-in synthetic generator.
+  * the data side is PyG-free (``moldiff_amd/data.py``): ``dataset: {name: records, path: ...}`` trains on the reference's
+    processed records (the dicts its LMDB stores) through ``FeaturizeMol.__call__`` (random conformer, centroid, half-edge
+    types; utils/transforms.py:35-62) and a collate with ``Drug3DData.__inc__`` offsets + ``follow_batch`` vectors
+    (utils/data.py:25-33); ``synthetic_records`` generates structurally valid records, ``synthetic`` random tensors.  SDF
+    parsing / RDKit / LMDB itself (utils/dataset.py, utils/parser.py) is CPU chemistry outside this path.
 """
 import argparse
 import os
@@ -86,11 +87,32 @@ def main(argv=None):
     if sc.type != 'plateau':
         raise NotImplementedError('Scheduler not supported: %s' % sc.type)
     scheduler = PlateauScheduler(trainer, factor=sc.factor, patience=sc.patience, min_lr=sc.min_lr)
-    if config.dataset.name != 'synthetic':
-        raise NotImplementedError("only `dataset: {name: synthetic}` is built in; plug a loader into batches(it) (module docstring)")
     nbc = 5 if is_bond else 5
-    batches = SyntheticMolecules(config.dataset, config.train.batch_size, config.train.seed + 1000 * rank, device, nbc)
-    val_batches = SyntheticMolecules(config.dataset, config.train.batch_size, config.train.seed + 777, device, nbc)
+    if config.dataset.name == 'synthetic':
+        batches = SyntheticMolecules(config.dataset, config.train.batch_size, config.train.seed + 1000 * rank, device, nbc)
+        val_batches = SyntheticMolecules(config.dataset, config.train.batch_size, config.train.seed + 777, device, nbc)
+    elif config.dataset.name in ('records', 'synthetic_records'):
+        # the reference's processed records (utils/dataset.py) -> FeaturizeMol.__call__ -> collate with __inc__ offsets
+        # (moldiff_amd/data.py); `records`: a torch.save'd list (or {'train': [...], 'val': [...]}) of the LMDB's record dicts
+        from .data import RecordLoader, synthetic_records
+        from .postprocess import FeaturizeMol
+        feat = FeaturizeMol([6, 7, 8, 9, 15, 16, 17], [1, 2, 3, 4], use_mask_node=True, use_mask_edge=True)
+        if config.dataset.name == 'records':
+            recs = torch.load(config.dataset.path, map_location='cpu', weights_only=False)
+        else:
+            recs = synthetic_records(int(config.dataset.get('num_mols', 2048)), config.train.seed)
+        if isinstance(recs, dict):
+            tr_recs, va_recs = recs['train'], recs.get('val', recs['train'][:256])
+        else:
+            n_val = max(1, min(len(recs) // 10, 1024))
+            tr_recs, va_recs = recs[n_val:], recs[:n_val]
+        tl = RecordLoader(tr_recs, feat, config.train.batch_size, seed=config.train.seed + 1000 * rank, device=device)
+        vl = list(RecordLoader(va_recs, feat, config.train.batch_size, seed=config.train.seed + 777, shuffle=False,
+                               device=device).epoch_batches())
+        batches = lambda it: tl(it).loss_args()
+        val_batches = lambda j: vl[j % len(vl)].loss_args()
+    else:
+        raise NotImplementedError("dataset.name must be `synthetic`, `synthetic_records` or `records` (module docstring)")
     ckpt_dir = os.path.join(args.logdir, 'checkpoints')
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)

@@ -486,3 +486,43 @@ def recipe_state_dict(shapes, seed):
             w = np.float32(0.1) * z
         out[k] = torch.from_numpy(w.astype(np.float32))
     return out
+
+
+# --------------------------------------------------------------------------------------
+# data side of the training loop (test infrastructure for moldiff_amd/data.py)
+# --------------------------------------------------------------------------------------
+
+
+def featurize_ref(record, ele_to_nodetype, idx):
+    """FeaturizeMol.__call__ (utils/transforms.py:35-62) with the conformer index passed in; plain loops like the reference."""
+    n = int(record['num_atoms'])
+    node_type = torch.LongTensor([ele_to_nodetype[int(e)] for e in record['element']])
+    pos = torch.as_tensor(record['pos_all_confs'][idx]).float()
+    pos = pos - pos.mean(dim=0)
+    mat = torch.zeros([n, n], dtype=torch.long)
+    for i in range(int(record['num_bonds']) * 2):
+        mat[int(record['bond_index'][0, i]), int(record['bond_index'][1, i])] = int(record['bond_type'][i])
+    hei = torch.triu_indices(n, n, offset=1)
+    het = mat[hei[0], hei[1]]
+    assert (het > 0).sum() == record['num_bonds']
+    return {'node_type': node_type, 'node_pos': pos, 'halfedge_index': hei, 'halfedge_type': het}
+
+
+def collate_ref(mols):
+    """torch_geometric Batch.from_data_list restricted to the keys the training loop reads, with Drug3DData.__inc__
+    (utils/data.py:25-33: '*index' keys are concatenated along the last dim and shifted by the running node count; everything else
+    along dim 0) and follow_batch=['node_type', 'halfedge_type'] (utils/transforms.py:31).  torch_geometric is an un-vendored
+    dependency that is absent here: this restates its documented collate rule one molecule at a time."""
+    out = {k: [] for k in ('node_type', 'node_pos', 'halfedge_type', 'halfedge_index', 'node_type_batch', 'halfedge_type_batch')}
+    inc = 0
+    for i, m in enumerate(mols):
+        out['node_type'].append(m['node_type'])
+        out['node_pos'].append(m['node_pos'])
+        out['halfedge_type'].append(m['halfedge_type'])
+        out['halfedge_index'].append(m['halfedge_index'] + inc)
+        out['node_type_batch'].append(torch.full((len(m['node_type']),), i, dtype=torch.long))
+        out['halfedge_type_batch'].append(torch.full((len(m['halfedge_type']),), i, dtype=torch.long))
+        inc += len(m['node_type'])
+    res = {k: torch.cat(v, dim=-1 if k == 'halfedge_index' else 0) for k, v in out.items()}
+    res['num_graphs'] = len(mols)
+    return res

@@ -103,6 +103,25 @@ def test_train_entry_point_end_to_end(tmp_path):
     assert any(not torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))    # weights moved
 
 
+def test_train_entry_point_on_processed_records(tmp_path):
+    """The PyG-free data side (moldiff_amd/data.py): records -> FeaturizeMol.__call__ -> collate with __inc__ offsets ->
+    get_loss/backward/AdamW, from a torch.save'd record file like an export of the reference's LMDB."""
+    import yaml
+    from moldiff_amd import train_drug3d
+    from moldiff_amd.data import synthetic_records
+    recs = synthetic_records(24, seed=9)
+    torch.save({'train': recs[:20], 'val': recs[20:]}, tmp_path / 'records.pt')
+    cfg = yaml.safe_load(open('configs/train_MolDiff_simple.yml'))
+    cfg['train'].update(batch_size=5, max_iters=3, val_freq=3)
+    cfg['dataset'] = {'name': 'records', 'path': str(tmp_path / 'records.pt')}
+    p = tmp_path / 'cfg.yml'
+    p.write_text(yaml.safe_dump(cfg))
+    assert train_drug3d.main(['--config', str(p), '--device', DEV, '--logdir', str(tmp_path / 'logs'), '--val_batches', '2',
+                              '--recipe-weights']) == 0
+    ck = torch.load(tmp_path / 'logs' / 'checkpoints' / '3.pt', map_location='cpu', weights_only=False)
+    assert ck['iteration'] == 3 and all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
+
+
 def _dp_rank(rank, world, port, q):
     """Two data-parallel ranks sharing the one GPU of the test box (gloo carries the all-reduce; on a real node it is
     RCCL, same code path): different batches per rank, identical parameters on every rank after every step."""

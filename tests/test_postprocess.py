@@ -31,8 +31,10 @@ def _check(info, g, i):
 
 def test_featurizer_attributes():
     assert (FEAT.num_element, FEAT.num_bond_types, FEAT.num_node_types, FEAT.num_edge_types) == (7, 4, 8, 6)
-    with pytest.raises(NotImplementedError):
-        FEAT(None)
+    from moldiff_amd.data import synthetic_records
+    rec = synthetic_records(1, seed=0)[0]
+    out = FEAT(rec)                                   # FeaturizeMol.__call__ of the training path (moldiff_amd/data.py)
+    assert out['node_type'].shape[0] == rec['num_atoms'] and int((out['halfedge_type'] > 0).sum()) == rec['num_bonds']
 
 
 def test_host_separate_and_decode_vs_reference_golden():
