@@ -37,7 +37,13 @@ extern "C" int mdx_debug_set_trace2(void* p, int which) {
 
 namespace {
 
-constexpr int RR = 2;                 // row tiles per wave: 32 edges
+#ifndef MDX_RR
+#define MDX_RR 2
+#endif
+#ifndef MDX_WPS
+#define MDX_WPS 1   // waves per SIMD the row-owner kernels are compiled for
+#endif
+constexpr int RR = MDX_RR;            // row tiles per wave: 32 edges
 constexpr int ROWS = 16 * RR;
 constexpr int PARK_FLOATS = ROWS * MDX_ND;  // per wave
 
@@ -147,7 +153,7 @@ __device__ __forceinline__ void prolog_rows(Prolog& p, const EdgeAArgs& a, int q
 // FLAGS (EA_*) is a template parameter: with run-time section flags every section sits behind a branch and the values that
 // cross it (He', the tile, the weight ring) get spilled around the control flow.
 template <int FLAGS>
-__global__ __launch_bounds__(MDX_WG, 1) void edge_a2_kernel(const EdgeAArgs a, const EdgePlan plan) {
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArgs a, const EdgePlan plan) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
@@ -373,7 +379,7 @@ struct PrologB {
 };
 
 template <int FLAGS>
-__global__ __launch_bounds__(MDX_WG, 1) void edge_b2_kernel(const EdgeBArgs a, const int nunits) {
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArgs a, const int nunits) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
@@ -575,7 +581,7 @@ static void launch_a2(const EdgeAArgs& a, hipStream_t s) {
     attr = true;
   }
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  const int grid = std::min((nunits + 3) / 4, mdx_num_cus());
+  const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
   constexpr bool all = FLAGS == (EA_EMB | EA_NODE | EA_FFN);
   static const bool nosplit = getenv("MDX_NO_TAIL_SPLIT") != nullptr;
   const EdgePlan plan = make_plan(nunits, grid * 4, all && !nosplit);
@@ -595,7 +601,7 @@ void launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
 template <int FLAGS>
 static void launch_b2(const EdgeBArgs& a, hipStream_t s) {
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_b2_kernel<FLAGS>, dim3(std::min((nunits + 3) / 4, mdx_num_cus())), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a,
+  hipLaunchKernelGGL(edge_b2_kernel<FLAGS>, dim3(std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS)), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a,
                      nunits);
 }
 
