@@ -423,7 +423,8 @@ def main():
         return line
 
     head_kind = 'MolDiff' if args.guided else 'MolDiff_simple'
-    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank)
+    hkw = {'overlap_guidance': False} if (args.guided and os.environ.get('MDX_BENCH_NO_OVERLAP')) else {}  # kernel A/B timing
+    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank, **hkw)
     N, E = sm.N, 2 * sm.Eh
     elapsed, prof = run_chain(sm, args.steps, args.warmup, barrier)
     if dist is not None:

@@ -151,6 +151,16 @@ struct PackCtx {
       for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
     pack_dense(slot, Wt, K, Fp, 0, Fp);
   }
+  // transposed stream pack: out[k][f] = W[f][col0 + k] in rgemm consumption order
+  void packTS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    const int Fp = (F + 15) / 16 * 16;
+    std::vector<float> Wt((size_t)K * Fp, 0.f);
+    for (int k = 0; k < K; ++k)
+      for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
+    pack_stream(slot, Wt, K, Fp, 0, Fp);
+  }
   std::map<int, std::vector<float>> wcat_dense;  // block -> dense (960 x 256) concatenated node-table weights
   void vec(const float** slot, const std::string& key, int n, int pad_to = 0) {
     const HostTensor* t = get(key, {n});
@@ -393,6 +403,23 @@ int pack_model(mdx_model_s* m) {
       }
       c.packT(&e.WselfT, eb + ".self_ffn.weight", ED, ED, 0, ED);
       c.packT(&e.WoutT, eb + ".out_transform.weight", ED, ED, 0, ED);
+      // the same transposes as stream packs for the row-owner backward kernel
+      c.packTS(&e.s.WembHT, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, 0, ED);
+      c.packTS(&e.s.WembDT, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, ED, MDX_NG);
+      c.packTS(&e.s.Wg1eT, nb + ".gate.net.0.weight", ND, GIN, 0, ED);
+      c.packTS(&e.s.Wg2T, nb + ".gate.net.3.weight", ND, ND, 0, ND);
+      c.packTS(&e.s.W1T, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
+      c.packTS(&e.s.W2T, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
+      c.packTS(&e.s.WmT, nb + ".msg_net.weight", ND, ND, 0, ND);
+      for (int s = 0; s < 2; ++s) {
+        const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
+        FfnTS& f = e.s.ffn[s];
+        c.packTS(&f.WblT, fp + ".bond_linear.weight", 2 * ED, ED, 0, ED);
+        c.packTS(&f.Wi1T, fp + ".inter_module.net.0.weight", 2 * ED, 2 * ED, 0, 2 * ED);
+        c.packTS(&f.Wi2T, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
+        c.packTS(&f.Wg1eT, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
+        c.packTS(&f.Wg2T, fp + ".gate.net.3.weight", ED, 32, 0, 32);
+      }
       NodeBwdW& n = m->nbw[i];
       c.packT(&n.WoutT, nb + ".out_transform.weight", ND, ND, 0, ND);
       c.packT(&n.W1T, nb + ".node_net.net.0.weight", ND, ND, 0, ND);
@@ -1246,7 +1273,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i];
-    { ProfScope ps(PK_EDGE_BWD, s); launch_edge_bwd(eb, s); }
+    { ProfScope ps(PK_EDGE_BWD, s); if (mdx_use_rowowner()) launch_edge_bwd2(eb, s); else launch_edge_bwd(eb, s); }
     launch_seg_reduce_ld(GH, g->col_ptr, g->col_eids, gH, MDX_ND, N, 256, s);
     launch_seg_reduce_ld(tp.GGX, g->col_ptr, g->col_eids, GNT + MDX_NT_GX, MDX_NTW, N, 256, s);
     launch_seg_reduce_ld(tp.GNL0, g->row_ptr, nullptr, GNT + MDX_NT_NLL, MDX_NTW, N, 128, s);

@@ -8,6 +8,17 @@
 // activations stay in registers from the He tile load to the M / F / He'' / Fe stores.  No LDS tile, no barrier.
 // LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (32 KiB per wave).
 #include "mdx_kernels.h"
+// Kernel A runs 16 rows per wave with two waves per SIMD (measured 4.70 vs 4.97 ms per step against 32 rows x one wave once
+// the weight ring moved to buffer loads: the second wave covers the row-gather waits); kernel B (mdx_edge2b.hip) keeps
+// 32 x 1.  -DMDX_A_RR / -DMDX_A_WPS override.
+#ifndef MDX_A_RR
+#define MDX_A_RR 1
+#define MDX_A_WPS 2
+#endif
+#undef MDX_RR
+#undef MDX_WPS
+#define MDX_RR MDX_A_RR
+#define MDX_WPS MDX_A_WPS
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
 #include <algorithm>
@@ -37,55 +48,7 @@ extern "C" int mdx_debug_set_trace2(void* p, int which) {
 
 namespace {
 
-#ifndef MDX_RR
-#define MDX_RR 2
-#endif
-#ifndef MDX_WPS
-#define MDX_WPS 1   // waves per SIMD the row-owner kernels are compiled for
-#endif
-constexpr int RR = MDX_RR;            // row tiles per wave: 32 edges
-constexpr int ROWS = 16 * RR;
-constexpr int PARK_FLOATS = ROWS * MDX_ND;  // per wave
-
-struct RowTile {
-  int row[RR], li[RR], ri[RR];
-  float tt[RR];
-  bool valid[RR];
-};
-
-__device__ __forceinline__ RowTile load_tile(const int* __restrict__ l, const int* __restrict__ r, const float* __restrict__ te,
-                                             int e0, int E, int c) {
-  RowTile t;
-#pragma unroll
-  for (int rt = 0; rt < RR; ++rt) {
-    const int e = e0 + 16 * rt + c;
-    t.valid[rt] = e < E;
-    t.row[rt] = t.valid[rt] ? e : E - 1;  // clamped: loads stay in bounds, stores are predicated on valid
-    t.li[rt] = l[t.row[rt]];
-    t.ri[rt] = r[t.row[rt]];
-    t.tt[rt] = te[t.row[rt]];
-  }
-  return t;
-}
-
-template <int FT>
-__device__ __forceinline__ void mul_inplace(f32x4 (&y)[FT][RR], const f32x4 (&v)[FT][RR]) {
-#pragma unroll
-  for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-    for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * v[ft][rt];
-}
-
-// Small per-layer vectors (biases, LayerNorm affine parameters, time columns) are copied once per workgroup into LDS: a
-// lone wave per SIMD has nobody to hide the L2 latency of these loads, a ds_read is an order of magnitude closer.
-template <int OFF, int N>
-__device__ __forceinline__ const float* lds_put(float* base, const float* __restrict__ src, int tid) {
-  static_assert(OFF % 4 == 0 && N % 4 == 0 && N <= 4 * MDX_WG, "constant vector layout");
-  if (4 * tid < N) sts4(base + OFF + 4 * tid, ldg4(src + 4 * tid));
-  return base + OFF;
-}
 constexpr int EA_CONST_FLOATS = 96 + 2560 + 2 * 640;
-constexpr int EB_CONST_FLOATS = 4 * 64 + 5 * 32 + 4 * 256;
 
 // Work list of a persistent wave ("slot"): nf full units (a contiguous range), then its share of the last, partial round.
 // When the last round is short and the kernel runs both sections, that round is cut by SECTION instead of by rows (a
@@ -160,13 +123,8 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   const int E = a.E;
   constexpr bool do_emb = FLAGS & EA_EMB, do_node = FLAGS & EA_NODE, do_ffn = FLAGS & EA_FFN;
   f32x4* park = reinterpret_cast<f32x4*>(smem + (size_t)wave * PARK_FLOATS) + lane;
-  // (the asm keeps the address arithmetic of a stream next to its loads: hoisted out of the persistent loop it would pin
-  // hundreds of 64-bit lane addresses in registers)
-  auto W = [&](const float* p) {
-    int z = 0;
-    asm volatile("" : "+s"(z));  // opaque zero: the pointer keeps its global address space, the sum cannot be hoisted
-    return reinterpret_cast<const f32x4*>(p + z) + lane;
-  };
+  const unsigned lane_off = 16u * lane;
+  auto W = [&](const float* p) { return make_ws(p, lane_off); };
 
   // fixed LDS layout (offsets in floats) so every constant address is cbase + immediate
   float* cb = smem + 4 * PARK_FLOATS;
@@ -209,9 +167,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   if (nitems <= 0) return;
 
   // first stream of a unit (the tail of every unit primes it again for the next one)
-  const f32x4* wfirst = do_emb ? W(a.w.s.Wemb) : do_node ? W(a.w.s.Wg1e) : W(a.w.s.ffn[0].Wbl);
+  const float* wfirst = do_emb ? a.w.s.Wemb : do_node ? a.w.s.Wg1e : a.w.s.ffn[0].Wbl;
   WRing ring;
-  ring_prime(ring, wfirst);
+  ring_prime(ring, W(wfirst));
   Prolog pr;
   int mode, mode_next;
   int unit = plan_item(plan, slot, 0, mode);
@@ -246,7 +204,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       }
       row_bias<4, RR>(hep, c_bemb, q);
       STAMP(1);
-      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, inode ? W(a.w.s.Wg1e) : iffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
+      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, W(inode ? a.w.s.Wg1e : iffn ? a.w.s.ffn[0].Wbl : wfirst));
       STAMP(2);
       if (mode & 4) row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
     } else {
@@ -303,7 +261,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       // msg_net, gated
       row_bias<16, RR>(y, c_bm, q);
       STAMP(11);
-      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, iffn ? W(a.w.s.ffn[0].Wbl) : wfirst);
+      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, W(iffn ? a.w.s.ffn[0].Wbl : wfirst));
       STAMP(12);
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft)
@@ -356,7 +314,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         rgemm<8, 4, RR>(o, h, W(ws.W2), ring, W(ws.Wg2));
         STAMP(20 + 10 * s);
         row_bias<4, RR>(g2, f_bg2[s], q);
-        rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, s == 0 ? W(a.w.s.ffn[1].Wbl) : wfirst);
+        rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, W(s == 0 ? a.w.s.ffn[1].Wbl : wfirst));
         STAMP(21 + 10 * s);
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
@@ -370,185 +328,6 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
     STAMP(47);
     unit = unext;
     mode = mode_next;
-  }
-}
-
-struct PrologB {
-  RowTile t;
-  f32x4 he[4][RR];
-};
-
-template <int FLAGS>
-__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArgs a, const int nunits) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q0 = lane >> 4;
-  const int E = a.E;
-  constexpr bool do_edge = FLAGS & EB_EDGE, do_pos = FLAGS & EB_POS;
-  // (the asm keeps the address arithmetic of a stream next to its loads: hoisted out of the persistent loop it would pin
-  // hundreds of 64-bit lane addresses in registers)
-  auto W = [&](const float* p) {
-    int z = 0;
-    asm volatile("" : "+s"(z));  // opaque zero: the pointer keeps its global address space, the sum cannot be hoisted
-    return reinterpret_cast<const f32x4*>(p + z) + lane;
-  };
-
-  float* cb = smem;
-  const float *c_bself = cb, *c_lng = cb + 64, *c_lnb = cb + 128, *c_bout = cb + 192;
-  if (do_edge) {
-    lds_put<0, 64>(cb, a.w.bself, tid); lds_put<64, 64>(cb, a.w.lng, tid); lds_put<128, 64>(cb, a.w.lnb, tid);
-    lds_put<192, 64>(cb, a.w.bout, tid);
-  }
-  const float *c_bg1 = cb + 256, *c_wtg1 = cb + 288, *c_gg = cb + 320, *c_gb = cb + 352, *c_wg2 = cb + 384, *c_bi1 = cb + 416,
-              *c_ig = cb + 672, *c_ib = cb + 928, *c_wi2 = cb + 1184;
-  if (do_pos) {
-    lds_put<256, 32>(cb, a.w.bg1, tid); lds_put<288, 32>(cb, a.w.wtg1, tid); lds_put<320, 32>(cb, a.w.gg, tid);
-    lds_put<352, 32>(cb, a.w.gb, tid); lds_put<384, 32>(cb, a.w.wg2, tid); lds_put<416, 256>(cb, a.w.bi1, tid);
-    lds_put<672, 256>(cb, a.w.ig, tid); lds_put<928, 256>(cb, a.w.ib, tid); lds_put<1184, 256>(cb, a.w.wi2, tid);
-  }
-  __syncthreads();
-
-  const int nslots = gridDim.x * 4;
-  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  const int per = (nunits + nslots - 1) / nslots;
-  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
-  if (ubeg >= uend) return;
-
-  const f32x4* wfirst = do_edge ? W(a.w.s.Wself) : W(a.w.s.Wbl);
-  WRing ring;
-  ring_prime(ring, wfirst);
-  PrologB pr;
-  pr.t = load_tile(a.l, a.r, a.te, ubeg * ROWS, E, c);
-  row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q0);
-
-#pragma unroll 1
-  for (int unit = ubeg; unit < uend; ++unit) {
-    int q = q0;
-    asm volatile("" : "+v"(q));  // see edge_a2_kernel
-    const RowTile t = pr.t;
-    const int unext = min(unit + 1, uend - 1);
-    STAMPB(46);
-    STAMPB(0);
-    f32x4 he[4][RR];  // He' on entry, He'' after the EdgeBlock tail
-#pragma unroll
-    for (int rt = 0; rt < RR; ++rt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) he[g][rt] = pr.he[g][rt];
-
-    // PosUpdate inputs that only depend on the tile's indices: requested first, consumed after the EdgeBlock tail
-    f32x4 aa[4][RR], bb[4][RR];
-    float rx[RR], ry[RR], rz[RR], dd[RR];
-    if (do_pos) {
-      row_gather<4, RR>(aa, a.Lf, t.li, 64, q);
-      row_gather<4, RR>(bb, a.Rf, t.ri, 64, q);
-#pragma unroll
-      for (int rt = 0; rt < RR; ++rt) {
-        if (a.rel_in) {
-          rx[rt] = a.rel_in[3 * (size_t)t.row[rt] + 0]; ry[rt] = a.rel_in[3 * (size_t)t.row[rt] + 1]; rz[rt] = a.rel_in[3 * (size_t)t.row[rt] + 2];
-          dd[rt] = a.dist_in[t.row[rt]];
-        } else {
-          rx[rt] = a.pos[3 * t.li[rt] + 0] - a.pos[3 * t.ri[rt] + 0];
-          ry[rt] = a.pos[3 * t.li[rt] + 1] - a.pos[3 * t.ri[rt] + 1];
-          rz[rt] = a.pos[3 * t.li[rt] + 2] - a.pos[3 * t.ri[rt] + 2];
-          dd[rt] = sqrtf(rx[rt] * rx[rt] + ry[rt] * ry[rt] + rz[rt] * rz[rt]);
-        }
-      }
-    }
-
-    // ---- EdgeBlock tail: He'' = He' + out_transform(relu(LN(SL[l] + SR[r] + nfl[l] + nfr[r] + self_ffn(He')))) ----
-    if (do_edge) {
-      f32x4 u[4][RR], v[4][RR], v2[4][RR], v3[4][RR];
-      row_gather<4, RR>(u, a.SL, t.li, 64, q);
-      row_gather<4, RR>(v, a.SR, t.ri, 64, q);
-      row_gather<4, RR>(v2, a.NT + MDX_NT_NFL, t.li, MDX_NTW, q);
-      row_gather<4, RR>(v3, a.NT + MDX_NT_NFR, t.ri, MDX_NTW, q);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        const f32x4 bs = lds4(c_bself + 16 * ft + 4 * q);
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) u[ft][rt] = (((u[ft][rt] + v[ft][rt]) + v2[ft][rt]) + v3[ft][rt]) + bs;
-      }
-      STAMPB(1);
-      rgemm<4, 4, RR>(u, he, W(a.w.s.Wself), ring, W(a.w.s.Wout));
-      STAMPB(2);
-      row_layernorm<4, RR>(u, c_lng, c_lnb, q);
-      row_bias<4, RR>(v, c_bout, q);
-      STAMPB(3);
-      rgemm<4, 4, RR>(v, u, W(a.w.s.Wout), ring, do_pos ? W(a.w.s.Wbl) : wfirst);
-      STAMPB(4);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) {
-          if (!(FLAGS & EB_DELTA)) v[ft][rt] = v[ft][rt] + he[ft][rt];
-          he[ft][rt] = v[ft][rt];
-        }
-      row_store<4, RR>(he, a.He_out, t.row, t.valid, 64, q);
-    }
-    pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);  // next unit's indices travel under the PosUpdate GEMMs
-
-    // ---- PosUpdate: w = inter((W_bl He'') * (W_nl a)) * sigmoid(gate([He'' | a | t])), a = Lf[l] * Rf[r]; Fe = w rel / d / (d+1) ----
-    if (do_pos) {
-      mul_inplace<4>(aa, bb);
-      f32x4 x[16][RR], h[16][RR], g1[2][RR];
-      // x = (W_bl He'') * (W_nl a): the second product is formed pair by pair in a 2-tile scratch accumulator and multiplied
-      // into x in place, so the two (32 x 256) operands are never both live (128 registers less at the kernel's tightest point)
-      row_zero<16, RR>(x);
-      STAMPB(5);
-      rgemm<4, 16, RR>(x, he, W(a.w.s.Wbl), ring, W(a.w.s.Wnl));
-      STAMPB(6);
-      {
-        const f32x4* wnl = W(a.w.s.Wnl);
-        const f32x4* wg1h = W(a.w.s.Wg1h);
-        static_for<0, 8>([&](auto fc) {
-          constexpr int ftp = decltype(fc)::value;
-          f32x4 tmp[2][RR];
-          row_zero<2, RR>(tmp);
-          rgemm<4, 2, RR>(tmp, aa, wnl + (size_t)ftp * 4 * 2 * 64, ring, ftp < 7 ? wnl + (size_t)(ftp + 1) * 4 * 2 * 64 : wg1h);
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rt = 0; rt < RR; ++rt) x[2 * ftp + j][rt] = x[2 * ftp + j][rt] * tmp[j][rt];
-        });
-      }
-      STAMPB(7);
-      // gate: ((b + t wt) + W_h He'') + W_a a, LN(32), ReLU, 32 -> 1
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
-        const f32x4 b = lds4(c_bg1 + 16 * ft + 4 * q), wt = lds4(c_wtg1 + 16 * ft + 4 * q);
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) g1[ft][rt] = b + splat4(t.tt[rt]) * wt;
-      }
-      rgemm<4, 2, RR>(g1, he, W(a.w.s.Wg1h), ring, W(a.w.s.Wg1a));
-      rgemm<4, 2, RR>(g1, aa, W(a.w.s.Wg1a), ring, W(a.w.s.Wi1));
-      STAMPB(8);
-      row_layernorm<2, RR>(g1, c_gg, c_gb, q);
-      float gate[RR], wd[RR];
-      row_dot<2, RR>(g1, c_wg2, q, gate);
-      row_bias<16, RR>(h, c_bi1, q);
-      STAMPB(9);
-      rgemm<16, 16, RR>(h, x, W(a.w.s.Wi1), ring, wfirst);
-      STAMPB(10);
-      row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);  // next unit's He' rows: their latency hides under the LayerNorm below
-      row_layernorm<16, RR>(h, c_ig, c_ib, q);
-      row_dot<16, RR>(h, c_wi2, q, wd);
-      if (q == 0) {
-#pragma unroll
-        for (int rt = 0; rt < RR; ++rt) {
-          if (!t.valid[rt]) continue;
-          const float w = (wd[rt] + a.w.bi2) * sigmoidf_(gate[rt] + a.w.bg2);
-          const float d = dd[rt], dp = d + 1.0f;
-          float* fe = a.Fe + 3 * (size_t)t.row[rt];
-          fe[0] = w * rx[rt] / d / dp;
-          fe[1] = w * ry[rt] / d / dp;
-          fe[2] = w * rz[rt] / d / dp;
-        }
-      }
-    } else {
-      row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q);
-    }
-    STAMPB(40);
-    STAMPB(47);
   }
 }
 
@@ -595,23 +374,5 @@ void launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
     case EA_NODE: return launch_a2<EA_NODE>(a, s);                                    // NodeBlock.forward
     case EA_FFN: return launch_a2<EA_FFN>(a, s);                                      // EdgeBlock.forward
     default: mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel A: unsupported section flags");
-  }
-}
-
-template <int FLAGS>
-static void launch_b2(const EdgeBArgs& a, hipStream_t s) {
-  const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_b2_kernel<FLAGS>, dim3(std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS)), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a,
-                     nunits);
-}
-
-void launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
-  switch (a.flags) {
-    case EB_EDGE | EB_POS: return launch_b2<EB_EDGE | EB_POS>(a, s);      // MolDiff denoiser
-    case EB_EDGE: return launch_b2<EB_EDGE>(a, s);                        // bond predictor (update_pos = False)
-    case EB_EDGE | EB_DELTA: return launch_b2<EB_EDGE | EB_DELTA>(a, s);  // EdgeBlock.forward
-    case EB_POS: return launch_b2<EB_POS>(a, s);                          // PosUpdate.forward
-    default: mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel B: unsupported section flags");
   }
 }

@@ -153,11 +153,19 @@ struct NodeArgs {
 struct FfnWT {
   const float *WblT, *Wi1T, *Wi2T, *Wg1eT, *Wg2T;
 };
+struct FfnTS {  // stream packs (mdx_row.h) of the transposed BondFFN matrices
+  const float *WblT, *Wi1T, *Wi2T, *Wg1eT, *Wg2T;
+};
+struct EdgeBwdS {
+  const float *WembHT, *WembDT, *Wg1eT, *Wg2T, *W1T, *W2T, *WmT;
+  FfnTS ffn[2];
+};
 struct EdgeBwdW {  // transposed packs (contraction over the forward's output features)
   const float *WembHT, *WembDT;                 // edge_embs^T: -> 64 (He part), -> 16 (distance part)
   const float *Wg1eT, *Wg2T, *W1T, *W2T, *WmT;  // NodeBlock gate / edge_net / msg_net
   FfnWT ffn[2];
   const float *WselfT, *WoutT;                  // EdgeBlock tail
+  EdgeBwdS s;                                   // row-owner kernel (mdx_bwd2.hip)
 };
 struct NodeBwdW {
   const float* WoutT;      // NodeBlock out_transform^T
@@ -225,6 +233,7 @@ struct BondDecArgs {
 
 void launch_edge_tail_bwd(const EdgeTailBwdArgs& a, hipStream_t s);
 void launch_edge_bwd(const EdgeBwdArgs& a, hipStream_t s);
+void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s);  // row-owner version (mdx_bwd2.hip)
 void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
 void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s);
 // generalized segment sum: C in {32,64,128,256}; out row stride out_ld (floats), column offset already applied to `out`

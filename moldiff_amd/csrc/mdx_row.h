@@ -35,13 +35,30 @@ struct WRing {
   f32x4 a[MDX_RING][2];
 };
 
-// first MDX_RING steps of a stream (w already carries the +lane offset; every stream pack ends in MDX_RING_PAD zero steps,
-// so priming a stream shorter than the ring stays in bounds)
-__device__ __forceinline__ void ring_prime(WRing& r, const f32x4* __restrict__ w) {
+// A weight stream as the ring sees it: a buffer resource (4 scalar registers: base, no stride, unbounded, raw dword format)
+// plus the lane's byte offset.  buffer_load takes the fragment offset as a scalar/immediate operand, so walking a stream costs
+// no vector ALU work and no 64-bit per-lane address -- with global_load every 4 KiB of stream needed a v_add_co/v_addc pair
+// (VALU does not overlap the f32 MFMAs on this core) and hoisted lane addresses were the main source of register spills.
+struct WS {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned off;
+};
+__device__ __forceinline__ WS make_ws(const float* p, unsigned lane_off) {
+  asm volatile("" : "+s"(p));  // per use: two scalar registers now instead of a hoisted descriptor per stream for the whole loop
+  return WS{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, -1, 0x00020000), lane_off};
+}
+// fragment `frag` (64 lanes x 16 bytes) of a stream pack
+__device__ __forceinline__ f32x4 ws_frag(const WS& w, int frag) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.r, w.off, frag * 1024, 0));
+}
+
+// first MDX_RING steps of a stream (every stream pack ends in MDX_RING_PAD zero steps, so priming a stream shorter than the
+// ring stays in bounds)
+__device__ __forceinline__ void ring_prime(WRing& r, const WS& w) {
 #pragma unroll
   for (int p = 0; p < MDX_RING; ++p) {
-    r.a[p][0] = w[(size_t)(2 * p) * 64];
-    r.a[p][1] = w[(size_t)(2 * p + 1) * 64];
+    r.a[p][0] = ws_frag(w, 2 * p);
+    r.a[p][1] = ws_frag(w, 2 * p + 1);
   }
 }
 
@@ -66,13 +83,13 @@ struct NoHook {
 };
 
 // y[ft][rt] += sum_g W(ft, g) x[g][rt]      (FT even; `ring` must hold the first MDX_RING steps of this stream)
-//   wnext : stream of the NEXT GEMM this wave will run (or nullptr): its first steps are requested a few steps before this
+//   wnext : stream of the NEXT GEMM this wave will run (never null -- a null test is a branch per GEMM): its first steps are requested a few steps before this
 //           GEMM ends and are in `ring` on return, so the L2 latency of a layer's first fragments never sits between layers
 //   hook(integral_constant<int, p>) runs in the load slot of step p (before its MFMAs): the caller's place for row gathers
 //           and other prefetches that should travel under this GEMM
 template <int KG, int FT, int R, class Hook = NoHook>
-__device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R], const f32x4* __restrict__ w, WRing& ring,
-                                      const f32x4* __restrict__ wnext = nullptr, Hook&& hook = Hook{}) {
+__device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R], const WS& w, WRing& ring, const WS& wnext,
+                                      Hook&& hook = Hook{}) {
   static_assert(FT % 2 == 0, "feature tiles come in pairs");
   constexpr int NP = (FT / 2) * KG;
   constexpr int PRIME_AT = NP > 3 ? NP - 3 : 0;
@@ -82,11 +99,10 @@ __device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R]
     constexpr int ftp = p / KG, g = p % KG;
     const f32x4 a0 = ring.a[p % MDX_RING][0], a1 = ring.a[p % MDX_RING][1];
     if constexpr (p + MDX_RING < NP) {
-      ring.a[p % MDX_RING][0] = w[(size_t)(2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING)) * 64];
-      ring.a[p % MDX_RING][1] = w[(size_t)(2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING) + 1) * 64];
+      ring.a[p % MDX_RING][0] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING));
+      ring.a[p % MDX_RING][1] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING) + 1);
     }
-    if constexpr (p == PRIME_AT)
-      if (wnext) ring_prime(nx, wnext);
+    if constexpr (p == PRIME_AT) ring_prime(nx, wnext);
     hook(pc);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -98,7 +114,7 @@ __device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R]
       }
     __builtin_amdgcn_sched_barrier(0);
   });
-  if (wnext) ring = nx;
+  ring = nx;
 }
 
 // y[ft][rt] = v[16 ft + 4 q ..]   (v: LDS or global, never null -- a null test here becomes one branch per feature tile)
@@ -179,6 +195,75 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&y)[FT][R], const float* __
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- backward building blocks (guidance gradient), row-local versions of mdx_tile.h's ln_xhat / ln_apply_relu / ln_relu_bwd ----
+// x (pre-LayerNorm) -> x_hat in place, rstd per row tile
+template <int FT, int R>
+__device__ __forceinline__ void row_ln_xhat(f32x4 (&x)[FT][R], float (&rstd)[R]) {
+  constexpr float inv_n = 1.0f / (float)(FT * 16);
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) {
+    float s = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) s += (x[ft][rt][0] + x[ft][rt][1]) + (x[ft][rt][2] + x[ft][rt][3]);
+    const float mean = red_q(s) * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      x[ft][rt] = x[ft][rt] - splat4(mean);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d2 = fmaf(x[ft][rt][r], x[ft][rt][r], d2);
+    }
+    rstd[rt] = 1.0f / sqrtf(red_q(d2) * inv_n + MDX_LN_EPS);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) x[ft][rt] = x[ft][rt] * splat4(rstd[rt]);
+  }
+}
+
+// y = relu(x_hat * gamma + beta)
+template <int FT, int R>
+__device__ __forceinline__ void row_ln_apply_relu(f32x4 (&y)[FT][R], const f32x4 (&xhat)[FT][R], const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int q) {
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    const f32x4 gm = ldg4(gamma + 16 * ft + 4 * q), bt = ldg4(beta + 16 * ft + 4 * q);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) y[ft][rt] = relu4(xhat[ft][rt] * gm + bt);
+  }
+}
+
+// g = dL/d relu(LN(x)) -> dL/dx in place:  gh = g * [x_hat gamma + beta > 0] * gamma ;  dx = rstd (gh - mean(gh) - x_hat mean(gh x_hat))
+template <int FT, int R>
+__device__ __forceinline__ void row_ln_relu_bwd(f32x4 (&g)[FT][R], const f32x4 (&xhat)[FT][R], const float (&rstd)[R],
+                                                const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
+  constexpr float inv_n = 1.0f / (float)(FT * 16);
+  float s1[R], s2[R];
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) s1[rt] = s2[rt] = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    if (ft % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+    const f32x4 gm = ldg4(gamma + 16 * ft + 4 * q), bt = ldg4(beta + 16 * ft + 4 * q);
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      const f32x4 y = xhat[ft][rt] * gm + bt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gh = (y[r] > 0.f) ? g[ft][rt][r] * gm[r] : 0.f;
+        g[ft][rt][r] = gh;
+        s1[rt] += gh;
+        s2[rt] = fmaf(gh, xhat[ft][rt][r], s2[rt]);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int rt = 0; rt < R; ++rt) {
+    const float m1 = red_q(s1[rt]) * inv_n, m2 = red_q(s2[rt]) * inv_n;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) g[ft][rt] = (g[ft][rt] - splat4(m1) - xhat[ft][rt] * splat4(m2)) * splat4(rstd[rt]);
+  }
+}
+
 // sum_f w[f] * y[row][f] over the FT*16 features of each row -> one scalar per row tile (all four q lanes get it)
 template <int FT, int R>
 __device__ __forceinline__ void row_dot(const f32x4 (&y)[FT][R], const float* __restrict__ w, int q, float (&out)[R]) {
@@ -195,4 +280,53 @@ __device__ __forceinline__ void row_dot(const f32x4 (&y)[FT][R], const float* __
   }
 #pragma unroll
   for (int rt = 0; rt < R; ++rt) out[rt] = red_q(s[rt]);
+}
+
+// ---- shared by the row-owner kernels (mdx_edge2.hip, mdx_bwd2.hip): tile shape, row indices, LDS constants ----
+#ifndef MDX_RR
+#define MDX_RR 2
+#endif
+#ifndef MDX_WPS
+#define MDX_WPS 1   // waves per SIMD the row-owner kernels are compiled for
+#endif
+constexpr int RR = MDX_RR;            // row tiles per wave: 32 edges
+constexpr int ROWS = 16 * RR;
+constexpr int PARK_FLOATS = ROWS * MDX_ND;  // per wave
+
+struct RowTile {
+  int row[RR], li[RR], ri[RR];
+  float tt[RR];
+  bool valid[RR];
+};
+
+__device__ __forceinline__ RowTile load_tile(const int* __restrict__ l, const int* __restrict__ r, const float* __restrict__ te,
+                                             int e0, int E, int c) {
+  RowTile t;
+#pragma unroll
+  for (int rt = 0; rt < RR; ++rt) {
+    const int e = e0 + 16 * rt + c;
+    t.valid[rt] = e < E;
+    t.row[rt] = t.valid[rt] ? e : E - 1;  // clamped: loads stay in bounds, stores are predicated on valid
+    t.li[rt] = l[t.row[rt]];
+    t.ri[rt] = r[t.row[rt]];
+    t.tt[rt] = te[t.row[rt]];
+  }
+  return t;
+}
+
+template <int FT>
+__device__ __forceinline__ void mul_inplace(f32x4 (&y)[FT][RR], const f32x4 (&v)[FT][RR]) {
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * v[ft][rt];
+}
+
+// Small per-layer vectors (biases, LayerNorm affine parameters, time columns) are copied once per workgroup into LDS: a
+// lone wave per SIMD has nobody to hide the L2 latency of these loads, a ds_read is an order of magnitude closer.
+template <int OFF, int N>
+__device__ __forceinline__ const float* lds_put(float* base, const float* __restrict__ src, int tid) {
+  static_assert(OFF % 4 == 0 && N % 4 == 0 && N <= 4 * MDX_WG, "constant vector layout");
+  if (4 * tid < N) sts4(base + OFF + 4 * tid, ldg4(src + 4 * tid));
+  return base + OFF;
 }

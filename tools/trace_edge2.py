@@ -40,8 +40,45 @@ for s in (0, 1):
              (f'ffn{s}: sigmoid + store', 21 + o, 22 + o, 0)]
 
 
+PH_W = [('tile + SG, M, dL/daggr[l] loads + park', 0, 1, 0), ('msg^T GEMM 256->256', 1, 2, 2 * 256 * 256),
+        ('HE load, GH store, H[r] gather, He gather', 2, 3, 0), ('en W2^T GEMM 256->256', 3, 4, 2 * 256 * 256),
+        ('en W1 recompute 64->256', 4, 5, 2 * 64 * 256), ('LN backward 256', 5, 6, 0), ('en W1^T GEMM 256->64', 6, 7, 2 * 256 * 64),
+        ('unpark', 7, 8, 0), ('gate W2^T GEMM 256->256', 8, 9, 2 * 256 * 256), ('gx[r] gather + bias', 9, 10, 0),
+        ('gate W1 recompute 64->256', 10, 11, 2 * 64 * 256), ('LN backward 256 + GGX store', 11, 12, 0),
+        ('gate W1^T GEMM 256->64', 12, 13, 2 * 256 * 64),
+        ('ffn0 recompute', 13, 14, 2 * (64 * 128 + 128 * 128 + 128 * 64 + 64 * 32 + 32 * 64)),
+        ('ffn0 backward inter', 14, 15, 2 * (64 * 128 + 128 * 128 + 128 * 64)), ('ffn0 backward gate', 15, 21, 2 * (64 * 32 + 32 * 64)),
+        ('ffn1 recompute', 21, 17, 2 * (64 * 128 + 128 * 128 + 128 * 64 + 64 * 32 + 32 * 64)),
+        ('ffn1 backward inter', 17, 18, 2 * (64 * 128 + 128 * 128 + 128 * 64)), ('ffn1 backward gate', 18, 20, 2 * (64 * 32 + 32 * 64)),
+        ('emb backward + gdist', 20, 40, 2 * (64 * 64 + 64 * 32))]
+
+
+def main_bwd():
+    dev = torch.device('cuda:0')
+    model, ph, sizes = bench.build_workload(256, 0, dev, 'MolDiff')
+    model = model.to(dev)
+    L = _lib.lib()
+    sm = model.sampler(256, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023, return_traj=False,
+                       bond_predictor=bench.build_bond_predictor().to(dev), guidance=['uncertainty', 1e-4], overlap_guidance=False)
+    sm.init()
+    for i in range(3):
+        sm.step(i)
+    torch.cuda.synchronize()
+    E = 2 * ph['halfedge_index'].shape[1]
+    rows = int(os.environ.get('MDX_BWD_ROWS', 16))
+    nunits = (E + rows - 1) // rows
+    buf = torch.zeros(nunits * 48, dtype=torch.int64, device=dev)
+    assert L.mdx_debug_set_trace_bwd(ctypes.c_void_p(buf.data_ptr())) == 0
+    sm.step(3)
+    torch.cuda.synchronize()
+    L.mdx_debug_set_trace_bwd(ctypes.c_void_p(0))
+    report('bwd', buf, nunits, PH_W, 40, rows)
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else 'a'
+    if which == 'w':
+        return main_bwd()
     phases, last = (PH_A, 40) if which == 'a' else (PH_B, 40)
     dev = torch.device('cuda:0')
     model, ph, sizes = bench.build_workload(256, 0, dev)
@@ -53,12 +90,18 @@ def main():
         sm.step(i)
     torch.cuda.synchronize()
     E = 2 * ph['halfedge_index'].shape[1]
-    nunits = (E + ROWS - 1) // ROWS
+    rows = int(os.environ.get('MDX_ROWS', 16 if which == 'a' else 32))   # rows per wave the kernel was built with
+    nunits = (E + rows - 1) // rows
     buf = torch.zeros(nunits * 48, dtype=torch.int64, device=dev)
-    assert L.mdx_debug_set_trace2(ctypes.c_void_p(buf.data_ptr()), 0 if which == 'a' else 1) == 0
+    setter = (lambda p: L.mdx_debug_set_trace2(p, 0)) if which == 'a' else L.mdx_debug_set_trace2b
+    assert setter(ctypes.c_void_p(buf.data_ptr())) == 0
     sm.step(3)
     torch.cuda.synchronize()
-    L.mdx_debug_set_trace2(ctypes.c_void_p(0), 0)
+    setter(ctypes.c_void_p(0))
+    report(which, buf, nunits, phases, last, rows)
+
+
+def report(which, buf, nunits, phases, last, ROWS=ROWS):
     tr = buf.cpu().numpy().reshape(nunits, 48).astype(np.int64)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     np.save(os.path.join(ROOT, 'gpurun_out', f'trace_edge2_{which}.npy'), tr)
