@@ -8,17 +8,6 @@
 // B-operand layout of the next GEMM), LayerNorm forward/backward reductions are wave-local, transposed weights stream
 // L2 -> registers through the ring of mdx_row.h.  No barrier after the constant prologue.
 #include "mdx_kernels.h"
-// This kernel is built with 16 rows per wave and two waves per SIMD (the forward kernels: 32 rows, one wave): a third of its
-// unit is tape and gradient-table traffic (three (E,256) reads, two (E,256) writes, four row gathers) that a lone wave would
-// sit through, and at 16 rows everything fits 256 registers without spills.  Measured 9.8 vs 11.2 ms per guided step.
-#ifndef MDX_BWD_RR
-#define MDX_BWD_RR 1
-#define MDX_BWD_WPS 2
-#endif
-#undef MDX_RR
-#undef MDX_WPS
-#define MDX_RR MDX_BWD_RR
-#define MDX_WPS MDX_BWD_WPS
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
 #include <algorithm>

@@ -8,17 +8,6 @@
 // activations stay in registers from the He tile load to the M / F / He'' / Fe stores.  No LDS tile, no barrier.
 // LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (32 KiB per wave).
 #include "mdx_kernels.h"
-// Kernel A runs 16 rows per wave with two waves per SIMD (measured 4.70 vs 4.97 ms per step against 32 rows x one wave once
-// the weight ring moved to buffer loads: the second wave covers the row-gather waits); kernel B (mdx_edge2b.hip) keeps
-// 32 x 1.  -DMDX_A_RR / -DMDX_A_WPS override.
-#ifndef MDX_A_RR
-#define MDX_A_RR 1
-#define MDX_A_WPS 2
-#endif
-#undef MDX_RR
-#undef MDX_WPS
-#define MDX_RR MDX_A_RR
-#define MDX_WPS MDX_A_WPS
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
 #include <algorithm>

@@ -1,6 +1,5 @@
 // Row-owner edge kernel B of one NodeEdgeNet block (gfx950): EdgeBlock tail + PosUpdate
-// (reference models/graph.py:286-294 and :384-393).  Design notes: mdx_edge2.hip / mdx_row.h.  This kernel keeps 32 rows per
-// wave and one wave per SIMD (2.05 vs 2.31 ms per step against 16 rows x two waves).
+// (reference models/graph.py:286-294 and :384-393).  Design notes: mdx_edge2.hip / mdx_row.h.
 #include "mdx_kernels.h"
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
@@ -138,24 +137,24 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArg
     if (do_pos) {
       mul_inplace<4>(aa, bb);
       f32x4 x[16][RR], h[16][RR], g1[2][RR];
-      // x = (W_bl He'') * (W_nl a): the second product is formed pair by pair in a 2-tile scratch accumulator and multiplied
-      // into x in place, so the two (32 x 256) operands are never both live (128 registers less at the kernel's tightest point)
-      row_zero<16, RR>(x);
+      // x = (W_bl He'') * (W_nl a), formed one pair of feature tiles at a time from the two streams alternately, so the two
+      // (rows x 256) products are never both live.  (Written as one 64->256 GEMM followed by pairwise 64->32 GEMMs the compiler
+      // sinks each pair's W_bl MFMAs down to their use -- same schedule, but with the weight ring loaded in the old order and
+      // spilled; stated explicitly, the ring order is the execution order.)
       STAMPB(5);
-      rgemm<4, 16, RR>(x, he, W(a.w.s.Wbl), ring, W(a.w.s.Wnl));
+      static_for<0, 8>([&](auto fc) {
+        constexpr int ftp = decltype(fc)::value;
+        f32x4 xb[2][RR], xn[2][RR];
+        row_zero<2, RR>(xb);
+        rgemm<4, 2, RR>(xb, he, W(a.w.s.Wbl + ftp * 2048), ring, W(a.w.s.Wnl + ftp * 2048));
+        row_zero<2, RR>(xn);
+        rgemm<4, 2, RR>(xn, aa, W(a.w.s.Wnl + ftp * 2048), ring, W(ftp < 7 ? a.w.s.Wbl + (ftp + 1) * 2048 : a.w.s.Wg1h));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rt = 0; rt < RR; ++rt) x[2 * ftp + j][rt] = xb[j][rt] * xn[j][rt];
+      });
       STAMPB(6);
-      {
-        static_for<0, 8>([&](auto fc) {
-          constexpr int ftp = decltype(fc)::value;
-          f32x4 tmp[2][RR];
-          row_zero<2, RR>(tmp);
-          rgemm<4, 2, RR>(tmp, aa, W(a.w.s.Wnl + ftp * 2048), ring, W(ftp < 7 ? a.w.s.Wnl + (ftp + 1) * 2048 : a.w.s.Wg1h));
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rt = 0; rt < RR; ++rt) x[2 * ftp + j][rt] = x[2 * ftp + j][rt] * tmp[j][rt];
-        });
-      }
       STAMPB(7);
       // gate: ((b + t wt) + W_h He'') + W_a a, LN(32), ReLU, 32 -> 1
 #pragma unroll

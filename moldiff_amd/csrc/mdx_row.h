@@ -115,6 +115,13 @@ __device__ __forceinline__ void rgemm(f32x4 (&y)[FT][R], const f32x4 (&x)[KG][R]
     __builtin_amdgcn_sched_barrier(0);
   });
   ring = nx;
+  // The results are pinned here: MFMA builtins are pure, and when an accumulator's next use is far away (a pairwise product,
+  // a running sum consumed sections later) LLVM's code sinking moves its whole MFMA chain down to that use -- across
+  // sched_barriers, which only bind the machine scheduler -- while the ring loads stay put: fragments then wait in scratch.
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) asm volatile("" : "+v"(y[ft][rt]));
 }
 
 // y[ft][rt] = v[16 ft + 4 q ..]   (v: LDS or global, never null -- a null test here becomes one branch per feature tile)
@@ -283,13 +290,16 @@ __device__ __forceinline__ void row_dot(const f32x4 (&y)[FT][R], const float* __
 }
 
 // ---- shared by the row-owner kernels (mdx_edge2.hip, mdx_bwd2.hip): tile shape, row indices, LDS constants ----
+// Rows per wave and waves per SIMD are build parameters of each kernel file.  Measured on the bench workload (ms per step,
+// kernel A / kernel B / backward): 32 rows x 1 wave  4.97 / 1.82 / 11.1;  16 rows x 2 waves  4.66 / 1.78 / 9.5 -- the second
+// wave covers the gather, store and LayerNorm phases of the first, and at 16 rows every kernel fits 256 registers.
 #ifndef MDX_RR
-#define MDX_RR 2
+#define MDX_RR 1
 #endif
 #ifndef MDX_WPS
-#define MDX_WPS 1   // waves per SIMD the row-owner kernels are compiled for
+#define MDX_WPS 2   // waves per SIMD the row-owner kernels are compiled for
 #endif
-constexpr int RR = MDX_RR;            // row tiles per wave: 32 edges
+constexpr int RR = MDX_RR;            // row tiles per wave: 16 * RR edges
 constexpr int ROWS = 16 * RR;
 constexpr int PARK_FLOATS = ROWS * MDX_ND;  // per wave
 
