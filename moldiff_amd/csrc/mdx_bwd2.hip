@@ -8,6 +8,9 @@
 // B-operand layout of the next GEMM), LayerNorm forward/backward reductions are wave-local, transposed weights stream
 // L2 -> registers through the ring of mdx_row.h.  No barrier after the constant prologue.
 #include "mdx_kernels.h"
+#ifndef MDX_RING
+#define MDX_RING 3  // weight-ring depth in steps (9.41 / 9.25 / 9.31 ms per guided step at depth 2 / 3 / 4 (4 spills))
+#endif
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
 #include <algorithm>

@@ -8,6 +8,9 @@
 // activations stay in registers from the He tile load to the M / F / He'' / Fe stores.  No LDS tile, no barrier.
 // LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (32 KiB per wave).
 #include "mdx_kernels.h"
+#ifndef MDX_RING
+#define MDX_RING 4  // weight-ring depth in steps (kernel A: 4.65 / 4.58 / 4.56 ms per step at depth 2 / 3 / 4)
+#endif
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
 #include <algorithm>

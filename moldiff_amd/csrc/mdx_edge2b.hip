@@ -1,6 +1,9 @@
 // Row-owner edge kernel B of one NodeEdgeNet block (gfx950): EdgeBlock tail + PosUpdate
 // (reference models/graph.py:286-294 and :384-393).  Design notes: mdx_edge2.hip / mdx_row.h.
 #include "mdx_kernels.h"
+#ifndef MDX_RING
+#define MDX_RING 4  // weight-ring depth in steps (kernel B: 1.743 / 1.727 / 1.723 ms per step at depth 2 / 3 / 4)
+#endif
 #include "mdx_row.h"
 #include "../../include/moldiff_hip.h"
 #include <algorithm>

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBV = os.environ.get('MDX_LIB_VARIANT')   # e.g. moldiff_amd/libmoldiff_hip_ring4.so -> run through tools/bench_with_lib.py
 CTRS = ['SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_VMEM', 'SQ_ACTIVE_INST_LDS',
         'SQ_VALU_MFMA_COEXEC_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES']
-KERNELS = ['edge_a2_kernel', 'edge_b2_kernel', 'edge_bwd_kernel', 'node_kernel(']
+KERNELS = ['edge_a2_kernel', 'edge_b2_kernel', 'edge_bwd2_kernel', 'edge_bwd_kernel', 'node_kernel(']
 work = tempfile.mkdtemp(dir='/tmp')
 cmd = ['rocprofv3', '--pmc'] + CTRS + ['--output-format', 'csv', '-d', work, '--', sys.executable] + ([os.path.join(ROOT, 'tools', 'bench_with_lib.py'), os.path.join(ROOT, LIBV)] if LIBV else [os.path.join(ROOT, 'bench.py')]) + [
                                        '--steps', '6', '--warmup', '2', '--headline-only'] + sys.argv[2:]
