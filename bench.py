@@ -41,8 +41,10 @@ sys.path.insert(0, ROOT)
 
 T_STEPS = 1000
 FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIGN.md / SURVEY Appendix D)
+FLOP_EDGE_B = 221184        # edge kernel B (EdgeBlock tail + PosUpdate): 2 * (2*64*64 + 2*64*256 + 2*64*32 + 256*256)
 FLOP_EDGE_BWD = 829440      # per directed edge per launch of the guidance backward's edge kernel
-EDGE_A_NAME = 'edge_a2_kernel (row-owner fused per-edge MLP chain, v_mfma_f32_16x16x4_f32)'
+EDGE_A_NAME = 'edge_a2_kernel (row-owner fused per-edge MLP chain, 16 rows x 2 waves per SIMD, v_mfma_f32_16x16x4_f32)'
+EDGE_B_NAME = 'edge_b2_kernel (row-owner EdgeBlock tail + PosUpdate, v_mfma_f32_16x16x4_f32)'
 REFERENCE_CPU_MOL_S = 0.097  # the REAL reference on 8 CPU cores, config #2 (2.64 s/step at 256 molecules)
 PEAK_FP32_MFMA = 157.3      # TFLOP/s (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0           # GB/s
@@ -444,6 +446,7 @@ def main():
             'config': {'workload': head['workload'], 'molecules_per_gpu': args.batch, 'num_timesteps': T_STEPS,
                        'parallelism': f'independent streams x{world}', 'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
             'roofline': roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, E, prof),
+            'roofline_edge_b': roofline_mfma('edge_b', EDGE_B_NAME, FLOP_EDGE_B, E, prof),
             'aggregation': aggregation_line(N, E, prof),
             'kernel_ms_per_step': head['kernel_ms_per_step'],
         }
@@ -484,7 +487,7 @@ def main():
             el3, prof3 = run_chain(sm3, 20, 3, barrier)
             ra = roofline_mfma('edge_a', EDGE_A_NAME + ' (14 launches per guided step: 6 denoiser + 8 predictor blocks)', FLOP_EDGE_A,
                                2 * sm3.Eh, prof3)
-            rb = roofline_mfma('edge_bwd', 'edge_bwd_kernel (guidance backward: residual recompute + dgrad chain, '
+            rb = roofline_mfma('edge_bwd', 'edge_bwd2_kernel (row-owner guidance backward: residual recompute + dgrad chain, '
                                'v_mfma_f32_16x16x4_f32)', FLOP_EDGE_BWD, 2 * sm3.Eh, prof3)
             tot_a, tot_b = prof3['edge_a'][1], prof3['edge_bwd'][1]
             line2['roofline'] = dict(ra if tot_a >= tot_b else rb,
