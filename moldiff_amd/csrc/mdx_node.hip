@@ -8,6 +8,10 @@
 //                  call sites graph.py:50,279,283,394): one wave-slice per node, sequential in CSR order.
 //   embed/decode : MolDiff.forward / BondPredictor.forward ends (model.py:210-213,225-228; bond_predictor.py:135-140)
 #include "mdx_kernels.h"
+#ifndef MDX_TILE_RING
+#define MDX_TILE_RING 4  // weight groups in flight per wave (node kernel at 256 molecules: 0.495 -> 0.444 ms per step against the two-stage
+                         // loop; cutting the per-tile chain over three workgroups or 32-node tiles on top of it: no further gain)
+#endif
 #include "mdx_tile.h"
 
 namespace {

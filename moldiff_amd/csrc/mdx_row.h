@@ -16,15 +16,6 @@
 #include <type_traits>
 #include "mdx_tile.h"
 
-// compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- guarantees static register-array indices
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-
 #ifndef MDX_ABL
 #define MDX_ABL 0  // timing-only ablations (wrong results): 1 no stores, 2 no row gathers, 4 weight stream served from L1
 #endif

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -65,6 +66,68 @@ __device__ __forceinline__ void load_w0(f32x4 (&a)[FTW], const float* __restrict
   for (int ft = 0; ft < FTW; ++ft) a[ft] = wp[(size_t)ft * 64];
 }
 
+// compile-time loop: f(std::integral_constant<int, i>) for i in [B, E) -- guarantees static register-array indices
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+#if defined(MDX_TILE_RING) && MDX_TILE_RING > 2
+// Ring variant of gemm_tile_impl (the kernels that run with fewer than two workgroups per CU, e.g. the node kernel at 256
+// molecules): MDX_TILE_RING - 1 weight groups in flight instead of one, fetched with buffer loads (scalar base and group offset,
+// one VGPR of lane offset), fully unrolled.  Same arithmetic and the same order of accumulation as the two-stage loop below.
+template <int FTW, int ET, int K, bool PRE>
+__device__ __forceinline__ void gemm_tile_impl(f32x4 (&acc)[FTW][ET], f32x4 (&a0)[FTW], const float* __restrict__ Wp, int FT,
+                                               int ft0, const float* X, int ldx, int lane) {
+  static_assert(K % 16 == 0, "K must be a multiple of 16");
+  constexpr int G = K / 16, D = MDX_TILE_RING;
+  const int c = lane & 15, q = lane >> 4;
+  const float* xb = X + c * ldx + 4 * q;
+  const float* base = Wp + (size_t)__builtin_amdgcn_readfirstlane(ft0) * 256;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000);
+  const unsigned off = 16u * lane;
+  const int gs = __builtin_amdgcn_readfirstlane(FT) * 1024;  // bytes between consecutive k-groups
+  f32x4 a[D][FTW], b[2][ET];
+  auto load_a = [&](f32x4(&dst)[FTW], int g) {
+#pragma unroll
+    for (int ft = 0; ft < FTW; ++ft)
+      dst[ft] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, g * gs + ft * 1024, 0));
+  };
+  auto load_b = [&](f32x4(&dst)[ET], int g) {
+#pragma unroll
+    for (int et = 0; et < ET; ++et) dst[et] = lds4(xb + et * 16 * ldx + g * 16);
+  };
+  static_for<0, D - 1>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    if constexpr (g < G) {
+      if constexpr (PRE && g == 0) {
+#pragma unroll
+        for (int ft = 0; ft < FTW; ++ft) a[0][ft] = a0[ft];
+      } else {
+        load_a(a[g], g);
+      }
+    }
+  });
+  load_b(b[0], 0);
+  static_for<0, G>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    if constexpr (g + D - 1 < G) load_a(a[(g + D - 1) % D], g + D - 1);
+    if constexpr (g + 1 < G) load_b(b[(g + 1) & 1], g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int ft = 0; ft < FTW; ++ft)
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+          acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][ft][s], b[g & 1][et][s], acc[ft][et], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+#else
 template <int FTW, int ET, int K, bool PRE>
 __device__ __forceinline__ void gemm_tile_impl(f32x4 (&acc)[FTW][ET], f32x4 (&a0)[FTW], const float* __restrict__ Wp, int FT,
                                                int ft0, const float* X, int ldx, int lane) {
@@ -128,6 +191,8 @@ __device__ __forceinline__ void gemm_tile_impl(f32x4 (&acc)[FTW][ET], f32x4 (&a0
 #endif
   }
 }
+
+#endif  // MDX_TILE_RING
 
 // ----------------------------------------------------------------------------------------------
 // acc[ft][et] += W[16*(ft0+ft) .. +16][0..K) * X[16*et .. +16][0..K)^T
