@@ -378,6 +378,121 @@ void run_ln(const float* W, const float* gb, float* out, int nmat) {
   fflush(stdout);
 }
 
+// ---- the same chain on v_mfma_f32_32x32x2_f32 (experiment (a)): 32 rows per wave, an accumulator tile is 32 features x
+// 32 rows in 16 registers; one 1-KiB weight fragment (32 features x 8 k, 4 floats per lane) feeds 4 MFMAs of 4096 FLOP -- the same
+// FLOP per weight byte as 32 rows with 16x16x4 tiles (two row tiles per fragment), half the MFMA instruction count.  As in the
+// 16x16 layout the accumulator registers are the B operand of the next layer (with k packed as 8 (r/4) + 4 (lane/32) + r%4),
+// so the chain needs no data movement; this variant only measures the rate.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int DEPTH, int WPS, bool LN>
+__global__ __launch_bounds__(256, WPS) void chain32_kernel(const float* __restrict__ W, const float* __restrict__ gb, float* out, int reps,
+                                                           int nmat) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x16 x[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = (float)((lane * 7 + t * 3 + r + blockIdx.x) % 13) * 0.05f - 0.3f;
+  int m = __builtin_amdgcn_readfirstlane((blockIdx.x + wave) % nmat);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, -1, 0x00020000);
+  const unsigned off = 16u * lane;
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) {
+    f32x16 y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) y[t][i] = 0.f;
+    const int mbase = m * 262144;  // bytes per 256 x 256 matrix
+    constexpr int NP = 4 * 32;     // steps: 4 pairs of output tiles x 32 k-groups of 8; a step = 2 fragments, 8 MFMAs
+    f32x4 ring[DEPTH][2];
+    auto frag = [&](int p, int j) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs0, off, mbase + (2 * p + j) * 1024, 0));
+    };
+#pragma unroll
+    for (int p = 0; p < DEPTH; ++p) { ring[p][0] = frag(p, 0); ring[p][1] = frag(p, 1); }
+    static_for<0, NP>([&](auto pc) {
+      constexpr int p = decltype(pc)::value, tp = p / 32, g = p % 32;
+      const f32x4 a0 = ring[p % DEPTH][0], a1 = ring[p % DEPTH][1];
+      if constexpr (p + DEPTH < NP) { ring[p % DEPTH][0] = frag(p + DEPTH, 0); ring[p % DEPTH][1] = frag(p + DEPTH, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float b = x[g / 4][(g % 4) * 4 + s];
+        y[2 * tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b, y[2 * tp], 0, 0, 0);
+        y[2 * tp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b, y[2 * tp + 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (LN) {  // LayerNorm + ReLU over the 256 features of a row: a row's features sit in the lane pair (l, l + 32)
+      float s1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s1 += y[t][i];
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+      const float mean = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * (1.0f / 256);
+      float d2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float d = y[t][i] - mean; d2 = fmaf(d, d, d2); }
+      const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d2), __float_as_uint(d2), false, false);
+      const float rstd = 1.0f / sqrtf((__uint_as_float(sw2[0]) + __uint_as_float(sw2[1])) * (1.0f / 256) + 1e-5f);
+      const float* gbp = gb;
+      asm volatile("" : "+s"(gbp));
+      const int h = lane >> 5;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(gbp + 32 * t + 8 * i4 + 4 * h);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(gbp + 256 + 32 * t + 8 * i4 + 4 * h);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) y[t][4 * i4 + k] = fmaxf((y[t][4 * i4 + k] - mean) * rstd * gm[k] + bt[k], 0.f);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = y[t];
+    m = (m + 1 == nmat) ? 0 : m + 1;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[t][i];
+  out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+template <int DEPTH, bool LN>
+void run32(const float* W, const float* gb, float* out, int nmat) {
+  auto kern = chain32_kernel<DEPTH, 1, LN>;
+  const int reps = 24, grid = 256 * 3;
+  hipFuncAttributes fa;
+  hipFuncGetAttributes(&fa, (const void*)kern);
+  const size_t lds = 100000;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+  hipDeviceSynchronize();
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  float best = 1e30f;
+  for (int it = 0; it < 5; ++it) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, W, gb, out, reps, nmat);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    best = ms < best ? ms : best;
+  }
+  const double flop = (double)grid * 4 * reps * 2.0 * 256 * 256 * 32;
+  printf("32x32x2 tiles: 32 rows/wave depth=%d wps=1 LN=%d buffer-load ring nmat=%d vgpr=%d : %.3f ms  %.1f TFLOP/s (%.3f of 157.3)\n", DEPTH,
+         (int)LN, nmat, fa.numRegs, best, flop / best / 1e9, flop / best / 1e9 / 157.3);
+  fflush(stdout);
+}
+
 int main() {
   const int nmat_max = 20;
   std::vector<float> h((size_t)nmat_max * 65536);
@@ -390,7 +505,13 @@ int main() {
   hipMalloc(&out, (size_t)256 * 3 * 3 * 256 * 4);
   hipMemcpy(W, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(gb, gbh.data(), 512 * 4, hipMemcpyHostToDevice);
+  run32<2, false>(W, gb, out, 5);
+  run32<4, false>(W, gb, out, 5);
+  run32<2, true>(W, gb, out, 5);
+  run32<4, true>(W, gb, out, 5);
   run<2, 2, 1, 1, false, 2, 0>(W, gb, out, 5, 0);
+  run<2, 2, 1, 1, true, 2, 0>(W, gb, out, 5, 0);
+  return 0;
   run<2, 2, 1, 1, false, 2, 0, true>(W, gb, out, 5, 0);
   run<2, 2, 1, 12, false, 2, 0, true>(W, gb, out, 5, 0);
   run<2, 2, 1, 12, false, 2, 0, false>(W, gb, out, 5, 0);
