@@ -62,3 +62,29 @@ def test_backward_of_arbitrary_logit_functional_vs_oracle_autograd():
     ref, = torch.autograd.grad((ref_logits * cot).sum(), p)
     assert U.maxdiff(logits, ref_logits) < 2e-5
     assert U.maxdiff(got, ref) <= 1e-3 * float(ref.abs().max())
+
+
+def test_guidance_gradient_with_distances_straddling_the_cutoff_vs_oracle_autograd():
+    """The clamp of GaussianSmearing passes the gradient on the closed interval [0, cutoff] and blocks it beyond
+    (torch.clamp's backward): pairs beyond the predictor's 20 A cutoff contribute nothing to dL/dpos through their own
+    distance, pairs inside do -- checked through the row-owner backward kernel against the oracle's autograd."""
+    bn, hei, bh, ei, be = U.graph_from_sizes([7, 5, 8])
+    N, Eh = len(bn), len(bh)
+    r = U.rng(47)
+    xn = F.one_hot(torch.from_numpy(r.integers(0, 8, N)), 8).float()
+    pos0 = U.t32(r.standard_normal((N, 3), dtype=np.float32) * 1.5)
+    pos0[0] += torch.tensor([30.0, 0.0, 0.0])   # beyond the cutoff from all of molecule 0
+    pos0[8] += torch.tensor([0.0, 19.0, 0.0])   # around the cutoff from molecule 1's atoms
+    d = (pos0[ei[0]] - pos0[ei[1]]).norm(dim=-1)
+    assert (d > 20).sum() >= 12 and ((d > 15) & (d <= 20)).sum() >= 2
+    t = torch.tensor([20, 400, 950])
+    cot = U.t32(r.standard_normal((Eh, 5), dtype=np.float32))
+    m = U.bondpred(DEV)
+    pos = pos0.to(DEV).requires_grad_(True)
+    logits = m(xn.to(DEV), pos, bn.to(DEV), ei.to(DEV), be.to(DEV), t.to(DEV))
+    got, = torch.autograd.grad((logits * cot.to(DEV)).sum(), pos)
+    p = pos0.clone().requires_grad_(True)
+    ref_logits = O.bondpred_forward(U.params(m), U.CFGB, xn, p, bn, ei, be, t)
+    ref, = torch.autograd.grad((ref_logits * cot).sum(), p)
+    assert U.maxdiff(logits, ref_logits) < 2e-5
+    assert U.maxdiff(got, ref) <= 1e-3 * float(ref.abs().max())

@@ -124,3 +124,25 @@ def test_wrong_handle_kind_and_small_workspace_are_reported():
     rc = _lib.lib().mdx_moldiff_forward(eng.h, g.h, _lib.ptr(x), _lib.ptr(pos), None, _lib.ptr(torch.zeros(g.Eh, 6, device=DEV)),
                                         _lib.ptr(t), None, None, None, ws, ctypes.c_size_t(1024), _lib.stream())
     assert rc == 3 and b'workspace too small' in _lib.lib().mdx_last_error()
+
+
+def test_distance_smearing_clamps_at_the_cutoff_like_the_reference():
+    """GaussianSmearing (models/common.py:233-237) clamps d to [0, cutoff] before the Gaussians: pairs beyond the denoiser's
+    15 A cutoff (and well inside the first Gaussian, d ~ 1e-3) must give what the reference gives, through the FUSED path
+    (edge kernel A's in-register smearing), not only through the host tables."""
+    bn, hei, bh, ei, be, xn, xh, pos, t = _fwd_inputs([9, 6], 11)
+    pos = pos * 0.6
+    pos[0] += torch.tensor([40.0, 0.0, 0.0])            # 40 A from its molecule: every pair with atom 0 is clamped
+    pos[3] = pos[2] + torch.tensor([1e-3, 0.0, 0.0])    # nearly coincident pair
+    pos[10] += torch.tensor([0.0, 15.0, 0.0])           # right around the cutoff from several partners
+    d = (pos[ei[0]] - pos[ei[1]]).norm(dim=-1)
+    assert (d > 15).sum() >= 16 and (d < 2e-3).sum() >= 2
+    m = U.moldiff('MolDiff', DEV)
+    out = m(xn.to(DEV), pos.to(DEV), bn.to(DEV), torch.cat([xh, xh]).to(DEV), ei.to(DEV), be.to(DEV), t.to(DEV))
+    with torch.no_grad():
+        ref = O.moldiff_forward(U.params(m), U.CFG, xn, pos, bn, torch.cat([xh, xh]), ei, be, t)
+    assert U.maxdiff(out['pred_node'], ref['pred_node']) < 5e-5
+    assert U.maxdiff(out['pred_halfedge'], ref['pred_halfedge']) < 5e-5
+    # positions: the 1/d/(d+1) force of the nearly coincident pair is ~1e3 times the usual scale; compare relative to it
+    scale = max(1.0, float(ref['pred_pos'].abs().max()))
+    assert U.maxdiff(out['pred_pos'], ref['pred_pos']) < 2e-4 * scale
