@@ -354,7 +354,7 @@ def main():
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 
 
-def reference_step(model, DF, st, bn, hei, bh, step, noise, bond, guid):
+def reference_step(model, DF, st, bn, hei, bh, step, noise, bond, guid, B=4):
     """Drive the reference's own modules through one iteration of its sampling loop body
     (models/model.py:272-372) with the random draws replaced by `noise` (draw order pos, node, halfedge)."""
     draws = [noise['eps_pos'], noise['u_node'], noise['u_halfedge']]
@@ -364,7 +364,6 @@ def reference_step(model, DF, st, bn, hei, bh, step, noise, bond, guid):
     torch.rand_like = lambda x, *a, **k: next(it)
     try:
         with torch.no_grad():
-            B = 4
             ei = torch.cat([hei, hei.flip(0)], 1)
             be = torch.cat([bh, bh])
             t = torch.full((B,), step, dtype=torch.long)

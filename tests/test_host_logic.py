@@ -280,3 +280,18 @@ def test_featurize_and_collate_match_the_restated_reference_pipeline():
     assert sum(sizes) == sum(int(r['num_atoms']) for r in recs)
     with __import__('pytest').raises(AssertionError):
         featurize(dict(recs[0], element=np.array([5] * recs[0]['num_atoms'])), feat, FixedRng(0))
+
+
+def test_config1_T100_schedule_tables_match_reference_golden():
+    """BASELINE config #1 runs the simple model with 100 diffusion steps: every table the chain reads, for every t, equals
+    what the real reference builds for num_timesteps = 100 (tests/golden/config1_T100.npz, oracle/make_goldens_config1.py)."""
+    g = U.gold('config1_T100.npz')
+    cfg = default_config('MolDiff_simple')
+    cfg.diff['num_timesteps'] = int(g['T'])
+    m = M.MolDiff(cfg, 8, 6)
+    assert m.num_timesteps == 100
+    for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar'):
+        assert np.array_equal(getattr(m.pos_transition, k).numpy(), g['pos_' + k])
+    for part, tr in (('node', m.node_transition), ('edge', m.edge_transition)):
+        for k in ('q_mats', 'transpopse_q_onestep_mats'):
+            assert np.array_equal(getattr(tr, k).numpy(), g[f'{part}_{k}'])
