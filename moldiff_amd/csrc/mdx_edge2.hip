@@ -6,7 +6,7 @@
 //   edge kernel B  (models/graph.py:286-294 EdgeBlock tail, :384-393 PosUpdate)
 // One WAVE owns 16*R consecutive edges of the (left,right)-sorted edge list and computes every layer for them; its
 // activations stay in registers from the He tile load to the M / F / He'' / Fe stores.  No LDS tile, no barrier.
-// LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (32 KiB per wave).
+// LDS is only a wave-private parking area for sigmoid(gate) while the message chain runs (16 KiB per wave at 16 rows).
 #include "mdx_kernels.h"
 #ifndef MDX_RING
 #define MDX_RING 4  // weight-ring depth in steps (kernel A: 4.65 / 4.58 / 4.56 ms per step at depth 2 / 3 / 4)

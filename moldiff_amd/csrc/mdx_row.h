@@ -1,17 +1,20 @@
 // Device-side building blocks of the "row-owner" fused edge kernels (gfx950 / CDNA4 only) -- round 2.
 //
-// Measured premise (tools/ubench_chain.hip, profiles/r2_ubench_chain.txt): on gfx950 the f32-input MFMA runs on the same
-// FMA lanes as the vector ALU, so VALU work does not hide under v_mfma_f32_16x16x4_f32 and a second wave on the SIMD buys
-// nothing; what pays is (a) MFMAs issued back to back by ONE wave per SIMD, (b) as few VALU instructions as possible,
-// (c) no barriers.  Hence:
-//   * one wave owns 16*R consecutive rows (edges) and ALL output features of every layer;
+// Measured premises (tools/ubench_chain.hip, profiles/r2_ubench_chain.txt): on gfx950 the f32-input
+// MFMA runs on the same FMA lanes as the vector ALU, so VALU work never hides under v_mfma_f32_16x16x4_f32 (PMC: zero co-execution
+// cycles); what pays is (a) MFMAs issued back to back, (b) as few VALU instructions as possible -- including address arithmetic --
+// and (c) no barriers.  A second wave per SIMD buys nothing in a pure GEMM loop, but it covers the gather / store / LayerNorm
+// phases of the real kernels, and at 16 rows per wave everything fits 256 registers.  Hence:
+//   * one wave owns 16*R consecutive rows (edges) and ALL output features of every layer (R = 1, two waves per SIMD, in the
+//     product build);
 //   * a layer's output accumulators ARE the next layer's B operand: acc[ft][rt][s] = Y[row 16 rt + c][16 ft + 4 q + s]
 //     (lane = 16 q + c) is exactly the B fragment of k-group ft when the weights are packed with k in the order
-//     16 g + 4 q + s -- activations never leave the registers, LayerNorm is wave-local, there is no LDS traffic and no
-//     __syncthreads() anywhere in the kernel;
-//   * weights stream L2 -> VGPR through a two-deep register ring in consumption order ("stream pack", host:
-//     PackCtx::pack_stream): step p = ftp*KG + g carries the two fragments (2 ftp + j, g), j = 0,1, 2 KiB contiguous;
-//   * 512 registers per wave (launch_bounds(256, 1)).
+//     16 g + 4 q + s -- activations never leave the registers, LayerNorm is wave-local, there is no LDS tile and no
+//     __syncthreads() after the constant prologue;
+//   * weights stream L2 -> VGPR through a register ring of MDX_RING steps in consumption order ("stream pack", host:
+//     PackCtx::pack_stream): step p = ftp*KG + g carries the two fragments (2 ftp + j, g), j = 0,1, 2 KiB contiguous,
+//     fetched with buffer loads (scalar base + scalar fragment offset: no vector address arithmetic);
+//   * GEMM results are pinned at the end of rgemm (LLVM would otherwise sink MFMA chains away from their ring loads).
 #pragma once
 #include <type_traits>
 #include "mdx_tile.h"
