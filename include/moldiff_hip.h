@@ -294,7 +294,9 @@ int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
  * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
  * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass), 4 = the guidance backward's fused edge kernel
- * (edge_bwd_kernel, MFMA).  read() drains pending events. */
+ * (edge_bwd2_kernel, MFMA).  enable(0) = off, enable(1) = every kernel, enable(m > 1) = kernel k iff bit (k+1) of m is set
+ * (an event pair costs ~3.4 us of stream time, 25 pairs per step: bench.py times only the roofline kernel inside its timed
+ * region).  read() drains pending events. */
 int mdx_profile_enable(int32_t on);
 int mdx_profile_read(int32_t kernel, int64_t* count, double* total_ms);
 

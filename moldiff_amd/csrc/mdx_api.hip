@@ -718,7 +718,7 @@ struct ProfSlot {
   double total_ms = 0.0;
   long long count = 0;
 };
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;  // bit k: kernel k is timed
 ProfSlot g_prof[PK_COUNT];
 
 void prof_drain(ProfSlot& p, int n) {
@@ -737,7 +737,7 @@ struct ProfScope {
   hipStream_t s;
   int i = 0;
   ProfScope(int k, hipStream_t st) : s(st) {
-    if (!g_prof_on) return;
+    if (!((g_prof_mask >> k) & 1u)) return;
     p = &g_prof[k];
     if (!p->made) {
       for (int j = 0; j < PROF_RING; ++j) {
@@ -760,7 +760,7 @@ struct ProfScope {
 }  // namespace
 
 extern "C" int mdx_profile_enable(int32_t on) {
-  g_prof_on = on != 0;
+  g_prof_mask = on == 1 ? ~0u : (unsigned)on >> 1;  // 0 off, 1 all kernels, else bit (k+1) selects kernel k
   if (on)
     for (auto& p : g_prof) { prof_drain(p, PROF_RING); p.total_ms = 0.0; p.count = 0; }
   return MDX_OK;
