@@ -331,7 +331,10 @@ def run_chain(sm, steps, warmup, barrier, start=0, prof=1):
     barrier()
     elapsed = time.perf_counter() - t0
     L.mdx_profile_enable(0)
-    return elapsed, {n: _profile(L, k) for n, k in (('edge_a', 0), ('edge_b', 1), ('node', 2), ('aggregate', 3), ('edge_bwd', 4))}
+    names = (('edge_a', 0), ('edge_b', 1), ('node', 2), ('aggregate', 3), ('edge_bwd', 4))
+    if not prof:
+        return elapsed, {n: (0, 0.0) for n, _ in names}
+    return elapsed, {n: _profile(L, k) for n, k in names}
 
 
 def roofline_mfma(name, kernel, flop_per_edge, E, prof):
