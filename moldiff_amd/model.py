@@ -190,10 +190,11 @@ class MolDiff(Module):
         return {'pred_node': pn, 'pred_pos': pp, 'pred_halfedge': ph}
 
     def sampler(self, n_graphs, batch_node, halfedge_index, batch_halfedge, *, seed=None, mol_ids=None, noise=None,
-                return_traj=True, bond_predictor=None, guidance=None, overlap_guidance=True):
+                return_traj=True, bond_predictor=None, guidance=None, overlap_guidance=False):
         """Stateful driver of the reverse chain (``init()`` then ``step(i)`` for i = 0..T-1); ``sample`` wraps it.
-        overlap_guidance=False runs the guidance chain in line on the caller's stream (same results; used to time the kernels
-        of the two chains without their mutual interference)."""
+        overlap_guidance=True runs the guidance chain on a side stream concurrently with the denoiser forward of the same step
+        (same results).  It paid in round 1 (0.7 ms per step, the kernels left tails for each other); with the round-2 kernels
+        filling every CU by themselves it costs 0.5 ms (27.6 vs 28.1 ms per step), so in line is the default."""
         return _Sampler(self, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
                         bond_predictor, guidance, overlap_guidance)
 
@@ -227,7 +228,7 @@ class _Sampler:
     edge (``traj.LazyOneHot``): 0.16 GB instead of 2.1 GB at 256 molecules."""
 
     def __init__(self, model, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
-                 bond_predictor, guidance, overlap_guidance=True):
+                 bond_predictor, guidance, overlap_guidance=False):
         _lib._need_gpu(batch_node, halfedge_index, batch_halfedge)
         self.guidance = None
         if guidance is not None:
@@ -273,8 +274,8 @@ class _Sampler:
             self.edge_index = edge_index
             self.batch_edge = torch.cat([self.bh, self.bh], dim=0)
             if self.guidance[0] == 'uncertainty':
-                # the default objective is part of the library call; it runs on a side stream with its own workspace,
-                # concurrently with the denoiser's forward of the same step (both only read the step's input state)
+                # the default objective is part of the library call, with its own workspace; on request (overlap_guidance) it runs
+                # on a side stream concurrently with the denoiser's forward of the same step (both only read the step's input state)
                 self.side = torch.cuda.Stream(device=dev)
                 nbytes = _lib.lib().mdx_workspace_bytes(self.N, 2 * self.Eh)
                 self._ws2 = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)

@@ -245,22 +245,24 @@ def test_full_size_guided_step_matches_small_batch_guided_step():
 
 
 def test_full_size_guided_chain_is_bit_reproducible_run_to_run():
-    """Config #3, 256 molecules, 6 free-running guided steps with the guidance chain on its side stream, twice from the same seed:
-    bit-identical states.  (Persistent waves, two waves per SIMD, the section-cut tail and the two-stream overlap all reorder
+    """Config #3, 256 molecules, 6 free-running guided steps from the same seed, twice with the guidance chain on a side stream
+    and once in line: bit-identical states.  (Persistent waves, two waves per SIMD, the section-cut tail and the two-stream overlap all reorder
     WHEN things run; none of it may reorder a floating-point sum.)"""
     ph, sizes = _workload('MolDiff')
     m, bp = U.moldiff('MolDiff', DEV), U.bondpred(DEV)
     bn, hei, bh = ph['batch_node'].to(DEV), ph['halfedge_index'].to(DEV), ph['batch_halfedge'].to(DEV)
 
-    def run():
-        sm = m.sampler(B, bn, hei, bh, seed=77, return_traj=False, bond_predictor=bp, guidance=['uncertainty', 1e-4])
+    def run(overlap):
+        sm = m.sampler(B, bn, hei, bh, seed=77, return_traj=False, bond_predictor=bp, guidance=['uncertainty', 1e-4],
+                       overlap_guidance=overlap)
         sm.init()
         for i in range(6):
             sm.step(i)
         torch.cuda.synchronize()
         return {k: v.cpu().clone() for k, v in sm.state().items()}
 
-    a, b = run(), run()
+    a, b, c = run(True), run(True), run(False)   # side stream twice, then in line (the default): all three identical
     assert torch.isfinite(a['pos']).all()
     for k in ('pos', 'h_node', 'h_halfedge', 'log_node', 'log_halfedge'):
         assert torch.equal(a[k], b[k]), k
+        assert torch.equal(a[k], c[k]), k
