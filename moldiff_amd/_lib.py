@@ -147,6 +147,11 @@ def _need_gpu(*tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError('moldiff_amd runs on a ROCm device only (got a CPU tensor); there is no CPU fallback. '
                                'The CPU oracle lives in oracle/ and is test infrastructure.')
+        # the library allocates and launches on the CURRENT HIP device and stream: tensors of another device would be addressed
+        # from the wrong GPU's queue (memory fault or unordered execution), so say so instead
+        if t is not None and t.device.index is not None and t.device.index != torch.cuda.current_device():
+            raise RuntimeError(f'tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: call '
+                               'torch.cuda.set_device(...) first (one process per GPU)')
 
 
 def ptr(t):
