@@ -349,12 +349,13 @@ def roofline_mfma(name, kernel, flop_per_edge, E, prof):
 def aggregation_line(N, E, prof):
     c, ms = prof['aggregate']
     avg = ms / max(c, 1)
-    nbytes = 1024.0 * (E + N)
+    nbytes = 1536.0 * (E + N)   # reads M (E,256) + FL, FR (E,64 each), writes aggr (N,256) + SL, SR (N,64 each)
     agg = nbytes / (avg * 1e-3) / 1e9 if c else None
-    return {'bound': 'hbm', 'kernel': 'seg_reduce_kernel<256> (E,256)->(N,256)', 'achieved': agg, 'peak': PEAK_HBM,
-            'unit': 'GB/s (HBM or Infinity Cache: the (E,256) operand was written by the preceding kernel and is smaller than '
-                    'the 256 MiB MALL when E*1 KiB < 256 MiB)', 'frac': (agg / PEAK_HBM) if agg else None,
-            'bytes_per_launch': nbytes, 'launches': c, 'avg_ms': avg, 'operand_mib': E * 1024.0 / 2 ** 20}
+    return {'bound': 'hbm', 'kernel': 'seg_reduce_block_kernel: (E,256)->(N,256) message aggregation + the two (E,64)->(N,64) BondFFN sums',
+            'achieved': agg, 'peak': PEAK_HBM,
+            'unit': 'GB/s (HBM or Infinity Cache: the operands were written by the preceding kernel and are smaller than '
+                    'the 256 MiB MALL when E*1.5 KiB < 256 MiB)', 'frac': (agg / PEAK_HBM) if agg else None,
+            'bytes_per_launch': nbytes, 'launches': c, 'avg_ms': avg, 'operand_mib': E * 1536.0 / 2 ** 20}
 
 
 def main():
@@ -473,7 +474,7 @@ def main():
                 if ka:
                     out['roofline']['traffic'] = ka['hbm_bytes_per_launch']
                     out['roofline']['traffic_source'] = os.path.relpath(pm[-1], ROOT) + ' (PMC passes of the same command; not measured in this run)'
-                kg = ks.get('seg_reduce_kernel<256>')
+                kg = ks.get('seg_reduce_block_kernel') or ks.get('seg_reduce_kernel<256>')
                 if kg:
                     out['aggregation']['traffic'] = kg['hbm_bytes_per_launch']
         except Exception:

@@ -828,9 +828,10 @@ void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const f
   launch_node(make_nd(m, g, w, -1, 0, ND_PRE, nullptr, NTcur), s);
   for (int i = 0; i < nb; ++i) {
     { ProfScope ps(PK_EDGE_A, s); launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN, NTcur), s); }
-    { ProfScope ps(PK_AGGR, s); launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s); }
-    launch_seg_reduce(w.FL, g->col_ptr, g->col_eids, w.SL, nullptr, (int)g->N, 64, s);
-    launch_seg_reduce(w.FR, g->row_ptr, nullptr, w.SR, nullptr, (int)g->N, 64, s);
+    {
+      ProfScope ps(PK_AGGR, s);
+      launch_seg_reduce_block(w.M, w.FL, w.FR, g->row_ptr, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
+    }
     int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (i + 1 < nb ? ND_PRE : 0);
     { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
     { ProfScope ps(PK_EDGE_B, s); launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s); }
@@ -1205,9 +1206,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
       }
       { ProfScope ps(PK_EDGE_A, s); launch_edge_a(ea_args, s); }
     }
-    launch_seg_reduce(wi.M, g->row_ptr, nullptr, wi.aggr, nullptr, (int)g->N, 256, s);
-    launch_seg_reduce(wi.FL, g->col_ptr, g->col_eids, wi.SL, nullptr, (int)g->N, 64, s);
-    launch_seg_reduce(wi.FR, g->row_ptr, nullptr, wi.SR, nullptr, (int)g->N, 64, s);
+    launch_seg_reduce_block(wi.M, wi.FL, wi.FR, g->row_ptr, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
     if (tape) {
       launch_node(make_nd(m, g, wi, i, -1, ND_MID, wi.NT, nullptr), s);
     } else {  // no tape: fuse the next block's PRE into this node launch (tables double-buffered like run_blocks)
@@ -1265,8 +1264,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
     et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
     launch_edge_tail_bwd(et, s);
-    launch_seg_reduce_ld(GU, g->row_ptr, nullptr, GNT + MDX_NT_NFL, MDX_NTW, N, 64, s);
-    launch_seg_reduce_ld(GU, g->col_ptr, g->col_eids, GNT + MDX_NT_NFR, MDX_NTW, N, 64, s);
+    launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
     eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
@@ -1274,12 +1272,12 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i];
     { ProfScope ps(PK_EDGE_BWD, s); if (mdx_use_rowowner()) launch_edge_bwd2(eb, s); else launch_edge_bwd(eb, s); }
-    launch_seg_reduce_ld(GH, g->col_ptr, g->col_eids, gH, MDX_ND, N, 256, s);
-    launch_seg_reduce_ld(tp.GGX, g->col_ptr, g->col_eids, GNT + MDX_NT_GX, MDX_NTW, N, 256, s);
-    launch_seg_reduce_ld(tp.GNL0, g->row_ptr, nullptr, GNT + MDX_NT_NLL, MDX_NTW, N, 128, s);
-    launch_seg_reduce_ld(tp.GNL1, g->col_ptr, g->col_eids, GNT + MDX_NT_NLR, MDX_NTW, N, 128, s);
-    launch_seg_reduce_ld(tp.GGXS0, g->row_ptr, nullptr, GNT + MDX_NT_GXL, MDX_NTW, N, 32, s);
-    launch_seg_reduce_ld(tp.GGXS1, g->col_ptr, g->col_eids, GNT + MDX_NT_GXR, MDX_NTW, N, 32, s);
+    {
+      SegBwdArgs sr{};
+      sr.N = N; sr.row_ptr = g->row_ptr; sr.col_ptr = g->col_ptr; sr.col_eids = g->col_eids; sr.GH = GH; sr.GGX = tp.GGX;
+      sr.GNL0 = tp.GNL0; sr.GNL1 = tp.GNL1; sr.GGXS0 = tp.GGXS0; sr.GGXS1 = tp.GGXS1; sr.gH = gH; sr.GNT = GNT;
+      launch_seg_reduce_bwd_block(sr, s);
+    }
     nt.flags = NB_PRE;
     launch_node_bwd(nt, s);
     std::swap(gHe, gHe2);

@@ -630,14 +630,8 @@ __global__ __launch_bounds__(MDX_WG, 2) void bond_decode_kernel(const BondDecArg
 // segment sum with an output leading dimension (writes straight into a column block of the gradient table)
 // =================================================================================================
 template <int C>
-__global__ __launch_bounds__(MDX_WG) void seg_reduce_ld_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
-                                                               const int* __restrict__ eids, float* __restrict__ out,
-                                                               int out_ld, int N) {
-  constexpr int LPN = C / 4;
-  constexpr int NPB = MDX_WG / LPN;
-  const int v = blockIdx.x * NPB + threadIdx.x / LPN;
-  const int c4 = threadIdx.x % LPN;
-  if (v >= N) return;
+__device__ __forceinline__ f32x4 seg_sum_ld(const float* __restrict__ src, const int* __restrict__ ptr, const int* __restrict__ eids,
+                                            int v, int c4) {
   const int j0 = ptr[v], j1 = ptr[v + 1];
   f32x4 s0 = splat4(0.f);
   int j = j0;
@@ -649,7 +643,63 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce_ld_kernel(const float* __re
     s0 = (((s0 + a0) + a1) + a2) + a3;
   }
   for (; j < j1; ++j) s0 = s0 + ldg4(src + (size_t)(eids ? eids[j] : j) * C + 4 * c4);
-  stg4(out + (size_t)v * out_ld + 4 * c4, s0);
+  return s0;
+}
+
+template <int C>
+__global__ __launch_bounds__(MDX_WG) void seg_reduce_ld_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
+                                                               const int* __restrict__ eids, float* __restrict__ out,
+                                                               int out_ld, int N) {
+  constexpr int LPN = C / 4;
+  constexpr int NPB = MDX_WG / LPN;
+  const int v = blockIdx.x * NPB + threadIdx.x / LPN;
+  const int c4 = threadIdx.x % LPN;
+  if (v >= N) return;
+  stg4(out + (size_t)v * out_ld + 4 * c4, seg_sum_ld<C>(src, ptr, eids, v, c4));
+}
+
+// The six payload reductions that follow the backward edge kernel of a block, in one launch (13 waves per four nodes: GH and GGX
+// four waves each, the two (E,128) BondFFN payloads two each, the two (E,32) gate payloads half a wave each); and the two
+// (E,64) reductions that follow the EdgeBlock-tail backward.  Same per-lane loop as seg_reduce_ld_kernel: same bits.
+__global__ __launch_bounds__(832) void seg_reduce_bwd_block_kernel(const SegBwdArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int v0 = blockIdx.x * 4, N = a.N;
+  if (wave < 8) {  // (E,256) by right endpoint: dL/dH rows and the gate's node part
+    const int v = v0 + (wave & 3);
+    if (v >= N) return;
+    if (wave < 4)
+      stg4(a.gH + (size_t)v * MDX_ND + 4 * lane, seg_sum_ld<256>(a.GH, a.col_ptr, a.col_eids, v, lane));
+    else
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GX + 4 * lane, seg_sum_ld<256>(a.GGX, a.col_ptr, a.col_eids, v, lane));
+  } else if (wave < 12) {  // (E,128): left FFN by left endpoint, right FFN by right endpoint
+    const int v = v0 + 2 * (wave & 1) + (lane >> 5), c4 = lane & 31;
+    if (v >= N) return;
+    if (wave < 10)
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_NLL + 4 * c4, seg_sum_ld<128>(a.GNL0, a.row_ptr, nullptr, v, c4));
+    else
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_NLR + 4 * c4, seg_sum_ld<128>(a.GNL1, a.col_ptr, a.col_eids, v, c4));
+  } else {  // (E,32)
+    const int v = v0 + ((lane & 31) >> 3), c4 = lane & 7;
+    if (v >= N) return;
+    if (lane < 32)
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GXL + 4 * c4, seg_sum_ld<32>(a.GGXS0, a.row_ptr, nullptr, v, c4));
+    else
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GXR + 4 * c4, seg_sum_ld<32>(a.GGXS1, a.col_ptr, a.col_eids, v, c4));
+  }
+}
+
+__global__ __launch_bounds__(MDX_WG) void seg_reduce_tail_block_kernel(const float* __restrict__ GU, const int* __restrict__ row_ptr,
+                                                                       const int* __restrict__ col_ptr,
+                                                                       const int* __restrict__ col_eids, float* __restrict__ GNT,
+                                                                       int N) {
+  // 8 nodes per workgroup: threads 0..127 the by-left sums (-> node_ffn_left columns), 128..255 the by-right sums
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const int v = blockIdx.x * 8 + (t >> 4), c4 = t & 15;
+  if (v >= N) return;
+  if (half == 0)
+    stg4(GNT + (size_t)v * MDX_NTW + MDX_NT_NFL + 4 * c4, seg_sum_ld<64>(GU, row_ptr, nullptr, v, c4));
+  else
+    stg4(GNT + (size_t)v * MDX_NTW + MDX_NT_NFR + 4 * c4, seg_sum_ld<64>(GU, col_ptr, col_eids, v, c4));
 }
 
 __global__ void dist_force_kernel(const float* __restrict__ gdist, const float* __restrict__ pos, const int* __restrict__ l,
@@ -728,6 +778,14 @@ void launch_seg_reduce_ld(const float* src, const int* ptr, const int* eids, flo
     default: break;
   }
 #undef MDX_SR
+}
+
+void launch_seg_reduce_bwd_block(const SegBwdArgs& a, hipStream_t s) {
+  if (a.N > 0) hipLaunchKernelGGL(seg_reduce_bwd_block_kernel, dim3((a.N + 3) / 4), dim3(832), 0, s, a);
+}
+void launch_seg_reduce_tail_block(const float* GU, const int* row_ptr, const int* col_ptr, const int* col_eids, float* GNT, int N,
+                                  hipStream_t s) {
+  if (N > 0) hipLaunchKernelGGL(seg_reduce_tail_block_kernel, dim3((N + 7) / 8), dim3(MDX_WG), 0, s, GU, row_ptr, col_ptr, col_eids, GNT, N);
 }
 
 void launch_dist_to_pos(const float* gdist, const float* pos, const int* l, const int* r, const int* row_ptr,

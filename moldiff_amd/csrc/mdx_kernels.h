@@ -237,6 +237,15 @@ void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s);  // row-owner versio
 void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
 void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s);
 // generalized segment sum: C in {32,64,128,256}; out row stride out_ld (floats), column offset already applied to `out`
+struct SegBwdArgs {  // the payload reductions after the backward edge kernel (mdx_bondpred.hip)
+  int N;
+  const int *row_ptr, *col_ptr, *col_eids;
+  const float *GH, *GGX, *GNL0, *GNL1, *GGXS0, *GGXS1;
+  float *gH, *GNT;
+};
+void launch_seg_reduce_bwd_block(const SegBwdArgs& a, hipStream_t s);
+void launch_seg_reduce_tail_block(const float* GU, const int* row_ptr, const int* col_ptr, const int* col_eids, float* GNT, int N,
+                                  hipStream_t s);
 void launch_seg_reduce_ld(const float* src, const int* ptr, const int* eids, float* out, int out_ld, int N, int C,
                           hipStream_t s);
 // dpos[v] = sum_{l=v} gd_e rel_e/d_e - sum_{r=v} gd_e rel_e/d_e   (two-pass, deterministic)
@@ -254,6 +263,8 @@ int mdx_num_cus();
 void launch_node(const NodeArgs& a, hipStream_t s);
 
 // out[v][0..C) (+)= sum_{j in ptr[v]..ptr[v+1]} src[(eids ? eids[j] : j)][0..C)
+void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, const int* row_ptr, const int* col_ptr,
+                             const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s);
 void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float* out, const float* addend, int N, int C,
                        hipStream_t s);
 

@@ -145,19 +145,14 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
 // Segmented sum.  C = 256: one wave per node (64 lanes x float4);  C = 64: 16 lanes per node;
 // C = 3: one lane per (node, component).  Sequential in CSR order => bit-reproducible.
 // ------------------------------------------------------------------------------------------------
+// sum over the run ptr[v] .. ptr[v+1] of row i (or eids[i]) of src, this lane's four features: 4 independent loads in flight,
+// summed in CSR order
 template <int C>
-__global__ __launch_bounds__(MDX_WG) void seg_reduce_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
-                                                            const int* __restrict__ eids, float* __restrict__ out,
-                                                            const float* __restrict__ addend, int N) {
-  constexpr int LPN = C / 4;              // lanes per node
-  constexpr int NPB = MDX_WG / LPN;       // nodes per block
-  const int v = blockIdx.x * NPB + threadIdx.x / LPN;
-  const int c4 = threadIdx.x % LPN;
-  if (v >= N) return;
+__device__ __forceinline__ f32x4 seg_sum(const float* __restrict__ src, const int* __restrict__ ptr, const int* __restrict__ eids,
+                                         int v, int c4) {
   const int j0 = ptr[v], j1 = ptr[v + 1];
   f32x4 s0 = splat4(0.f);
   int j = j0;
-  // 4 independent loads in flight, summed in order
   for (; j + 4 <= j1; j += 4) {
     const int i0 = eids ? eids[j] : j, i1 = eids ? eids[j + 1] : j + 1, i2 = eids ? eids[j + 2] : j + 2,
               i3 = eids ? eids[j + 3] : j + 3;
@@ -169,8 +164,45 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce_kernel(const float* __restr
     const int i0 = eids ? eids[j] : j;
     s0 = s0 + ldg4(src + (size_t)i0 * C + 4 * c4);
   }
+  return s0;
+}
+
+template <int C>
+__global__ __launch_bounds__(MDX_WG) void seg_reduce_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
+                                                            const int* __restrict__ eids, float* __restrict__ out,
+                                                            const float* __restrict__ addend, int N) {
+  constexpr int LPN = C / 4;              // lanes per node
+  constexpr int NPB = MDX_WG / LPN;       // nodes per block
+  const int v = blockIdx.x * NPB + threadIdx.x / LPN;
+  const int c4 = threadIdx.x % LPN;
+  if (v >= N) return;
+  f32x4 s0 = seg_sum<C>(src, ptr, eids, v, c4);
   if (addend) s0 = ldg4(addend + (size_t)v * C + 4 * c4) + s0;
   stg4(out + (size_t)v * C + 4 * c4, s0);
+}
+
+// The three reductions that follow edge kernel A in one launch: aggr = sum_{left = v} M (E,256), SR = sum_{left = v} FR (E,64),
+// SL = sum_{right = v} FL (E,64, through the by-right index list).  A workgroup of six waves serves four nodes: waves 0-3 one
+// node's M run each, wave 4 the four FR runs (16 lanes each), wave 5 the four FL runs.  The 64-wide sums are latency-bound on their
+// own (3.2 TB/s); side by side with the 256-wide one they disappear under it.  Same per-lane loop as seg_reduce_kernel: same bits.
+__global__ __launch_bounds__(384) void seg_reduce_block_kernel(const float* __restrict__ M, const float* __restrict__ FL,
+                                                               const float* __restrict__ FR, const int* __restrict__ row_ptr,
+                                                               const int* __restrict__ col_ptr, const int* __restrict__ col_eids,
+                                                               float* __restrict__ aggr, float* __restrict__ SL,
+                                                               float* __restrict__ SR, int N) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int v0 = blockIdx.x * 4;
+  if (wave < 4) {
+    const int v = v0 + wave;
+    if (v < N) stg4(aggr + (size_t)v * 256 + 4 * lane, seg_sum<256>(M, row_ptr, nullptr, v, lane));
+  } else {
+    const int v = v0 + (lane >> 4), c4 = lane & 15;
+    if (v >= N) return;
+    if (wave == 4)
+      stg4(SR + (size_t)v * 64 + 4 * c4, seg_sum<64>(FR, row_ptr, nullptr, v, c4));
+    else
+      stg4(SL + (size_t)v * 64 + 4 * c4, seg_sum<64>(FL, col_ptr, col_eids, v, c4));
+  }
 }
 
 __global__ __launch_bounds__(MDX_WG) void seg_reduce3_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
@@ -340,6 +372,13 @@ void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float*
   else
     hipLaunchKernelGGL(seg_reduce3_kernel, dim3((3 * N + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, src, ptr, eids, out,
                        addend, N);
+}
+
+void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, const int* row_ptr, const int* col_ptr,
+                             const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(seg_reduce_block_kernel, dim3((N + 3) / 4), dim3(384), 0, s, M, FL, FR, row_ptr, col_ptr, col_eids, aggr, SL, SR,
+                     N);
 }
 
 void launch_embed(const EmbedArgs& a, hipStream_t s) {

@@ -19,7 +19,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [['SQ_WAVE_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_ANY', 'GRBM_GUI_ACTIVE'], ['FETCH_SIZE'], ['WRITE_SIZE']]
 KERNELS = {'edge_a2_kernel': 'edge_a2_kernel', 'edge_b2_kernel': 'edge_b2_kernel', 'edge_a_kernel': 'edge_a_kernel',
-           'edge_b_kernel': 'edge_b_kernel', 'node_kernel(': 'node_kernel', 'seg_reduce_kernel<256>': 'seg_reduce_kernel<256>',
+           'edge_b_kernel': 'edge_b_kernel', 'node_kernel(': 'node_kernel', 'seg_reduce_block_kernel': 'seg_reduce_block_kernel', 'seg_reduce_kernel<256>': 'seg_reduce_kernel<256>',
            'edge_bwd2_kernel': 'edge_bwd2_kernel', 'edge_bwd_kernel': 'edge_bwd_kernel'}
 
 
