@@ -694,15 +694,6 @@ static void gather_rows(const float* src, const int* idx, float* dst, int64_t n,
   hipLaunchKernelGGL(gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, src, idx, dst, (int)n, C);
 }
 
-__global__ void expand_halfedge_kernel(const float* __restrict__ xh, const int* __restrict__ int2ref, float* __restrict__ dst,
-                                       int E, int Eh, int K) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)E * K) return;
-  const int e = i / K, k = i - (size_t)e * K;
-  int r = int2ref[e];
-  if (r >= Eh) r -= Eh;
-  dst[i] = xh[(size_t)r * K + k];
-}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -816,7 +807,7 @@ NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int im
 
 // Runs all blocks.  In: w.Hn, w.HeA (internal order), pos_in, w.tn / w.te.  Out: w.Hn, He (returned pointer), pos (returned).
 void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
-                const float** pos_final, hipStream_t s) {
+                const float** pos_final, hipStream_t s, float* pos_out = nullptr) {
   const int nb = m->cfg.num_blocks;
   const bool upos = m->cfg.update_pos != 0;
   const float* pos = pos_in;
@@ -836,6 +827,7 @@ void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const f
     { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
     { ProfScope ps(PK_EDGE_B, s); launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s); }
     if (upos) {
+      if (pos_out && i + 1 == nb) pos_next = pos_out;  // the last update lands in the caller's buffer (no copy afterwards)
       launch_seg_reduce(w.Fe, g->row_ptr, nullptr, pos_next, pos, (int)g->N, 3, s);
       pos = pos_next;
       pos_next = (pos_next == w.posA) ? w.posB : w.posA;
@@ -995,25 +987,19 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
   ea.We = m->We; ea.toff = m->toff; ea.tcoef = m->tcoef; ea.Hn = w.Hn; ea.He = w.HeA; ea.tn = w.tn; ea.te = w.te;
   if (h_edge_pert) {
     ea.xe = h_edge_pert;
-  } else {  // both directions share the half-edge one-hot (model.py:273); expand into reference order
-    const size_t tot = (size_t)g->E * cf.num_edge_types;
-    if (tot) {
-      // write directly in *internal* order into tmpE, then read with identity mapping
-      hipLaunchKernelGGL(expand_halfedge_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, h_halfedge_pert, g->int2ref,
-                         w.tmpE, (int)g->E, (int)g->Eh, cf.num_edge_types);
-    }
-    ea.xe = w.tmpE;
-    ea.int2ref = nullptr;
+  } else {  // both directions share the half-edge one-hot (model.py:273): the embed kernel folds reference row r onto r mod Eh
+    ea.xe = h_halfedge_pert;
+    ea.half_rows = (int)g->Eh;
   }
   launch_embed(ea, s);
   const float *He, *pf;
-  run_blocks(m, g, w, pos_pert, &He, &pf, s);
+  run_blocks(m, g, w, pos_pert, &He, &pf, s, m->cfg.update_pos ? pred_pos : nullptr);
   DecodeArgs da{};
   da.N = (int)g->N; da.Eh = (int)g->Eh; da.Kn = cf.num_node_types; da.Ke = cf.num_edge_types; da.Hn = w.Hn; da.He = He;
   da.ref2int = g->ref2int; da.nodedec = m->nodedec; da.edgedec = m->edgedec; da.pred_node = pred_node;
   da.pred_halfedge = pred_halfedge;
   launch_decode(da, s);
-  if (pred_pos) HIPCHK(hipMemcpyAsync(pred_pos, pf, (size_t)g->N * 12, hipMemcpyDeviceToDevice, s));
+  if (pred_pos && pf != pred_pos) HIPCHK(hipMemcpyAsync(pred_pos, pf, (size_t)g->N * 12, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
   return MDX_OK;
 }
@@ -1035,6 +1021,19 @@ static int sample_step_core(mdx_model_t m, mdx_graph_t g, const mdx_tables* tb, 
   if (rc != MDX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   const mdx_config& cf = m->cfg;
+  if (cf.num_node_types == 8 && cf.num_edge_types == 6) {  // MolDiff's class counts: all five transition launches in one
+    StepTransArgs ta{};
+    ta.N = N; ta.Eh = Eh; ta.T = cf.num_timesteps; ta.c0 = tb->pos_coef_x0; ta.ct = tb->pos_coef_xt; ta.sd = tb->pos_std;
+    ta.node_q = tb->node_q_mats; ta.node_qT1 = tb->node_qT_onestep; ta.edge_q = tb->edge_q_mats; ta.edge_qT1 = tb->edge_qT_onestep;
+    ta.t = t; ta.batch_node = batch_node; ta.batch_half = batch_halfedge; ta.pos = cur->pos; ta.pred_pos = pred_pos; ta.eps = eps_pos;
+    ta.pred_node = pred_node; ta.log_node = cur->log_node; ta.u_node = u_node; ta.pred_half = pred_halfedge;
+    ta.log_half = cur->log_halfedge; ta.u_half = u_halfedge; ta.pos_next = next->pos; ta.log_node_next = next->log_node;
+    ta.h_node_next = next->h_node; ta.log_half_next = next->log_halfedge; ta.h_half_next = next->h_halfedge; ta.node_cls = node_cls;
+    ta.half_cls = halfedge_cls;
+    launch_step_transition(ta, s);
+    HIPCHK(hipGetLastError());
+    return MDX_OK;
+  }
   launch_pos_posterior(tb->pos_coef_x0, tb->pos_coef_xt, tb->pos_std, cur->pos, pred_pos, eps_pos, t, batch_node, N, next->pos, s);
   launch_cat_posterior(tb->node_q_mats, tb->node_qT_onestep, cf.num_node_types, cf.num_timesteps, pred_node, 1, cur->log_node, t,
                        batch_node, N, next->log_node, s);
@@ -1067,11 +1066,13 @@ extern "C" int mdx_sample_step_full(mdx_model_t m, mdx_graph_t g, const mdx_tabl
   if (g->N == 0) return MDX_OK;
   hipStream_t s = (hipStream_t)stream;
   const mdx_config& cf = m->cfg;
-  launch_fill_i64(t_buf, step, (int)g->B, s);
-  if (noise->draw >= 0) {
-    int rc = mdx_noise(g, noise->seed, noise->draw, cf.num_node_types, cf.num_edge_types, noise->eps_pos, noise->u_node,
-                       noise->u_halfedge, stream);
-    if (rc != MDX_OK) return rc;
+  if (noise->draw >= 0) {  // the Philox launch also fills the time tensor
+    if (cf.num_node_types > 8 || cf.num_edge_types > 8) return fail(MDX_ERR_ARG, "class counts must be in 1..8");
+    launch_philox_noise(noise->seed, noise->draw, g->node_graph, g->node_local, g->he_graph, g->he_local, g->mol_ids, (int)g->N,
+                        (int)g->Eh, cf.num_node_types, cf.num_edge_types, noise->eps_pos, noise->u_node, noise->u_halfedge, s, t_buf,
+                        step, (int)g->B);
+  } else {
+    launch_fill_i64(t_buf, step, (int)g->B, s);
   }
   hipStream_t gs = s;  // the stream the guidance chain runs on
   if (gd) {

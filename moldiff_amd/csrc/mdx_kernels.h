@@ -263,6 +263,15 @@ int mdx_num_cus();
 void launch_node(const NodeArgs& a, hipStream_t s);
 
 // out[v][0..C) (+)= sum_{j in ptr[v]..ptr[v+1]} src[(eids ? eids[j] : j)][0..C)
+struct StepTransArgs {  // mdx_transition.hip: the transitions of one sampling step in one launch (Kn = 8, Ke = 6)
+  int N, Eh, T;
+  const float *c0, *ct, *sd, *node_q, *node_qT1, *edge_q, *edge_qT1;
+  const int64_t *t, *batch_node, *batch_half;
+  const float *pos, *pred_pos, *eps, *pred_node, *log_node, *u_node, *pred_half, *log_half, *u_half;
+  float *pos_next, *log_node_next, *h_node_next, *log_half_next, *h_half_next;
+  uint8_t *node_cls, *half_cls;
+};
+void launch_step_transition(const StepTransArgs& a, hipStream_t s);
 void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, const int* row_ptr, const int* col_ptr,
                              const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s);
 void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float* out, const float* addend, int N, int C,
@@ -273,6 +282,7 @@ struct EmbedArgs {
   const float* xn;        // (N,Kn)
   const float* xe;        // (E_ref,Ke) reference edge order (MolDiff)   | nullptr for the bond predictor
   const int* int2ref;     // (E)
+  int half_rows;          // > 0: xe holds (half_rows,Ke) half-edge rows, reference row r reads row r mod half_rows (model.py:273)
   const int *l, *r;       // internal
   const int* node_graph;  // (N)
   const int64_t* t;       // (B) device
@@ -304,4 +314,5 @@ void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int
 void launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t s);
 void launch_philox_noise(uint64_t seed, int step, const int* node_graph, const int* node_local, const int* he_graph,
                          const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,
-                         float* u_node, float* u_half, hipStream_t s);
+                         float* u_node, float* u_half, hipStream_t s, int64_t* t_buf = nullptr, int64_t t_val = 0,
+                         int B = 0);  // t_buf: also fill (B) int64 with t_val

@@ -220,8 +220,7 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce3_kernel(const float* __rest
 // Embedding: h_node = [x_n W_n^T | smear(t)],  h_edge = [x_e W_e^T | smear(t)]  (internal edge order),
 // plus the per-row time arrays t/T used by the gates.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MDX_WG) void embed_node_kernel(const EmbedArgs a) {
-  const int i = blockIdx.x * MDX_WG + threadIdx.x;
+__device__ __forceinline__ void embed_node_thread(const EmbedArgs& a, int i) {
   if (i >= a.N * MDX_ND) return;
   const int v = i / MDX_ND, f = i - v * MDX_ND;
   const int64_t t = a.t[a.node_graph[v]];
@@ -239,8 +238,7 @@ __global__ __launch_bounds__(MDX_WG) void embed_node_kernel(const EmbedArgs a) {
   if (f == 0) a.tn[v] = (float)t / (float)a.T;
 }
 
-__global__ __launch_bounds__(MDX_WG) void embed_edge_kernel(const EmbedArgs a) {
-  const int i = blockIdx.x * MDX_WG + threadIdx.x;
+__device__ __forceinline__ void embed_edge_thread(const EmbedArgs& a, int i) {
   if (i >= a.E * MDX_ED) return;
   const int e = i / MDX_ED, f = i - e * MDX_ED;
   const int nl = a.l[e], nr = a.r[e];
@@ -249,7 +247,9 @@ __global__ __launch_bounds__(MDX_WG) void embed_edge_kernel(const EmbedArgs a) {
   if (f < a.ed_emb) {
     float s = 0.f;
     if (a.xe) {
-      const float* x = a.xe + (size_t)(a.int2ref ? a.int2ref[e] : e) * a.Ke;
+      int ref = a.int2ref ? a.int2ref[e] : e;
+      if (a.half_rows > 0 && ref >= a.half_rows) ref -= a.half_rows;  // both directions share the half-edge row
+      const float* x = a.xe + (size_t)ref * a.Ke;
       for (int k = 0; k < a.Ke; ++k) s = fmaf(x[k], a.We[f * a.Ke + k], s);
     } else {  // bond predictor: cat[x_n[left], x_n[right]]
       const int K2 = 2 * a.Kn;
@@ -264,6 +264,14 @@ __global__ __launch_bounds__(MDX_WG) void embed_edge_kernel(const EmbedArgs a) {
   }
   a.He[i] = out;
   if (f == 0) a.te[e] = (float)t / (float)a.T;
+}
+
+// one launch for both: the first nb_node workgroups embed atoms, the rest edges
+__global__ __launch_bounds__(MDX_WG) void embed_kernel(const EmbedArgs a, const int nb_node) {
+  if ((int)blockIdx.x < nb_node)
+    embed_node_thread(a, blockIdx.x * MDX_WG + threadIdx.x);
+  else
+    embed_edge_thread(a, (blockIdx.x - nb_node) * MDX_WG + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -382,10 +390,9 @@ void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, c
 }
 
 void launch_embed(const EmbedArgs& a, hipStream_t s) {
-  if (a.N > 0)
-    hipLaunchKernelGGL(embed_node_kernel, dim3(((size_t)a.N * MDX_ND + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, a);
-  if (a.E > 0)
-    hipLaunchKernelGGL(embed_edge_kernel, dim3(((size_t)a.E * MDX_ED + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, a);
+  const int nbn = a.N > 0 ? (int)(((size_t)a.N * MDX_ND + MDX_WG - 1) / MDX_WG) : 0;
+  const int nbe = a.E > 0 ? (int)(((size_t)a.E * MDX_ED + MDX_WG - 1) / MDX_WG) : 0;
+  if (nbn + nbe > 0) hipLaunchKernelGGL(embed_kernel, dim3(nbn + nbe), dim3(MDX_WG), 0, s, a, nbn);
 }
 
 void launch_decode(const DecodeArgs& a, hipStream_t s) {

@@ -8,17 +8,17 @@
 //                      molecule's noise does not depend on how the batch is sharded over GPUs.
 // Compiled with -ffp-contract=off: the reference evaluates these formulas with separate mul/add.
 #include "mdx_kernels.h"
+#include <algorithm>
 
 #define MDX_MAXK 8
 
 namespace {
 
-__global__ void pos_posterior_kernel(const float* __restrict__ c0, const float* __restrict__ ct,
-                                     const float* __restrict__ sd, const float* __restrict__ xt,
-                                     const float* __restrict__ x0, const float* __restrict__ eps,
-                                     const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
-                                     float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pos_posterior_elem(const float* __restrict__ c0, const float* __restrict__ ct,
+                                                   const float* __restrict__ sd, const float* __restrict__ xt,
+                                                   const float* __restrict__ x0, const float* __restrict__ eps,
+                                                   const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
+                                                   float* __restrict__ out, int i) {
   if (i >= 3 * n) return;
   const int v = i / 3;
   const int64_t tv = t[batch[v]];
@@ -26,13 +26,19 @@ __global__ void pos_posterior_kernel(const float* __restrict__ c0, const float* 
   const float x = mu + sd[tv] * eps[i];
   out[i] = (tv == 0) ? mu : x;
 }
-
-template <int K>
-__global__ void cat_posterior_kernel(const float* __restrict__ qmats, const float* __restrict__ qT1, int T,
-                                     const float* __restrict__ in0, int is_logits, const float* __restrict__ log_vt,
+__global__ void pos_posterior_kernel(const float* __restrict__ c0, const float* __restrict__ ct,
+                                     const float* __restrict__ sd, const float* __restrict__ xt,
+                                     const float* __restrict__ x0, const float* __restrict__ eps,
                                      const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
                                      float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  pos_posterior_elem(c0, ct, sd, xt, x0, eps, t, batch, n, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+template <int K>
+__device__ __forceinline__ void cat_posterior_row(const float* __restrict__ qmats, const float* __restrict__ qT1, int T,
+                                                  const float* __restrict__ in0, int is_logits, const float* __restrict__ log_vt,
+                                                  const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
+                                                  float* __restrict__ out, int i) {
   if (i >= n) return;
   const int64_t tv = t[batch[i]];
   const int64_t tm1 = tv > 0 ? tv - 1 : 0;
@@ -81,10 +87,17 @@ __global__ void cat_posterior_kernel(const float* __restrict__ qmats, const floa
 #pragma unroll
   for (int k = 0; k < K; ++k) out[(size_t)i * K + k] = (tv == 0) ? l0[k] : (o[k] - lse);
 }
+template <int K>
+__global__ void cat_posterior_kernel(const float* __restrict__ qmats, const float* __restrict__ qT1, int T,
+                                     const float* __restrict__ in0, int is_logits, const float* __restrict__ log_vt,
+                                     const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n,
+                                     float* __restrict__ out) {
+  cat_posterior_row<K>(qmats, qT1, T, in0, is_logits, log_vt, t, batch, n, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
 
-__global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const float* __restrict__ u, int K, int n,
-                                     int64_t* __restrict__ cls, float* __restrict__ onehot, uint8_t* __restrict__ cls8) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void gumbel_argmax_row(const float* __restrict__ logits, const float* __restrict__ u, int K, int n,
+                                                  int64_t* __restrict__ cls, float* __restrict__ onehot,
+                                                  uint8_t* __restrict__ cls8, int i) {
   if (i >= n) return;
   int best = 0;
   float bv = -INFINITY;
@@ -100,6 +113,26 @@ __global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const flo
   if (cls8) cls8[i] = (uint8_t)best;  // compact trajectory frame (one byte per atom / half-edge)
   if (onehot)
     for (int k = 0; k < K; ++k) onehot[(size_t)i * K + k] = (k == best) ? 1.f : 0.f;
+}
+__global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const float* __restrict__ u, int K, int n,
+                                     int64_t* __restrict__ cls, float* __restrict__ onehot, uint8_t* __restrict__ cls8) {
+  gumbel_argmax_row(logits, u, K, n, cls, onehot, cls8, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// The five transition launches of a sampling step (models/model.py:287-307) in one: thread i does position component i, atom
+// row i and half-edge row i through the same row functions as the stand-alone kernels (a row's posterior is written and read
+// back by the same thread).  MolDiff's class counts (8 atom types, 6 bond types) only; other counts take the separate kernels.
+__global__ void step_transition_kernel(const StepTransArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  pos_posterior_elem(a.c0, a.ct, a.sd, a.pos, a.pred_pos, a.eps, a.t, a.batch_node, a.N, a.pos_next, i);
+  if (i < a.N) {
+    cat_posterior_row<8>(a.node_q, a.node_qT1, a.T, a.pred_node, 1, a.log_node, a.t, a.batch_node, a.N, a.log_node_next, i);
+    gumbel_argmax_row(a.log_node_next, a.u_node, 8, a.N, nullptr, a.h_node_next, a.node_cls, i);
+  }
+  if (i < a.Eh) {
+    cat_posterior_row<6>(a.edge_q, a.edge_qT1, a.T, a.pred_half, 1, a.log_half, a.t, a.batch_half, a.Eh, a.log_half_next, i);
+    gumbel_argmax_row(a.log_half_next, a.u_half, 6, a.Eh, nullptr, a.h_half_next, a.half_cls, i);
+  }
 }
 
 // 'uncertainty' guidance objective (models/model.py:322-324): U = sum_h log sigmoid(-logsumexp_k logits[h,k]);
@@ -142,8 +175,9 @@ __global__ void philox_noise_kernel(uint64_t seed, int draw, const int* __restri
                                     const int* __restrict__ node_local, const int* __restrict__ he_graph,
                                     const int* __restrict__ he_local, const int64_t* __restrict__ mol_ids, int N, int Eh,
                                     int Kn, int Ke, float* __restrict__ eps_pos, float* __restrict__ u_node,
-                                    float* __restrict__ u_half) {
+                                    float* __restrict__ u_half, int64_t* __restrict__ t_buf, int64_t t_val, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t_buf && i < B) t_buf[i] = t_val;  // the step's time tensor rides along (one launch less per sampling step)
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   if (i < N) {
     const uint64_t mol = (uint64_t)mol_ids[node_graph[i]];
@@ -204,6 +238,11 @@ void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, co
 #undef MDX_CP
 }
 
+void launch_step_transition(const StepTransArgs& a, hipStream_t s) {
+  const int n = std::max(3 * a.N, a.Eh);
+  if (n > 0) hipLaunchKernelGGL(step_transition_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
 void launch_uncertainty_grad(const float* logits, int K, int n, float* glogits, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(uncertainty_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, K, n, glogits);
@@ -233,9 +272,9 @@ void launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t s) {
 
 void launch_philox_noise(uint64_t seed, int draw, const int* node_graph, const int* node_local, const int* he_graph,
                          const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,
-                         float* u_node, float* u_half, hipStream_t s) {
-  const int n = N > Eh ? N : Eh;
+                         float* u_node, float* u_half, hipStream_t s, int64_t* t_buf, int64_t t_val, int B) {
+  const int n = std::max(N > Eh ? N : Eh, t_buf ? B : 0);
   if (n <= 0) return;
   hipLaunchKernelGGL(philox_noise_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, draw, node_graph, node_local,
-                     he_graph, he_local, mol_ids, N, Eh, Kn, Ke, eps_pos, u_node, u_half);
+                     he_graph, he_local, mol_ids, N, Eh, Kn, Ke, eps_pos, u_node, u_half, t_buf, t_val, B);
 }
