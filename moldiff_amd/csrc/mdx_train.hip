@@ -519,6 +519,35 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// One launch for the two reductions a weight gradient needs (dW partials, then -- in the extra workgroups -- the bias partials):
+// the same per-output summation as reduce_partials_kernel with S <= RED_CHUNK.
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __restrict__ P, int S, int M, int N, float* __restrict__ C,
+                                                                int ldc, int gx_w, const float* __restrict__ Pb, int Nb,
+                                                                float* __restrict__ db) {
+  __shared__ float sh[8][32];
+  const int o = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const bool bias_part = (int)blockIdx.x >= gx_w;
+  const float* src = bias_part ? Pb : P;
+  const size_t total = bias_part ? (size_t)Nb : (size_t)M * N;
+  const size_t i = (size_t)(bias_part ? blockIdx.x - gx_w : blockIdx.x) * 32 + o;
+  float s = 0.f;
+  if (i < total)
+    for (int k = z; k < S; k += 8) s += src[(size_t)k * total + i];
+  sh[z][o] = s;
+  __syncthreads();
+  if (z == 0 && i < total) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += sh[k][o];
+    if (bias_part) {
+      db[i] = r;
+    } else {
+      const int row = (int)(i / N), col = (int)(i % N);
+      C[(size_t)row * ldc + col] = r;
+    }
+  }
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, int ldi, int R, int Cn, float* __restrict__ out, int ldo) {
   __shared__ float t[32][33];
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -1144,8 +1173,14 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
   hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
-  launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
-  if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
+  if (db && S <= RED_CHUNK) {  // both reductions in one launch
+    const unsigned gxw = (unsigned)(((size_t)N * K + 31) / 32), gxb = (unsigned)((N + 31) / 32);
+    hipLaunchKernelGGL(reduce_partials2_kernel, dim3(gxw + gxb), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K, dW, (int)ldw,
+                       (int)gxw, (const float*)pb, (int)N, db);
+  } else {
+    launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
+    if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
+  }
   return launched();
 }
 
@@ -1173,8 +1208,14 @@ extern "C" int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int6
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
   hipLaunchKernelGGL(hgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
-  launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
-  if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
+  if (db && S <= RED_CHUNK) {  // both reductions in one launch
+    const unsigned gxw = (unsigned)(((size_t)N * K + 31) / 32), gxb = (unsigned)((N + 31) / 32);
+    hipLaunchKernelGGL(reduce_partials2_kernel, dim3(gxw + gxb), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K, dW, (int)ldw,
+                       (int)gxw, (const float*)pb, (int)N, db);
+  } else {
+    launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
+    if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
+  }
   return launched();
 }
 
