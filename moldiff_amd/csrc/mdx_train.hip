@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "../../include/moldiff_hip.h"
 #include "mdx_tile.h"
@@ -704,6 +705,113 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(const float* __restric
   }
 }
 
+
+// ---- vectorised LayerNorm for the widths the networks use (F = 32, 64, 128, 256): a row is F/4 lanes x float4, a wave covers
+// 64 / (F/4) rows per step; the row sums are DPP / permlane butterflies over the row's lanes (the generic kernels above spend
+// twelve ds_bpermute round trips per row and a whole wave per row whatever its width).
+template <int LPR>  // lanes per row: 8, 16, 32, 64
+__device__ __forceinline__ float row_lanes_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror: + the other quad of the 8-lane group
+  if (LPR >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: + the other half of the 16-lane row
+  if (LPR >= 32) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  }
+  if (LPR >= 64) {
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  }
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int M, int relu, float* __restrict__ y,
+                                                            float* __restrict__ stats) {
+  constexpr int F = 4 * LPR, RPS = 64 / LPR;
+  const int lane = threadIdx.x & 63, wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = wg * RPS + lane / LPR, c4 = lane % LPR;
+  const bool ok = row < M;
+  const f32x4 v = ok ? ldg4(x + (size_t)row * F + 4 * c4) : splat4(0.f);
+  const float mean = row_lanes_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / F);
+  const f32x4 d = v - splat4(mean);
+  const float rstd = 1.0f / sqrtf(row_lanes_sum<LPR>(fmaf(d[0], d[0], fmaf(d[1], d[1], fmaf(d[2], d[2], d[3] * d[3])))) * (1.0f / F) + MDX_LN_EPS);
+  if (!ok) return;
+  f32x4 o = d * splat4(rstd) * ldg4(gamma + 4 * c4) + ldg4(beta + 4 * c4);
+  if (relu) o = relu4(o);
+  stg4(y + (size_t)row * F + 4 * c4, o);
+  if (c4 == 0) {
+    stats[2 * (size_t)row] = mean;
+    stats[2 * (size_t)row + 1] = rstd;
+  }
+}
+
+// backward: a wave walks `steps` consecutive row groups; dx per row; the wave's partial of dgamma / dbeta -> part[wave][2F]
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int M, int relu, int rows_per,
+                                                            float* __restrict__ dx, float* __restrict__ part) {
+  constexpr int F = 4 * LPR, RPS = 64 / LPR;
+  const int lane = threadIdx.x & 63, wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sub = lane / LPR, c4 = lane % LPR;
+  const int r0 = wg * rows_per, r1 = min(M, r0 + rows_per);
+  const f32x4 gm = ldg4(gamma + 4 * c4), bt = ldg4(beta + 4 * c4);
+  f32x4 dg = splat4(0.f), db = splat4(0.f);
+  for (int rb = r0; rb < r1; rb += RPS) {
+    const int row = rb + sub;
+    const bool ok = row < r1;
+    const size_t o = (size_t)(ok ? row : r0) * F + 4 * c4;
+    const float mean = stats[2 * (size_t)(ok ? row : r0)], rstd = stats[2 * (size_t)(ok ? row : r0) + 1];
+    const f32x4 xh = (ldg4(x + o) - splat4(mean)) * splat4(rstd);
+    f32x4 g = ok ? ldg4(dy + o) : splat4(0.f);
+    if (relu) {
+      const f32x4 yv = xh * gm + bt;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!(yv[k] > 0.f)) g[k] = 0.f;
+    }
+    dg = dg + g * xh;
+    db = db + g;
+    const f32x4 gh = g * gm;
+    const float m1 = row_lanes_sum<LPR>((gh[0] + gh[1]) + (gh[2] + gh[3])) * (1.0f / F);
+    const float m2 = row_lanes_sum<LPR>(fmaf(gh[0], xh[0], fmaf(gh[1], xh[1], fmaf(gh[2], xh[2], gh[3] * xh[3])))) * (1.0f / F);
+    if (ok) stg4(dx + o, (gh - splat4(m1) - xh * splat4(m2)) * splat4(rstd));
+  }
+  // the 64 / LPR row groups of the wave hold the same features: combine them (lane bits >= LPR), then the first group writes
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = dg[k], b = db[k];
+    if (LPR <= 8) {  // + lanes ^ 8 (row_ror:8 within the 16-lane row)
+      a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x128, 0xf, 0xf, false));
+      b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x128, 0xf, 0xf, false));
+    }
+    if (LPR <= 16) {
+      const auto sa = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+      const auto sb = __builtin_amdgcn_permlane16_swap(__float_as_uint(b), __float_as_uint(b), false, false);
+      a = __uint_as_float(sa[0]) + __uint_as_float(sa[1]);
+      b = __uint_as_float(sb[0]) + __uint_as_float(sb[1]);
+    }
+    if (LPR <= 32) {
+      const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+      const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(b), __float_as_uint(b), false, false);
+      a = __uint_as_float(sa[0]) + __uint_as_float(sa[1]);
+      b = __uint_as_float(sb[0]) + __uint_as_float(sb[1]);
+    }
+    dg[k] = a;
+    db[k] = b;
+  }
+  if (sub == 0) {
+    stg4(part + (size_t)wg * 2 * F + 4 * c4, dg);
+    stg4(part + (size_t)wg * 2 * F + F + 4 * c4, db);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // element-wise pairs.  op: 0 add, 1 sub, 2 mul, 3 gate (a * sigmoid(b))
 // ------------------------------------------------------------------------------------------------------------------
@@ -1033,6 +1141,15 @@ extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const floa
                                   float* stats, void* stream) {
   if (M <= 0) return MDX_OK;
   if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
+                    reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+#define MDX_LNF(LPR)                                                                                                              \
+  case 4 * LPR:                                                                                                                   \
+    hipLaunchKernelGGL(ln_relu_fwd4_kernel<LPR>, dim3((unsigned)((M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0,         \
+                       (hipStream_t)stream, x, gamma, beta, (int)M, relu, y, stats);                                              \
+    return launched();
+  if (al) switch (F) { MDX_LNF(8) MDX_LNF(16) MDX_LNF(32) MDX_LNF(64) default: break; }
+#undef MDX_LNF
   hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (int)M, F,
                      relu, y, stats);
   return launched();
@@ -1048,7 +1165,19 @@ extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* 
   const int RPW = MDX_LN_RPW;
   const int nw = (int)((M + RPW - 1) / RPW);     // waves
   const int nwp = (nw + 3) / 4 * 4;              // rows of `part` actually written (whole workgroups)
-  hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, F, relu, RPW, dx, ws);
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                    reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
+  bool done = false;
+#define MDX_LNB(LPR)                                                                                                              \
+  case 4 * LPR:                                                                                                                   \
+    hipLaunchKernelGGL(ln_relu_bwd4_kernel<LPR>, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, relu, \
+                       RPW, dx, ws);                                                                                              \
+    done = true;                                                                                                                  \
+    break;
+  if (al) switch (F) { MDX_LNB(8) MDX_LNB(16) MDX_LNB(32) MDX_LNB(64) default: break; }
+#undef MDX_LNB
+  if (!done)
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, F, relu, RPW, dx, ws);
   // [dgamma | dbeta] = sum over the nwp per-wave partial rows, fixed-order parallel reduction
   launch_reduce_partials(ws, nwp, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)nwp * 2 * F, s);
   return launched();
