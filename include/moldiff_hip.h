@@ -247,6 +247,14 @@ int mdx_op_hgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, co
                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
 int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
                     int64_t K, int32_t splits, float* partial, void* stream);
+/* The same Linear on MANY rows (the edge rows of a training batch) with the row-owner decomposition of the sampling kernels:
+ * Y (M,N) = X (M,K) W^T + bias + addend with W (N,K) [transW = 0], or X W with W (K,N) [transW = 1: the grad_input GEMM, no
+ * separate transpose].  K % 16 == 0, K/16 in {1,2,4,5,8,16}, N % 4 == 0, N <= 256 (mdx_op_linear_rows_supported); rows 16-byte
+ * aligned.  pack_ws: mdx_op_linear_rows_ws(N, K) bytes of scratch (the weight in streaming order, rebuilt per call). */
+int mdx_op_linear_rows_supported(int64_t N, int64_t K);
+size_t mdx_op_linear_rows_ws(int64_t N, int64_t K);
+int mdx_op_linear_rows(const float* X, int64_t ldx, const float* W, int64_t ldw, int32_t transW, const float* bias, const float* addend,
+                       int64_t ldd, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float* pack_ws, void* stream);
 int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream);
 int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream);
 /* y = relu?(LayerNorm(x) * gamma + beta) over F <= 1024 features (nn.LayerNorm eps 1e-5, models/common.py MLP);

@@ -66,6 +66,29 @@ def sgemm_nt(a, b, bias=None, splits=1, addend=None):
     return out
 
 
+ROWS_MIN = 16384   # from this many rows on a Linear runs on the row-owner kernel (one wave per 16 rows; the weight is re-packed per call)
+
+
+def linear_rows_ok(a, n, k, addend=None):
+    """Can `a` (M,k) @ W -> (M,n) take the row-owner kernel?  Shape built, enough rows, 16-byte aligned rows, fp32 mode."""
+    return (not _GEMM_BF16 and a.shape[0] >= ROWS_MIN and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+            and (addend is None or (addend.stride(1) == 1 and addend.stride(0) % 4 == 0 and addend.data_ptr() % 16 == 0))
+            and _L().mdx_op_linear_rows_supported(n, k) == 1)
+
+
+def linear_rows(a, w, trans_w, bias=None, addend=None):
+    """a (M,K) @ W^T (W (N,K), trans_w = False) or a @ W (W (K,N), trans_w = True) + bias + addend -> (M,N) on the row-owner
+    kernel (csrc/mdx_linear_rows.hip)."""
+    M, K = a.shape
+    N = w.shape[1] if trans_w else w.shape[0]
+    assert w.stride(1) == 1 and (w.shape[0] if trans_w else w.shape[1]) == K
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    ws = torch.empty(_L().mdx_op_linear_rows_ws(N, K) // 4, dtype=torch.float32, device=a.device)
+    check(_L().mdx_op_linear_rows(ptr(a), a.stride(0), ptr(w), w.stride(0), 1 if trans_w else 0, ptr(bias), ptr(addend),
+                                  addend.stride(0) if addend is not None else 0, ptr(out), N, M, N, K, ptr(ws), stream()))
+    return out
+
+
 def sgemm_tn(g, x, splits, want_bias=False):
     """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors; with want_bias also the
     column sums of g (the bias gradient) from the same pass -> (dW, db)."""
@@ -120,7 +143,10 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.has_addend = b is not None, addend is not None
         ctx.prec = 'bf16' if _GEMM_BF16 else 'f32'     # the backward of this layer runs in the forward's precision
-        return sgemm_nt(xc, wc, _c(b) if b is not None else None, addend=_c(addend) if addend is not None else None)
+        bc, ac = (_c(b) if b is not None else None), (_c(addend) if addend is not None else None)
+        if linear_rows_ok(xc, wc.shape[0], wc.shape[1], ac):
+            return linear_rows(xc, wc, False, bc, ac)
+        return sgemm_nt(xc, wc, bc, addend=ac)
 
     @staticmethod
     def backward(ctx, gy):
@@ -130,7 +156,10 @@ class _Linear(torch.autograd.Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         with precision(ctx.prec):
             if ctx.needs_input_grad[0]:
-                gx = sgemm_nt(gy, transpose(w))                       # (M,N) @ (K,N)^T
+                if linear_rows_ok(gy, w.shape[1], w.shape[0]):
+                    gx = linear_rows(gy, w, True)                     # (M,N) @ (N,K), the weight read transposed by the pack
+                else:
+                    gx = sgemm_nt(gy, transpose(w))                   # (M,N) @ (K,N)^T
             if ctx.needs_input_grad[1]:
                 r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
                 gw, gb = r if want_b else (r, None)

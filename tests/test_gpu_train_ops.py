@@ -37,6 +37,36 @@ def test_linear_forward_and_all_gradients(M, K, N):
     assert _rel(x.grad, x2.grad) < 2e-6 and _rel(w.grad, w2.grad) < 5e-6 and _rel(b.grad, b2.grad) < 5e-6
 
 
+@pytest.mark.parametrize('K,N', [(256, 256), (64, 256), (256, 64), (80, 64), (128, 128), (64, 128), (128, 64), (32, 64), (64, 32),
+                                 (16, 64), (64, 20), (256, 252)])
+@pytest.mark.parametrize('with_addend', [False, True])
+def test_linear_on_many_rows_takes_the_row_owner_kernel(K, N, with_addend):
+    """From train_ops.ROWS_MIN rows on, Linear forward and grad_input run on csrc/mdx_linear_rows.hip (weight packed per call,
+    read transposed for grad_input).  Ragged row count, every built (K, N) class incl. N not a multiple of 16 / 32; the input
+    is a column slice of a wider tensor (row stride != K)."""
+    M = T.ROWS_MIN + 123
+    assert T._L().mdx_op_linear_rows_supported(N, K) == 1
+    g = U.rng(K * 1000 + N)
+    wide = _leaf(g, M, K + 16)
+    w, b = _leaf(g, N, K, scale=K ** -0.5), _leaf(g, N)
+    add = _leaf(g, M, N) if with_addend else None
+    gy = U.t32(g.standard_normal((M, N))).to(DEV)
+    x = wide[:, 8:8 + K]
+    assert T.linear_rows_ok(T._rows(x), N, K, add)
+    y = T.linear(x, w, b, add)
+    y.backward(gy)
+    w2, b2, wide2 = (t.detach().clone().requires_grad_(True) for t in (w, b, wide))
+    y2 = F.linear(wide2[:, 8:8 + K].double(), w2.double(), b2.double())
+    if with_addend:
+        a2 = add.detach().clone().requires_grad_(True)
+        y2 = y2 + a2.double()
+    y2.backward(gy.double())
+    assert _rel(y, y2) < 2e-6
+    assert _rel(wide.grad, wide2.grad) < 2e-6 and _rel(w.grad, w2.grad) < 5e-6 and _rel(b.grad, b2.grad) < 5e-6
+    if with_addend:
+        assert _rel(add.grad, a2.grad) < 1e-6
+
+
 def test_linear_without_bias_and_noncontiguous_input():
     g = U.rng(5)
     big = _leaf(g, 700, 100)
