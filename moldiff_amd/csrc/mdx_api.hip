@@ -411,6 +411,8 @@ int pack_model(mdx_model_s* m) {
       c.packTS(&e.s.W1T, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
       c.packTS(&e.s.W2T, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
       c.packTS(&e.s.WmT, nb + ".msg_net.weight", ND, ND, 0, ND);
+      c.packTS(&e.s.WselfT, eb + ".self_ffn.weight", ED, ED, 0, ED);
+      c.packTS(&e.s.WoutT, eb + ".out_transform.weight", ED, ED, 0, ED);
       for (int s = 0; s < 2; ++s) {
         const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
         FfnTS& f = e.s.ffn[s];
@@ -1264,7 +1266,8 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     EdgeTailBwdArgs et{};
     et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
     et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
-    launch_edge_tail_bwd(et, s);
+    et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT;
+    if (mdx_use_rowowner()) launch_edge_tail_bwd2(et, s); else launch_edge_tail_bwd(et, s);
     launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;

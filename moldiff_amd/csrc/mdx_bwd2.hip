@@ -316,7 +316,63 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBw
   }
 }
 
+// EdgeBlock tail backward (reference models/graph.py:286-294 through autograd), row-owner: He'' = He' + out(relu(LN(u))),
+// u = self_ffn(He') + SL[l] + SR[r] + nfl[l] + nfr[r].  In: dL/dHe''.  Out: GU = dL/du (reduced per node by the caller) and
+// GHEP = dL/dHe'' + self_ffn^T dL/du (the part of dL/dHe' that does not go through the BondFFNs).  Same math as
+// mdx_bondpred.hip's edge_tail_bwd_kernel (tile design, MDX_TILE_KERNELS=1).
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_tail_bwd2_kernel(const EdgeTailBwdArgs a, const int nunits) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q0 = lane >> 4;
+  const unsigned lane_off = 16u * lane;
+  auto W = [&](const float* p) { return make_ws(p, lane_off); };
+  const int nslots = gridDim.x * 4;
+  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  const int per = (nunits + nslots - 1) / nslots;
+  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
+  if (ubeg >= uend) return;
+  WRing ring;
+  ring_prime(ring, W(a.w.s.Wself));
+#pragma unroll 1
+  for (int unit = ubeg; unit < uend; ++unit) {
+    int q = q0;
+    asm volatile("" : "+v"(q));
+    const RowTile t = load_tile(a.l, a.r, a.te, unit * ROWS, a.E, c);
+    f32x4 hep[4][RR], g[4][RR], u[4][RR];
+    row_gather<4, RR>(hep, a.Hep, t.row, 64, q);
+    row_gather<4, RR>(g, a.gHe, t.row, 64, q);
+    {  // u's per-node part, in the forward's order of additions
+      f32x4 v1[4][RR], v2[4][RR], v3[4][RR];
+      row_gather<4, RR>(u, a.SL, t.li, 64, q);
+      row_gather<4, RR>(v1, a.SR, t.ri, 64, q);
+      row_gather<4, RR>(v2, a.NT + MDX_NT_NFL, t.li, MDX_NTW, q);
+      row_gather<4, RR>(v3, a.NT + MDX_NT_NFR, t.ri, MDX_NTW, q);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        const f32x4 bs = ldg4(a.w.bself + 16 * ft + 4 * q);
+#pragma unroll
+        for (int rt = 0; rt < RR; ++rt) u[ft][rt] = (((u[ft][rt] + v1[ft][rt]) + v2[ft][rt]) + v3[ft][rt]) + bs;
+      }
+    }
+    rgemm<4, 4, RR>(u, hep, W(a.w.s.Wself), ring, W(a.sWoutT));
+    float rstd[RR];
+    row_ln_xhat<4, RR>(u, rstd);
+    f32x4 gy[4][RR];
+    row_zero<4, RR>(gy);
+    rgemm<4, 4, RR>(gy, g, W(a.sWoutT), ring, W(a.sWselfT));
+    row_ln_relu_bwd<4, RR>(gy, u, rstd, a.w.lng, a.w.lnb, q);
+    row_store<4, RR>(gy, a.GU, t.row, t.valid, 64, q);
+    rgemm<4, 4, RR>(g, gy, W(a.sWselfT), ring, W(a.w.s.Wself));
+    row_store<4, RR>(g, a.GHEP, t.row, t.valid, 64, q);
+  }
+}
+
 }  // namespace
+
+void launch_edge_tail_bwd2(const EdgeTailBwdArgs& a, hipStream_t s) {
+  if (a.E <= 0) return;
+  const int nunits = (a.E + ROWS - 1) / ROWS;
+  hipLaunchKernelGGL(edge_tail_bwd2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS)), dim3(MDX_WG), 0, s, a, nunits);
+}
 
 void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s) {
   if (a.E <= 0) return;

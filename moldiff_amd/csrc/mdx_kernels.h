@@ -159,6 +159,7 @@ struct FfnTS {  // stream packs (mdx_row.h) of the transposed BondFFN matrices
 struct EdgeBwdS {
   const float *WembHT, *WembDT, *Wg1eT, *Wg2T, *W1T, *W2T, *WmT;
   FfnTS ffn[2];
+  const float *WselfT, *WoutT;  // EdgeBlock tail
 };
 struct EdgeBwdW {  // transposed packs (contraction over the forward's output features)
   const float *WembHT, *WembDT;                 // edge_embs^T: -> 64 (He part), -> 16 (distance part)
@@ -182,6 +183,7 @@ struct EdgeTailBwdArgs {
   float *GU, *GHEP;            // (E,64): dL/du ; gHe + self_ffn^T dL/du
   EdgeBW w;
   const float *WselfT, *WoutT;
+  const float *sWselfT, *sWoutT;  // the same as stream packs (row-owner kernel, mdx_bwd2.hip)
 };
 
 struct EdgeBwdArgs {
@@ -234,6 +236,7 @@ struct BondDecArgs {
 void launch_edge_tail_bwd(const EdgeTailBwdArgs& a, hipStream_t s);
 void launch_edge_bwd(const EdgeBwdArgs& a, hipStream_t s);
 void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s);  // row-owner version (mdx_bwd2.hip)
+void launch_edge_tail_bwd2(const EdgeTailBwdArgs& a, hipStream_t s);
 void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
 void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s);
 // generalized segment sum: C in {32,64,128,256}; out row stride out_ld (floats), column offset already applied to `out`
