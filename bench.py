@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_STEPS = 1000
+_ORIG_ARGV = list(sys.argv[1:])   # main_train() strips --train before parsing; a self-launch must pass it on
 FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIGN.md / SURVEY Appendix D)
 FLOP_EDGE_B = 221184        # edge kernel B (EdgeBlock tail + PosUpdate): 2 * (2*64*64 + 2*64*256 + 2*64*32 + 256*256)
 FLOP_EDGE_BWD = 829440      # per directed edge per launch of the guidance backward's edge kernel
@@ -48,6 +49,33 @@ EDGE_B_NAME = 'edge_b2_kernel (row-owner EdgeBlock tail + PosUpdate, v_mfma_f32_
 REFERENCE_CPU_MOL_S = 0.097  # the REAL reference on 8 CPU cores, config #2 (2.64 s/step at 256 molecules)
 PEAK_FP32_MFMA = 157.3      # TFLOP/s (MI355X_MICROARCH.md)
 PEAK_HBM = 8000.0           # GB/s
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU through
+    torch.distributed.run on 127.0.0.1 and a free port), stream their output through and exit with their status.  Under an
+    external launcher (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + _ORIG_ARGV
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def launch_env(args_gpus):
+    """(world, rank, local_rank); starts the ranks when --gpus N > 1 was given to a plain `python bench.py`."""
+    if 'WORLD_SIZE' not in os.environ and args_gpus > 1:
+        self_launch(args_gpus)
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+    if args_gpus != world:
+        raise SystemExit(f'--gpus {args_gpus} != WORLD_SIZE {world}')
+    return world, rank, local_rank
 
 
 def build_bond_predictor():
@@ -72,28 +100,61 @@ def build_workload(batch, rank, device, kind='MolDiff_simple'):
     return model, ph, sizes
 
 
-def cpu_baseline(model, ph_cpu, batch, budget_s=20.0, bond_predictor=None):
-    """Time the CPU oracle on a bounded sample of the same workload: the first `nmol` molecules of the batch (per-step cost is
-    proportional to the directed edges, so the result is scaled by the edge ratio), thread count chosen by a ladder on that
-    same sample, 1 warm-up + >= 3 timed consecutive steps."""
+def numa_physical_cores():
+    """(node id, [one logical CPU per physical core of that NUMA node]) restricted to this process's affinity mask: the node with
+    the most usable cores.  Read from sysfs; falls back to the affinity mask when the topology files are absent."""
+    def parse(txt):
+        out = []
+        for part in txt.strip().split(','):
+            if part:
+                lo, _, hi = part.partition('-')
+                out.extend(range(int(lo), int(hi or lo) + 1))
+        return out
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except Exception:
+        allowed = set(range(os.cpu_count() or 1))
+    best = (-1, sorted(allowed))
+    try:
+        import glob
+        found = {}
+        for nd in glob.glob('/sys/devices/system/node/node[0-9]*'):
+            cpus = [c for c in parse(open(os.path.join(nd, 'cpulist')).read()) if c in allowed]
+            phys = []
+            for c in cpus:
+                try:
+                    sib = parse(open(f'/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list').read())
+                except Exception:
+                    sib = [c]
+                if c == min(x for x in sib if x in allowed):
+                    phys.append(c)
+            found[int(os.path.basename(nd)[4:])] = phys
+        if found:
+            node = max(sorted(found), key=lambda k: len(found[k]))
+            if found[node]:
+                best = (node, found[node])
+    except Exception:
+        pass
+    return best
+
+
+def cpu_worker(spec):
+    """Child process of cpu_baseline (already pinned by its parent): time the CPU oracle and print one JSON line."""
     import torch.nn.functional as F
     from oracle import moldiff_oracle as O
     from moldiff_amd.harness import placeholder_from_sizes
+    kind, batch, budget_s, ncores = spec['kind'], spec['batch'], spec['budget_s'], spec['ncores']
+    model, ph_cpu, sizes = build_workload(batch, 0, None, kind)
     gkw = {}
-    if bond_predictor is not None:
-        gkw = dict(Pb={k: v.detach().cpu() for k, v in bond_predictor.state_dict().items()},
+    if kind == 'MolDiff':
+        gkw = dict(Pb={k: v.detach().cpu() for k, v in build_bond_predictor().state_dict().items()},
                    cfgb=dict(num_timesteps=1000, num_blocks=8, cutoff=20), guidance=['uncertainty', 1e-4])
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
     P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     tabs = {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std')},
             'node': {k: P['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
             'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
     cfg = dict(num_timesteps=1000, num_blocks=6, cutoff=15)
-    sizes = torch.bincount(ph_cpu['batch_node'], minlength=batch).numpy()
+    sizes = np.asarray(sizes, dtype=np.int64)
     e_all = int((sizes * (sizes - 1)).sum())
     g = torch.Generator().manual_seed(0)
 
@@ -109,53 +170,74 @@ def cpu_baseline(model, ph_cpu, batch, budget_s=20.0, bond_predictor=None):
     def one(graph, st, N, Eh, step):
         noise = {'eps_pos': torch.randn(N, 3, generator=g), 'u_node': torch.rand(N, 8, generator=g),
                  'u_halfedge': torch.rand(Eh, 6, generator=g)}
+        t0 = time.perf_counter()
         with torch.no_grad():
             new, _ = O.sample_step(P, cfg, tabs, st, graph, step, noise, **gkw)
-        return {k: new[k] for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')}
+        return {k: new[k] for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')}, time.perf_counter() - t0
 
-    # 1. size of the sample: one probe step on 32 molecules at 16 threads -> molecules that fit 4 steps into the budget
-    torch.set_num_threads(min(16, cores))
-    graph, st, N, Eh = make(min(32, batch))
-    one(graph, st, N, Eh, 999)
-    t0 = time.perf_counter()
-    one(graph, st, N, Eh, 998)
-    probe = time.perf_counter() - t0
-    e_probe = int((sizes[:min(32, batch)] * (sizes[:min(32, batch)] - 1)).sum())
-    nmol = int(max(min(32, batch), min(batch, (budget_s / 7.0) / max(probe, 1e-4) * min(32, batch))))   # ~budget/7 per step
-    graph, st, N, Eh = make(nmol)
-    e_sub = int((sizes[:nmol] * (sizes[:nmol] - 1)).sum())
-    # 2. thread ladder on that sample (many-core hosts are far slower with one thread per logical CPU)
-    best = (float('inf'), 1)
-    ladder = []
-    for th in sorted({c for c in (16, 32, 64) if c <= cores} | {min(cores, 16)}):
+    # 1. thread ladder on a 32-molecule sample (all threads stay on the parent's pinned set: physical cores of one NUMA node)
+    nprobe = min(32, batch)
+    graph, st, N, Eh = make(nprobe)
+    e_probe = int((sizes[:nprobe] * (sizes[:nprobe] - 1)).sum())
+    torch.set_num_threads(min(8, ncores))
+    one(graph, st, N, Eh, 999)          # page in / MKL init
+    ladder, best = [], (float('inf'), 1)
+    for th in sorted({c for c in (8, 16, 32, 64, 128) if c <= ncores} | {ncores}):
         torch.set_num_threads(th)
-        t0 = time.perf_counter()
-        one(graph, st, N, Eh, 997)
-        dt = time.perf_counter() - t0
+        one(graph, st, N, Eh, 998)
+        _, dt = one(graph, st, N, Eh, 997)
         ladder.append((th, round(dt, 3)))
         if dt < best[0]:
             best = (dt, th)
-        if dt > 1.15 * best[0]:
-            break
     threads = best[1]
     torch.set_num_threads(threads)
-    # 3. warm-up + >= 3 timed consecutive steps
-    st = one(graph, st, N, Eh, 996)
-    nsteps = int(max(3, min(10, (budget_s * 0.45) / max(best[0], 1e-3))))
-    t0 = time.perf_counter()
-    for j in range(nsteps):
-        st = one(graph, st, N, Eh, 995 - j)
-    per_step = (time.perf_counter() - t0) / nsteps * e_all / e_sub
+    # 2. the sample: the FULL batch when warm-up + 3 steps fit ~2x the budget (estimated from the probe), else the largest prefix
+    est_full = best[0] * e_all / e_probe
+    nmol = batch if 4 * est_full <= 2.0 * budget_s else int(max(nprobe, min(batch, batch * (2.0 * budget_s / 4) / est_full)))
+    graph, st, N, Eh = make(nmol)
+    e_sub = int((sizes[:nmol] * (sizes[:nmol] - 1)).sum())
+    st, _ = one(graph, st, N, Eh, 996)  # warm-up at this size
+    times = []
+    for j in range(3):
+        st, dt = one(graph, st, N, Eh, 995 - j)
+        times.append(dt)
+    print('CPU_WORKER ' + json.dumps({'threads': threads, 'ladder': ladder, 'nmol': nmol, 'e_sub': e_sub, 'e_all': e_all, 'times': times}))
+
+
+def cpu_baseline(kind, batch, budget_s=20.0):
+    """Time the CPU oracle (oracle/moldiff_oracle.py, pinned to the reference) on the host: a child process pinned (taskset) to one
+    logical CPU per PHYSICAL core of ONE NUMA node, thread count chosen by a ladder inside that set, then 1 warm-up + 3 timed
+    consecutive denoising steps of the full batch (config #2) or of the largest prefix of it that fits the budget (config #3; cost is
+    proportional to the directed edges and scaled by that ratio)."""
+    import shutil
+    import subprocess
+    node, cpus = numa_physical_cores()
+    spec = {'kind': kind, 'batch': batch, 'budget_s': budget_s, 'ncores': len(cpus)}
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', json.dumps(spec)]
+    if shutil.which('taskset'):
+        cmd = ['taskset', '-c', ','.join(map(str, cpus))] + cmd
+    env = dict(os.environ, OMP_NUM_THREADS=str(len(cpus)), MKL_NUM_THREADS=str(len(cpus)), HIP_VISIBLE_DEVICES='')
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    line = next((ln for ln in r.stdout.splitlines() if ln.startswith('CPU_WORKER ')), None)
+    if line is None:
+        raise RuntimeError('cpu baseline worker failed: ' + r.stderr[-2000:])
+    w = json.loads(line[len('CPU_WORKER '):])
+    per_step = float(np.mean(w['times'])) * w['e_all'] / w['e_sub']
     value = batch / (per_step * T_STEPS)
-    return {'value': value, 'unit': 'molecules/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{nsteps} consecutive denoising steps (after 1 warm-up) of the first {nmol} of the {batch} molecules '
-                      f'({e_sub} of {e_all} directed edges; cost scaled by that ratio) with the torch-CPU oracle, fp32, {threads} '
-                      f'threads = best of the ladder {ladder} (threads, s/step) on the same sample, host has {cores} logical CPUs; '
-                      f'scaled to T=1000 (per-step cost is step-independent)',
-            'ms_per_step': per_step * 1e3, 'host_logical_cpus': cores, 'timed_steps': nsteps, 'sample_molecules': nmol,
-            'reference_cpu_mol_s': REFERENCE_CPU_MOL_S if bond_predictor is None else None,
-            'reference_cpu_note': 'BASELINE.md: the real reference (PyTorch CPU), config #2, 8 cores: 2.64 s/step at 256 molecules'
-                                  if bond_predictor is None else 'BASELINE.md has no measured CPU number for config #3'}
+    guided = kind == 'MolDiff'
+    return {'value': value, 'unit': 'molecules/sec', 'cores': w['threads'], 'kind': 'port',
+            'sample': f"3 consecutive denoising steps (after 1 warm-up) of {'the full batch' if w['nmol'] == batch else 'the first %d' % w['nmol']} "
+                      f"of the {batch} molecules ({w['e_sub']} of {w['e_all']} directed edges; cost scaled by that ratio) with the torch-CPU "
+                      f"oracle, fp32, process pinned to the {len(cpus)} physical cores of NUMA node {node} (one logical CPU per core), "
+                      f"{w['threads']} threads = best of the ladder {w['ladder']} (threads, s/step on a 32-molecule sample); scaled to "
+                      f"T=1000 (per-step cost is step-independent)",
+            'ms_per_step': per_step * 1e3, 'step_seconds': w['times'], 'pinned_physical_cores': len(cpus), 'numa_node': node,
+            'host_logical_cpus': os.cpu_count(), 'timed_steps': 3, 'sample_molecules': w['nmol'],
+            'reference_cpu_mol_s': None if guided else REFERENCE_CPU_MOL_S,
+            'reference_cpu_note': ('BASELINE.md has no measured CPU number for config #3' if guided else
+                                   'BASELINE.md: the real reference (PyTorch CPU), config #2, 8 cores of the survey container: 2.64 s/step at '
+                                   '256 molecules.  Port vs reference on the SAME host at the SAME time (build container, 8 cores, round 3): '
+                                   'reference 12.0 s/step, port 10.5 s/step -- the port is not slower than the reference; hosts differ')}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -231,9 +313,7 @@ def main_train():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
-    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
-    if args.gpus != world:
-        raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world} (launch with python -m torch.distributed.run --nproc-per-node N)')
+    world, rank, local_rank = launch_env(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py --train needs a ROCm GPU (no CPU fallback).')
     torch.cuda.set_device(local_rank)
@@ -372,14 +452,7 @@ def main():
     ap.add_argument('--headline-only', action='store_true', help='skip the extra single-GPU measurements (configs, sample(), B=2048)')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nnodes=1 '
-                             f'--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus}')
-        raise SystemExit(f'--gpus {args.gpus} != WORLD_SIZE {world}')
+    world, rank, local_rank = launch_env(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (no CPU fallback).')
     # one process per GPU over RCCL.  MDX_BENCH_BACKEND=gloo (+ ranks sharing a GPU when there are fewer devices than
@@ -439,10 +512,39 @@ def main():
     elapsed, prof = run_chain(sm, args.steps, args.warmup, barrier, prof=2 << 0)
     _, prof_all = run_chain(sm, min(args.steps, 40), 0, barrier, start=args.steps + args.warmup)
     steps_all = min(args.steps, 40)
+    multi = None
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+        comm_dev = dev if backend == 'nccl' else torch.device('cpu')
+        mine = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=comm_dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # the path's ONLY data collective: the end-of-run gather of every rank's last-step predictions to rank 0
+        # (moldiff_amd/distributed.gather_pred = what sample_drug3d does once per batch).  Timed twice, outside the step
+        # loop's timed region: the first call pays the communicator's lazy setup, the second is the steady cost.
+        from moldiff_amd.distributed import gather_pred
+        pred = sm.result()['pred']
+        gt = []
+        for _ in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            got = gather_pred([p.to(comm_dev) for p in pred], dst=0)
+            torch.cuda.synchronize()
+            g = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gt.append(float(g.item()) * 1e3)
+        nrows = torch.tensor([sm.N, sm.Eh], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(nrows)
+        if rank == 0:
+            assert got[0].shape[0] == int(nrows[0]) and got[2].shape[0] == int(nrows[1]), 'gather_pred lost rows'
+        multi = {'ranks_seen': dist.get_world_size(), 'backend': 'rccl (torch "nccl")' if backend == 'nccl' else backend,
+                 'per_rank_ms_per_step': [float(x.item()) for x in per_rank], 'gather_first_ms': gt[0], 'gather_ms': gt[1],
+                 'gather_rows': [int(nrows[0]), int(nrows[1])],
+                 'gather_bytes': int(nrows[0]) * (8 + 3) * 4 + int(nrows[1]) * 6 * 4,
+                 'gather_what': 'one distributed.gather_pred of all ranks\' last-step predictions to rank 0 (1 size all_gather + 1 '
+                                'padded all_gather per tensor), max over ranks; happens once per 1000-step run, outside ms_per_step'}
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world / (ms_per_step * T_STEPS / 1e3)
 
@@ -462,7 +564,12 @@ def main():
             'roofline_edge_b': roofline_mfma('edge_b', EDGE_B_NAME, FLOP_EDGE_B, E, prof_all),
             'aggregation': aggregation_line(N, E, prof_all),
             'kernel_ms_per_step': head['kernel_ms_per_step'], 'kernel_ms_note': head['kernel_ms_note'],
+            'ranks_seen': 1,
         }
+        if multi is not None:
+            out.update(multi)
+            # a complete 1000-step run of every rank plus the gather, i.e. what the entry point's batch loop costs
+            out['value_incl_gather'] = args.batch * world / (ms_per_step * T_STEPS / 1e3 + multi['gather_ms'] / 1e3)
         # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
         # gfx950 correction applied) committed under profiles/; a Python process cannot collect PMCs on itself.
         try:
@@ -551,8 +658,7 @@ def main():
         out['configs'] = configs
         if not args.no_cpu_baseline:
             for name, kind in (('simple', 'MolDiff_simple'), ('guided', 'MolDiff')):
-                mc, phc, _ = build_workload(args.batch, 0, None, kind)
-                cb = cpu_baseline(mc, phc, args.batch, args.cpu_budget, build_bond_predictor() if kind == 'MolDiff' else None)
+                cb = cpu_baseline(kind, args.batch, args.cpu_budget)
                 configs[name]['cpu_baseline'] = cb
                 configs[name]['speedup_vs_cpu_baseline'] = configs[name]['value'] / cb['value']
             hk = 'guided' if args.guided else 'simple'
@@ -568,7 +674,9 @@ def main():
 
 
 if __name__ == '__main__':
-    if '--train' in sys.argv:
+    if '--cpu-worker' in sys.argv:
+        cpu_worker(json.loads(sys.argv[sys.argv.index('--cpu-worker') + 1]))
+    elif '--train' in sys.argv:
         sys.argv.remove('--train')
         main_train()
     else:

@@ -504,6 +504,10 @@ struct mdx_graph_s {
   int64_t* mol_ids = nullptr;
   const int32_t *left, *right, *int2ref, *ref2int, *row_ptr, *col_ptr, *col_eids, *node_graph, *node_local, *he_graph,
       *he_local, *half_of_int, *node_ptr, *he_ptr;
+  // graph-aligned 16-row units of edge kernel A's in-kernel aggregation (EA_AGG, mdx_kernels.h): units (2 ints per unit: first
+  // edge, rows), per-edge partial-row offset, per-node partial-row ranges
+  const int32_t *units = nullptr, *epo = nullptr, *pbase = nullptr;
+  int64_t nunits = 0, nparts = 0;
   hipEvent_t ev_in = nullptr, ev_done = nullptr;  // stream hand-offs of mdx_sample_step_full's concurrent guidance chain
 };
 
@@ -611,6 +615,37 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   for (int64_t h = 0; h < Eh; ++h) he_ptr[he_graph[h] + 1]++;
   for (int64_t b = 0; b < B; ++b) { node_ptr[b + 1] += node_ptr[b]; he_ptr[b + 1] += he_ptr[b]; }
   const size_t o_np = add(node_ptr), o_hp = add(he_ptr);
+  // Units of 16 edges aligned to each graph's first edge: graph b owns the edges row_ptr[node_ptr[b]] .. row_ptr[node_ptr[b+1]]
+  // (batch_node is non-decreasing and edges are sorted by left node).  A node's run is cut where a unit ends, so the cuts --
+  // and the association of the in-kernel sums -- are a function of the graph alone, not of its offset in the batch.
+  std::vector<int32_t> units, epo(E), pbase(N + 1, 0);
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t e_lo = p.row_ptr[node_ptr[b]], e_hi = p.row_ptr[node_ptr[b + 1]];
+    for (int32_t e0 = e_lo; e0 < e_hi; e0 += 16) {
+      units.push_back(e0);
+      units.push_back(std::min<int32_t>(16, e_hi - e0));
+    }
+  }
+  {
+    const int64_t U = (int64_t)units.size() / 2;
+    int64_t u = 0;  // unit of the current edge (units are in edge order)
+    for (int64_t v = 0; v < N; ++v) {
+      const int32_t r0 = p.row_ptr[v], r1 = p.row_ptr[v + 1];
+      int32_t pieces = 0, ufirst = 0;
+      if (r1 > r0) {
+        while (u + 1 < U && units[2 * (u + 1)] <= r0) ++u;
+        ufirst = (int32_t)u;
+        int64_t ul = u;
+        while (ul + 1 < U && units[2 * (ul + 1)] <= r1 - 1) ++ul;
+        pieces = (int32_t)(ul - u + 1);
+      }
+      pbase[v + 1] = pbase[v] + pieces;
+      for (int32_t e = r0; e < r1; ++e) epo[e] = pbase[v] - ufirst;
+    }
+  }
+  g->nunits = (int64_t)units.size() / 2;
+  g->nparts = pbase[N];
+  const size_t o_un = add(units), o_epo = add(epo), o_pb = add(pbase);
   std::vector<int32_t> half_of_int(E);
   for (int64_t i = 0; i < E; ++i) half_of_int[i] = Eh > 0 ? (int32_t)(p.int2ref[i] % Eh) : 0;
   const size_t o_hoi = add(half_of_int);
@@ -633,6 +668,7 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   g->half_of_int = g->dev + o_hoi;
   g->node_ptr = g->dev + o_np;
   g->he_ptr = g->dev + o_hp;
+  g->units = g->dev + o_un; g->epo = g->dev + o_epo; g->pbase = g->dev + o_pb;
   *out = g;
   return MDX_OK;
 }
@@ -654,6 +690,7 @@ namespace {
 struct Ws {
   float *Hn, *H, *NT, *NT2, *aggr, *SL, *SR, *Lf, *Rf, *tn, *posA, *posB;
   float *HeA, *HeB, *M, *FL, *FR, *Fe, *te, *tnr, *tmpE;  // tmpE: (E,64) scratch for boundary permutes
+  float *P, *PR;  // partial rows of the in-kernel aggregation: (2N + E/16 + 1) x 256 / x 64 (bound on a graph's partial rows)
   bool tnr_set;  // tnr holds node_time[right] (only the bare NodeEdgeNet API can make it differ from te)
   size_t bytes;
 };
@@ -672,6 +709,9 @@ size_t ws_layout(int64_t N, int64_t E, char* base, Ws* w) {
   t.posA = take(n * 3); t.posB = take(n * 3);
   t.HeA = take(e * 64); t.HeB = take(e * 64); t.M = take(e * MDX_ND); t.FL = take(e * 64); t.FR = take(e * 64);
   t.Fe = take(e * 3); t.te = take(e); t.tnr = take(e); t.tmpE = take(e * 64);
+  // every node with edges has one piece per unit its run touches: <= N + (#units) <= N + (E/16 + #graphs) <= 2N + E/16 rows
+  const size_t np = 2 * n + e / 16 + 1;
+  t.P = take(np * MDX_ND); t.PR = take(np * 64);
   t.bytes = off;
   if (w) *w = t;
   return off;
@@ -785,8 +825,26 @@ EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i
   a.pos = pos; a.dist_in = nullptr;
   a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = NT ? NT : w.NT;
   a.M = w.M; a.F[0] = w.FL; a.F[1] = w.FR; a.w = m->blocks[i].ea;
+  if (flags & EA_AGG) {  // segment sums inside the kernel: M and the BondFFN-right rows stay out of HBM
+    a.M = nullptr; a.F[1] = nullptr;
+    a.units = g->units; a.nunits = (int)g->nunits; a.epo = g->epo; a.P = w.P; a.PR = w.PR;
+  }
   return a;
 }
+
+// Edge kernel A with its segment sums fused (round 3) unless the tile kernels (no EA_AGG) or MDX_NO_AGG=1 (A/B) are selected
+bool use_agg() {
+  static const bool v = [] {
+    const char* e = getenv("MDX_NO_AGG");
+    return mdx_use_rowowner() && !(e && e[0] == '1');
+  }();
+  return v;
+}
+#define LCHK(x)                    \
+  do {                             \
+    const int rc_ = (x);           \
+    if (rc_ != MDX_OK) return rc_; \
+  } while (0)
 
 EdgeBArgs make_eb(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i, const float* pos, const float* Hep,
                   float* He_out, int flags, const float* NT = nullptr) {
@@ -808,8 +866,8 @@ NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int im
 }
 
 // Runs all blocks.  In: w.Hn, w.HeA (internal order), pos_in, w.tn / w.te.  Out: w.Hn, He (returned pointer), pos (returned).
-void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
-                const float** pos_final, hipStream_t s, float* pos_out = nullptr) {
+int run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
+               const float** pos_final, hipStream_t s, float* pos_out = nullptr) {
   const int nb = m->cfg.num_blocks;
   const bool upos = m->cfg.update_pos != 0;
   const float* pos = pos_in;
@@ -820,14 +878,24 @@ void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const f
   float* NTnxt = w.NT2;
   launch_node(make_nd(m, g, w, -1, 0, ND_PRE, nullptr, NTcur), s);
   for (int i = 0; i < nb; ++i) {
-    { ProfScope ps(PK_EDGE_A, s); launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN, NTcur), s); }
+    const bool agg = use_agg();
+    {
+      ProfScope ps(PK_EDGE_A, s);
+      LCHK(launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0), NTcur), s));
+    }
     {
       ProfScope ps(PK_AGGR, s);
-      launch_seg_reduce_block(w.M, w.FL, w.FR, g->row_ptr, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
+      if (agg)
+        launch_seg_reduce_block2(w.P, w.PR, w.FL, g->pbase, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
+      else
+        launch_seg_reduce_block(w.M, w.FL, w.FR, g->row_ptr, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
     }
     int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (i + 1 < nb ? ND_PRE : 0);
     { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
-    { ProfScope ps(PK_EDGE_B, s); launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s); }
+    {
+      ProfScope ps(PK_EDGE_B, s);
+      LCHK(launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s));
+    }
     if (upos) {
       if (pos_out && i + 1 == nb) pos_next = pos_out;  // the last update lands in the caller's buffer (no copy afterwards)
       launch_seg_reduce(w.Fe, g->row_ptr, nullptr, pos_next, pos, (int)g->N, 3, s);
@@ -838,6 +906,7 @@ void run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const f
   }
   *He_final = w.HeA;
   *pos_final = pos;
+  return MDX_OK;
 }
 
 }  // namespace
@@ -857,7 +926,7 @@ extern "C" int mdx_net_forward(mdx_model_t m, mdx_graph_t g, const float* h_node
   gather_rows(node_time, g->right, w.tnr, g->E, 1, s);
   w.tnr_set = true;
   const float *He, *pf;
-  run_blocks(m, g, w, pos, &He, &pf, s);
+  LCHK(run_blocks(m, g, w, pos, &He, &pf, s));
   if (h_node_out) HIPCHK(hipMemcpyAsync(h_node_out, w.Hn, (size_t)g->N * MDX_ND * 4, hipMemcpyDeviceToDevice, s));
   if (pos_out) HIPCHK(hipMemcpyAsync(pos_out, pf, (size_t)g->N * 12, hipMemcpyDeviceToDevice, s));
   if (h_edge_out) gather_rows(He, g->ref2int, h_edge_out, g->E, 64, s);
@@ -877,7 +946,7 @@ extern "C" int mdx_node_block(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   // NodeBlock's gate sees node_time[col]: per-edge time = node_time[right]
   gather_rows(node_time, g->right, w.te, g->E, 1, s);
   launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
-  launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_NODE), s);
+  LCHK(launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_NODE), s));
   launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s);
   NodeArgs na = make_nd(m, g, w, i, -1, ND_MID | ND_DELTA);
   na.dHn = out;
@@ -897,10 +966,10 @@ extern "C" int mdx_edge_block(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   gather_rows(h_bond, g->int2ref, w.HeA, g->E, 64, s);
   gather_rows(bond_time, g->int2ref, w.te, g->E, 1, s);
   launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
-  launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s);
+  LCHK(launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s));
   launch_seg_reduce(w.FL, g->col_ptr, g->col_eids, w.SL, nullptr, (int)g->N, 64, s);
   launch_seg_reduce(w.FR, g->row_ptr, nullptr, w.SR, nullptr, (int)g->N, 64, s);
-  launch_edge_b(make_eb(m, g, w, i, nullptr, w.HeA, w.HeB, EB_EDGE | EB_DELTA), s);
+  LCHK(launch_edge_b(make_eb(m, g, w, i, nullptr, w.HeA, w.HeB, EB_EDGE | EB_DELTA), s));
   gather_rows(w.HeB, g->ref2int, out, g->E, 64, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
@@ -920,7 +989,7 @@ extern "C" int mdx_bond_ffn(mdx_model_t m, mdx_graph_t g, int32_t i, int32_t sid
   gather_rows(bond_feat, g->int2ref, w.HeA, g->E, 64, s);
   gather_rows(time, g->int2ref, w.te, g->E, 1, s);
   launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
-  launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s);
+  LCHK(launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s));
   gather_rows(side ? w.FR : w.FL, g->ref2int, out, g->E, 64, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
@@ -945,7 +1014,7 @@ extern "C" int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   EdgeBArgs eb = make_eb(m, g, w, i, nullptr, w.HeA, nullptr, EB_POS);
   eb.rel_in = w.M;
   eb.dist_in = w.FL;
-  launch_edge_b(eb, s);
+  LCHK(launch_edge_b(eb, s));
   launch_seg_reduce(w.Fe, g->row_ptr, nullptr, out, nullptr, (int)g->N, 3, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
@@ -995,7 +1064,7 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
   }
   launch_embed(ea, s);
   const float *He, *pf;
-  run_blocks(m, g, w, pos_pert, &He, &pf, s, m->cfg.update_pos ? pred_pos : nullptr);
+  LCHK(run_blocks(m, g, w, pos_pert, &He, &pf, s, m->cfg.update_pos ? pred_pos : nullptr));
   DecodeArgs da{};
   da.N = (int)g->N; da.Eh = (int)g->Eh; da.Kn = cf.num_node_types; da.Ke = cf.num_edge_types; da.Hn = w.Hn; da.He = He;
   da.ref2int = g->ref2int; da.nodedec = m->nodedec; da.edgedec = m->edgedec; da.pred_node = pred_node;
@@ -1202,24 +1271,28 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
     }
     if (i == 0 || tape) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
     {
-      EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN, wi.NT);
+      EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN | (use_agg() ? EA_AGG : 0), wi.NT);
       if (tape) {
         ea_args.tSG = tp.b[i].SG;
         ea_args.tHE = tp.b[i].HE;
+        ea_args.M = tp.b[i].M;  // the backward reads the gated message back (with EA_AGG it is no longer the reduction's input)
       }
-      { ProfScope ps(PK_EDGE_A, s); launch_edge_a(ea_args, s); }
+      { ProfScope ps(PK_EDGE_A, s); LCHK(launch_edge_a(ea_args, s)); }
     }
-    launch_seg_reduce_block(wi.M, wi.FL, wi.FR, g->row_ptr, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
+    if (use_agg())
+      launch_seg_reduce_block2(wi.P, wi.PR, wi.FL, g->pbase, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
+    else
+      launch_seg_reduce_block(wi.M, wi.FL, wi.FR, g->row_ptr, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
     if (tape) {
       launch_node(make_nd(m, g, wi, i, -1, ND_MID, wi.NT, nullptr), s);
     } else {  // no tape: fuse the next block's PRE into this node launch (tables double-buffered like run_blocks)
       float* NTn = (wr.NT == w.NT) ? w.NT2 : w.NT;
       launch_node(make_nd(m, g, wi, i, i + 1 < nb ? i + 1 : -1, ND_MID | (i + 1 < nb ? ND_PRE : 0), wi.NT, NTn), s);
-      launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s);
+      LCHK(launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
       wr.NT = NTn;
       continue;
     }
-    launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s);
+    LCHK(launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
   }
   if (tape) {
     HIPCHK(hipMemcpyAsync(tp.HnF, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));

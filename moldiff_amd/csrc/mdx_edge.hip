@@ -16,6 +16,8 @@
 // computes as Linear(h_node[idx])) are gathered from the hoisted node tables H / NT.
 #include "mdx_kernels.h"
 #include "mdx_tile.h"
+#include "../../include/moldiff_hip.h"
+int mdx_set_error(int code, const char* msg);
 
 // Phase trace (tools/trace_edge_a.py; build with `make EXTRA=-DMDX_TRACE`): thread 0 of every workgroup stamps the
 // shader clock at each phase boundary of edge_a into a 32-slot record.  Compiled out of the shipped library.
@@ -486,18 +488,21 @@ static void ensure_attr() {
   g_attr_set = true;
 }
 
-void launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
+int launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
+  if (a.E <= 0) return MDX_OK;
   if (mdx_use_rowowner()) return launch_edge_a2(a, s);
+  if (a.flags & EA_AGG) return mdx_set_error(MDX_ERR_UNSUPPORTED, "the tile kernels have no in-kernel aggregation (EA_AGG)");
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;
   hipLaunchKernelGGL(edge_a_kernel, dim3(ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
+  return MDX_OK;
 }
 
-void launch_edge_b(const EdgeBArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
+int launch_edge_b(const EdgeBArgs& a, hipStream_t s) {
+  if (a.E <= 0) return MDX_OK;
   if (mdx_use_rowowner()) return launch_edge_b2(a, s);
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;
   hipLaunchKernelGGL(edge_b_kernel, dim3(ntiles), dim3(MDX_WG), LDS_FLOATS * 4, s, a, ntiles);
+  return MDX_OK;
 }

@@ -44,8 +44,13 @@ constexpr int EA_CONST_FLOATS = 96 + 2560 + 2 * 640;
 
 // Work list of a persistent wave ("slot"): nf full units (a contiguous range), then its share of the last, partial round.
 // When the last round is short and the kernel runs both sections, that round is cut by SECTION instead of by rows (a
-// 16-row MFMA tile cannot be split further): the first `rem` slots run the NodeBlock message path of one unit each, the other
-// slots the BondFFN sections of `m` units each -- 0.76 + 3 x 0.25 of a unit instead of a whole extra round.
+// 16-row MFMA tile cannot be split further).  Unit costs measured with tools/trace_edge2.py (fractions of a unit): message path
+// incl. edge_embs 0.72, left BondFFN 0.13, right BondFFN 0.15 (with its in-kernel segment sum), edge_embs recomputed by a slot
+// that only runs BondFFNs 0.03.  Two cuts:
+//   split 1: the first `rem` slots run the message path of one unit each (0.72), the other slots both BondFFNs of `m` <= 2 units
+//            each (0.31 m);
+//   split 2: the first `rem` slots run the message path AND the right BondFFN of one unit each (0.87), the other slots the left
+//            BondFFN of `m` <= 5 units each (0.16 m)   -- covers rem up to 5/6 of the slots (split 1 with m = 3 would take 0.93).
 struct EdgePlan {
   int nslots, nf, rem, split, m;
 };
@@ -55,26 +60,29 @@ __host__ __device__ inline int plan_items(const EdgePlan& p, int slot) {
   const int k = slot - p.rem, left = p.rem - k * p.m;
   return p.nf + (left < 0 ? 0 : left < p.m ? left : p.m);
 }
-// item it of a slot -> unit index; mode bits: 1 message path, 2 BondFFNs, 4 this item owns the He' store
+// item it of a slot -> unit index; mode bits: 1 message path, 2 left BondFFN, 8 right BondFFN, 4 this item owns the He' store
 __device__ __forceinline__ int plan_item(const EdgePlan& p, int slot, int it, int& mode) {
   if (it < p.nf) {
-    mode = 7;
+    mode = 15;
     return slot * p.nf + it;
   }
   const int base = p.nf * p.nslots;
   if (!p.split || slot < p.rem) {
-    mode = p.split ? 5 : 7;
+    mode = p.split == 0 ? 15 : p.split == 1 ? 5 : 13;
     return base + slot;
   }
-  mode = 2;
+  mode = p.split == 1 ? 10 : 2;
   return base + (slot - p.rem) * p.m + (it - p.nf);
 }
 inline EdgePlan make_plan(int nunits, int nslots, bool can_split) {
   EdgePlan p{nslots, nunits / nslots, nunits % nslots, 0, 0};
   if (can_split && p.rem > 0 && p.rem < nslots) {
     const int m = (p.rem + (nslots - p.rem) - 1) / (nslots - p.rem);
-    if (0.27f * m < 0.9f) {
+    if (m <= 2) {
       p.split = 1;
+      p.m = m;
+    } else if (m <= 5) {
+      p.split = 2;
       p.m = m;
     }
   }
@@ -113,7 +121,17 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
   const int E = a.E;
-  constexpr bool do_emb = FLAGS & EA_EMB, do_node = FLAGS & EA_NODE, do_ffn = FLAGS & EA_FFN;
+  constexpr bool do_emb = FLAGS & EA_EMB, do_node = FLAGS & EA_NODE, do_ffn = FLAGS & EA_FFN, do_agg = FLAGS & EA_AGG;
+  static_assert(!do_agg || RR == 1, "the in-kernel segment sums are written for one 16-row tile per wave");
+  // rows of unit u: graph-aligned units from the plan's table (EA_AGG) or 16 consecutive rows of the batch
+  auto tile_of = [&](int u) {
+    if constexpr (do_agg) {
+      const int2 ue = reinterpret_cast<const int2*>(a.units)[u];
+      return load_tile_u(a.l, a.r, a.te, a.epo, ue.x, ue.y, E, c);
+    } else {
+      return load_tile(a.l, a.r, a.te, u * ROWS, E, c);
+    }
+  };
   f32x4* park = reinterpret_cast<f32x4*>(smem + (size_t)wave * PARK_FLOATS) + lane;
   const unsigned lane_off = 16u * lane;
   auto W = [&](const float* p) { return make_ws(p, lane_off); };
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   Prolog pr;
   int mode, mode_next;
   int unit = plan_item(plan, slot, 0, mode);
-  pr.t = load_tile(a.l, a.r, a.te, unit * ROWS, E, c);
+  pr.t = tile_of(unit);
   prolog_rows(pr, a, q0);
 
 #pragma unroll 1
@@ -174,8 +192,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
     asm volatile("" : "+v"(q));  // opaque per iteration: lane-dependent address parts stay next to their loads instead of
                                  // being hoisted out of the persistent loop into (spilled) registers
     const RowTile t = pr.t;
+    const int ucnt = do_agg ? __builtin_amdgcn_readfirstlane(t.cnt) : 0;
     const int unext = plan_item(plan, slot, min(it + 1, nitems - 1), mode_next);
-    const bool inode = do_node && (mode & 1), iffn = do_ffn && (mode & 2);
+    const bool inode = do_node && (mode & 1), iffn = do_ffn && (mode & 10);
+    const int sfirst = (mode & 2) ? 0 : 1, slast = (mode & 8) ? 1 : 0;  // BondFFN sections of this item (wave-uniform)
     STAMP(46);
     STAMP(0);
     // ---- He' = edge_embs([He | smear(d)]) -------------------------------------------------------
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       }
       row_bias<4, RR>(hep, c_bemb, q);
       STAMP(1);
-      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, W(inode ? a.w.s.Wg1e : iffn ? a.w.s.ffn[0].Wbl : wfirst));
+      rgemm<5, 4, RR>(hep, x, W(a.w.s.Wemb), ring, W(inode ? a.w.s.Wg1e : iffn ? a.w.s.ffn[sfirst].Wbl : wfirst));
       STAMP(2);
       if (mode & 4) row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
     } else {
@@ -253,24 +273,32 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       // msg_net, gated
       row_bias<16, RR>(y, c_bm, q);
       STAMP(11);
-      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, W(iffn ? a.w.s.ffn[0].Wbl : wfirst));
+      rgemm<16, 16, RR>(y, z, W(a.w.s.Wm), ring, W(iffn ? a.w.s.ffn[sfirst].Wbl : wfirst));
       STAMP(12);
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft)
 #pragma unroll
         for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * park[(ft * RR + rt) * 64];
-      row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
+      if constexpr (do_agg) {
+        // aggr[v] = sum over v's edge run of M (models/graph.py:50), the part of it that lies in this unit: segmented sum over
+        // the tile's rows, one partial row per left node stored by the last row of its segment
+        if (a.M) row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
+        seg_sum_store<16>(y, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.P);
+      } else {
+        row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
+      }
       STAMP(13);
     }
-    if (!iffn) {  // next unit's tile (the FFN section does this under its own GEMMs)
-      pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);
-      prolog_rows(pr, a, q);
-    }
+    // next unit's tile: indices, He rows and edge lengths are requested here, ahead of the BondFFN sections, and arrive under
+    // their GEMMs (requested inside a section they would sit behind that section's run-time condition: spills)
+    pr.t = tile_of(unext);
+    prolog_rows(pr, a, q);
 
     // ---- EdgeBlock BondFFNs: F_s = inter_s((W_bl He') * nl_s[idx_s]) * sigmoid(gate_s([He' | x[idx_s] | t])) ----
     if (iffn) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (!(mode & (s ? 8 : 2))) continue;
         const FfnS& ws = a.w.s.ffn[s];
         int idx[RR];
 #pragma unroll
@@ -278,7 +306,6 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         f32x4 bl[8][RR], nl[8][RR], g1[2][RR];
         row_gather<8, RR>(nl, a.NT + (s ? MDX_NT_NLR : MDX_NT_NLL), idx, MDX_NTW, q);
         row_gather<2, RR>(g1, a.NT + (s ? MDX_NT_GXR : MDX_NT_GXL), idx, MDX_NTW, q);
-        if (s == 1) pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);  // next unit's indices, a few GEMMs ahead of their use
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft) {
           const f32x4 b = lds4(f_bg1[s] + 16 * ft + 4 * q), wt = lds4(f_wtg1[s] + 16 * ft + 4 * q);
@@ -301,18 +328,26 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         row_layernorm<8, RR>(h, f_ig[s], f_ibe[s], q);
         f32x4 o[4][RR], g2[4][RR];
         row_bias<4, RR>(o, f_ib2[s], q);
-        if (s == 1) prolog_rows(pr, a, q);  // next unit's He rows + edge lengths travel under the last two GEMMs
         STAMP(19 + 10 * s);
         rgemm<8, 4, RR>(o, h, W(ws.W2), ring, W(ws.Wg2));
         STAMP(20 + 10 * s);
         row_bias<4, RR>(g2, f_bg2[s], q);
-        rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, W(s == 0 ? a.w.s.ffn[1].Wbl : wfirst));
+        rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, W(s < slast ? a.w.s.ffn[1].Wbl : wfirst));
         STAMP(21 + 10 * s);
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
           for (int rt = 0; rt < RR; ++rt) o[ft][rt] = o[ft][rt] * row_sigmoid4(g2[ft][rt]);
-        row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
+        if constexpr (do_agg) {
+          if (s == 1) {  // SR[v] = sum over v's edge run of bond_ffn_right (graph.py:283): same segments as M
+            if (a.F[1]) row_store<4, RR>(o, a.F[1], t.row, t.valid, 64, q);
+            seg_sum_store<4>(o, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.PR);
+          } else {
+            row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
+          }
+        } else {
+          row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
+        }
         STAMP(22 + 10 * s);
       }
     }
@@ -351,20 +386,22 @@ static void launch_a2(const EdgeAArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)edge_a2_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  const int nunits = (a.E + ROWS - 1) / ROWS;
+  const int nunits = (FLAGS & EA_AGG) ? a.nunits : (a.E + ROWS - 1) / ROWS;
+  if (nunits <= 0) return;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
-  constexpr bool all = FLAGS == (EA_EMB | EA_NODE | EA_FFN);
+  constexpr bool all = (FLAGS & ~EA_AGG) == (EA_EMB | EA_NODE | EA_FFN);
   static const bool nosplit = getenv("MDX_NO_TAIL_SPLIT") != nullptr;
   const EdgePlan plan = make_plan(nunits, grid * 4, all && !nosplit);
   hipLaunchKernelGGL(edge_a2_kernel<FLAGS>, dim3(grid), dim3(MDX_WG), lds, s, a, plan);
 }
 
-void launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
+int launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
+  if (a.E <= 0) return MDX_OK;
   switch (a.flags) {
-    case EA_EMB | EA_NODE | EA_FFN: return launch_a2<EA_EMB | EA_NODE | EA_FFN>(a, s);  // product path
-    case EA_NODE: return launch_a2<EA_NODE>(a, s);                                    // NodeBlock.forward
-    case EA_FFN: return launch_a2<EA_FFN>(a, s);                                      // EdgeBlock.forward
-    default: mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel A: unsupported section flags");
+    case EA_EMB | EA_NODE | EA_FFN | EA_AGG: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_AGG>(a, s); return MDX_OK;  // product path
+    case EA_EMB | EA_NODE | EA_FFN: launch_a2<EA_EMB | EA_NODE | EA_FFN>(a, s); return MDX_OK;  // a block with M / FR in HBM
+    case EA_NODE: launch_a2<EA_NODE>(a, s); return MDX_OK;                                    // NodeBlock.forward
+    case EA_FFN: launch_a2<EA_FFN>(a, s); return MDX_OK;                                      // EdgeBlock.forward
+    default: return mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel A: unsupported section flags");
   }
 }

@@ -208,13 +208,13 @@ static void launch_b2(const EdgeBArgs& a, hipStream_t s) {
                      nunits);
 }
 
-void launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
+int launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {
+  if (a.E <= 0) return MDX_OK;
   switch (a.flags) {
-    case EB_EDGE | EB_POS: return launch_b2<EB_EDGE | EB_POS>(a, s);      // MolDiff denoiser
-    case EB_EDGE: return launch_b2<EB_EDGE>(a, s);                        // bond predictor (update_pos = False)
-    case EB_EDGE | EB_DELTA: return launch_b2<EB_EDGE | EB_DELTA>(a, s);  // EdgeBlock.forward
-    case EB_POS: return launch_b2<EB_POS>(a, s);                          // PosUpdate.forward
-    default: mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel B: unsupported section flags");
+    case EB_EDGE | EB_POS: launch_b2<EB_EDGE | EB_POS>(a, s); return MDX_OK;      // MolDiff denoiser
+    case EB_EDGE: launch_b2<EB_EDGE>(a, s); return MDX_OK;                        // bond predictor (update_pos = False)
+    case EB_EDGE | EB_DELTA: launch_b2<EB_EDGE | EB_DELTA>(a, s); return MDX_OK;  // EdgeBlock.forward
+    case EB_POS: launch_b2<EB_POS>(a, s); return MDX_OK;                          // PosUpdate.forward
+    default: return mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel B: unsupported section flags");
   }
 }

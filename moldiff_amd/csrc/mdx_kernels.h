@@ -109,11 +109,22 @@ struct EdgeAArgs {
   float* M;               // (E,256) gated messages
   float* F[2];            // (E,64) bond_ffn_left / right outputs
   float *tSG, *tHE;       // optional tape for the guidance backward: sigmoid(gate) and edge_net output, (E,256) each
+  // EA_AGG (round 3): the segment sums over each left node's edge run happen INSIDE the kernel.  Units are aligned to each
+  // graph's first edge (units[2u] = first edge, units[2u+1] = rows of unit u, <= 16) so that where a node's run is cut -- and with
+  // it the association of its sum -- depends on the molecule only, never on its position in the batch.  A unit emits one partial
+  // row per left node it touches: row epo[e] + u of P (256 wide: gated messages) and of PR (64 wide: BondFFN-right outputs),
+  // u = the unit index; a node's pieces are consecutive rows, combined in order by seg_reduce_block2.  M / F[1] are then only
+  // written when non-null (the guidance tape wants M).
+  const int* units;
+  int nunits;
+  const int* epo;         // (E) partial-row offset of each edge's left node: row = epo[e] + unit
+  float *P, *PR;
   EdgeAW w;
 };
 #define EA_EMB 1
 #define EA_NODE 2
 #define EA_FFN 4
+#define EA_AGG 8
 
 struct EdgeBArgs {
   int E, flags;
@@ -256,11 +267,12 @@ void launch_dist_to_pos(const float* gdist, const float* pos, const int* l, cons
                         const int* col_ptr, const int* col_eids, float* tmpE3, float* tmpN3, float* gpos, float scale, int N,
                         int E, float cutoff, hipStream_t s);
 
-void launch_edge_a(const EdgeAArgs& a, hipStream_t s);
-void launch_edge_b(const EdgeBArgs& a, hipStream_t s);
+// all four return MDX_OK or an error code with mdx_last_error set (a section-flag combination that is not built)
+int launch_edge_a(const EdgeAArgs& a, hipStream_t s);
+int launch_edge_b(const EdgeBArgs& a, hipStream_t s);
 // row-owner versions (mdx_edge2.hip); launch_edge_a/b dispatch to them unless MDX_TILE_KERNELS=1 is set in the environment
-void launch_edge_a2(const EdgeAArgs& a, hipStream_t s);
-void launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
+int launch_edge_a2(const EdgeAArgs& a, hipStream_t s);
+int launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
 bool mdx_use_rowowner();
 int mdx_num_cus();
 void launch_node(const NodeArgs& a, hipStream_t s);
@@ -277,6 +289,10 @@ struct StepTransArgs {  // mdx_transition.hip: the transitions of one sampling s
 void launch_step_transition(const StepTransArgs& a, hipStream_t s);
 void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, const int* row_ptr, const int* col_ptr,
                              const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s);
+// the same three sums after an EA_AGG edge kernel A: aggr / SR combine each node's partial rows pbase[v] .. pbase[v+1] of P / PR
+// in order, SL is still the indexed sum over FL
+void launch_seg_reduce_block2(const float* P, const float* PR, const float* FL, const int* pbase, const int* col_ptr,
+                              const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s);
 void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float* out, const float* addend, int N, int C,
                        hipStream_t s);
 

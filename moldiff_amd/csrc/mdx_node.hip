@@ -205,6 +205,34 @@ __global__ __launch_bounds__(384) void seg_reduce_block_kernel(const float* __re
   }
 }
 
+// The same three sums after an EA_AGG edge kernel A (round 3): the kernel has already summed every node's run inside each 16-row
+// unit, so aggr[v] / SR[v] are the in-order sums of v's partial rows pbase[v] .. pbase[v+1] of P (256 wide) / PR (64 wide) -- at most
+// ceil(run / 16) + 1 rows instead of the whole run of M.  SL is still the indexed sum over FL.  Eight waves serve eight nodes:
+// waves 0-3 two nodes' P rows each (one after the other), waves 4-5 the PR rows of four nodes each (16 lanes per node), waves 6-7 the
+// FL runs of four nodes each.
+__global__ __launch_bounds__(512) void seg_reduce_block2_kernel(const float* __restrict__ P, const float* __restrict__ PR,
+                                                                const float* __restrict__ FL, const int* __restrict__ pbase,
+                                                                const int* __restrict__ col_ptr, const int* __restrict__ col_eids,
+                                                                float* __restrict__ aggr, float* __restrict__ SL,
+                                                                float* __restrict__ SR, int N) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int v0 = blockIdx.x * 8;
+  if (wave < 4) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = v0 + 2 * wave + k;
+      if (v < N) stg4(aggr + (size_t)v * 256 + 4 * lane, seg_sum<256>(P, pbase, nullptr, v, lane));
+    }
+  } else {
+    const int v = v0 + 4 * (wave & 1) + (lane >> 4), c4 = lane & 15;
+    if (v >= N) return;
+    if (wave < 6)
+      stg4(SR + (size_t)v * 64 + 4 * c4, seg_sum<64>(PR, pbase, nullptr, v, c4));
+    else
+      stg4(SL + (size_t)v * 64 + 4 * c4, seg_sum<64>(FL, col_ptr, col_eids, v, c4));
+  }
+}
+
 __global__ __launch_bounds__(MDX_WG) void seg_reduce3_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
                                                              const int* __restrict__ eids, float* __restrict__ out,
                                                              const float* __restrict__ addend, int N) {
@@ -386,6 +414,13 @@ void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, c
                              const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s) {
   if (N <= 0) return;
   hipLaunchKernelGGL(seg_reduce_block_kernel, dim3((N + 3) / 4), dim3(384), 0, s, M, FL, FR, row_ptr, col_ptr, col_eids, aggr, SL, SR,
+                     N);
+}
+
+void launch_seg_reduce_block2(const float* P, const float* PR, const float* FL, const int* pbase, const int* col_ptr,
+                              const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(seg_reduce_block2_kernel, dim3((N + 7) / 8), dim3(512), 0, s, P, PR, FL, pbase, col_ptr, col_eids, aggr, SL, SR,
                      N);
 }
 

@@ -303,6 +303,8 @@ struct RowTile {
   int row[RR], li[RR], ri[RR];
   float tt[RR];
   bool valid[RR];
+  int pf[RR];  // EA_AGG kernels only: partial-row offset of the row's left node
+  int cnt;     // EA_AGG kernels only: valid rows of the unit (wave-uniform)
 };
 
 __device__ __forceinline__ RowTile load_tile(const int* __restrict__ l, const int* __restrict__ r, const float* __restrict__ te,
@@ -318,6 +320,84 @@ __device__ __forceinline__ RowTile load_tile(const int* __restrict__ l, const in
     t.tt[rt] = te[t.row[rt]];
   }
   return t;
+}
+
+// unit = `cnt` (<= 16 RR) rows from edge e0 (graph-aligned units of the EA_AGG kernels); epo: per-edge partial-row offset
+__device__ __forceinline__ RowTile load_tile_u(const int* __restrict__ l, const int* __restrict__ r, const float* __restrict__ te,
+                                               const int* __restrict__ epo, int e0, int cnt, int E, int c) {
+  RowTile t;
+#pragma unroll
+  for (int rt = 0; rt < RR; ++rt) {
+    t.valid[rt] = 16 * rt + c < cnt;
+    t.row[rt] = t.valid[rt] ? e0 + 16 * rt + c : e0;  // clamped to the unit's first row (always a row of the same graph)
+    t.li[rt] = l[t.row[rt]];
+    t.ri[rt] = r[t.row[rt]];
+    t.tt[rt] = te[t.row[rt]];
+    t.pf[rt] = epo[t.row[rt]];
+  }
+  t.cnt = cnt;
+  return t;
+}
+
+// In-kernel segment sums of the EA_AGG kernels: y (accumulator layout: lane (q, c) holds features 16 ft + 4 q .. of row c) is
+// summed over runs of rows with equal `key` (sorted; the unit's first `cnt` rows are valid) and every run's sum is stored as ONE
+// row of `out` (FT*16 floats wide) at row index `prow` (taken from the run's rows; all rows of a run carry the same one).
+// The tile goes through the wave's private LDS area once so that each lane owns four FEATURES of every row instead of four
+// features of one row: the sums are then plain sequential adds in row order (the order of the CSR segment sum they replace) at
+// 2 packed adds per row and lane, a run's sum is one contiguous 16-byte-per-lane store, and no cross-lane VALU work is spent
+// (on this core VALU time is additive to MFMA time; a DPP scan of the 64 accumulator registers costs ~1,000 VALU issues per
+// unit, this ~50).  XOR swizzle of the 16-byte column by the row: writes (16 rows x 4 adjacent columns per instruction) and reads
+// (one row, 64 or 16 adjacent columns) are both bank-conflict free without padding, so the 16 KiB sigmoid parking area is reused.
+template <int FT>
+__device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][1], float* wbuf, int lane, int cnt, int key, int prow,
+                                              float* __restrict__ out) {
+  constexpr int C4 = 4 * FT;  // 16-byte columns per row
+  static_assert(C4 == 64 || C4 == 16, "256- or 64-wide rows");
+  asm volatile("" : "+v"(lane));  // opaque per call: the 32 swizzled LDS addresses are cheap to rebuild and must not be hoisted out
+                                  // of the persistent loop (they would live in scratch)
+  const int c = lane & 15, q = lane >> 4;
+  char* base = reinterpret_cast<char*>(wbuf);
+  {
+    // physical column of (row c, column 4 ft + q) = (4 ft + q) ^ c = 16 (ft >> 2) + 4 ((ft & 3) ^ (c >> 2)) + (q ^ (c & 3)):
+    // four address registers, the rest is an immediate offset
+    const unsigned lo = (unsigned)(c * C4 + (q ^ (c & 3))) * 16u, cc = (unsigned)(c >> 2);
+    unsigned a4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a4[j] = lo + (((unsigned)j ^ cc) << 6);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) *reinterpret_cast<f32x4*>(base + a4[ft & 3] + 256 * (ft >> 2)) = y[ft][0];
+  }
+  // lanes read what OTHER lanes of the wave wrote: DS operations of a wave execute in order, the compiler only has to keep them so
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int col = lane & (C4 - 1);
+  const unsigned col16 = (unsigned)col * 16u;
+  f32x4 acc = splat4(0.f);
+  int k_r = __builtin_amdgcn_readlane(key, 0);
+  // eight rows at a time (32 registers in flight); every condition below is wave-uniform (scalar branches)
+  static_for<0, 2>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    if (8 * h < cnt) {
+      f32x4 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const f32x4*>(base + (col16 ^ (16u * (8 * h + r))) + (8 * h + r) * C4 * 16);
+      static_for<0, 8>([&](auto rc) {
+        constexpr int r = 8 * h + decltype(rc)::value;
+        const int k_next = __builtin_amdgcn_readlane(key, r < 15 ? r + 1 : 15);
+        if (r < cnt) {
+          acc = acc + v[r - 8 * h];
+          if (r + 1 == cnt || k_next != k_r) {  // last row of a run
+            const int row = __builtin_amdgcn_readlane(prow, r);
+            if ((C4 == 64 || lane < C4) && !(MDX_ABL & 1)) stg4(out + (size_t)row * (16 * FT) + 4 * col, acc);
+            acc = splat4(0.f);
+          }
+        }
+        k_r = k_next;
+      });
+    }
+  });
+  __builtin_amdgcn_wave_barrier();  // the area is rewritten (parking, next unit) only after every lane has read it
 }
 
 template <int FT>

@@ -195,7 +195,6 @@ def main(argv=None):
                            seed=seed + i_batch, mol_ids=ids, return_traj=save_traj_prob > 0)
         # trajectories stay rank-local (scripts/sample_drug3d.py:155 looks at ~2 % of them): the owner decodes and writes
         # them, named by global molecule id; whether a molecule is drawn depends only on (seed, id), not on the sharding
-        traj_of = {}
         if save_traj_prob > 0:
             local = featurizer.decode_batch(out['pred'], ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], hi - lo)
             sel = [j for j, info in enumerate(local)
@@ -207,7 +206,6 @@ def main(argv=None):
                     with open(path, 'w') as f:
                         for info in frames:
                             f.write(mol_block(info) + '$$$$\n')
-                    traj_of[int(ids[j])] = os.path.basename(path)
         # the only data-path collective: this batch's last-step predictions to rank 0 (one size all_gather + one padded
         # all_gather per tensor, RCCL over xGMI; about 2 MB per rank at 256 molecules)
         pred = out['pred']
@@ -230,8 +228,11 @@ def main(argv=None):
             for i, info in enumerate(gen):
                 with open(os.path.join(log_dir + '_SDF', '%d.sdf' % (i + len(pool['finished']))), 'w') as f:
                     f.write(mol_block(info) + '$$$$\n')
-                if info['mol_id'] in traj_of:
-                    info['traj_file'] = traj_of[info['mol_id']]
+                # whether a finished molecule's trajectory was written is a function of (seed, global id) and of its connectivity
+                # (tested above) -- not of the rank that sampled it: rank 0 re-derives the file name its owner used, so every
+                # selected molecule carries its trajectory like in the reference (scripts/sample_drug3d.py:155-190)
+                if save_traj_prob > 0 and np.random.default_rng([seed, int(info['mol_id'])]).random() < save_traj_prob:
+                    info['traj_file'] = 'traj_mol%d.sdf' % info['mol_id']
             pool['finished'].extend(gen)
             print('[Pool] Finished %d | Failed %d' % (len(pool['finished']), len(pool['failed'])))
             counts[0], counts[1] = len(pool['finished']), len(pool['failed'])

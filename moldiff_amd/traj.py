@@ -64,9 +64,16 @@ class LazyOneHot(torch.Tensor):
                 return rewrap(func(self.ids, dim, *args[2:], **kwargs))
         if func is _aten.index.Tensor and args[0] is self:
             idx = list(args[1])
-            if len(idx) <= nd:
+            # dimensions the indices consume: a bool mask covers as many dimensions as it has, everything else (incl. None) one.
+            # Only when they all fall on the frame / row dimensions is this an operation on the ids.
+            used = sum(i.dim() if (torch.is_tensor(i) and i.dtype in (torch.bool, torch.uint8)) else 1 for i in idx)
+            if used <= nd:
                 return rewrap(func(self.ids, idx))
-        if func in (_aten._to_copy.default, _aten.clone.default, _aten.detach.default, _aten.alias.default):
+        if func in (_aten.clone.default, _aten.detach.default, _aten.alias.default):
+            return rewrap(func(self.ids, **kwargs))
+        if func is _aten._to_copy.default and kwargs.get('dtype') in (None, torch.float32):
+            # device / layout moves keep the ids; a dtype change (.double(), .half(), .long()) is an operation on the VALUES and
+            # takes the dense path below so that the result really has the requested dtype
             kw = {k: v for k, v in kwargs.items() if k != 'dtype'}
             return rewrap(func(self.ids, **kw))
         dense = lambda x: x.dense() if isinstance(x, LazyOneHot) else x

@@ -1,0 +1,256 @@
+"""GPU tests added in round 3: the self-launching N-rank bench, BASELINE config #4 with its OWN model (sample_MolDiff.yml: full
+model + bond-predictor guidance) shard by shard, and the tail of the parity contract -- 20 free-running steps bit-equal in
+the class ids and a complete config-#1 chain (T = 100) that agrees with the oracle's chain statistically."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util as U
+from oracle import moldiff_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_gather():
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts its two ranks itself (torch.distributed.run on 127.0.0.1), they
+    share this box's single GPU over gloo (MDX_BENCH_BACKEND -- the product default is RCCL, one GPU per rank), and rank 0 prints
+    ONE JSON line carrying the world size the process group saw, every rank's own step time and the separately timed end-of-run
+    gather (distributed.gather_pred)."""
+    env = dict(os.environ, MDX_BENCH_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '16',
+                        '--headline-only'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    assert len(out['per_rank_ms_per_step']) == 2 and all(x > 0 for x in out['per_rank_ms_per_step'])
+    assert out['ms_per_step'] >= max(out['per_rank_ms_per_step']) - 1e-6          # max over ranks
+    assert out['gather_ms'] > 0 and out['gather_first_ms'] > 0
+    # both ranks' rows arrived on rank 0 (rank r samples the r-th block of 16 sizes of the seed-2920 stream)
+    import bench
+    n_rows = sum(int(bench.build_workload(16, rk, None)[2].sum()) for rk in range(2))
+    assert out['gather_rows'][0] == n_rows
+    assert abs(out['value'] - 2 * 16 / (out['ms_per_step'] * 1000 / 1e3)) < 1e-6 * out['value']
+    assert out['value_incl_gather'] < out['value']
+
+
+def _config4_sizes():
+    from moldiff_amd.harness import GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
+    np.random.seed(2920)
+    return np.maximum(np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=2048).astype('int64'), 2)
+
+
+def _guided_run(m, bp, sizes, mol_idx, seed, steps):
+    from moldiff_amd.harness import placeholder_from_sizes
+    ph = placeholder_from_sizes(sizes[mol_idx], DEV)
+    sm = m.sampler(len(mol_idx), ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=seed,
+                   mol_ids=np.asarray(mol_idx, dtype=np.int64), return_traj=False, bond_predictor=bp, guidance=['uncertainty', 1e-4])
+    sm.init()
+    for i in range(steps):
+        sm.step(i)
+    st = sm.state()
+    torch.cuda.synchronize()
+    bn, bh = ph['batch_node'].cpu(), ph['batch_halfedge'].cpu()
+    node_cls, half_cls, pos = st['h_node'].argmax(-1).cpu(), st['h_halfedge'].argmax(-1).cpu(), st['pos'].cpu()
+    delta = sm.delta.cpu()
+    res = {int(g): (node_cls[bn == j], pos[bn == j], half_cls[bh == j], delta[bn == j]) for j, g in enumerate(mol_idx)}
+    del sm
+    torch.cuda.empty_cache()
+    return res
+
+
+def test_config4_guided_shards_equal_the_unsharded_batch():
+    """BASELINE config #4 with its own model: sample_MolDiff.yml = full model + bond-predictor guidance ['uncertainty', 1e-4], 2048
+    molecules over 8 ranks.  The 2048 molecules are sampled as ONE guided batch (prior + 2 chain steps: denoiser, predictor forward
+    with tape, edge_bwd2 backward, delta) and compared, molecule by molecule, with the entry point's cost-balanced shard 0 -- which
+    holds BOTH the smallest (n = 4) and the largest (n = 44) molecule of the draw -- and shard 7: class ids, positions and the
+    guidance increment bit-identical."""
+    from moldiff_amd.distributed import balanced_order, shard_bounds
+    m, bp = U.moldiff('MolDiff', DEV), U.bondpred(DEV)
+    sizes = _config4_sizes()
+    world, steps, seed = 8, 2, 4243
+    whole = _guided_run(m, bp, sizes, np.arange(2048), seed, steps)
+    order = balanced_order(sizes, world)
+    for r in (0, 7):
+        lo, hi = shard_bounds(2048, world, r)
+        mine = order[lo:hi]
+        if r == 0:
+            assert sizes[mine].min() == sizes.min() == 4 and sizes[mine].max() == sizes.max() == 44
+        part = _guided_run(m, bp, sizes, mine, seed, steps)
+        for g, got in part.items():
+            for a, b, what in zip(got, whole[g], ('node class', 'pos', 'bond class', 'guidance delta')):
+                assert torch.equal(a, b), (r, g, int(sizes[g]), what)
+            assert torch.isfinite(got[1]).all()
+
+
+def test_config4_guided_shard_step_matches_oracle():
+    """One guided step of config #4's shard 0, oracle-checked.  A molecule's HIP result does not depend on its batch (previous
+    test), so the oracle is run on the 24 molecules of the shard that matter most -- the 12 smallest (incl. n = 4) and the 12
+    largest (incl. n = 44) -- teacher-forced from the state the HIP chain is in after the prior draw, with the HIP path's own
+    Philox noise: positions 1e-4 (guided), log-posteriors 1e-4, class ids bit-exact; and the same 24 molecules inside the full
+    256-molecule shard give bit-identical results."""
+    from moldiff_amd.distributed import balanced_order, shard_bounds
+    from moldiff_amd.harness import placeholder_from_sizes
+    m, bp = U.moldiff('MolDiff', DEV), U.bondpred(DEV)
+    sizes = _config4_sizes()
+    order = balanced_order(sizes, 8)
+    lo, hi = shard_bounds(2048, 8, 0)
+    mine = order[lo:hi]
+    by_size = mine[np.argsort(sizes[mine], kind='stable')]
+    sub = np.concatenate([by_size[:12], by_size[-12:]])
+    assert sizes[sub].min() == 4 and sizes[sub].max() == 44
+    seed = 99
+    ph = placeholder_from_sizes(sizes[sub])
+    phd = {k: v.to(DEV) for k, v in ph.items()}
+    sm = m.sampler(len(sub), phd['batch_node'], phd['halfedge_index'], phd['batch_halfedge'], seed=seed, mol_ids=sub.astype(np.int64),
+                   return_traj=False, bond_predictor=bp, guidance=['uncertainty', 1e-4])
+    sm.init()
+    st = {k: v.cpu().clone() for k, v in sm.state().items()}
+    sm.step(0)
+    torch.cuda.synchronize()
+    noise = {'eps_pos': sm.eps.cpu(), 'u_node': sm.u_n.cpu(), 'u_halfedge': sm.u_h.cpu()}
+    P, Pb = U.params(m), U.params(bp)
+    with torch.no_grad():
+        want, _ = O.sample_step(P, U.CFG, U.tables(P), st, dict(ph, n_graphs=len(sub)), 999, noise, Pb=Pb, cfgb=U.CFGB,
+                                guidance=['uncertainty', 1e-4])
+    got = sm.state()
+    assert U.maxdiff(got['pos'], want['pos']) < 1e-4
+    assert U.maxdiff(got['log_node'], want['log_node']) < 1e-4 and U.maxdiff(got['log_halfedge'], want['log_halfedge']) < 1e-4
+    assert torch.equal(got['h_node'].argmax(-1).cpu(), want['node_type'])
+    assert torch.equal(got['h_halfedge'].argmax(-1).cpu(), want['halfedge_type'])
+    # the same molecules inside the full shard
+    small = _guided_run(m, bp, sizes, sub, seed, 1)
+    full = _guided_run(m, bp, sizes, mine, seed, 1)
+    for g in sub:
+        for a, b in zip(small[int(g)], full[int(g)]):
+            assert torch.equal(a, b), int(g)
+
+
+def test_free_running_chain_bit_equal_for_twenty_steps():
+    """Free-running (NOT teacher-forced) chains on identical explicit noise, HIP vs oracle: SURVEY 8(c) says class ids stay bit-equal
+    for ~20 steps before fp32 chaos separates any two implementations (the reference differs from itself across thread counts).
+    Asserted: bit-equal class ids and positions within 1e-3 for all of the first 20 steps; the first diverging step within a
+    60-step horizon is printed for the record."""
+    m = U.moldiff('MolDiff_simple', DEV)
+    P, sizes = U.params(m), [7, 10, 5, 12]
+    tabs = U.tables(P)
+    bn, hei, bh, ei, be = U.graph_from_sizes(sizes)
+    sm = m.sampler(len(sizes), bn.to(DEV), hei.to(DEV), bh.to(DEV), seed=5)
+    sm.init()
+    st = {k: v.cpu().clone() for k, v in sm.state().items()}
+    graph = {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': len(sizes)}
+    first = None
+    for i in range(60):
+        sm.step(i)
+        noise = {'eps_pos': sm.eps.cpu(), 'u_node': sm.u_n.cpu(), 'u_halfedge': sm.u_h.cpu()}
+        with torch.no_grad():
+            new, _ = O.sample_step(P, U.CFG, tabs, st, graph, 999 - i, noise)
+        got = sm.state()
+        same = (torch.equal(got['h_node'].argmax(-1).cpu(), new['node_type']) and
+                torch.equal(got['h_halfedge'].argmax(-1).cpu(), new['halfedge_type']))
+        if not same:
+            first = i
+            break
+        if i < 20:
+            assert U.maxdiff(got['pos'], new['pos']) < 1e-3, i
+        st = {k: new[k] for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')}
+    print(f'\n[free-running] first step with a differing class id within 60 steps: {first}')
+    assert first is None or first >= 20, f'class ids diverged at free-running step {first}'
+
+
+def _chi2_two_sample(a, b):
+    """Two-sample chi-square statistic of two count vectors over the classes either one populates -> (statistic, dof)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    keep = (a + b) > 0
+    a, b = a[keep], b[keep]
+    ka, kb = np.sqrt(b.sum() / a.sum()), np.sqrt(a.sum() / b.sum())
+    return float((((ka * a - kb * b) ** 2) / (a + b)).sum()), int(keep.sum() - 1)
+
+
+def test_config1_whole_chain_agrees_with_the_oracle_statistically():
+    """BASELINE config #1 end to end: 64 molecules of the reference's size recipe, T = 100, the COMPLETE reverse chain run
+    free on the HIP path and on the CPU oracle from the same prior draw with the same per-step noise (the HIP path's Philox
+    draws are handed to the oracle).  Chains are chaotic (here the first bond class differs at step 34 of 100 and the positions
+    are O(1) apart at the end), so the end states are compared as distributions: atom-type and bond-type histograms by a
+    two-sample chi-square below the p = 0.001 critical value of their degrees of freedom, the mean distance over bonded pairs
+    (bond classes 1..4) by a molecule-level two-sample test, and the early, pre-chaos part of the chains by their distance."""
+    import moldiff_amd as M
+    from moldiff_amd.harness import GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, default_config
+    from scipy.stats import chi2
+    T, B = 100, 64
+    cfg = default_config('MolDiff_simple')
+    cfg.diff['num_timesteps'] = T
+    m = M.MolDiff(cfg, 8, 6).eval()
+    m.load_state_dict(M.recipe_state_dict(m, U.KEYS['seeds']['MolDiff']), strict=True)
+    P = U.params(m)
+    tabs = U.tables(P)
+    m = m.to(DEV)
+    np.random.seed(2920)
+    sizes = np.maximum(np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=B).astype('int64'), 2)
+    bn, hei, bh, ei, be = U.graph_from_sizes(sizes)
+    sm = m.sampler(B, bn.to(DEV), hei.to(DEV), bh.to(DEV), seed=2023, return_traj=False)
+    sm.init()
+    st = {k: v.cpu().clone() for k, v in sm.state().items()}
+    graph = {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': B}
+    ocfg = dict(U.CFG, num_timesteps=T)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    first, trace = None, []
+    try:
+        for i in range(T):
+            sm.step(i)
+            noise = {'eps_pos': sm.eps.cpu(), 'u_node': sm.u_n.cpu(), 'u_halfedge': sm.u_h.cpu()}
+            with torch.no_grad():
+                new, _ = O.sample_step(P, ocfg, tabs, st, graph, T - 1 - i, noise)
+            st = {k: new[k] for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')}
+            if first is None and not torch.equal(sm.state()['h_halfedge'].argmax(-1).cpu(), new['halfedge_type']):
+                first = i
+            if i % 10 == 9 or i == first:
+                trace.append((i, U.maxdiff(sm.state()['pos'], new['pos']),
+                              int((sm.state()['h_halfedge'].argmax(-1).cpu() != new['halfedge_type']).sum())))
+    finally:
+        torch.set_num_threads(nthreads)
+    got = {k: v.cpu() for k, v in sm.state().items()}
+    print(f'\n[config #1 chain] first step with a differing bond class: {first} of {T}; (step, max |pos diff|, differing bond classes): {trace}')
+    assert torch.isfinite(got['pos']).all() and torch.isfinite(st['pos']).all()
+    for name, K, a, b in (('atom', 8, got['h_node'].argmax(-1), st['h_node'].argmax(-1)),
+                          ('bond', 6, got['h_halfedge'].argmax(-1), st['h_halfedge'].argmax(-1))):
+        ha, hb = np.bincount(a.numpy(), minlength=K), np.bincount(b.numpy(), minlength=K)
+        stat, dof = _chi2_two_sample(ha, hb)
+        crit = float(chi2.ppf(0.999, max(dof, 1)))
+        print(f'    {name}-type histogram HIP {ha.tolist()} oracle {hb.tolist()}: chi2 = {stat:.3f} (dof {dof}, p=0.001 critical {crit:.2f})')
+        assert stat < crit, (name, ha, hb, stat)
+
+    # early agreement before chaos takes over: the two chains are the same computation up to fp32 rounding, so their distance
+    # grows smoothly (a kernel bug would show as a jump): < 1e-4 after 10 steps, < 1e-3 after 20
+    assert trace[0][0] == 9 and trace[0][1] < 1e-4 and trace[0][2] == 0, trace
+    assert [x for x in trace if x[0] == 19][0][1] < 1e-3, trace
+
+    def bonded(s):
+        """per-molecule mean distance over bonded pairs (bond classes 1..4)"""
+        cls = s['h_halfedge'].argmax(-1)
+        k = (cls >= 1) & (cls <= 4)
+        d = (s['pos'][hei[0][k]] - s['pos'][hei[1][k]]).norm(dim=-1)
+        cnt = torch.bincount(bh[k], minlength=B)
+        per = torch.zeros(B).index_add_(0, bh[k], d)[cnt > 0] / cnt[cnt > 0]
+        return float(d.mean()), int(k.sum()), per
+    (da, na, pa), (db, nb, pb) = bonded(got), bonded(st)
+    se = float(((pa.var() + pb.var()) / B) ** 0.5)
+    print(f'    mean bonded distance HIP {da:.5f} ({na} bonds) oracle {db:.5f} ({nb} bonds); per-molecule means {float(pa.mean()):.4f} vs '
+          f'{float(pb.mean()):.4f}, standard error of their difference {se:.4f}')
+    # Recipe (random) weights give no chemically tight bond lengths: the per-molecule mean bonded distance has a standard
+    # deviation of ~35 % here, and an oracle chain restarted with its initial positions moved by 1e-6 ends 0.4 - 1.4 % away from
+    # itself (mean / median).  "Within 1 %" needs trained weights (unavailable offline); what can be asserted with 64 chaotic
+    # molecules is a two-sample test at molecule level: |difference of the per-molecule means| <= 3.5 standard errors.
+    assert na > 0 and nb > 0 and abs(float(pa.mean()) - float(pb.mean())) <= 3.5 * se

@@ -7,6 +7,7 @@ import re
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import moldiff_amd as M
 from moldiff_amd import _lib
@@ -295,3 +296,21 @@ def test_config1_T100_schedule_tables_match_reference_golden():
     for part, tr in (('node', m.node_transition), ('edge', m.edge_transition)):
         for k in ('q_mats', 'transpopse_q_onestep_mats'):
             assert np.array_equal(getattr(tr, k).numpy(), g[f'{part}_{k}'])
+
+
+def test_lazy_one_hot_dtype_changes_and_masks_take_the_dense_path():
+    """`.double()/.half()/.long()` must return a tensor of THAT dtype (values of the one-hot rows), and a bool mask that
+    also covers the class dimension must not be applied to the ids."""
+    from moldiff_amd.traj import LazyOneHot
+    ids = torch.tensor([[0, 2, 1], [3, 3, 0]], dtype=torch.uint8)
+    t = LazyOneHot(ids, 4)
+    dense = F.one_hot(ids.long(), 4).float()
+    assert isinstance(t[1], LazyOneHot) and isinstance(t[:, torch.tensor([True, False, True])], LazyOneHot)
+    assert isinstance(t.to('cpu'), LazyOneHot) and isinstance(t.float(), LazyOneHot)
+    for conv, dt in ((t.double(), torch.float64), (t.half(), torch.float16), (t.long(), torch.int64)):
+        assert not isinstance(conv, LazyOneHot) and conv.dtype == dt and torch.equal(conv, dense.to(dt))
+    full_mask = dense > 0.5                                  # (2,3,4): covers the class dimension too
+    picked = t[full_mask]
+    assert not isinstance(picked, LazyOneHot) and torch.equal(picked, dense[full_mask])
+    row_mask = torch.tensor([[True, False, True], [False, True, False]])   # (2,3): frame x row -> still compact
+    assert isinstance(t[row_mask], LazyOneHot) and torch.equal(t[row_mask].dense(), dense[row_mask])

@@ -219,6 +219,15 @@ def test_init_and_placeholder():
 
 
 def test_pinning_record_says_bit_exact():
-    rec = json.load(open(os.path.join(U.GOLD, 'PINNING.json')))
-    worst = max(rec['max_abs_diff_oracle_vs_reference'].values())
-    assert worst < 1e-8, rec
+    """oracle/make_goldens.py's record of max |oracle - reference| per function: EXACTLY 0.0 on every forward quantity; the two
+    quantities that pass through autograd (the guidance increment and the guided position it is added to) are pinned to one fp32
+    ulp of a unit-scale position (1.2e-7), not to 0 -- CPU autograd accumulates in thread-dependent order, so regenerating the
+    record gives between 9e-10 and 6e-8 there."""
+    rec = json.load(open(os.path.join(U.GOLD, 'PINNING.json')))['max_abs_diff_oracle_vs_reference']
+    autograd = {'guidance_delta', 'sample_step_pos'}
+    assert autograd <= set(rec)
+    for name, d in rec.items():
+        if name in autograd:
+            assert d <= 2.0 ** -23, (name, d)
+        else:
+            assert d == 0.0, (name, d)

@@ -155,7 +155,7 @@ def test_two_rank_sampling_run_equals_the_single_rank_run(tmp_path):
     import sys
     import yaml
     cfg = yaml.safe_load(open('configs/sample_MolDiff_simple.yml'))
-    cfg['sample'].update(num_mols=6, batch_size=8)
+    cfg['sample'].update(num_mols=6, batch_size=8, save_traj_prob=1.0)
     p = tmp_path / 'sample_MolDiff_simple.yml'
     p.write_text(yaml.safe_dump(cfg))
 
@@ -174,7 +174,12 @@ def test_two_rank_sampling_run_equals_the_single_rank_run(tmp_path):
         outs = [q.communicate(timeout=600)[0] for q in procs]
         assert all(q.returncode == 0 for q in procs), outs
         run_dir = [d for d in os.listdir(outdir) if not d.endswith('_SDF')][0]
-        return torch.load(os.path.join(outdir, run_dir, 'samples_all.pt'), weights_only=False)
+        pool = torch.load(os.path.join(outdir, run_dir, 'samples_all.pt'), weights_only=False)
+        # every selected molecule carries its trajectory, whichever rank sampled (and wrote) it
+        for info in pool['finished']:
+            assert info['traj_file'] == 'traj_mol%d.sdf' % info['mol_id']
+            assert os.path.exists(os.path.join(outdir, run_dir + '_SDF', info['traj_file'])), (world, info['mol_id'])
+        return pool
 
     # the seed depends on the characters of --outdir (scripts/sample_drug3d.py:47): same string length/sum for both runs
     one = run(1, str(tmp_path / 'oa'))

@@ -92,6 +92,8 @@ def main():
     E = 2 * ph['halfedge_index'].shape[1]
     rows = int(os.environ.get('MDX_ROWS', 16 if which == 'a' else 32))   # rows per wave the kernel was built with
     nunits = (E + rows - 1) // rows
+    if which == 'a' and os.environ.get('MDX_NO_AGG') != '1':   # EA_AGG: units are aligned to each molecule's first edge
+        nunits = int(sum((int(n) * (int(n) - 1) + 15) // 16 for n in sizes))
     buf = torch.zeros(nunits * 48, dtype=torch.int64, device=dev)
     setter = (lambda p: L.mdx_debug_set_trace2(p, 0)) if which == 'a' else L.mdx_debug_set_trace2b
     assert setter(ctypes.c_void_p(buf.data_ptr())) == 0
