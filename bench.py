@@ -22,7 +22,8 @@ Extra objects on the JSON line:
   roofline     -- dominant kernel = fused edge kernel A (fp32 MFMA): algorithmic FLOPs (617,088 per directed
                   edge) / its average launch duration measured with hipEvents on its launch stream
                   during the timed region, against the 157.3 TFLOP/s fp32-matrix peak.
-  aggregation  -- the HBM-bound message aggregation pass (E,256)->(N,256): 1,024*(E+N) bytes / duration vs 8 TB/s.
+  aggregation  -- the reduction pass after edge kernel A (round 3: combines the partial rows the kernel's in-kernel segment sums emit
+                  + the by-right BondFFN sum); segment_sum -- the scatter/gather primitive (E,256)->(N,256) by itself vs 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/moldiff_oracle.py, a torch-CPU restatement pinned bit-exact to the
                   reference here) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -44,7 +45,8 @@ _ORIG_ARGV = list(sys.argv[1:])   # main_train() strips --train before parsing; 
 FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIGN.md / SURVEY Appendix D)
 FLOP_EDGE_B = 221184        # edge kernel B (EdgeBlock tail + PosUpdate): 2 * (2*64*64 + 2*64*256 + 2*64*32 + 256*256)
 FLOP_EDGE_BWD = 829440      # per directed edge per launch of the guidance backward's edge kernel
-EDGE_A_NAME = 'edge_a2_kernel (row-owner fused per-edge MLP chain, 16 rows x 2 waves per SIMD, v_mfma_f32_16x16x4_f32)'
+EDGE_A_NAME = ('edge_a2_kernel<15> (row-owner fused per-edge MLP chain + in-kernel segment sums of its messages, 16 rows x 2 waves per '
+               'SIMD, v_mfma_f32_16x16x4_f32)')
 EDGE_B_NAME = 'edge_b2_kernel (row-owner EdgeBlock tail + PosUpdate, v_mfma_f32_16x16x4_f32)'
 REFERENCE_CPU_MOL_S = 0.097  # the REAL reference on 8 CPU cores, config #2 (2.64 s/step at 256 molecules)
 PEAK_FP32_MFMA = 157.3      # TFLOP/s (MI355X_MICROARCH.md)
@@ -426,16 +428,66 @@ def roofline_mfma(name, kernel, flop_per_edge, E, prof):
             'flops_per_launch': flop_per_edge * E, 'flops_per_edge': flop_per_edge}
 
 
-def aggregation_line(N, E, prof):
+def partial_rows(sizes):
+    """Partial rows edge kernel A's in-kernel aggregation emits for fully connected molecules of these sizes: node j of an n-atom
+    molecule owns edges j(n-1) .. (j+1)(n-1) of the molecule, cut wherever one of the molecule's 16-edge units ends."""
+    tot = 0
+    for n in sizes:
+        n = int(n)
+        if n < 2:
+            continue
+        j = np.arange(n, dtype=np.int64)
+        tot += int((((j + 1) * (n - 1) - 1) // 16 - (j * (n - 1)) // 16 + 1).sum())
+    return tot
+
+
+def aggregation_line(N, E, prof, sizes=None, agg=True):
+    """The reduction pass after edge kernel A.  Round 3: the 256-wide message sums and the BondFFN-right sums are formed INSIDE
+    edge kernel A (one partial row per node and 16-edge unit), so this pass only combines ~2.5 partial rows per node and still
+    sums the BondFFN-left rows through the by-right index list."""
     c, ms = prof['aggregate']
     avg = ms / max(c, 1)
-    nbytes = 1536.0 * (E + N)   # reads M (E,256) + FL, FR (E,64 each), writes aggr (N,256) + SL, SR (N,64 each)
-    agg = nbytes / (avg * 1e-3) / 1e9 if c else None
-    return {'bound': 'hbm', 'kernel': 'seg_reduce_block_kernel: (E,256)->(N,256) message aggregation + the two (E,64)->(N,64) BondFFN sums',
-            'achieved': agg, 'peak': PEAK_HBM,
-            'unit': 'GB/s (HBM or Infinity Cache: the operands were written by the preceding kernel and are smaller than '
-                    'the 256 MiB MALL when E*1.5 KiB < 256 MiB)', 'frac': (agg / PEAK_HBM) if agg else None,
-            'bytes_per_launch': nbytes, 'launches': c, 'avg_ms': avg, 'operand_mib': E * 1536.0 / 2 ** 20}
+    if agg and sizes is not None:
+        P = partial_rows(sizes)
+        nbytes = P * (1024.0 + 256.0) + E * (256.0 + 4.0) + N * 1536.0
+        what = ('seg_reduce_block2_kernel: %d partial rows (256- and 64-wide, written by edge kernel A) -> aggr (N,256), SR (N,64); '
+                'FL (E,64) -> SL (N,64) through the by-right index list' % P)
+    else:
+        nbytes = 1536.0 * (E + N)   # reads M (E,256) + FL, FR (E,64 each), writes aggr (N,256) + SL, SR (N,64 each)
+        what = 'seg_reduce_block_kernel: (E,256)->(N,256) message aggregation + the two (E,64)->(N,64) BondFFN sums'
+    agg_bw = nbytes / (avg * 1e-3) / 1e9 if c else None
+    return {'bound': 'hbm', 'kernel': what, 'achieved': agg_bw, 'peak': PEAK_HBM,
+            'unit': 'GB/s (HBM or Infinity Cache: the operands were written by the preceding kernel and fit the 256 MiB MALL)',
+            'frac': (agg_bw / PEAK_HBM) if agg_bw else None, 'bytes_per_launch': nbytes, 'launches': c, 'avg_ms': avg}
+
+
+def segment_sum_line(sm, dev):
+    """The scatter/gather primitive by itself (mdx_segment_sum = the deterministic replacement of torch_scatter.scatter_sum,
+    models/graph.py:50): (E,256) -> (N,256) by left node, hipEvent-timed stand-alone on this workload's graph.  Inside the sampling
+    step the same sum is now fused into edge kernel A; the primitive still serves NodeBlock.forward and the training operators."""
+    from moldiff_amd import _lib
+    L = _lib.lib()
+    N, E = sm.N, 2 * sm.Eh
+    src = torch.randn(E, 256, device=dev)
+    out = torch.empty(N, 256, device=dev)
+    ws, nb = sm.g.workspace(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(3):
+        _lib.check(L.mdx_segment_sum(sm.g.h, _lib.ptr(src), 256, 0, _lib.ptr(out), ws, nb, _lib.stream()))
+    torch.cuda.synchronize()
+    reps = 20
+    ev[0].record()
+    for _ in range(reps):
+        _lib.check(L.mdx_segment_sum(sm.g.h, _lib.ptr(src), 256, 0, _lib.ptr(out), ws, nb, _lib.stream()))
+    ev[1].record()
+    torch.cuda.synchronize()
+    avg = ev[0].elapsed_time(ev[1]) / reps
+    nbytes = 1024.0 * (E + N)
+    bw = nbytes / (avg * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'seg_reduce_kernel<256> via mdx_segment_sum: (E,256)->(N,256) by left node, stand-alone, %d launches back to '
+                                      'back on torch\'s current stream (torch events)' % reps,
+            'achieved': bw, 'peak': PEAK_HBM, 'unit': 'GB/s', 'frac': bw / PEAK_HBM, 'bytes_per_launch': nbytes, 'avg_ms': avg,
+            'operand_mib': E * 1024.0 / 2 ** 20}
 
 
 def main():
@@ -505,6 +557,7 @@ def main():
     head_kind = 'MolDiff' if args.guided else 'MolDiff_simple'
     hkw = {'overlap_guidance': True} if (args.guided and os.environ.get('MDX_BENCH_OVERLAP')) else {}  # A/B: guidance on a side stream
     sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank, **hkw)
+    sizes_head = torch.bincount(ph_cpu['batch_node'], minlength=args.batch).numpy()
     N, E = sm.N, 2 * sm.Eh
     # Timed region: only the roofline kernel (edge kernel A) carries hipEvent brackets -- 25 event pairs per step on every kernel
     # cost 0.17 ms of a 7.3 ms step (tools/profile_overhead.py).  The other kernels' durations come from a short second pass
@@ -562,7 +615,7 @@ def main():
                        'parallelism': f'independent streams x{world}', 'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
             'roofline': roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, E, prof),
             'roofline_edge_b': roofline_mfma('edge_b', EDGE_B_NAME, FLOP_EDGE_B, E, prof_all),
-            'aggregation': aggregation_line(N, E, prof_all),
+            'aggregation': aggregation_line(N, E, prof_all, sizes_head, os.environ.get('MDX_NO_AGG') != '1'),
             'kernel_ms_per_step': head['kernel_ms_per_step'], 'kernel_ms_note': head['kernel_ms_note'],
             'ranks_seen': 1,
         }
@@ -571,25 +624,33 @@ def main():
             # a complete 1000-step run of every rank plus the gather, i.e. what the entry point's batch loop costs
             out['value_incl_gather'] = args.batch * world / (ms_per_step * T_STEPS / 1e3 + multi['gather_ms'] / 1e3)
         # HBM traffic per launch comes from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs,
-        # gfx950 correction applied) committed under profiles/; a Python process cannot collect PMCs on itself.
+        # gfx950 correction applied) committed under profiles/; a Python process cannot collect PMCs on itself.  The figure is
+        # quoted only when the summary was taken with THIS build's kernels (the library names the kernel each timing slot
+        # brackets; a summary that does not know that exact name -- template arguments included -- is stale and refused).
         try:
             import glob
+            from moldiff_amd import _lib
+            L = _lib.lib()
+            name_a, name_g = (L.mdx_profile_kernel_name(k).decode() for k in (0, 3))
+            out['roofline']['kernel_symbol'], out['aggregation']['kernel_symbol'] = name_a, name_g
             pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
             if pm and args.batch == 256 and not args.guided:
                 ks = json.load(open(pm[-1]))['kernels']
-                ka = next((v for k, v in ks.items() if k.startswith('edge_a')), None)
-                if ka:
-                    out['roofline']['traffic'] = ka['hbm_bytes_per_launch']
-                    out['roofline']['traffic_source'] = os.path.relpath(pm[-1], ROOT) + ' (PMC passes of the same command; not measured in this run)'
-                kg = ks.get('seg_reduce_block_kernel') or ks.get('seg_reduce_kernel<256>')
-                if kg:
-                    out['aggregation']['traffic'] = kg['hbm_bytes_per_launch']
+                src = os.path.relpath(pm[-1], ROOT)
+                if name_a in ks:
+                    out['roofline']['traffic'] = ks[name_a]['hbm_bytes_per_launch']
+                    out['roofline']['traffic_source'] = src + ' (PMC passes of the same command; not measured in this run)'
+                else:
+                    out['roofline']['traffic_source'] = f'refused: {src} has no kernel {name_a} (taken with another kernel set: {sorted(ks)})'
+                if name_g in ks:
+                    out['aggregation']['traffic'] = ks[name_g]['hbm_bytes_per_launch']
         except Exception:
             pass
 
     # ---- single-GPU extras, all OUTSIDE the headline's timed region --------------------------------------------------
     if world == 1 and not args.headline_only:
         configs = {'guided' if args.guided else 'simple': dict(head, roofline=out['roofline'])}
+        out['segment_sum'] = segment_sum_line(sm, dev)
         other_kind = 'MolDiff_simple' if args.guided else 'MolDiff'
         del sm
         torch.cuda.empty_cache()
@@ -648,8 +709,10 @@ def main():
             smb = mb.sampler(big, phb['batch_node'], phb['halfedge_index'], phb['batch_halfedge'], seed=5, return_traj=False)
             smb.init()
             elb, profb = run_chain(smb, 5, 2, barrier)
-            out['aggregation_large'] = dict(aggregation_line(smb.N, 2 * smb.Eh, profb), molecules=big,
+            szb = torch.bincount(phb['batch_node'], minlength=big).cpu().numpy()
+            out['aggregation_large'] = dict(aggregation_line(smb.N, 2 * smb.Eh, profb, szb, os.environ.get('MDX_NO_AGG') != '1'), molecules=big,
                                             ms_per_step=elb / 5 * 1e3, molecules_per_sec=big / (elb / 5 * T_STEPS))
+            out['aggregation_large']['segment_sum'] = segment_sum_line(smb, dev)
             out['aggregation_large']['roofline_edge_a'] = roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, 2 * smb.Eh, profb)['frac']
             del smb, mb
             torch.cuda.empty_cache()

@@ -307,6 +307,8 @@ int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
  * region).  read() drains pending events. */
 int mdx_profile_enable(int32_t on);
 int mdx_profile_read(int32_t kernel, int64_t* count, double* total_ms);
+/* the kernel function name slot `kernel` brackets in this build ("" for an unknown slot); static storage */
+const char* mdx_profile_kernel_name(int32_t kernel);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
     'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
-    'mdx_profile_enable', 'mdx_profile_read',
+    'mdx_profile_enable', 'mdx_profile_read', 'mdx_profile_kernel_name',
     'mdx_op_sgemm_nt', 'mdx_op_sgemm_tn', 'mdx_op_hgemm_nt', 'mdx_op_hgemm_tn', 'mdx_op_transpose', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_mul_gather_fwd', 'mdx_op_mul_gather_bwd', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
@@ -104,6 +104,8 @@ def lib():
         L.mdx_device_count.argtypes = [POINTER(c_int)]
         L.mdx_profile_enable.argtypes = [c_int32]
         L.mdx_profile_read.argtypes = [c_int32, POINTER(c_int64), POINTER(ctypes.c_double)]
+        L.mdx_profile_kernel_name.argtypes = [c_int32]
+        L.mdx_profile_kernel_name.restype = c_char_p
         # layer-level training operators
         L.mdx_op_sgemm_nt.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                       c_int64, c_int64, c_int32, c_void_p, c_void_p]

@@ -509,6 +509,9 @@ struct mdx_graph_s {
   const int32_t *units = nullptr, *epo = nullptr, *pbase = nullptr;
   int64_t nunits = 0, nparts = 0;
   hipEvent_t ev_in = nullptr, ev_done = nullptr;  // stream hand-offs of mdx_sample_step_full's concurrent guidance chain
+  // run_blocks' side stream: the next block's per-node PRE stage runs beside edge kernel B of the current block (see there)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_mid = nullptr, ev_pre = nullptr;
 };
 
 namespace {
@@ -679,6 +682,9 @@ extern "C" int mdx_graph_destroy(mdx_graph_t g) {
   if (g->mol_ids) hipFree(g->mol_ids);
   if (g->ev_in) hipEventDestroy(g->ev_in);
   if (g->ev_done) hipEventDestroy(g->ev_done);
+  if (g->ev_mid) hipEventDestroy(g->ev_mid);
+  if (g->ev_pre) hipEventDestroy(g->ev_pre);
+  if (g->side) hipStreamDestroy(g->side);
   delete g;
   return MDX_OK;
 }
@@ -751,6 +757,7 @@ struct ProfSlot {
   double total_ms = 0.0;
   long long count = 0;
 };
+bool use_agg();  // below
 unsigned g_prof_mask = 0;  // bit k: kernel k is timed
 ProfSlot g_prof[PK_COUNT];
 
@@ -797,6 +804,19 @@ extern "C" int mdx_profile_enable(int32_t on) {
   if (on)
     for (auto& p : g_prof) { prof_drain(p, PROF_RING); p.total_ms = 0.0; p.count = 0; }
   return MDX_OK;
+}
+// name of the kernel function slot `kernel` brackets in THIS build (bench.py checks a committed PMC summary against it before
+// quoting its traffic figure)
+extern "C" const char* mdx_profile_kernel_name(int32_t kernel) {
+  const bool ro = mdx_use_rowowner();
+  switch (kernel) {
+    case PK_EDGE_A: return ro ? (use_agg() ? "edge_a2_kernel<15>" : "edge_a2_kernel<7>") : "edge_a_kernel";
+    case PK_EDGE_B: return ro ? "edge_b2_kernel" : "edge_b_kernel";
+    case PK_NODE: return "node_kernel";
+    case PK_AGGR: return ro && use_agg() ? "seg_reduce_block2_kernel" : "seg_reduce_block_kernel";
+    case PK_EDGE_BWD: return ro ? "edge_bwd2_kernel" : "edge_bwd_kernel";
+    default: return "";
+  }
 }
 extern "C" int mdx_profile_read(int32_t kernel, int64_t* count, double* total_ms) {
   if (kernel < 0 || kernel >= PK_COUNT || !count || !total_ms) return fail(MDX_ERR_ARG, "bad argument");
@@ -866,7 +886,22 @@ NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int im
 }
 
 // Runs all blocks.  In: w.Hn, w.HeA (internal order), pos_in, w.tn / w.te.  Out: w.Hn, He (returned pointer), pos (returned).
-int run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
+// Experiment kept behind MDX_NODE_OVERLAP=1 (round 3, measured NEGATIVE, default off).  Edge kernel B runs 4.72 rounds of 16-edge
+// units on 2,048 persistent waves as 5: in its last round 28 % of the wave slots retire early.  The next block's PRE stage (node_net +
+// the 960-wide hoisted table: 78 % of the node kernel's work) depends only on the node state the MID stage has just written, and edge
+// kernel B reads none of its outputs, so PRE can go to a low-priority side stream behind kernel B's launch in the hope that its
+// workgroups back-fill the CUs kernel B's early finishers free.  They do not wait for that: the dispatcher interleaves both kernels
+// from the start, kernel B's statically partitioned persistent waves lose CU slots and it takes 2.01 ms per step instead of 1.69
+// (step: 7.41 vs 6.99 ms).  A stream priority is a hint the workgroup dispatcher does not honour here.
+bool node_overlap() {
+  static const bool v = [] {
+    const char* e = getenv("MDX_NODE_OVERLAP");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
+int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
                const float** pos_final, hipStream_t s, float* pos_out = nullptr) {
   const int nb = m->cfg.num_blocks;
   const bool upos = m->cfg.update_pos != 0;
@@ -876,6 +911,14 @@ int run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const fl
   // after the node kernel has already produced block i+1's table.
   float* NTcur = w.NT;
   float* NTnxt = w.NT2;
+  const bool overlap = node_overlap() && nb > 1;
+  if (overlap && !g->side) {
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
+    HIPCHK(hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, lo));
+    HIPCHK(hipEventCreateWithFlags(&g->ev_mid, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&g->ev_pre, hipEventDisableTiming));
+  }
   launch_node(make_nd(m, g, w, -1, 0, ND_PRE, nullptr, NTcur), s);
   for (int i = 0; i < nb; ++i) {
     const bool agg = use_agg();
@@ -890,11 +933,19 @@ int run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const fl
       else
         launch_seg_reduce_block(w.M, w.FL, w.FR, g->row_ptr, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
     }
-    int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (i + 1 < nb ? ND_PRE : 0);
-    { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, i + 1 < nb ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
+    const bool pre = i + 1 < nb;
+    const bool split = overlap && pre;
+    int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (pre && !split ? ND_PRE : 0);
+    { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, pre ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
+    if (split) HIPCHK(hipEventRecord(g->ev_mid, s));
     {
       ProfScope ps(PK_EDGE_B, s);
       LCHK(launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s));
+    }
+    if (split) {
+      HIPCHK(hipStreamWaitEvent(g->side, g->ev_mid, 0));
+      launch_node(make_nd(m, g, w, -1, i + 1, ND_PRE, NTcur, NTnxt), g->side);
+      HIPCHK(hipEventRecord(g->ev_pre, g->side));
     }
     if (upos) {
       if (pos_out && i + 1 == nb) pos_next = pos_out;  // the last update lands in the caller's buffer (no copy afterwards)
@@ -902,6 +953,7 @@ int run_blocks(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, const fl
       pos = pos_next;
       pos_next = (pos_next == w.posA) ? w.posB : w.posA;
     }
+    if (split) HIPCHK(hipStreamWaitEvent(s, g->ev_pre, 0));
     std::swap(NTcur, NTnxt);
   }
   *He_final = w.HeA;

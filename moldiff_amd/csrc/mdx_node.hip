@@ -239,8 +239,19 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce3_kernel(const float* __rest
   const int i = blockIdx.x * MDX_WG + threadIdx.x;
   if (i >= 3 * N) return;
   const int v = i / 3, k = i - 3 * v;
+  // sequential in CSR order like before (same bits), but eight independent loads in flight per step: the loop is latency-bound
+  // (a run of ~24 edges used to be 24 dependent L2 round trips = 11.5 us per launch, six launches per step)
   float s = 0.f;
-  for (int j = ptr[v]; j < ptr[v + 1]; ++j) s += src[3 * (size_t)(eids ? eids[j] : j) + k];
+  const int j1 = ptr[v + 1];
+  int j = ptr[v];
+  for (; j + 8 <= j1; j += 8) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = src[3 * (size_t)(eids ? eids[j + u] : j + u) + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += x[u];
+  }
+  for (; j < j1; ++j) s += src[3 * (size_t)(eids ? eids[j] : j) + k];
   out[i] = addend ? addend[i] + s : s;
 }
 
@@ -266,40 +277,60 @@ __device__ __forceinline__ void embed_node_thread(const EmbedArgs& a, int i) {
   if (f == 0) a.tn[v] = (float)t / (float)a.T;
 }
 
-__device__ __forceinline__ void embed_edge_thread(const EmbedArgs& a, int i) {
-  if (i >= a.E * MDX_ED) return;
-  const int e = i / MDX_ED, f = i - e * MDX_ED;
+// Edge rows: 16 threads per edge, four features each (one 16-byte store per thread; round 2's one-thread-per-element version
+// spent 95 us per step on 40 MB of output).  The embedder's weight sits transposed in LDS ([k][feature]); each feature is the
+// same fmaf chain over k as before, so the result has the same bits.
+constexpr int EMB_KMAX = 16;  // Ke (MolDiff: 6) or 2 Kn (bond predictor: 16)
+__device__ __forceinline__ void embed_edge_block(const EmbedArgs& a, int blk, float* WT) {
+  const int tid = threadIdx.x;
+  const int K = a.xe ? a.Ke : 2 * a.Kn;
+  for (int i = tid; i < K * MDX_ED; i += MDX_WG) {
+    const int k = i / MDX_ED, f = i - k * MDX_ED;
+    WT[i] = f < a.ed_emb ? a.We[f * K + k] : 0.f;
+  }
+  __syncthreads();
+  const int e = blk * (MDX_WG / 16) + (tid >> 4), f0 = 4 * (tid & 15);
+  if (e >= a.E) return;
   const int nl = a.l[e], nr = a.r[e];
   const int64_t t = a.t[a.node_graph[nl]];
-  float out;
-  if (f < a.ed_emb) {
-    float s = 0.f;
-    if (a.xe) {
-      int ref = a.int2ref ? a.int2ref[e] : e;
-      if (a.half_rows > 0 && ref >= a.half_rows) ref -= a.half_rows;  // both directions share the half-edge row
-      const float* x = a.xe + (size_t)ref * a.Ke;
-      for (int k = 0; k < a.Ke; ++k) s = fmaf(x[k], a.We[f * a.Ke + k], s);
-    } else {  // bond predictor: cat[x_n[left], x_n[right]]
-      const int K2 = 2 * a.Kn;
-      for (int k = 0; k < a.Kn; ++k) s = fmaf(a.xn[(size_t)nl * a.Kn + k], a.We[f * K2 + k], s);
-      for (int k = 0; k < a.Kn; ++k) s = fmaf(a.xn[(size_t)nr * a.Kn + k], a.We[f * K2 + a.Kn + k], s);
-    }
-    out = s;
-  } else {
-    const int k = f - a.ed_emb;
-    const float x = fminf(fmaxf((float)t, 0.f), (float)a.T) - a.toff[k];
-    out = expf(a.tcoef[k] * (x * x));
+  float x[EMB_KMAX];
+  if (a.xe) {
+    int ref = a.int2ref ? a.int2ref[e] : e;
+    if (a.half_rows > 0 && ref >= a.half_rows) ref -= a.half_rows;  // both directions share the half-edge row
+#pragma unroll
+    for (int k = 0; k < EMB_KMAX; ++k) x[k] = k < K ? a.xe[(size_t)ref * a.Ke + k] : 0.f;
+  } else {  // bond predictor: cat[x_n[left], x_n[right]]
+#pragma unroll
+    for (int k = 0; k < EMB_KMAX; ++k)
+      x[k] = k < a.Kn ? a.xn[(size_t)nl * a.Kn + k] : k < K ? a.xn[(size_t)nr * a.Kn + (k - a.Kn)] : 0.f;
   }
-  a.He[i] = out;
-  if (f == 0) a.te[e] = (float)t / (float)a.T;
+  f32x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int f = f0 + j;
+    if (f < a.ed_emb) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < EMB_KMAX; ++k)
+        if (k < K) s = fmaf(x[k], WT[k * MDX_ED + f], s);
+      out[j] = s;
+    } else {
+      const int k = f - a.ed_emb;
+      const float u = fminf(fmaxf((float)t, 0.f), (float)a.T) - a.toff[k];
+      out[j] = expf(a.tcoef[k] * (u * u));
+    }
+  }
+  stg4(a.He + (size_t)e * MDX_ED + f0, out);
+  if (f0 == 0) a.te[e] = (float)t / (float)a.T;
 }
 
-// one launch for both: the first nb_node workgroups embed atoms, the rest edges
+// one launch for both: the first nb_node workgroups embed atoms (one thread per element), the rest edges
 __global__ __launch_bounds__(MDX_WG) void embed_kernel(const EmbedArgs a, const int nb_node) {
+  __shared__ float WT[EMB_KMAX * MDX_ED];
   if ((int)blockIdx.x < nb_node)
     embed_node_thread(a, blockIdx.x * MDX_WG + threadIdx.x);
   else
-    embed_edge_thread(a, (blockIdx.x - nb_node) * MDX_WG + threadIdx.x);
+    embed_edge_block(a, blockIdx.x - nb_node, WT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,7 +457,7 @@ void launch_seg_reduce_block2(const float* P, const float* PR, const float* FL, 
 
 void launch_embed(const EmbedArgs& a, hipStream_t s) {
   const int nbn = a.N > 0 ? (int)(((size_t)a.N * MDX_ND + MDX_WG - 1) / MDX_WG) : 0;
-  const int nbe = a.E > 0 ? (int)(((size_t)a.E * MDX_ED + MDX_WG - 1) / MDX_WG) : 0;
+  const int nbe = a.E > 0 ? (int)((a.E + MDX_WG / 16 - 1) / (MDX_WG / 16)) : 0;  // 16 edges per workgroup
   if (nbn + nbe > 0) hipLaunchKernelGGL(embed_kernel, dim3(nbn + nbe), dim3(MDX_WG), 0, s, a, nbn);
 }
 
