@@ -15,7 +15,7 @@ Each rank samples its own independent batch (weak scaling, no data-path collecti
 is the barrier + the max-reduce of the elapsed time).  Inputs (index tensors, weights) are resident in
 HBM before the timed region; weights are synthetic "recipe" weights (no checkpoint offline).
 
-`python bench.py --train [--model MolDiff|bondpred] [--precision f32|bf16] ...` runs the training-step benchmark instead
+`python bench.py --train [--model MolDiff|bondpred] [--precision f32|fp16|bf16] ...` runs the training-step benchmark instead
 (BASELINE.json configs[4]; same launch contract, its own JSON line; see main_train).
 
 Extra objects on the JSON line:
@@ -311,7 +311,8 @@ def main_train():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--model', default='MolDiff', choices=['MolDiff', 'MolDiff_simple', 'bondpred'])
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16'], help="GEMM operand precision ('bf16' = mixed precision)")
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'fp16', 'bf16_autocast'],
+                    help="'fp16' = the reference's use_amp arithmetic (autocast float16 + dynamic loss scale); 'bf16' = GEMM operands only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
@@ -370,7 +371,10 @@ def main_train():
         out = {'metric': 'molecules/sec (training step: forward + backward + all-reduce + clip + AdamW)', 'value': args.batch * world / (ms / 1e3),
                'unit': 'molecules/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.precision == 'f32' else 'bf16 GEMM operands, f32 accumulate / elsewhere', 'data': 'synthetic',
+               'dtype': {'f32': 'f32', 'bf16': 'bf16 GEMM operands, f32 accumulate / elsewhere',
+                         'fp16': 'f16 Linear operands and results (f32 accumulate), f32 LayerNorm / loss / sums, dynamic loss scale '
+                                 '(the reference\'s use_amp: True)',
+                         'bf16_autocast': 'bf16 Linear operands and results, f32 elsewhere'}[args.precision], 'data': 'synthetic',
                'config': {'workload': f'train_{args.model}.yml: batch_size={args.batch} molecules/GPU (rank 0: N={N} atoms, E={E} directed '
                                       f'edges), AdamW lr 1e-4 betas (0.99,0.999) wd 1e-8, max_grad_norm 50; recipe weights',
                           'parallelism': f'data-parallel x{world}, one flat-gradient all-reduce per step',

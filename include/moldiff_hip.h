@@ -299,6 +299,25 @@ int mdx_op_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream)
 int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int64_t step, const float* gnorm2, float max_norm, void* stream);
 
+/* Mixed-precision forms of mdx_op_sgemm_nt / mdx_op_sgemm_tn (the reference trains under torch.autocast(dtype=float16) + GradScaler,
+ * scripts/train_drug3d.py:86-109): operands rounded to half_kind (1 = bfloat16, 2 = float16) on their way into LDS, half MFMAs,
+ * fp32 accumulation; round_out != 0 rounds the result to the same type before it is stored in its fp32 container -- the value a
+ * Linear (and the gradient of a weight autocast cast to half) has there; float16 overflows to +-inf beyond 65504.
+ * mdx_op_ew_fwd: op | (kind << 8) and mdx_op_mul_gather_fwd: F | (kind << 16) round their products the same way. */
+int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ldd,
+                    float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out, void* stream);
+int mdx_op_xgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
+                    int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, void* stream);
+
+/* One optimisation step with torch.cuda.amp.GradScaler semantics and ALL of its state on the device (no host round trip):
+ * g = gradient of (S x loss).  state (16 floats): [0] loss scale S, [1] growth tracker, [2] optimizer steps taken, [3] steps skipped,
+ * [4] unscaled squared gradient norm of this step (inf / nan if a gradient overflowed); [5..8] internal.  Finite: clip to max_norm
+ * (<= 0: none), AdamW with t = ++state[2]; after growth_interval consecutive finite steps S *= growth.  Not finite: no update, the
+ * step count does not advance, S *= backoff.  S = growth = backoff = 1 is the plain fp32 step.  ws: 1024 floats. */
+int mdx_op_amp_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, float max_norm, float* state, float growth, float backoff, int32_t growth_interval, float* ws,
+                     void* stream);
+
 /* ---- measurement hooks (bench.py): hipEvent timing of the block kernels on their launch stream.
  * kernel: 0 = fused edge kernel A (MFMA), 1 = fused edge kernel B, 2 = node kernel, 3 = message aggregation
  * (segment sum (E,256)->(N,256), the HBM-bound scatter/gather pass), 4 = the guidance backward's fused edge kernel

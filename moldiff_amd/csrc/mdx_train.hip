@@ -161,22 +161,52 @@ __device__ __forceinline__ uint16_t to_bf16(float a) {
   return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ bf16x8_t lds_bf16x8(const uint16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+// The low-precision operand type of the mixed-precision GEMMs: HT = 0 bfloat16 (round 2's mode), HT = 1 IEEE half -- the type the
+// reference's torch.autocast(dtype=torch.float16) casts Linear operands to (scripts/train_drug3d.py:93).  cvt rounds to nearest
+// even; a float16 overflows to infinity beyond 65504 like the cast autocast inserts (GradScaler's found_inf then skips the step).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <int HT>
+struct HalfT;
+template <>
+struct HalfT<0> {
+  typedef bf16x8_t v8;
+  static __device__ __forceinline__ uint16_t cvt(float a) { return to_bf16(a); }
+  static __device__ __forceinline__ float back(uint16_t u) { return __uint_as_float((uint32_t)u << 16); }
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct HalfT<1> {
+  typedef f16x8_t v8;
+  static __device__ __forceinline__ uint16_t cvt(float a) { return __builtin_bit_cast(uint16_t, (_Float16)a); }
+  static __device__ __forceinline__ float back(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <int HT>
+__device__ __forceinline__ float round_half(float a) { return HalfT<HT>::back(HalfT<HT>::cvt(a)); }
+template <int HT>
+__device__ __forceinline__ typename HalfT<HT>::v8 lds_h8(const uint16_t* p) { return *reinterpret_cast<const typename HalfT<HT>::v8*>(p); }
+// run-time form for the element-wise kernels: kind 0 = keep fp32, 1 = bf16, 2 = fp16
+__device__ __forceinline__ float round_kind(float a, int kind) { return kind == 2 ? round_half<1>(a) : kind == 1 ? round_half<0>(a) : a; }
 
 constexpr int H_KC = 64, H_LD = H_KC + 8;  // bf16 elements per staged row (+8 = 16 bytes of padding)
 
+// TN = width of the workgroup's column tile (64, 128 or 256; the launcher picks the smallest TN >= N up to MDX_HGEMM_TN_MAX, default
+// 128): fewer passes over the big operand A (rows x K, fp32 in HBM); the weight slab (TN x 64 halves per K step) sits in LDS.
+template <int HT, bool ROUND, int TN>
 __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                         const float* __restrict__ bias, const float* __restrict__ addend,
                                                         int ldd, float* __restrict__ C, int ldc, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) uint16_t As[G_TM * H_LD];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[G_TN * H_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[TN * H_LD];
+  constexpr int FT = TN / 16, BJ = TN / 16;   // feature tiles per wave; B staging slots per thread (TN rows x 16 float4 / 256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * G_TN;
+  const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * TN;
   const bool veca = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  f32x4 acc[4][2];
-  acc_zero<4, 2>(acc);
-  f32x4 ra[8], rb[4];   // 16 float4 per row of 64 k: A 128 rows -> 8 slots per thread, B 64 rows -> 4
+  f32x4 acc[FT][2];
+  acc_zero<FT, 2>(acc);
+  f32x4 ra[8], rb[BJ];   // 16 float4 per row of 64 k: A 128 rows -> 8 slots per thread, B 64 rows -> 4
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -185,7 +215,7 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
       ra[j] = load4_guard(A + (size_t)gm * lda, k0 + k4, K, gm < M, veca);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < BJ; ++j) {
       const int slot = tid + 256 * j, row = slot >> 4, k4 = (slot & 15) * 4;
       const int gn = n0 + row;
       rb[j] = load4_guard(B + (size_t)gn * ldb, k0 + k4, K, gn < N, vecb);
@@ -196,34 +226,36 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int slot = tid + 256 * j;
-      uint2 v = {pack_bf16x2(ra[j][0], ra[j][1]), pack_bf16x2(ra[j][2], ra[j][3])};
+      uint2 v = {(uint32_t)HalfT<HT>::cvt(ra[j][0]) | ((uint32_t)HalfT<HT>::cvt(ra[j][1]) << 16),
+                 (uint32_t)HalfT<HT>::cvt(ra[j][2]) | ((uint32_t)HalfT<HT>::cvt(ra[j][3]) << 16)};
       *reinterpret_cast<uint2*>(As + (slot >> 4) * H_LD + (slot & 15) * 4) = v;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < BJ; ++j) {
       const int slot = tid + 256 * j;
-      uint2 v = {pack_bf16x2(rb[j][0], rb[j][1]), pack_bf16x2(rb[j][2], rb[j][3])};
+      uint2 v = {(uint32_t)HalfT<HT>::cvt(rb[j][0]) | ((uint32_t)HalfT<HT>::cvt(rb[j][1]) << 16),
+                 (uint32_t)HalfT<HT>::cvt(rb[j][2]) | ((uint32_t)HalfT<HT>::cvt(rb[j][3]) << 16)};
       *reinterpret_cast<uint2*>(Bs + (slot >> 4) * H_LD + (slot & 15) * 4) = v;
     }
     __syncthreads();
     if (k0 + H_KC < K) fetch(k0 + H_KC);
 #pragma unroll
     for (int ks = 0; ks < H_KC / 32; ++ks) {
-      bf16x8_t a[4], b[2];
+      typename HalfT<HT>::v8 a[FT], b[2];
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) a[ft] = lds_bf16x8(Bs + (16 * ft + c) * H_LD + 32 * ks + 8 * q);
+      for (int ft = 0; ft < FT; ++ft) a[ft] = lds_h8<HT>(Bs + (16 * ft + c) * H_LD + 32 * ks + 8 * q);
 #pragma unroll
-      for (int et = 0; et < 2; ++et) b[et] = lds_bf16x8(As + (32 * wave + 16 * et + c) * H_LD + 32 * ks + 8 * q);
+      for (int et = 0; et < 2; ++et) b[et] = lds_h8<HT>(As + (32 * wave + 16 * et + c) * H_LD + 32 * ks + 8 * q);
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
-        for (int et = 0; et < 2; ++et) acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ft], b[et], acc[ft][et], 0, 0, 0);
+        for (int et = 0; et < 2; ++et) acc[ft][et] = HalfT<HT>::mfma(a[ft], b[et], acc[ft][et]);
     }
     __syncthreads();
   }
   const bool veco = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
 #pragma unroll
-  for (int ft = 0; ft < 4; ++ft) {
+  for (int ft = 0; ft < FT; ++ft) {
     const int col = n0 + 16 * ft + 4 * q;
     f32x4 bv = splat4(0.f);
     if (bias) {
@@ -240,6 +272,10 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (col + r < N) v[r] += addend[(size_t)row * ldd + col + r];
+      }
+      if (ROUND) {  // the Linear's output in the low-precision type, like autocast's fp16 / bf16 result (held in an fp32 container)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = round_half<HT>(v[r]);
       }
       float* o = C + (size_t)row * ldc + col;
       if (veco && col + 3 < N) {
@@ -343,6 +379,7 @@ __global__ __launch_bounds__(256) void hgemm3_nt_kernel(const float* __restrict_
 // bf16 weight gradient: 64 rows of G and X per step are transposed into LDS ([column][row], so that the 8 consecutive
 // contraction values a lane needs are one 16-byte read); otherwise the structure of sgemm_tn_split_kernel.
 constexpr int HW_MC = 64;
+template <int HT>
 __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
                                                               int M, int N, int K, int mper, float* __restrict__ P,
                                                               float* __restrict__ Pb) {
@@ -376,8 +413,8 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const float* __rest
       const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        Gt[(c4 + e) * H_LD + row] = to_bf16(rg[j][e]);
-        Xt[(c4 + e) * H_LD + row] = to_bf16(rx[j][e]);
+        Gt[(c4 + e) * H_LD + row] = HalfT<HT>::cvt(rg[j][e]);
+        Xt[(c4 + e) * H_LD + row] = HalfT<HT>::cvt(rx[j][e]);
       }
     }
     __syncthreads();
@@ -385,21 +422,21 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const float* __rest
     if (do_bias) {  // bias gradient partial: column tid of the staged (bf16-rounded) G tile, fp32 sum
       float sacc = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < HW_MC; ++r) sacc += __uint_as_float((uint32_t)Gt[tid * H_LD + r] << 16);
+      for (int r = 0; r < HW_MC; ++r) sacc += HalfT<HT>::back(Gt[tid * H_LD + r]);
       bsum += sacc;
     }
 #pragma unroll
     for (int ks = 0; ks < HW_MC / 32; ++ks) {
-      bf16x8_t a[2], b[2];
+      typename HalfT<HT>::v8 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a[i] = lds_bf16x8(Gt + (wn + 16 * i + c) * H_LD + 32 * ks + 8 * q);
-        b[i] = lds_bf16x8(Xt + (wk + 16 * i + c) * H_LD + 32 * ks + 8 * q);
+        a[i] = lds_h8<HT>(Gt + (wn + 16 * i + c) * H_LD + 32 * ks + 8 * q);
+        b[i] = lds_h8<HT>(Xt + (wk + 16 * i + c) * H_LD + 32 * ks + 8 * q);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = HalfT<HT>::mfma(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -500,7 +537,8 @@ __global__ __launch_bounds__(256) void sgemm_tn_split_kernel(const float* __rest
 // of its chunk (coalesced 128-byte reads), the 8 lane sums are combined in lane order -> a fixed summation tree,
 // deterministic.  blockIdx.y selects a chunk of `chunk` splits and writes row blockIdx.y of the output (two-stage use).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ P, int S, int chunk, int M, int N,
-                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc) {
+                                                               const float* __restrict__ bias, float* __restrict__ C, int ldc,
+                                                               int rkind = 0) {
   __shared__ float sh[8][32];
   const int o = threadIdx.x & 31, z = threadIdx.x >> 5;
   const size_t total = (size_t)M * N;
@@ -516,7 +554,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     float r = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) r += sh[k][o];
-    C[(size_t)blockIdx.y * total + (size_t)row * ldc + col] = r;
+    C[(size_t)blockIdx.y * total + (size_t)row * ldc + col] = round_kind(r, rkind);
   }
 }
 
@@ -524,7 +562,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // the same per-output summation as reduce_partials_kernel with S <= RED_CHUNK.
 __global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __restrict__ P, int S, int M, int N, float* __restrict__ C,
                                                                 int ldc, int gx_w, const float* __restrict__ Pb, int Nb,
-                                                                float* __restrict__ db) {
+                                                                float* __restrict__ db, int rkind = 0) {
   __shared__ float sh[8][32];
   const int o = threadIdx.x & 31, z = threadIdx.x >> 5;
   const bool bias_part = (int)blockIdx.x >= gx_w;
@@ -540,6 +578,7 @@ __global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __re
     float r = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) r += sh[k][o];
+    r = round_kind(r, rkind);  // mixed precision: the gradient of a weight autocast cast to half arrives in half
     if (bias_part) {
       db[i] = r;
     } else {
@@ -818,18 +857,21 @@ __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------------------------
 // element-wise pairs.  op: 0 add, 1 sub, 2 mul, 3 gate (a * sigmoid(b))
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void ew_fwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+// opr = op | (rkind << 8): rkind != 0 rounds the result (and the sigmoid of the gate) to bfloat16 / float16 -- the value the
+// reference's fp16 tensors hold under autocast (both factors of these products are Linear outputs there)
+__global__ void ew_fwd_kernel(int opr, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int op = opr & 255, rk = opr >> 8;
   const float x = a[i], y = b[i];
   float r;
   switch (op) {
     case 0: r = x + y; break;
     case 1: r = x - y; break;
     case 2: r = x * y; break;
-    default: r = x * sigmoidf_(y); break;
+    default: r = x * round_kind(sigmoidf_(y), rk); break;
   }
-  o[i] = r;
+  o[i] = round_kind(r, rk);
 }
 template <typename V>
 __device__ __forceinline__ V ew_apply(int op, V x, V y);
@@ -842,9 +884,22 @@ __device__ __forceinline__ f32x4 ew_apply<f32x4>(int op, f32x4 x, f32x4 y) {
     default: return x * sigmoid4(y);
   }
 }
-__global__ void ew_fwd4_kernel(int op, const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, size_t n4) {
+__global__ void ew_fwd4_kernel(int opr, const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n4) o[i] = ew_apply<f32x4>(op, a[i], b[i]);
+  if (i >= n4) return;
+  const int op = opr & 255, rk = opr >> 8;
+  if (rk == 0) {
+    o[i] = ew_apply<f32x4>(op, a[i], b[i]);
+    return;
+  }
+  const f32x4 x = a[i], y = b[i];
+  f32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = op == 0 ? x[j] + y[j] : op == 1 ? x[j] - y[j] : op == 2 ? x[j] * y[j] : x[j] * round_kind(sigmoidf_(y[j]), rk);
+    r[j] = round_kind(v, rk);
+  }
+  o[i] = r;
 }
 __global__ void ew_bwd4_kernel(int op, const f32x4* __restrict__ a, const f32x4* __restrict__ b, const f32x4* __restrict__ g,
                                f32x4* __restrict__ da, f32x4* __restrict__ db, size_t n4) {
@@ -915,12 +970,17 @@ __global__ void segsum_rows4_kernel(const f32x4* __restrict__ src, const int64_t
 // y[i] = a[i] * t[idx[i]] and its two gradients (da = g * t[idx];  dt[r] = sum_{j in seg r} g[order[j]] * a[order[j]]):
 // the product with a gathered per-node row without materialising the gathered (rows x F) tensor.  F % 4 == 0.
 __global__ void mulg_fwd_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ t, const int64_t* __restrict__ idx, int64_t M,
-                                int F4, const f32x4* __restrict__ g, f32x4* __restrict__ y) {
+                                int F4, const f32x4* __restrict__ g, f32x4* __restrict__ y, int rk) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * F4) return;
   const int64_t row = i / F4;
   const f32x4 tv = t[(size_t)idx[row] * F4 + (int)(i % F4)];
-  y[i] = (g ? g[i] : a[i]) * tv;      // forward: a * t[idx];  backward wrt a: g * t[idx]
+  f32x4 r = (g ? g[i] : a[i]) * tv;      // forward: a * t[idx];  backward wrt a: g * t[idx]
+  if (rk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = round_kind(r[j], rk);
+  }
+  y[i] = r;
 }
 __global__ void mulg_segsum_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ a, const int64_t* __restrict__ order,
                                    const int64_t* __restrict__ ptr, int64_t R, int F4, f32x4* __restrict__ out) {
@@ -1065,6 +1125,55 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pi;
 }
 
+// ---- GradScaler-equivalent step with its state on the device (scripts/train_drug3d.py:105-109: scaler.scale(loss).backward(),
+// unscale_, clip_grad_norm_, scaler.step, scaler.update) ----
+// state: [0] loss scale S  [1] growth tracker  [2] optimizer steps taken  [3] steps skipped  [4] unscaled squared gradient norm of the
+//        last step (inf / nan when a gradient overflowed)  [5] apply flag  [6] gradient multiplier (1/S x clip factor)  [7] 1 - b1^t
+//        [8] sqrt(1 - b2^t)
+constexpr int AMP_STATE = 16;
+__global__ void amp_decide_kernel(const float* __restrict__ part, int nparts, float* __restrict__ st, float b1, float b2, float max_norm,
+                                  float growth, float backoff, int growth_interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float tot = 0.f;
+  for (int i = 0; i < nparts; ++i) tot += part[i];
+  const float S = st[0], inv = 1.0f / S;
+  const float n2 = tot * inv * inv;
+  st[4] = n2;
+  if (isfinite(n2)) {
+    const float t = st[2] + 1.0f;
+    st[2] = t;
+    st[5] = 1.0f;
+    st[6] = inv * fminf(max_norm / (sqrtf(n2) + 1e-6f), 1.0f);
+    st[7] = 1.0f - powf(b1, t);
+    st[8] = sqrtf(1.0f - powf(b2, t));
+    const float tr = st[1] + 1.0f;
+    if (growth_interval > 0 && tr >= (float)growth_interval) {
+      st[0] = S * growth;
+      st[1] = 0.f;
+    } else {
+      st[1] = tr;
+    }
+  } else {  // found_inf: the optimizer does not step (its step count and moments stay), the scale backs off
+    st[5] = 0.f;
+    st[3] += 1.0f;
+    st[0] = S * backoff;
+    st[1] = 0.f;
+  }
+}
+__global__ void adamw_amp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                 float lr, float b1, float b2, float eps, float wd, const float* __restrict__ st) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || st[5] == 0.f) return;
+  const float gi = g[i] * st[6];
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  pi -= (lr / st[7]) * mi / (sqrtf(vi) / st[8] + eps);
+  p[i] = pi;
+}
+
 inline unsigned nblk(size_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
 inline int bad(const char* m) { return mdx_set_error(MDX_ERR_ARG, m); }
 // out (M x N, ld) = bias + sum over the S partial copies in P; more than 256 copies go through `scratch`
@@ -1072,16 +1181,16 @@ inline int bad(const char* m) { return mdx_set_error(MDX_ERR_ARG, m); }
 constexpr int RED_CHUNK = 256;
 inline size_t reduce_scratch_floats(int64_t S, int64_t total) { return S > RED_CHUNK ? (size_t)((S + RED_CHUNK - 1) / RED_CHUNK) * total : 0; }
 inline void launch_reduce_partials(const float* P, int S, int M, int N, const float* bias, float* out, int ld, float* scratch,
-                                   hipStream_t s) {
+                                   hipStream_t s, int rkind = 0) {
   const size_t total = (size_t)M * N;
   const unsigned gx = (unsigned)((total + 31) / 32);
   if (S <= RED_CHUNK || !scratch) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, P, S, S, M, N, bias, out, ld);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, P, S, S, M, N, bias, out, ld, rkind);
     return;
   }
   const int nc = (S + RED_CHUNK - 1) / RED_CHUNK;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, nc), dim3(256), 0, s, P, S, RED_CHUNK, M, N, (const float*)nullptr, scratch, N);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)scratch, nc, nc, M, N, bias, out, ld);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, nc), dim3(256), 0, s, P, S, RED_CHUNK, M, N, (const float*)nullptr, scratch, N, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, 1), dim3(256), 0, s, (const float*)scratch, nc, nc, M, N, bias, out, ld, rkind);
 }
 inline int launched() {
   const hipError_t e = hipGetLastError();
@@ -1191,7 +1300,7 @@ extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
 
 extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
   if (n <= 0) return MDX_OK;
-  if (op < 0 || op > 3) return bad("ew: unknown op");
+  if ((op & 255) > 3 || (op >> 8) < 0 || (op >> 8) > 2) return bad("ew: unknown op");
   if ((n & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0)
     hipLaunchKernelGGL(ew_fwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, (const f32x4*)a, (const f32x4*)b,
                        (f32x4*)out, (size_t)n / 4);
@@ -1285,6 +1394,27 @@ extern "C" int mdx_op_adamw(float* p, const float* g, float* m, float* v, int64_
   return launched();
 }
 
+// One optimisation step with torch.cuda.amp.GradScaler semantics, state on the device (see amp_decide_kernel): g holds the
+// gradient of (S x loss).  Unscales, measures the global norm (state[4], unscaled), clips to max_norm (<= 0 or inf: no clipping),
+// and applies AdamW -- or, if any gradient is not finite, skips the update (the step count does not advance) and multiplies S by
+// `backoff`; after `growth_interval` consecutive finite steps S is multiplied by `growth`.  With S = growth = backoff = 1 this is the
+// plain fp32 step.  ws: 1024 floats.  No host synchronisation.
+extern "C" int mdx_op_amp_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float max_norm, float* state, float growth, float backoff, int32_t growth_interval,
+                                float* ws, void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (!p || !g || !m || !v || !state || !ws) return bad("amp_adamw: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 65535) / 65536));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, s, g, (size_t)n, ws);
+  const float mn = (max_norm > 0.f) ? max_norm : INFINITY;
+  hipLaunchKernelGGL(amp_decide_kernel, dim3(1), dim3(64), 0, s, (const float*)ws, nb, state, beta1, beta2, mn, growth, backoff,
+                     (int)growth_interval);
+  hipLaunchKernelGGL(adamw_amp_kernel, dim3(nblk((size_t)n)), dim3(256), 0, s, p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay,
+                     (const float*)state);
+  return launched();
+}
+
 // Weight gradient of a Linear layer: dW[N,K] = G[M,N]^T X[M,K] (row-major operands as stored by the forward/backward;
 // no transposes).  The M rows are cut into `splits` ranges whose partial products are summed in a fixed order
 // (partial: (splits + ceil(splits/256)) * (N*K + N) floats: the partial products plus the first reduction stage, for dW
@@ -1307,7 +1437,7 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   if (db && S <= RED_CHUNK) {  // both reductions in one launch
     const unsigned gxw = (unsigned)(((size_t)N * K + 31) / 32), gxb = (unsigned)((N + 31) / 32);
     hipLaunchKernelGGL(reduce_partials2_kernel, dim3(gxw + gxb), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K, dW, (int)ldw,
-                       (int)gxw, (const float*)pb, (int)N, db);
+                       (int)gxw, (const float*)pb, (int)N, db, 0);
   } else {
     launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
     if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
@@ -1315,21 +1445,46 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   return launched();
 }
 
-// bf16-operand forms of sgemm_nt / sgemm_tn (same arguments; no split-K for the forward form).
-extern "C" int mdx_op_hgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
-                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+// Mixed-precision forms of sgemm_nt / sgemm_tn: operands rounded to `half_kind` (1 = bfloat16, 2 = float16) on their way into
+// LDS, products on the 16x16x32 half MFMAs, fp32 accumulation.  round_out != 0: the result is rounded to the same type before it
+// is stored (in an fp32 container) -- the value a Linear returns under torch.autocast (float16 overflows to infinity).  The forward
+// form has no split-K.  mdx_op_hgemm_* = half_kind 1, round_out 0 (round 2's 'bf16 operands' mode).
+extern "C" int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
+                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out,
+                               void* stream) {
   if (M <= 0 || N <= 0) return MDX_OK;
-  if (!A || !B || !C || K < 0) return bad("hgemm_nt: null operand");
-  dim3 grid((unsigned)((N + G_TN - 1) / G_TN), (unsigned)((M + G_TM - 1) / G_TM), 1);
-  hipLaunchKernelGGL(hgemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C,
-                     (int)ldc, (int)M, (int)N, (int)K);
+  if (!A || !B || !C || K < 0) return bad("xgemm_nt: null operand");
+  if (half_kind != 1 && half_kind != 2) return bad("xgemm_nt: half_kind must be 1 (bfloat16) or 2 (float16)");
+  hipStream_t s = (hipStream_t)stream;
+  // measured on the training step (ms per step, fp16 mode): TN <= 64: 52.0, <= 128: 51.5, <= 256: 54.7 (one workgroup per CU) -- the
+  // re-reads of A were L2 hits all along; the kernel is bound by its short K loop (one 64-wide chunk in flight per workgroup)
+  static const int tn_max = [] { const char* e = getenv("MDX_HGEMM_TN_MAX"); return e ? atoi(e) : 128; }();
+  const int tn = std::min(tn_max, N <= 64 ? 64 : N <= 128 ? 128 : 256);
+  dim3 grid((unsigned)((N + tn - 1) / tn), (unsigned)((M + G_TM - 1) / G_TM), 1);
+#define MDX_XNT3(HT, R, TNv)                                                                                                          \
+  hipLaunchKernelGGL((hgemm_nt_kernel<HT, R, TNv>), grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, \
+                     (int)M, (int)N, (int)K)
+#define MDX_XNT(HT, R)                                  \
+  do {                                                  \
+    if (tn == 64) MDX_XNT3(HT, R, 64);                  \
+    else if (tn == 128) MDX_XNT3(HT, R, 128);           \
+    else MDX_XNT3(HT, R, 256);                          \
+  } while (0)
+  if (half_kind == 1) {
+    if (round_out) MDX_XNT(0, true); else MDX_XNT(0, false);
+  } else {
+    if (round_out) MDX_XNT(1, true); else MDX_XNT(1, false);
+  }
+#undef MDX_XNT3
+#undef MDX_XNT
   return launched();
 }
-extern "C" int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
-                               int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
+extern "C" int mdx_op_xgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
+                               int64_t N, int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, void* stream) {
   if (N <= 0 || K <= 0) return MDX_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (!G || !X || !dW || !partial) return bad("hgemm_tn: null operand / partial buffer");
+  if (!G || !X || !dW || !partial) return bad("xgemm_tn: null operand / partial buffer");
+  if (half_kind != 1 && half_kind != 2) return bad("xgemm_tn: half_kind must be 1 (bfloat16) or 2 (float16)");
   if (splits < 1) splits = 1;
   int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
   mper = (mper + HW_MC - 1) / HW_MC * HW_MC;
@@ -1338,16 +1493,28 @@ extern "C" int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int6
   const size_t nc = (size_t)(S + RED_CHUNK - 1) / RED_CHUNK;
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
-  hipLaunchKernelGGL(hgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+  if (half_kind == 1)
+    hipLaunchKernelGGL((hgemm_tn_split_kernel<0>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+  else
+    hipLaunchKernelGGL((hgemm_tn_split_kernel<1>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+  const int rkind = round_out ? half_kind : 0;
   if (db && S <= RED_CHUNK) {  // both reductions in one launch
     const unsigned gxw = (unsigned)(((size_t)N * K + 31) / 32), gxb = (unsigned)((N + 31) / 32);
     hipLaunchKernelGGL(reduce_partials2_kernel, dim3(gxw + gxb), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K, dW, (int)ldw,
-                       (int)gxw, (const float*)pb, (int)N, db);
+                       (int)gxw, (const float*)pb, (int)N, db, rkind);
   } else {
-    launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
-    if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
+    launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s, rkind);
+    if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s, rkind);
   }
   return launched();
+}
+extern "C" int mdx_op_hgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
+                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+  return mdx_op_xgemm_nt(A, lda, B, ldb, bias, addend, ldd, C, ldc, M, N, K, 1, 0, stream);
+}
+extern "C" int mdx_op_hgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
+                               int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
+  return mdx_op_xgemm_tn(G, ldg, X, ldx, dW, ldw, db, M, N, K, splits, partial, 1, 0, stream);
 }
 
 // Experimental: fp32-accurate product on the bf16 matrix pipe (three-way operand split, 6 MFMAs per k-step); benchmark only,
@@ -1363,11 +1530,15 @@ extern "C" int mdx_debug_hgemm3_nt(const float* A, int64_t lda, const float* B, 
 #endif
 
 // y = a * t[idx] (rows of F floats, F % 4 == 0) and its gradients; see mulg_*_kernel.
+// F: feature count in its low 16 bits; bits 16.. = rounding kind of the product (0 fp32, 1 bfloat16, 2 float16; mixed precision)
 extern "C" int mdx_op_mul_gather_fwd(const float* a, const float* t, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
+  const int rk = F >> 16;
+  F &= 0xffff;
   if (M <= 0 || F <= 0) return MDX_OK;
   if (F & 3) return bad("mul_gather: F must be a multiple of 4");
+  if (rk < 0 || rk > 2) return bad("mul_gather: unknown rounding kind");
   hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (const f32x4*)t,
-                     idx, M, F / 4, (const f32x4*)nullptr, (f32x4*)y);
+                     idx, M, F / 4, (const f32x4*)nullptr, (f32x4*)y, rk);
   return launched();
 }
 extern "C" int mdx_op_mul_gather_bwd(const float* g, const float* a, const float* t, const int64_t* idx, const int64_t* order,
@@ -1377,7 +1548,7 @@ extern "C" int mdx_op_mul_gather_bwd(const float* g, const float* a, const float
   hipStream_t s = (hipStream_t)stream;
   if (da && M > 0)
     hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, s, (const f32x4*)a, (const f32x4*)t, idx, M, F / 4,
-                       (const f32x4*)g, (f32x4*)da);
+                       (const f32x4*)g, (f32x4*)da, 0);
   if (dt && R > 0)
     hipLaunchKernelGGL(mulg_segsum_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, s, (const f32x4*)g, (const f32x4*)a, order, ptr, R,
                        F / 4, (f32x4*)dt);

@@ -7,7 +7,9 @@ Same loop (scripts/train_drug3d.py:88-190): per iteration a batch, ``pos_noise_s
 ``model.get_loss``, backward, clip_grad_norm_(max_grad_norm), AdamW; every ``val_freq`` iterations a validation pass
 under no_grad, the plateau scheduler on the validation loss and a checkpoint ``{config, model, optimizer, scheduler,
 iteration}`` under ``<logdir>/checkpoints/<it>.pt`` that ``sample_drug3d`` loads.  What differs, deliberately:
-  * forward/backward run on the HIP layer operators, the optimizer on flat buffers (``trainer.Trainer``), fp32 (no AMP);
+  * forward/backward run on the HIP layer operators, the optimizer on flat buffers (``trainer.Trainer``); ``train.use_amp: true``
+    selects the reference's mixed-precision arithmetic (float16 Linear operands / results with fp32 accumulation, dynamic loss scale
+    with skip-on-overflow -- ``Trainer(precision='fp16')``, state on the device), ``false`` plain fp32;
   * data parallelism is one process per GPU with one gradient all-reduce per step (torch.distributed / RCCL); every rank
     draws its own batches (seed + rank), rank 0 validates, logs and checkpoints;
   * the data side is PyG-free (``moldiff_amd/data.py``): ``dataset: {name: records, path: ...}`` trains on the reference's
@@ -81,7 +83,9 @@ def main(argv=None):
         raise NotImplementedError('Optimizer not supported: %s' % oc.type)
     # ... and Trainer broadcasts rank 0's flat parameter buffer on top of that (sync_replicas), so the replicas agree even if a
     # module draws its initial values from somewhere else
-    trainer = Trainer(model, lr=oc.lr, betas=(oc.beta1, oc.beta2), weight_decay=oc.weight_decay, max_grad_norm=config.train.max_grad_norm)
+    precision = 'fp16' if bool(config.train.get('use_amp', False)) else 'f32'     # scripts/train_drug3d.py:86,93
+    trainer = Trainer(model, lr=oc.lr, betas=(oc.beta1, oc.beta2), weight_decay=oc.weight_decay, max_grad_norm=config.train.max_grad_norm,
+                      precision=precision)
     seed_all(config.train.seed + rank)   # from here on: per-rank streams (position perturbation, time steps, noise)
     sc = config.train.scheduler
     if sc.type != 'plateau':

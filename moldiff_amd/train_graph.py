@@ -63,7 +63,7 @@ def node_block(m, x, g, edge_attr, node_time):
     h_edge = mlp(m.edge_net, edge_attr)
     msg = T.linear(T.mul_gather(h_edge, h_node, g.right), m.msg_net.weight, m.msg_net.bias)
     g0, ed = m.gate.net[0], edge_attr.shape[1]
-    per_node = T.linear(cat(x, node_time), g0.weight[:, ed:])                      # x[col] and node_time[col] columns
+    per_node = T.linear(cat(x, node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
     gt = mlp_from_pre(m.gate, T.linear(edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right)))
     msg = T.gate(msg, gt)
     out = T.linear(x, m.centroid_lin.weight, m.centroid_lin.bias, addend=T.scatter_sum(msg, g.left))
@@ -78,12 +78,12 @@ def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
     bond_feat = T.linear(bond_in, m.bond_linear.weight)
     if node_edges is None:
         prod = T.mul_gather(bond_feat, T.linear(node_rows, m.node_linear.weight), plan)
-        gate_node = T.gather(T.linear(node_rows, g0.weight[:, bd:bd + nd]), plan)
+        gate_node = T.gather(T.linear(node_rows, g0.weight[:, bd:bd + nd], keep32=True), plan)
     else:
         prod = T.mul(bond_feat, T.linear(node_edges, m.node_linear.weight))
-        gate_node = T.linear(node_edges, g0.weight[:, bd:bd + nd])
+        gate_node = T.linear(node_edges, g0.weight[:, bd:bd + nd], keep32=True)
     inter = mlp(m.inter_module, prod)
-    pre = T.linear(bond_in, g0.weight[:, :bd], g0.bias, addend=T.linear(time, g0.weight[:, bd + nd:], None, addend=gate_node))
+    pre = T.linear(bond_in, g0.weight[:, :bd], g0.bias, addend=T.linear(time, g0.weight[:, bd + nd:], None, addend=gate_node, keep32=True))
     return T.gate(inter, mlp_from_pre(m.gate, pre))
 
 

@@ -27,38 +27,53 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-_GEMM_BF16 = False
+# Mixed precision of the Linear layers: None = exact fp32, else (half_kind, autocast) with half_kind 1 = bfloat16, 2 = float16.
+#   autocast = False ('bf16'): operands rounded, everything else fp32 (round 2's mode).
+#   autocast = True  ('fp16', 'bf16_autocast'): the arithmetic of the reference's training loop, which wraps get_loss in
+#     torch.autocast(dtype=float16) (scripts/train_drug3d.py:93): a Linear takes operands AND returns its result in the half type
+#     (fp32 accumulation), so do its data / weight / bias gradients; products of two such results (gates, pairwise products) are
+#     half too; LayerNorm, softmax, the posteriors, the loss and every segment sum stay fp32.  Tensors live in fp32 containers
+#     holding half-representable values.
+_AMP = None
+KINDS = {'f32': None, 'bf16': (1, False), 'fp16': (2, True), 'bf16_autocast': (1, True)}
 
 
 class precision:
-    """Context manager selecting the GEMM operand precision of `linear` (forward, data and weight gradients):
-    'f32' (default: exact fp32 MFMA) or 'bf16' (operands rounded to bf16, fp32 accumulate -- mixed-precision training in
-    the spirit of the reference's fp16 autocast; everything outside the GEMMs stays fp32)."""
+    """Context manager selecting the precision of `linear` (forward, data and weight gradients) and of the element-wise products:
+    'f32' (default: exact fp32 MFMA), 'bf16' (GEMM operands rounded to bf16, fp32 accumulate and results), 'fp16' / 'bf16_autocast'
+    (autocast-equivalent: see _AMP above)."""
 
     def __init__(self, kind):
-        if kind not in ('f32', 'bf16'):
-            raise ValueError(kind)
+        if isinstance(kind, str):
+            if kind not in KINDS:
+                raise ValueError(kind)
+            kind = KINDS[kind]
         self.kind = kind
 
     def __enter__(self):
-        global _GEMM_BF16
-        self.prev, _GEMM_BF16 = _GEMM_BF16, self.kind == 'bf16'
+        global _AMP
+        self.prev, _AMP = _AMP, self.kind
         return self
 
     def __exit__(self, *exc):
-        global _GEMM_BF16
-        _GEMM_BF16 = self.prev
+        global _AMP
+        _AMP = self.prev
 
 
-def sgemm_nt(a, b, bias=None, splits=1, addend=None):
-    """a (M,K) @ b (N,K)^T + bias + addend -> (M,N).  Rows of a / b may be strided (column slices of a wider matrix)."""
+def _round_kind():
+    return _AMP[0] if (_AMP is not None and _AMP[1]) else 0
+
+
+def sgemm_nt(a, b, bias=None, splits=1, addend=None, keep32=False):
+    """a (M,K) @ b (N,K)^T + bias + addend -> (M,N).  Rows of a / b may be strided (column slices of a wider matrix).
+    keep32: in an autocast mode, do not round the result (it is a partial sum that enters another Linear as its addend)."""
     M, K = a.shape
     N = b.shape[0]
     assert a.stride(1) == 1 and b.stride(1) == 1
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    if _GEMM_BF16 and splits <= 1:
-        check(_L().mdx_op_hgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0,
-                                   ptr(out), N, M, N, K, stream()))
+    if _AMP is not None and splits <= 1:
+        check(_L().mdx_op_xgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0,
+                                   ptr(out), N, M, N, K, _AMP[0], int(_AMP[1] and not keep32), stream()))
         return out
     part = torch.empty(splits * M * N, dtype=torch.float32, device=a.device) if splits > 1 else None
     check(_L().mdx_op_sgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0, ptr(out),
@@ -71,7 +86,7 @@ ROWS_MIN = 16384   # from this many rows on a Linear runs on the row-owner kerne
 
 def linear_rows_ok(a, n, k, addend=None):
     """Can `a` (M,k) @ W -> (M,n) take the row-owner kernel?  Shape built, enough rows, 16-byte aligned rows, fp32 mode."""
-    return (not _GEMM_BF16 and a.shape[0] >= ROWS_MIN and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+    return (_AMP is None and a.shape[0] >= ROWS_MIN and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
             and (addend is None or (addend.stride(1) == 1 and addend.stride(0) % 4 == 0 and addend.data_ptr() % 16 == 0))
             and _L().mdx_op_linear_rows_supported(n, k) == 1)
 
@@ -98,8 +113,11 @@ def sgemm_tn(g, x, splits, want_bias=False):
     out = torch.empty(N, K, dtype=torch.float32, device=g.device)
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
     part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
-    fn = _L().mdx_op_hgemm_tn if _GEMM_BF16 else _L().mdx_op_sgemm_tn
-    check(fn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), stream()))
+    if _AMP is not None:
+        check(_L().mdx_op_xgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), _AMP[0],
+                                   int(_AMP[1]), stream()))
+    else:
+        check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), stream()))
     return (out, db) if want_bias else out
 
 
@@ -138,15 +156,15 @@ def _rows(t):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, addend):
+    def forward(ctx, x, w, b, addend, keep32):
         xc, wc = _rows(x), _rows(w)
         ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.has_addend = b is not None, addend is not None
-        ctx.prec = 'bf16' if _GEMM_BF16 else 'f32'     # the backward of this layer runs in the forward's precision
+        ctx.prec = _AMP     # the backward of this layer runs in the forward's precision
         bc, ac = (_c(b) if b is not None else None), (_c(addend) if addend is not None else None)
         if linear_rows_ok(xc, wc.shape[0], wc.shape[1], ac):
             return linear_rows(xc, wc, False, bc, ac)
-        return sgemm_nt(xc, wc, bc, addend=ac)
+        return sgemm_nt(xc, wc, bc, addend=ac, keep32=keep32)
 
     @staticmethod
     def backward(ctx, gy):
@@ -165,13 +183,15 @@ class _Linear(torch.autograd.Function):
                 gw, gb = r if want_b else (r, None)
             elif want_b:
                 gb = colreduce(gy)
-        return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None)
+        return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None), None
 
 
-def linear(x, w, b=None, addend=None):
+def linear(x, w, b=None, addend=None, keep32=False):
     """y = x @ w.T + b + addend for 2-D x (rows, in_features); `addend` (rows, out_features) is added in the GEMM epilogue
-    (used for the per-node part of a layer whose reference input is a concatenation [edge part | node part | time])."""
-    return _Linear.apply(x, w, b, addend)
+    (used for the per-node part of a layer whose reference input is a concatenation [edge part | node part | time]).
+    keep32: the result is itself such a partial sum -- an autocast mode must not round it (the reference rounds the WHOLE layer's
+    result once)."""
+    return _Linear.apply(x, w, b, addend, keep32)
 
 
 class _LnRelu(torch.autograd.Function):
@@ -208,7 +228,8 @@ class _Ew(torch.autograd.Function):
         ac, bc = _c(a), _c(b)
         assert ac.shape == bc.shape, (ac.shape, bc.shape)
         out = torch.empty_like(ac)
-        check(_L().mdx_op_ew_fwd(op, ptr(ac), ptr(bc), ptr(out), ac.numel(), stream()))
+        rk = _round_kind() if op in (MUL, GATE) else 0     # autocast: a product of two half tensors is a half tensor
+        check(_L().mdx_op_ew_fwd(op | (rk << 8), ptr(ac), ptr(bc), ptr(out), ac.numel(), stream()))
         ctx.op = op
         ctx.save_for_backward(ac, bc)
         return out
@@ -306,7 +327,7 @@ class _MulGather(torch.autograd.Function):
         ac, tc = _c(a), _c(table)
         M, F = ac.shape
         y = torch.empty_like(ac)
-        check(_L().mdx_op_mul_gather_fwd(ptr(ac), ptr(tc), ptr(plan.index), M, F, ptr(y), stream()))
+        check(_L().mdx_op_mul_gather_fwd(ptr(ac), ptr(tc), ptr(plan.index), M, F | (_round_kind() << 16), ptr(y), stream()))
         ctx.plan = plan
         ctx.save_for_backward(ac, tc)
         return y

@@ -9,7 +9,10 @@ a second one, so that
     collectives beat many small ones; the buffer is ~10 M floats),
   * clip_grad_norm_ + AdamW (utils/train.py:64-70: lr 1e-4, betas (0.99, 0.999), weight_decay 1e-8; max_grad_norm 50)
     are two kernel launches (``mdx_op_sumsq``, ``mdx_op_adamw``) regardless of the number of parameter tensors.
-The reference trains under fp16 autocast (use_amp); this path keeps fp32 throughout (no loss scaling needed).
+The reference trains under fp16 autocast with a GradScaler (use_amp: True, scripts/train_drug3d.py:86-109).  `precision='fp16'`
+is that arithmetic (train_ops.precision) with the scaler's dynamic loss scale kept ON THE DEVICE: the loss is multiplied by a device
+scalar, one library call unscales, measures the norm, clips, steps or skips and grows / backs off the scale -- no host round trip
+(torch's GradScaler synchronises on found_inf every step).  `precision='f32'` runs the same call with the scale pinned to 1.
 """
 import math
 
@@ -92,20 +95,41 @@ class PlateauScheduler:
 
 class Trainer:
     def __init__(self, model, lr=1e-4, betas=(0.99, 0.999), eps=1e-8, weight_decay=1e-8, max_grad_norm=50.0, group=None,
-                 precision='f32'):
+                 precision='f32', init_scale=None, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
         p0 = next(model.parameters())
         _lib._need_gpu(p0)
+        from . import train_ops
+        if precision not in train_ops.KINDS:
+            raise ValueError(precision)
         self.model, self.group = model, group
-        self.precision = precision      # 'f32' | 'bf16' (GEMM operands only, see train_ops.precision)
+        # 'f32' | 'bf16' (GEMM operands only) | 'fp16' (the reference's autocast + GradScaler semantics) | 'bf16_autocast'
+        self.precision = precision
         self.flat = FlatParams(model)
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         dev = p0.device
         self.m = torch.zeros_like(self.flat.data)
         self.v = torch.zeros_like(self.flat.data)
-        self.norm2 = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
-        self.steps = 0
+        # torch.cuda.amp.GradScaler's defaults (init 2**16, x2 after 2000 clean steps, x0.5 on overflow) for float16; every other
+        # mode needs no scaling: scale pinned to 1, same code path
+        scaled = precision == 'fp16'
+        self.growth = (float(growth_factor), float(backoff_factor), int(growth_interval)) if scaled else (1.0, 1.0, 0)
+        self.state = torch.zeros(16, dtype=torch.float32, device=dev)     # mdx_op_amp_adamw: [scale, tracker, steps, skipped, norm2, ...]
+        self.state[0] = float(init_scale if init_scale is not None else (65536.0 if scaled else 1.0))
         self.sync_replicas()
+
+    @property
+    def steps(self):
+        """optimizer steps actually taken (skipped steps do not count, like torch's GradScaler + optimizer); reads the device state"""
+        return int(self.state[2].item())
+
+    @property
+    def skipped(self):
+        return int(self.state[3].item())
+
+    @property
+    def loss_scale(self):
+        return float(self.state[0].item())
 
     def sync_replicas(self, src=0):
         """Data-parallel replicas must start from ONE set of weights: broadcast rank `src`'s flat parameter buffer (nn.Linear /
@@ -124,22 +148,19 @@ class Trainer:
         self.flat.zero_grad()
 
     def backward_and_step(self, loss):
-        """loss.backward() -> gradient averaging over ranks -> clip -> AdamW.  Returns the pre-clip global gradient norm
-        (0-d device tensor, like clip_grad_norm_)."""
+        """(scale x loss).backward() -> gradient averaging over ranks -> unscale, clip, AdamW or skip, scale update (one library
+        call, state on the device).  Returns the pre-clip global gradient norm of the UNSCALED gradient (0-d device tensor, like
+        clip_grad_norm_ after scaler.unscale_; inf / nan on a skipped step)."""
         L = _lib.lib()
-        loss.backward()
+        (loss * self.state[0]).backward()
         allreduce_mean_(self.flat.grad, self.group)
         f = self.flat
-        _lib.check(L.mdx_op_sumsq(_lib.ptr(f.grad), f.numel, _lib.ptr(self.norm2), _lib.ptr(self.ws), _lib.stream()))
-        self.steps += 1
-        # the squared norm always travels to the kernel: it is also the guard that skips the update when the gradient is not
-        # finite (max_norm = inf disables the clipping itself)
-        max_norm = float(self.max_grad_norm) if self.max_grad_norm is not None else float('inf')
-        _lib.check(L.mdx_op_adamw(_lib.ptr(f.data), _lib.ptr(f.grad), _lib.ptr(self.m), _lib.ptr(self.v), f.numel, self.lr,
-                                  self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
-                                  _lib.ptr(self.norm2), max_norm, _lib.stream()))
+        max_norm = float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0
+        _lib.check(L.mdx_op_amp_adamw(_lib.ptr(f.data), _lib.ptr(f.grad), _lib.ptr(self.m), _lib.ptr(self.v), f.numel, self.lr,
+                                      self.betas[0], self.betas[1], self.eps, self.weight_decay, max_norm, _lib.ptr(self.state),
+                                      self.growth[0], self.growth[1], self.growth[2], _lib.ptr(self.ws), _lib.stream()))
         self._stale()
-        return self.norm2.sqrt()[0]
+        return self.state[4].sqrt()
 
     def step(self, *batch, **kw):
         """zero_grad -> model.get_loss(*batch) -> backward_and_step.  Returns the loss dict plus 'grad_norm'."""
@@ -153,8 +174,12 @@ class Trainer:
         return res
 
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr}
+        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr, 'amp_state': self.state.clone()}
 
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v'])
-        self.steps, self.lr = int(sd['steps']), float(sd['lr'])
+        self.lr = float(sd['lr'])
+        if 'amp_state' in sd:
+            self.state.copy_(sd['amp_state'])
+        else:
+            self.state[2] = float(sd['steps'])

@@ -182,3 +182,73 @@ def test_checkpoint_written_by_training_is_sampled_by_the_sampling_entry_point(t
     log_dir = sample_drug3d.main(['--config', str(sp), '--outdir', str(tmp_path / 'out'), '--device', DEV, '--batch_size', '3'])
     pool = torch.load(str(log_dir) + '/samples_all.pt', weights_only=False)
     assert len(pool['finished']) + len(pool['failed']) >= 3
+
+
+def _toy(shapes, seed=11):
+    g = U.rng(seed)
+    ps = [torch.nn.Parameter(U.t32(g.standard_normal(s)).to(DEV)) for s in shapes]
+    mod = torch.nn.Module()
+    mod.ps = torch.nn.ParameterList(ps)
+    return g, ps, mod
+
+
+def test_non_finite_gradient_skips_the_step_and_does_not_advance_adam(  ):
+    """a skipped update must not advance the Adam bias-correction step (torch's GradScaler does not call optimizer.step
+    on found_inf).  Step 1 finite, step 2 carries a NaN gradient (skipped: parameters, moments and the step count untouched, the norm
+    reported as non-finite), step 3 finite: identical to torch.optim.AdamW that only saw steps 1 and 3."""
+    shapes = [(17, 5), (64,), (33, 33)]
+    g, ps, mod = _toy(shapes)
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    tr = Trainer(mod, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, max_grad_norm=5.0)
+    opt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    for it in range(3):
+        grads = [U.t32(g.standard_normal(s)).to(DEV) for s in shapes]
+        if it == 1:
+            grads[1][7] = float('nan')
+        tr.zero_grad()
+        before = [p.detach().clone() for p in ps]
+        gn = tr.backward_and_step(sum((p * gr).sum() for p, gr in zip(ps, grads)))
+        if it == 1:
+            assert not torch.isfinite(gn)
+            assert all(torch.equal(p.detach(), b) for p, b in zip(ps, before))
+            continue
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        opt.step()
+    assert tr.steps == 2 and tr.skipped == 1
+    for p, r in zip(ps, ref):
+        assert U.maxdiff(p, r) <= 2e-6 * max(1.0, float(r.abs().max()))
+
+
+def test_fp16_loss_scale_follows_grad_scaler():
+    """precision='fp16' carries torch.cuda.amp.GradScaler's state machine on the device: the gradient the optimizer sees is
+    unscaled (the update equals the fp32 update), `growth_interval` consecutive finite steps double the scale, an overflow halves it,
+    skips the step and restarts the count (scripts/train_drug3d.py:105-109)."""
+    shapes = [(9, 4), (30,)]
+    g, ps, mod = _toy(shapes, 12)
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    tr = Trainer(mod, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.0, max_grad_norm=None, precision='fp16', init_scale=1024.0,
+                 growth_interval=2)
+    opt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.99), weight_decay=0.0)
+    scales = [tr.loss_scale]
+    for it in range(5):
+        grads = [U.t32(g.standard_normal(s)).to(DEV) for s in shapes]
+        if it == 3:
+            grads[0][0, 0] = float('inf')
+        tr.zero_grad()
+        gn = tr.backward_and_step(sum((p * gr).sum() for p, gr in zip(ps, grads)))
+        scales.append(tr.loss_scale)
+        if it == 3:
+            assert not torch.isfinite(gn)
+            continue
+        want = float(torch.cat([x.flatten() for x in grads]).double().norm())
+        assert abs(float(gn) - want) <= 1e-5 * want                    # the norm of the UNSCALED gradient
+        for r, gr in zip(ref, grads):
+            r.grad = gr.clone()
+        opt.step()
+    #            init    it0     it1 (2 clean: x2)  it2    it3 (overflow: /2)  it4
+    assert scales == [1024.0, 1024.0, 2048.0, 2048.0, 1024.0, 1024.0], scales
+    assert tr.steps == 4 and tr.skipped == 1
+    for p, r in zip(ps, ref):
+        assert U.maxdiff(p, r) <= 2e-6 * max(1.0, float(r.abs().max()))
