@@ -105,7 +105,9 @@ int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const float* h_node,
                    const float* rel, const float* dist, const float* edge_time, float* out, void* ws,
                    size_t ws_bytes, void* stream);
 /* torch_scatter.scatter_sum(src, index, dim=0, dim_size=N) for index = left (by_right = 0) or right
- * (by_right = 1) of the graph; src (E,C) reference order, C in {3, 64, 256}; call sites graph.py:50,279,283,394. */
+ * (by_right = 1) of the graph; src (E,C) reference order, C in {3, 64, 256}; call sites graph.py:50,279,283,394.
+ * by_right | 2: src is already in the plan's internal edge order (mdx_graph_plan_host) -- the segment-sum kernel alone, without the
+ * boundary permutation (what bench.py times as the scatter/gather primitive). */
 int mdx_segment_sum(mdx_graph_t g, const float* src, int32_t C, int32_t by_right, float* out, void* ws,
                     size_t ws_bytes, void* stream);
 

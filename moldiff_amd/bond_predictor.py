@@ -69,21 +69,22 @@ class BondPredictor(Module):
         return d
 
     def __init__(self, config, num_node_types, num_edge_types, **kwargs):
+        # variants the kernels are not built for are rejected BEFORE any sub-module exists (INTEGRATION.md "unsupported variants")
+        if config.diff.num_timesteps == 0:
+            raise NotImplementedError('num_timesteps == 0 (time-free predictor, models/bond_predictor.py:27-31) is not built')
+        if config.encoder.get('update_pos', True) if hasattr(config.encoder, 'get') else getattr(config.encoder, 'update_pos', True):
+            raise NotImplementedError('the bond predictor kernels assume encoder.update_pos=False (the shipped config)')
         super().__init__()
         self.config = config
         self.num_node_types = num_node_types
         self.num_edge_types = num_edge_types
         self.define_betas_alphas(config.diff)
-        if self.num_timesteps == 0:
-            raise NotImplementedError('num_timesteps == 0 (time-free predictor) is not built')
         node_dim, edge_dim = config.node_dim, config.edge_dim
         time_dim = config.diff.time_dim
         self.node_embedder = nn.Linear(num_node_types, node_dim - time_dim, bias=False)
         self.edge_embedder = nn.Linear(num_node_types * 2, edge_dim - time_dim, bias=False)
         self.time_emb = GaussianSmearing(stop=self.num_timesteps, num_gaussians=time_dim, type_='linear')
         self.encoder = NodeEdgeNet(node_dim, edge_dim, **config.encoder)
-        if self.encoder.update_pos:
-            raise NotImplementedError('the bond predictor kernels assume update_pos=False (the shipped config)')
         self.edge_decoder = MLP(edge_dim + node_dim, num_edge_types, edge_dim, num_layer=3)
         self.edge_weight = torch.tensor([0.1] + [1.] * (self.num_edge_types - 1), dtype=torch.float32)
         self.ce_loss = torch.nn.CrossEntropyLoss(self.edge_weight)

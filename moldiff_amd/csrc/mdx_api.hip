@@ -1080,11 +1080,15 @@ extern "C" int mdx_segment_sum(mdx_graph_t g, const float* src, int32_t C, int32
   hipStream_t s = (hipStream_t)stream;
   Ws w;
   ws_layout(g->N, g->E, (char*)ws, &w);
-  gather_rows(src, g->int2ref, w.M, g->E, C, s);
-  if (by_right)
-    launch_seg_reduce(w.M, g->col_ptr, g->col_eids, out, nullptr, (int)g->N, C, s);
+  const float* rows = src;
+  if (!(by_right & 2)) {  // reference edge order -> internal order (bit 1 set: src already is in the graph plan's internal order)
+    gather_rows(src, g->int2ref, w.M, g->E, C, s);
+    rows = w.M;
+  }
+  if (by_right & 1)
+    launch_seg_reduce(rows, g->col_ptr, g->col_eids, out, nullptr, (int)g->N, C, s);
   else
-    launch_seg_reduce(w.M, g->row_ptr, nullptr, out, nullptr, (int)g->N, C, s);
+    launch_seg_reduce(rows, g->row_ptr, nullptr, out, nullptr, (int)g->N, C, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
 }

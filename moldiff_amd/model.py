@@ -280,7 +280,12 @@ class _Sampler:
                 nbytes = _lib.lib().mdx_workspace_bytes(self.N, 2 * self.Eh)
                 self._ws2 = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
                 off = (-self._ws2.data_ptr()) % 256
-                _, tptr, tbytes = self.g.tape(dev, self.bp.encoder.num_blocks)
+                # the sampler OWNS its tape: Graph.tape() hands out a per-graph buffer that is re-allocated when another predictor
+                # (other device / block count) asks for it, and the library keeps using the pointer captured here on every step
+                nb_t = _lib.lib().mdx_bondpred_tape_bytes(self.N, 2 * self.Eh, self.bp.encoder.num_blocks)
+                self._tape = torch.empty(nb_t + 256, dtype=torch.uint8, device=dev)
+                toff = (-self._tape.data_ptr()) % 256
+                tptr, tbytes = ctypes.c_void_p(self._tape.data_ptr() + toff), ctypes.c_size_t(self._tape.numel() - toff)
                 self.gd = _lib.MdxGuidance(self.bp_eng.h, self.guidance[1], tptr, tbytes.value,
                                            ctypes.c_void_p(self._ws2.data_ptr() + off), self._ws2.numel() - off,
                                            _lib.ptr(self.bp_logits), _lib.ptr(self.bp_glogits), _lib.ptr(self.delta),
