@@ -85,20 +85,33 @@ def test_training_steps_reduce_the_loss_and_refresh_the_fused_engine(which):
     assert abs(after_fused - after_train) <= 2e-5 * max(1.0, abs(after_train))
 
 
-def test_train_entry_point_end_to_end(tmp_path):
-    """python -m moldiff_amd.train_drug3d on a cut-down config: trains, validates, writes a checkpoint that loads strictly."""
+@pytest.mark.parametrize('use_amp', [False, True])
+def test_train_entry_point_end_to_end(tmp_path, use_amp):
+    """python -m moldiff_amd.train_drug3d on a cut-down config: trains, validates, writes a checkpoint that loads strictly.
+    use_amp=False (fp32): every iteration is an optimizer step.  use_amp=True (the shipped configs, like the reference's): float16
+    arithmetic with GradScaler semantics -- the scale starts at 65536 like torch's, so with recipe weights (gradient norms of O(10))
+    the first iterations overflow float16, are SKIPPED and halve the scale, exactly what the reference's scaler does in its first
+    iterations; steps + skipped = iterations, and the scale ends at 65536 / 2^skipped."""
     import yaml
     from moldiff_amd import train_drug3d, MolDiff
     cfg = yaml.safe_load(open('configs/train_MolDiff_simple.yml'))
-    cfg['train'].update(batch_size=6, max_iters=4, val_freq=2)
+    iters = 12 if use_amp else 4
+    cfg['train'].update(batch_size=6, max_iters=iters, val_freq=iters // 2, use_amp=use_amp)
     p = tmp_path / 'cfg.yml'
     p.write_text(yaml.safe_dump(cfg))
     assert train_drug3d.main(['--config', str(p), '--device', DEV, '--logdir', str(tmp_path / 'logs'), '--val_batches', '1',
                               '--recipe-weights']) == 0
-    ck = torch.load(tmp_path / 'logs' / 'checkpoints' / '4.pt', map_location='cpu', weights_only=False)
-    assert ck['iteration'] == 4 and ck['optimizer']['steps'] == 4
+    ck = torch.load(tmp_path / 'logs' / 'checkpoints' / f'{iters}.pt', map_location='cpu', weights_only=False)
+    st = ck['optimizer']['amp_state']
+    steps, skipped, scale = int(st[2]), int(st[3]), float(st[0])
+    assert ck['iteration'] == iters and ck['optimizer']['steps'] == steps and steps + skipped == iters
+    if use_amp:
+        assert 0 < skipped < iters and steps > 0 and scale == 65536.0 / 2 ** skipped
+    else:
+        assert skipped == 0 and scale == 1.0
     m = MolDiff(ck['config'].model, 8, 6)
     m.load_state_dict(ck['model'], strict=True)
+    assert all(torch.isfinite(v).all() for v in ck['model'].values() if v.is_floating_point())
     ref = U.moldiff('MolDiff_simple')
     assert any(not torch.equal(a, b) for a, b in zip(m.state_dict().values(), ref.state_dict().values()))    # weights moved
 
