@@ -311,7 +311,7 @@ def main_train():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--model', default='MolDiff', choices=['MolDiff', 'MolDiff_simple', 'bondpred'])
-    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'fp16', 'bf16_autocast'],
+    ap.add_argument('--precision', default='f32', choices=['f32', 'bf16', 'fp16', 'fp16_f32store', 'bf16_autocast'],
                     help="'fp16' = the reference's use_amp arithmetic (autocast float16 + dynamic loss scale); 'bf16' = GEMM operands only")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=20.0)
@@ -374,6 +374,7 @@ def main_train():
                'dtype': {'f32': 'f32', 'bf16': 'bf16 GEMM operands, f32 accumulate / elsewhere',
                          'fp16': 'f16 Linear operands and results (f32 accumulate), f32 LayerNorm / loss / sums, dynamic loss scale '
                                  '(the reference\'s use_amp: True)',
+                         'fp16_f32store': 'as fp16, but the float16 values kept in fp32 containers',
                          'bf16_autocast': 'bf16 Linear operands and results, f32 elsewhere'}[args.precision], 'data': 'synthetic',
                'config': {'workload': f'train_{args.model}.yml: batch_size={args.batch} molecules/GPU (rank 0: N={N} atoms, E={E} directed '
                                       f'edges), AdamW lr 1e-4 betas (0.99,0.999) wd 1e-8, max_grad_norm 50; recipe weights',

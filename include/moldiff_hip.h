@@ -311,6 +311,30 @@ int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, co
 int mdx_op_xgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
                     int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, void* stream);
 
+/* Half storage (round 3): the `_t` forms of the training operators take `dt`, a bit mask of the tensors that are stored as float16
+ * instead of fp32 (element strides and feature counts are unchanged).  In the mixed-precision mode every Linear / LayerNorm / product
+ * result is a float16 VALUE; keeping it in a float16 container halves the HBM traffic these memory-bound operators are limited by.
+ * Bits, in argument order -- xgemm_nt_t: 0 A, 1 addend, 2 C (needs half_kind 2);  xgemm_tn_t: 0 G, 1 X (dW, db stay fp32);
+ * ln_relu_fwd_t: 0 x, 1 y;  ln_relu_bwd_t: 0 dy, 1 x, 2 dx;  ew_fwd_t: 0 a, 1 b, 2 out;  ew_bwd_t: 0 a, 1 b, 2 g, 3 da, 4 db;
+ * gather_rows_t: 0 x, 1 y;  segsum_rows_t: 0 src, 1 out;  mul_gather_fwd_t: 0 a, 1 t, 2 y;  mul_gather_bwd_t: 0 g, 1 a, 2 t, 3 da, 4 dt.
+ * dt = 0 is the fp32 operator of the same name without `_t`.  Half storage needs feature counts that are multiples of 4. */
+int mdx_op_xgemm_nt_t(const void* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const void* addend, int64_t ldd,
+                      void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out, int32_t dt, void* stream);
+int mdx_op_xgemm_tn_t(const void* G, int64_t ldg, const void* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
+                      int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, int32_t dt, void* stream);
+int mdx_op_ln_relu_fwd_t(const void* x, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, void* y, float* stats,
+                         int32_t dt, void* stream);
+int mdx_op_ln_relu_bwd_t(const void* dy, const void* x, const float* stats, const float* gamma, const float* beta, int64_t M, int32_t F,
+                         int32_t relu, void* dx, float* dgb, float* ws, int32_t dt, void* stream);
+int mdx_op_ew_fwd_t(int32_t op, const void* a, const void* b, void* out, int64_t n, int32_t dt, void* stream);
+int mdx_op_ew_bwd_t(int32_t op, const void* a, const void* b, const void* g, void* da, void* db, int64_t n, int32_t dt, void* stream);
+int mdx_op_gather_rows_t(const void* x, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt, void* stream);
+int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, void* out, int32_t dt,
+                         void* stream);
+int mdx_op_mul_gather_fwd_t(const void* a, const void* t, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt, void* stream);
+int mdx_op_mul_gather_bwd_t(const void* g, const void* a, const void* t, const int64_t* idx, const int64_t* order, const int64_t* ptr,
+                            int64_t M, int64_t R, int32_t F, void* da, void* dtab, int32_t dt, void* stream);
+
 /* One optimisation step with torch.cuda.amp.GradScaler semantics and ALL of its state on the device (no host round trip):
  * g = gradient of (S x loss).  state (16 floats): [0] loss scale S, [1] growth tracker, [2] optimizer steps taken, [3] steps skipped,
  * [4] unscaled squared gradient norm of this step (inf / nan if a gradient overflowed); [5..8] internal.  Finite: clip to max_norm

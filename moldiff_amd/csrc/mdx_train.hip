@@ -33,6 +33,55 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int G_TM = 128, G_TN = 64, G_KC = 32, G_LD = G_KC + 8;
 
+// Half storage (round 3): a tensor of the training operators is stored as fp32 (h = 0) or as float16 (h = 1; the mixed-precision
+// mode keeps every Linear / LayerNorm / product result -- float16 VALUES anyway -- in float16 containers).  The flag is wave-uniform,
+// one scalar branch per access; offsets are in elements.
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+struct TP {
+  const void* p;
+  int h;
+};
+struct TPW {
+  void* p;
+  int h;
+};
+__device__ __forceinline__ f32x4 ld4(const TP& t, size_t i) {
+  if (t.h) {
+    const f16x4_t v = *reinterpret_cast<const f16x4_t*>(reinterpret_cast<const _Float16*>(t.p) + i);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+  }
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t.p) + i);
+}
+__device__ __forceinline__ float ld1(const TP& t, size_t i) {
+  return t.h ? (float)reinterpret_cast<const _Float16*>(t.p)[i] : reinterpret_cast<const float*>(t.p)[i];
+}
+__device__ __forceinline__ void st4(const TPW& t, size_t i, f32x4 v) {
+  if (t.h) {
+    f16x4_t r = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *reinterpret_cast<f16x4_t*>(reinterpret_cast<_Float16*>(t.p) + i) = r;
+  } else {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(t.p) + i) = v;
+  }
+}
+__device__ __forceinline__ void st1(const TPW& t, size_t i, float v) {
+  if (t.h) reinterpret_cast<_Float16*>(t.p)[i] = (_Float16)v;
+  else reinterpret_cast<float*>(t.p)[i] = v;
+}
+// 4 consecutive k-values of row `row_off` (element offset of the row), zero beyond K or outside the matrix
+__device__ __forceinline__ f32x4 load4_guard_t(const TP& t, size_t row_off, int k, int K, bool row_ok, bool vec_ok) {
+  if (!row_ok || k >= K) return splat4(0.f);
+  if (vec_ok && k + 3 < K) return ld4(t, row_off + k);
+  f32x4 v = splat4(0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k + j < K) v[j] = ld1(t, row_off + k + j);
+  return v;
+}
+__host__ __device__ inline bool tp_vec_ok(const void* p, int h, int ld) {  // rows of 4 elements are naturally aligned
+  return ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & (h ? 7 : 15)) == 0);
+}
+
 __device__ __forceinline__ f32x4 load4_guard(const float* __restrict__ p, int k, int K, bool row_ok, bool vec_ok) {
   // 4 consecutive k-values of one row, zero beyond K or outside the matrix
   if (!row_ok || k >= K) return splat4(0.f);
@@ -192,27 +241,52 @@ constexpr int H_KC = 64, H_LD = H_KC + 8;  // bf16 elements per staged row (+8 =
 
 // TN = width of the workgroup's column tile (64, 128 or 256; the launcher picks the smallest TN >= N up to MDX_HGEMM_TN_MAX, default
 // 128): fewer passes over the big operand A (rows x K, fp32 in HBM); the weight slab (TN x 64 halves per K step) sits in LDS.
-template <int HT, bool ROUND, int TN>
-__global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                        const float* __restrict__ bias, const float* __restrict__ addend,
-                                                        int ldd, float* __restrict__ C, int ldc, int M, int N, int K) {
+template <int HT, bool ROUND, int TN, bool AH>
+__global__ __launch_bounds__(256) void hgemm_nt_kernel(const TP A, int lda, const float* __restrict__ B, int ldb,
+                                                        const float* __restrict__ bias, const TP addend,
+                                                        int ldd, const TPW C, int ldc, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) uint16_t As[G_TM * H_LD];
   __shared__ __attribute__((aligned(16))) uint16_t Bs[TN * H_LD];
   constexpr int FT = TN / 16, BJ = TN / 16;   // feature tiles per wave; B staging slots per thread (TN rows x 16 float4 / 256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * TN;
-  const bool veca = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool veca = tp_vec_ok(A.p, A.h, lda);
   const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
   f32x4 acc[FT][2];
   acc_zero<FT, 2>(acc);
-  f32x4 ra[8], rb[BJ];   // 16 float4 per row of 64 k: A 128 rows -> 8 slots per thread, B 64 rows -> 4
+  f32x4 ra[8], rb[BJ];   // 16 float4 per row of 64 k: A 128 rows -> 8 slots per thread, B TN rows -> BJ
+  uint4 rah[AH ? 4 : 1];  // A already stored as float16: 8 slots of 8 halves per row, copied to LDS as they are (no conversion either way)
+  constexpr bool ah = AH;   // compile-time: the fp32-container variant must not carry the half path's registers (occupancy 3 -> 2)
+  const bool veca8 = ((lda & 7) == 0) && ((reinterpret_cast<uintptr_t>(A.p) & 15) == 0);
   auto fetch = [&](int k0) {
+    if (ah) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int slot = tid + 256 * j, row = slot >> 4, k4 = (slot & 15) * 4;
-      const int gm = m0 + row;
-      ra[j] = load4_guard(A + (size_t)gm * lda, k0 + k4, K, gm < M, veca);
+      for (int j = 0; j < 4; ++j) {
+        const int slot = tid + 256 * j, row = slot >> 3, k8 = (slot & 7) * 8;
+        const int gm = m0 + row, kk = k0 + k8;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(A.p) + (size_t)gm * lda + kk;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (gm < M && kk < K) {
+          if (veca8 && kk + 7 < K) {
+            v = *reinterpret_cast<const uint4*>(src);
+          } else {
+            uint16_t e[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e[u] = kk + u < K ? src[u] : (uint16_t)0;
+            v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+            v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+          }
+        }
+        rah[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int slot = tid + 256 * j, row = slot >> 4, k4 = (slot & 15) * 4;
+        const int gm = m0 + row;
+        ra[j] = load4_guard(reinterpret_cast<const float*>(A.p) + (size_t)gm * lda, k0 + k4, K, gm < M, veca);  // AH == false: fp32 container
+      }
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
@@ -223,12 +297,20 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
   };
   if (K > 0) fetch(0);
   for (int k0 = 0; k0 < K; k0 += H_KC) {
+    if (ah) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int slot = tid + 256 * j;
-      uint2 v = {(uint32_t)HalfT<HT>::cvt(ra[j][0]) | ((uint32_t)HalfT<HT>::cvt(ra[j][1]) << 16),
-                 (uint32_t)HalfT<HT>::cvt(ra[j][2]) | ((uint32_t)HalfT<HT>::cvt(ra[j][3]) << 16)};
-      *reinterpret_cast<uint2*>(As + (slot >> 4) * H_LD + (slot & 15) * 4) = v;
+      for (int j = 0; j < 4; ++j) {
+        const int slot = tid + 256 * j;
+        *reinterpret_cast<uint4*>(As + (slot >> 3) * H_LD + (slot & 7) * 8) = rah[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int slot = tid + 256 * j;
+        uint2 v = {(uint32_t)HalfT<HT>::cvt(ra[j][0]) | ((uint32_t)HalfT<HT>::cvt(ra[j][1]) << 16),
+                   (uint32_t)HalfT<HT>::cvt(ra[j][2]) | ((uint32_t)HalfT<HT>::cvt(ra[j][3]) << 16)};
+        *reinterpret_cast<uint2*>(As + (slot >> 4) * H_LD + (slot & 15) * 4) = v;
+      }
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
@@ -253,7 +335,7 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
     }
     __syncthreads();
   }
-  const bool veco = ((ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  const bool veco = tp_vec_ok(C.p, C.h, ldc);
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft) {
     const int col = n0 + 16 * ft + 4 * q;
@@ -268,22 +350,22 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const float* __restrict__
       const int row = m0 + 32 * wave + 16 * et + c;
       if (row >= M || col >= N) continue;
       f32x4 v = acc[ft][et] + bv;
-      if (addend) {
+      if (addend.p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (col + r < N) v[r] += addend[(size_t)row * ldd + col + r];
+          if (col + r < N) v[r] += ld1(addend, (size_t)row * ldd + col + r);
       }
       if (ROUND) {  // the Linear's output in the low-precision type, like autocast's fp16 / bf16 result (held in an fp32 container)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = round_half<HT>(v[r]);
       }
-      float* o = C + (size_t)row * ldc + col;
+      const size_t o = (size_t)row * ldc + col;
       if (veco && col + 3 < N) {
-        stg4(o, v);
+        st4(C, o, v);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (col + r < N) o[r] = v[r];
+          if (col + r < N) st1(C, o + r, v[r]);
       }
     }
   }
@@ -380,7 +462,7 @@ __global__ __launch_bounds__(256) void hgemm3_nt_kernel(const float* __restrict_
 // contraction values a lane needs are one 16-byte read); otherwise the structure of sgemm_tn_split_kernel.
 constexpr int HW_MC = 64;
 template <int HT>
-__global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx,
+__global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg, const TP X, int ldx,
                                                               int M, int N, int K, int mper, float* __restrict__ P,
                                                               float* __restrict__ Pb) {
   __shared__ __attribute__((aligned(16))) uint16_t Gt[W_T * H_LD];
@@ -390,31 +472,37 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const float* __rest
   const int n0 = blockIdx.y * W_T, k0 = blockIdx.x * W_T;
   const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
   const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
-  const bool vecg = ((ldg & 3) == 0) && ((reinterpret_cast<uintptr_t>(G) & 15) == 0) && ((n0 & 3) == 0);
-  const bool vecx = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((k0 & 3) == 0);
+  const bool vecg = tp_vec_ok(G.p, G.h, ldg) && ((n0 & 3) == 0);
+  const bool vecx = tp_vec_ok(X.p, X.h, ldx) && ((k0 & 3) == 0);
   f32x4 acc[2][2];
   acc_zero<2, 2>(acc);
   const bool do_bias = Pb && blockIdx.x == 0 && tid < W_T;
   float bsum = 0.f;
-  f32x4 rg[4], rx[4];   // 64 rows x 16 float4 = 1024 slots per tile -> 4 per thread
+  // One 4x4 block per thread and step: rows 4 (tid >> 4) + j, columns 4 (tid & 15) ..+3 of the 64 x 64 tile of G and of X.  The block
+  // is transposed in registers and leaves as four 8-byte LDS stores per matrix ([column][4 consecutive rows]) -- round 2 wrote sixteen
+  // 2-byte stores per matrix and thread, which (with the conversions) bound this kernel, not its traffic.
+  f32x4 rg[4], rx[4];
   auto fetch = [&](int m0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
+      const int row = 4 * (tid >> 4) + j, c4 = (tid & 15) * 4;
       const int gm = m0 + row;
-      rg[j] = load4_guard(G + (size_t)gm * ldg + n0, c4, N - n0, gm < mend, vecg);
-      rx[j] = load4_guard(X + (size_t)gm * ldx + k0, c4, K - k0, gm < mend, vecx);
+      rg[j] = load4_guard_t(G, (size_t)gm * ldg + n0, c4, N - n0, gm < mend, vecg);
+      rx[j] = load4_guard_t(X, (size_t)gm * ldx + k0, c4, K - k0, gm < mend, vecx);
     }
   };
   if (mbeg < mend) fetch(mbeg);
   for (int m0 = mbeg; m0 < mend; m0 += HW_MC) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int slot = tid + 256 * j, row = slot >> 4, c4 = (slot & 15) * 4;
+    {
+      const int r4 = 4 * (tid >> 4), c4 = (tid & 15) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        Gt[(c4 + e) * H_LD + row] = HalfT<HT>::cvt(rg[j][e]);
-        Xt[(c4 + e) * H_LD + row] = HalfT<HT>::cvt(rx[j][e]);
+        const uint2 vg = {(uint32_t)HalfT<HT>::cvt(rg[0][e]) | ((uint32_t)HalfT<HT>::cvt(rg[1][e]) << 16),
+                          (uint32_t)HalfT<HT>::cvt(rg[2][e]) | ((uint32_t)HalfT<HT>::cvt(rg[3][e]) << 16)};
+        const uint2 vx = {(uint32_t)HalfT<HT>::cvt(rx[0][e]) | ((uint32_t)HalfT<HT>::cvt(rx[1][e]) << 16),
+                          (uint32_t)HalfT<HT>::cvt(rx[2][e]) | ((uint32_t)HalfT<HT>::cvt(rx[3][e]) << 16)};
+        *reinterpret_cast<uint2*>(Gt + (c4 + e) * H_LD + r4) = vg;
+        *reinterpret_cast<uint2*>(Xt + (c4 + e) * H_LD + r4) = vx;
       }
     }
     __syncthreads();
@@ -769,14 +857,14 @@ __device__ __forceinline__ float row_lanes_sum(float v) {
 }
 
 template <int LPR>
-__global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int M, int relu, float* __restrict__ y,
+__global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const TP x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int M, int relu, const TPW y,
                                                             float* __restrict__ stats) {
   constexpr int F = 4 * LPR, RPS = 64 / LPR;
   const int lane = threadIdx.x & 63, wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int row = wg * RPS + lane / LPR, c4 = lane % LPR;
   const bool ok = row < M;
-  const f32x4 v = ok ? ldg4(x + (size_t)row * F + 4 * c4) : splat4(0.f);
+  const f32x4 v = ok ? ld4(x, (size_t)row * F + 4 * c4) : splat4(0.f);
   const float mean = row_lanes_sum<LPR>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / F);
   const f32x4 d = v - splat4(mean);
   const float rstd = 1.0f / sqrtf(row_lanes_sum<LPR>(fmaf(d[0], d[0], fmaf(d[1], d[1], fmaf(d[2], d[2], d[3] * d[3])))) * (1.0f / F) + MDX_LN_EPS);
@@ -785,7 +873,7 @@ __global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const float* __restri
   const f32x4 btv = {beta[4 * c4], beta[4 * c4 + 1], beta[4 * c4 + 2], beta[4 * c4 + 3]};
   f32x4 o = d * splat4(rstd) * gmv + btv;
   if (relu) o = relu4(o);
-  stg4(y + (size_t)row * F + 4 * c4, o);
+  st4(y, (size_t)row * F + 4 * c4, o);
   if (c4 == 0) {
     stats[2 * (size_t)row] = mean;
     stats[2 * (size_t)row + 1] = rstd;
@@ -794,10 +882,10 @@ __global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const float* __restri
 
 // backward: a wave walks `steps` consecutive row groups; dx per row; the wave's partial of dgamma / dbeta -> part[wave][2F]
 template <int LPR>
-__global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const TP dy, const TP x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int M, int relu, int rows_per,
-                                                            float* __restrict__ dx, float* __restrict__ part) {
+                                                            const TPW dx, float* __restrict__ part) {
   constexpr int F = 4 * LPR, RPS = 64 / LPR;
   const int lane = threadIdx.x & 63, wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int sub = lane / LPR, c4 = lane % LPR;
@@ -810,8 +898,8 @@ __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const float* __restri
     const bool ok = row < r1;
     const size_t o = (size_t)(ok ? row : r0) * F + 4 * c4;
     const float mean = stats[2 * (size_t)(ok ? row : r0)], rstd = stats[2 * (size_t)(ok ? row : r0) + 1];
-    const f32x4 xh = (ldg4(x + o) - splat4(mean)) * splat4(rstd);
-    f32x4 g = ok ? ldg4(dy + o) : splat4(0.f);
+    const f32x4 xh = (ld4(x, o) - splat4(mean)) * splat4(rstd);
+    f32x4 g = ok ? ld4(dy, o) : splat4(0.f);
     if (relu) {
       const f32x4 yv = xh * gm + bt;
 #pragma unroll
@@ -823,7 +911,7 @@ __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const float* __restri
     const f32x4 gh = g * gm;
     const float m1 = row_lanes_sum<LPR>((gh[0] + gh[1]) + (gh[2] + gh[3])) * (1.0f / F);
     const float m2 = row_lanes_sum<LPR>(fmaf(gh[0], xh[0], fmaf(gh[1], xh[1], fmaf(gh[2], xh[2], gh[3] * xh[3])))) * (1.0f / F);
-    if (ok) stg4(dx + o, (gh - splat4(m1) - xh * splat4(m2)) * splat4(rstd));
+    if (ok) st4(dx, o, (gh - splat4(m1) - xh * splat4(m2)) * splat4(rstd));
   }
   // the 64 / LPR row groups of the wave hold the same features: combine them (lane bits >= LPR), then the first group writes
 #pragma unroll
@@ -884,41 +972,40 @@ __device__ __forceinline__ f32x4 ew_apply<f32x4>(int op, f32x4 x, f32x4 y) {
     default: return x * sigmoid4(y);
   }
 }
-__global__ void ew_fwd4_kernel(int opr, const f32x4* __restrict__ a, const f32x4* __restrict__ b, f32x4* __restrict__ o, size_t n4) {
+__global__ void ew_fwd4_kernel(int opr, const TP a, const TP b, const TPW o, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const int op = opr & 255, rk = opr >> 8;
+  const f32x4 x = ld4(a, 4 * i), y = ld4(b, 4 * i);
   if (rk == 0) {
-    o[i] = ew_apply<f32x4>(op, a[i], b[i]);
+    st4(o, 4 * i, ew_apply<f32x4>(op, x, y));
     return;
   }
-  const f32x4 x = a[i], y = b[i];
   f32x4 r;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float v = op == 0 ? x[j] + y[j] : op == 1 ? x[j] - y[j] : op == 2 ? x[j] * y[j] : x[j] * round_kind(sigmoidf_(y[j]), rk);
     r[j] = round_kind(v, rk);
   }
-  o[i] = r;
+  st4(o, 4 * i, r);
 }
-__global__ void ew_bwd4_kernel(int op, const f32x4* __restrict__ a, const f32x4* __restrict__ b, const f32x4* __restrict__ g,
-                               f32x4* __restrict__ da, f32x4* __restrict__ db, size_t n4) {
+__global__ void ew_bwd4_kernel(int op, const TP a, const TP b, const TP g, const TPW da, const TPW db, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const f32x4 go = g[i];
+  const f32x4 go = ld4(g, 4 * i);
   f32x4 ga, gb;
   switch (op) {
     case 0: ga = go; gb = go; break;
     case 1: ga = go; gb = splat4(0.f) - go; break;
-    case 2: ga = go * b[i]; gb = go * a[i]; break;
+    case 2: ga = go * ld4(b, 4 * i); gb = go * ld4(a, 4 * i); break;
     default: {
-      const f32x4 sg = sigmoid4(b[i]);
+      const f32x4 sg = sigmoid4(ld4(b, 4 * i));
       ga = go * sg;
-      gb = go * a[i] * sg * (splat4(1.f) - sg);
+      gb = go * ld4(a, 4 * i) * sg * (splat4(1.f) - sg);
     }
   }
-  if (da) da[i] = ga;
-  if (db) db[i] = gb;
+  if (da.p) st4(da, 4 * i, ga);
+  if (db.p) st4(db, 4 * i, gb);
 }
 __global__ void ew_bwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
                               float* __restrict__ da, float* __restrict__ db, size_t n) {
@@ -950,50 +1037,48 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* _
   y[i] = x[(size_t)idx[row] * F + f];
 }
 // 16-byte variants (F % 4 == 0, 16-byte aligned bases): one thread per (row, 4 features)
-__global__ void gather_rows4_kernel(const f32x4* __restrict__ x, const int64_t* __restrict__ idx, int64_t M, int F4,
-                                    f32x4* __restrict__ y) {
+__global__ void gather_rows4_kernel(const TP x, const int64_t* __restrict__ idx, int64_t M, int F4, const TPW y) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * F4) return;
   const int64_t row = i / F4;
-  y[i] = x[(size_t)idx[row] * F4 + (int)(i % F4)];
+  st4(y, 4 * i, ld4(x, 4 * ((size_t)idx[row] * F4 + (int)(i % F4))));
 }
-__global__ void segsum_rows4_kernel(const f32x4* __restrict__ src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
-                                    int64_t R, int F4, f32x4* __restrict__ out) {
+__global__ void segsum_rows4_kernel(const TP src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
+                                    int64_t R, int F4, const TPW out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)R * F4) return;
   const int64_t r = i / F4;
   const int f = (int)(i % F4);
   f32x4 s = splat4(0.f);
-  for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) s = s + src[(size_t)order[j] * F4 + f];
-  out[i] = s;
+  for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) s = s + ld4(src, 4 * ((size_t)order[j] * F4 + f));
+  st4(out, 4 * i, s);
 }
 // y[i] = a[i] * t[idx[i]] and its two gradients (da = g * t[idx];  dt[r] = sum_{j in seg r} g[order[j]] * a[order[j]]):
 // the product with a gathered per-node row without materialising the gathered (rows x F) tensor.  F % 4 == 0.
-__global__ void mulg_fwd_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ t, const int64_t* __restrict__ idx, int64_t M,
-                                int F4, const f32x4* __restrict__ g, f32x4* __restrict__ y, int rk) {
+__global__ void mulg_fwd_kernel(const TP a, const TP t, const int64_t* __restrict__ idx, int64_t M, int F4, const TPW y, int rk) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * F4) return;
   const int64_t row = i / F4;
-  const f32x4 tv = t[(size_t)idx[row] * F4 + (int)(i % F4)];
-  f32x4 r = (g ? g[i] : a[i]) * tv;      // forward: a * t[idx];  backward wrt a: g * t[idx]
+  const f32x4 tv = ld4(t, 4 * ((size_t)idx[row] * F4 + (int)(i % F4)));
+  f32x4 r = ld4(a, 4 * i) * tv;      // forward: a * t[idx];  backward wrt a: g * t[idx] (the caller passes g as `a`)
   if (rk) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = round_kind(r[j], rk);
   }
-  y[i] = r;
+  st4(y, 4 * i, r);
 }
-__global__ void mulg_segsum_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ a, const int64_t* __restrict__ order,
-                                   const int64_t* __restrict__ ptr, int64_t R, int F4, f32x4* __restrict__ out) {
+__global__ void mulg_segsum_kernel(const TP g, const TP a, const int64_t* __restrict__ order,
+                                   const int64_t* __restrict__ ptr, int64_t R, int F4, const TPW out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)R * F4) return;
   const int64_t r = i / F4;
   const int f = (int)(i % F4);
   f32x4 s = splat4(0.f);
   for (int64_t j = ptr[r]; j < ptr[r + 1]; ++j) {
-    const size_t o = (size_t)order[j] * F4 + f;
-    s = s + g[o] * a[o];
+    const size_t o = 4 * ((size_t)order[j] * F4 + f);
+    s = s + ld4(g, o) * ld4(a, o);
   }
-  out[i] = s;
+  st4(out, 4 * i, s);
 }
 // out[r] = sum_{j in [ptr[r], ptr[r+1])} src[order[j]]   (sequential per element: bitwise deterministic)
 __global__ void segsum_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
@@ -1249,11 +1334,16 @@ extern "C" int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int6
   return launched();
 }
 
-extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, float* y,
-                                  float* stats, void* stream) {
+// `_t` forms of the row operators: dt = bit mask of the tensors stored as float16 (ln_relu_fwd: bit 0 x, 1 y; ln_relu_bwd: bit 0 dy, 1 x,
+// 2 dx; ew_fwd: 0 a, 1 b, 2 out; ew_bwd: 0 a, 1 b, 2 g, 3 da, 4 db; gather_rows: 0 x, 1 y; segsum_rows: 0 src, 1 out; mul_gather_fwd:
+// 0 a, 1 t, 2 y; mul_gather_bwd: 0 g, 1 a, 2 t, 3 da, 4 dt).  Half storage needs the 4-wide kernels (F % 4 == 0, aligned rows).
+extern "C" int mdx_op_ln_relu_fwd_t(const void* xv, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, void* yv,
+                                    float* stats, int32_t dt, void* stream) {
   if (M <= 0) return MDX_OK;
   if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
-  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  const TP x{xv, dt & 1};
+  const TPW y{yv, (dt >> 1) & 1};
+  const bool al = tp_vec_ok(xv, x.h, 4) && tp_vec_ok(yv, y.h, 4);
 #define MDX_LNF(LPR)                                                                                                              \
   case 4 * LPR:                                                                                                                   \
     hipLaunchKernelGGL(ln_relu_fwd4_kernel<LPR>, dim3((unsigned)((M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), dim3(256), 0,         \
@@ -1261,23 +1351,29 @@ extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const floa
     return launched();
   if (al) switch (F) { MDX_LNF(8) MDX_LNF(16) MDX_LNF(32) MDX_LNF(64) default: break; }
 #undef MDX_LNF
-  hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (int)M, F,
-                     relu, y, stats);
+  if (dt) return bad("ln_relu: half storage needs F in {32, 64, 128, 256} and aligned rows");
+  hipLaunchKernelGGL(ln_relu_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)xv, gamma, beta,
+                     (int)M, F, relu, (float*)yv, stats);
   return launched();
+}
+extern "C" int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, float* y,
+                                  float* stats, void* stream) {
+  return mdx_op_ln_relu_fwd_t(x, gamma, beta, M, F, relu, y, stats, 0, stream);
 }
 
 // dx (M,F); dgb (2F) = [dgamma | dbeta].  ws: mdx_op_ln_relu_bwd_ws(M, F) bytes.
-extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
-                                  int32_t F, int32_t relu, float* dx, float* dgb, float* ws, void* stream) {
+extern "C" int mdx_op_ln_relu_bwd_t(const void* dyv, const void* xv, const float* stats, const float* gamma, const float* beta, int64_t M,
+                                    int32_t F, int32_t relu, void* dxv, float* dgb, float* ws, int32_t dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
   if (M <= 0) return hipMemsetAsync(dgb, 0, (size_t)F * 8, s) == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "memset");
   if (!ws) return bad("ln_relu_bwd: workspace required");
+  const TP dy{dyv, dt & 1}, x{xv, (dt >> 1) & 1};
+  const TPW dx{dxv, (dt >> 2) & 1};
   const int RPW = MDX_LN_RPW;
   const int nw = (int)((M + RPW - 1) / RPW);     // waves
   const int nwp = (nw + 3) / 4 * 4;              // rows of `part` actually written (whole workgroups)
-  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
-                    reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
+  const bool al = tp_vec_ok(xv, x.h, 4) && tp_vec_ok(dyv, dy.h, 4) && tp_vec_ok(dxv, dx.h, 4) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   bool done = false;
 #define MDX_LNB(LPR)                                                                                                              \
   case 4 * LPR:                                                                                                                   \
@@ -1287,55 +1383,92 @@ extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* 
     break;
   if (al) switch (F) { MDX_LNB(8) MDX_LNB(16) MDX_LNB(32) MDX_LNB(64) default: break; }
 #undef MDX_LNB
-  if (!done)
-    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, F, relu, RPW, dx, ws);
+  if (!done) {
+    if (dt) return bad("ln_relu_bwd: half storage needs F in {32, 64, 128, 256} and aligned rows");
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, (const float*)dyv, (const float*)xv, stats, gamma, beta,
+                       (int)M, F, relu, RPW, (float*)dxv, ws);
+  }
   // [dgamma | dbeta] = sum over the nwp per-wave partial rows, fixed-order parallel reduction
   launch_reduce_partials(ws, nwp, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)nwp * 2 * F, s);
   return launched();
+}
+extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
+                                  int32_t F, int32_t relu, float* dx, float* dgb, float* ws, void* stream) {
+  return mdx_op_ln_relu_bwd_t(dy, x, stats, gamma, beta, M, F, relu, dx, dgb, ws, 0, stream);
 }
 extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
   const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW, nwp = (nw + 3) / 4 * 4;
   return ((size_t)std::max<int64_t>(nwp, 1) * 2 * F + reduce_scratch_floats(nwp, 2 * F)) * sizeof(float);
 }
 
-extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
+extern "C" int mdx_op_ew_fwd_t(int32_t op, const void* a, const void* b, void* out, int64_t n, int32_t dt, void* stream) {
   if (n <= 0) return MDX_OK;
   if ((op & 255) > 3 || (op >> 8) < 0 || (op >> 8) > 2) return bad("ew: unknown op");
-  if ((n & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0)
-    hipLaunchKernelGGL(ew_fwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, (const f32x4*)a, (const f32x4*)b,
-                       (f32x4*)out, (size_t)n / 4);
-  else
-    hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, (size_t)n);
+  const TP ta{a, dt & 1}, tb{b, (dt >> 1) & 1};
+  const TPW to{out, (dt >> 2) & 1};
+  if ((n & 3) == 0 && tp_vec_ok(a, ta.h, 4) && tp_vec_ok(b, tb.h, 4) && tp_vec_ok(out, to.h, 4)) {
+    hipLaunchKernelGGL(ew_fwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, ta, tb, to, (size_t)n / 4);
+  } else {
+    if (dt) return bad("ew: half storage needs n % 4 == 0 and aligned operands");
+    hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, (const float*)a, (const float*)b,
+                       (float*)out, (size_t)n);
+  }
+  return launched();
+}
+extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {
+  return mdx_op_ew_fwd_t(op, a, b, out, n, 0, stream);
+}
+extern "C" int mdx_op_ew_bwd_t(int32_t op, const void* a, const void* b, const void* g, void* da, void* db, int64_t n, int32_t dt,
+                               void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (op < 0 || op > 3) return bad("ew: unknown op");
+  const TP ta{a, dt & 1}, tb{b, (dt >> 1) & 1}, tg{g, (dt >> 2) & 1};
+  const TPW tda{da, (dt >> 3) & 1}, tdb{db, (dt >> 4) & 1};
+  if ((n & 3) == 0 && tp_vec_ok(a, ta.h, 4) && tp_vec_ok(b, tb.h, 4) && tp_vec_ok(g, tg.h, 4) && tp_vec_ok(da, tda.h, 4) &&
+      tp_vec_ok(db, tdb.h, 4)) {
+    hipLaunchKernelGGL(ew_bwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, ta, tb, tg, tda, tdb, (size_t)n / 4);
+  } else {
+    if (dt) return bad("ew: half storage needs n % 4 == 0 and aligned operands");
+    hipLaunchKernelGGL(ew_bwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, (const float*)a, (const float*)b,
+                       (const float*)g, (float*)da, (float*)db, (size_t)n);
+  }
   return launched();
 }
 extern "C" int mdx_op_ew_bwd(int32_t op, const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream) {
-  if (n <= 0) return MDX_OK;
-  if (op < 0 || op > 3) return bad("ew: unknown op");
-  if ((n & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)g | (uintptr_t)da | (uintptr_t)db) & 15) == 0)
-    hipLaunchKernelGGL(ew_bwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, (const f32x4*)a, (const f32x4*)b,
-                       (const f32x4*)g, (f32x4*)da, (f32x4*)db, (size_t)n / 4);
-  else
-    hipLaunchKernelGGL(ew_bwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, a, b, g, da, db, (size_t)n);
+  return mdx_op_ew_bwd_t(op, a, b, g, da, db, n, 0, stream);
+}
+extern "C" int mdx_op_gather_rows_t(const void* x, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt, void* stream) {
+  if (M <= 0 || F <= 0) return MDX_OK;
+  const TP tx{x, dt & 1};
+  const TPW ty{y, (dt >> 1) & 1};
+  if ((F & 3) == 0 && tp_vec_ok(x, tx.h, 4) && tp_vec_ok(y, ty.h, 4)) {
+    hipLaunchKernelGGL(gather_rows4_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, tx, idx, M, F / 4, ty);
+  } else {
+    if (dt) return bad("gather_rows: half storage needs F % 4 == 0 and aligned rows");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)M * F)), dim3(256), 0, (hipStream_t)stream, (const float*)x, idx, M, F, (float*)y);
+  }
   return launched();
 }
 extern "C" int mdx_op_gather_rows(const float* x, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
-  if (M <= 0 || F <= 0) return MDX_OK;
-  if ((F & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
-    hipLaunchKernelGGL(gather_rows4_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, idx, M,
-                       F / 4, (f32x4*)y);
-  else
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((size_t)M * F)), dim3(256), 0, (hipStream_t)stream, x, idx, M, F, y);
+  return mdx_op_gather_rows_t(x, idx, M, F, y, 0, stream);
+}
+extern "C" int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, void* out, int32_t dt,
+                                    void* stream) {
+  if (R <= 0 || F <= 0) return MDX_OK;
+  const TP ts{src, dt & 1};
+  const TPW to{out, (dt >> 1) & 1};
+  if ((F & 3) == 0 && tp_vec_ok(src, ts.h, 4) && tp_vec_ok(out, to.h, 4)) {
+    hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
+  } else {
+    if (dt) return bad("segsum_rows: half storage needs F % 4 == 0 and aligned rows");
+    hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, (const float*)src, order, ptr, R, F,
+                       (float*)out);
+  }
   return launched();
 }
 extern "C" int mdx_op_segsum_rows(const float* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, float* out,
                                   void* stream) {
-  if (R <= 0 || F <= 0) return MDX_OK;
-  if ((F & 3) == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0)
-    hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, order,
-                       ptr, R, F / 4, (f32x4*)out);
-  else
-    hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, src, order, ptr, R, F, out);
-  return launched();
+  return mdx_op_segsum_rows_t(src, order, ptr, R, F, out, 0, stream);
 }
 extern "C" int mdx_op_edge_geom_fwd(const float* pos, const int64_t* l, const int64_t* r, int64_t E, float* rel, float* dist, void* stream) {
   if (E <= 0) return MDX_OK;
@@ -1449,11 +1582,16 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
 // LDS, products on the 16x16x32 half MFMAs, fp32 accumulation.  round_out != 0: the result is rounded to the same type before it
 // is stored (in an fp32 container) -- the value a Linear returns under torch.autocast (float16 overflows to infinity).  The forward
 // form has no split-K.  mdx_op_hgemm_* = half_kind 1, round_out 0 (round 2's 'bf16 operands' mode).
-extern "C" int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
-                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out,
-                               void* stream) {
+// `_t` forms: dt is a bit mask of the tensors stored as float16 instead of fp32 (half storage): xgemm_nt bit 0 A, 1 addend, 2 C;
+// xgemm_tn bit 0 G, 1 X (dW / db are always fp32).  A float16 C holds the rounded result by construction.
+extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, int64_t ldb, const float* bias, const void* addendv,
+                                 int64_t ldd, void* Cv, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out,
+                                 int32_t dt, void* stream) {
   if (M <= 0 || N <= 0) return MDX_OK;
-  if (!A || !B || !C || K < 0) return bad("xgemm_nt: null operand");
+  if (!Av || !B || !Cv || K < 0) return bad("xgemm_nt: null operand");
+  if ((dt & 5) && half_kind != 2) return bad("xgemm_nt: float16 containers (A or C) need half_kind 2");
+  const TP A{Av, dt & 1}, addend{addendv, (dt >> 1) & 1};
+  const TPW C{Cv, (dt >> 2) & 1};
   if (half_kind != 1 && half_kind != 2) return bad("xgemm_nt: half_kind must be 1 (bfloat16) or 2 (float16)");
   hipStream_t s = (hipStream_t)stream;
   // measured on the training step (ms per step, fp16 mode): TN <= 64: 52.0, <= 128: 51.5, <= 256: 54.7 (one workgroup per CU) -- the
@@ -1461,9 +1599,15 @@ extern "C" int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int6
   static const int tn_max = [] { const char* e = getenv("MDX_HGEMM_TN_MAX"); return e ? atoi(e) : 128; }();
   const int tn = std::min(tn_max, N <= 64 ? 64 : N <= 128 ? 128 : 256);
   dim3 grid((unsigned)((N + tn - 1) / tn), (unsigned)((M + G_TM - 1) / G_TM), 1);
-#define MDX_XNT3(HT, R, TNv)                                                                                                          \
-  hipLaunchKernelGGL((hgemm_nt_kernel<HT, R, TNv>), grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, \
-                     (int)M, (int)N, (int)K)
+#define MDX_XNT3(HT, R, TNv)                                                                                                              \
+  do {                                                                                                                                    \
+    if (HT == 1 && A.h)                                                                                                                   \
+      hipLaunchKernelGGL((hgemm_nt_kernel<HT, R, TNv, (HT == 1)>), grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, \
+                         (int)ldc, (int)M, (int)N, (int)K);                                                                               \
+    else                                                                                                                                  \
+      hipLaunchKernelGGL((hgemm_nt_kernel<HT, R, TNv, false>), grid, dim3(256), 0, s, A, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C,     \
+                         (int)ldc, (int)M, (int)N, (int)K);                                                                               \
+  } while (0)
 #define MDX_XNT(HT, R)                                  \
   do {                                                  \
     if (tn == 64) MDX_XNT3(HT, R, 64);                  \
@@ -1479,11 +1623,18 @@ extern "C" int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int6
 #undef MDX_XNT
   return launched();
 }
-extern "C" int mdx_op_xgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
-                               int64_t N, int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, void* stream) {
+extern "C" int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
+                               int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out,
+                               void* stream) {
+  return mdx_op_xgemm_nt_t(A, lda, B, ldb, bias, addend, ldd, C, ldc, M, N, K, half_kind, round_out, 0, stream);
+}
+extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
+                                 int64_t N, int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, int32_t dt,
+                                 void* stream) {
   if (N <= 0 || K <= 0) return MDX_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (!G || !X || !dW || !partial) return bad("xgemm_tn: null operand / partial buffer");
+  if (!Gv || !Xv || !dW || !partial) return bad("xgemm_tn: null operand / partial buffer");
+  const TP G{Gv, dt & 1}, X{Xv, (dt >> 1) & 1};
   if (half_kind != 1 && half_kind != 2) return bad("xgemm_tn: half_kind must be 1 (bfloat16) or 2 (float16)");
   if (splits < 1) splits = 1;
   int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
@@ -1508,6 +1659,10 @@ extern "C" int mdx_op_xgemm_tn(const float* G, int64_t ldg, const float* X, int6
   }
   return launched();
 }
+extern "C" int mdx_op_xgemm_tn(const float* G, int64_t ldg, const float* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M,
+                               int64_t N, int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, void* stream) {
+  return mdx_op_xgemm_tn_t(G, ldg, X, ldx, dW, ldw, db, M, N, K, splits, partial, half_kind, round_out, 0, stream);
+}
 extern "C" int mdx_op_hgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,
                                int64_t ldd, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
   return mdx_op_xgemm_nt(A, lda, B, ldb, bias, addend, ldd, C, ldc, M, N, K, 1, 0, stream);
@@ -1531,26 +1686,36 @@ extern "C" int mdx_debug_hgemm3_nt(const float* A, int64_t lda, const float* B, 
 
 // y = a * t[idx] (rows of F floats, F % 4 == 0) and its gradients; see mulg_*_kernel.
 // F: feature count in its low 16 bits; bits 16.. = rounding kind of the product (0 fp32, 1 bfloat16, 2 float16; mixed precision)
-extern "C" int mdx_op_mul_gather_fwd(const float* a, const float* t, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
+extern "C" int mdx_op_mul_gather_fwd_t(const void* a, const void* t, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt,
+                                       void* stream) {
   const int rk = F >> 16;
   F &= 0xffff;
   if (M <= 0 || F <= 0) return MDX_OK;
   if (F & 3) return bad("mul_gather: F must be a multiple of 4");
   if (rk < 0 || rk > 2) return bad("mul_gather: unknown rounding kind");
-  hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a, (const f32x4*)t,
-                     idx, M, F / 4, (const f32x4*)nullptr, (f32x4*)y, rk);
+  const TP ta{a, dt & 1}, tt{t, (dt >> 1) & 1};
+  const TPW ty{y, (dt >> 2) & 1};
+  if (!(tp_vec_ok(a, ta.h, 4) && tp_vec_ok(t, tt.h, 4) && tp_vec_ok(y, ty.h, 4))) return bad("mul_gather: rows must be aligned");
+  hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, (hipStream_t)stream, ta, tt, idx, M, F / 4, ty, rk);
+  return launched();
+}
+extern "C" int mdx_op_mul_gather_fwd(const float* a, const float* t, const int64_t* idx, int64_t M, int32_t F, float* y, void* stream) {
+  return mdx_op_mul_gather_fwd_t(a, t, idx, M, F, y, 0, stream);
+}
+extern "C" int mdx_op_mul_gather_bwd_t(const void* g, const void* a, const void* t, const int64_t* idx, const int64_t* order,
+                                       const int64_t* ptr, int64_t M, int64_t R, int32_t F, void* da, void* dtab, int32_t dt, void* stream) {
+  if (F <= 0) return MDX_OK;
+  if (F & 3) return bad("mul_gather: F must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const TP tg{g, dt & 1}, ta{a, (dt >> 1) & 1}, tt{t, (dt >> 2) & 1};
+  const TPW tda{da, (dt >> 3) & 1}, tdt{dtab, (dt >> 4) & 1};
+  if (da && M > 0)
+    hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, s, tg, tt, idx, M, F / 4, tda, 0);
+  if (dtab && R > 0)
+    hipLaunchKernelGGL(mulg_segsum_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, s, tg, ta, order, ptr, R, F / 4, tdt);
   return launched();
 }
 extern "C" int mdx_op_mul_gather_bwd(const float* g, const float* a, const float* t, const int64_t* idx, const int64_t* order,
                                      const int64_t* ptr, int64_t M, int64_t R, int32_t F, float* da, float* dt, void* stream) {
-  if (F <= 0) return MDX_OK;
-  if (F & 3) return bad("mul_gather: F must be a multiple of 4");
-  hipStream_t s = (hipStream_t)stream;
-  if (da && M > 0)
-    hipLaunchKernelGGL(mulg_fwd_kernel, dim3(nblk((size_t)M * (F / 4))), dim3(256), 0, s, (const f32x4*)a, (const f32x4*)t, idx, M, F / 4,
-                       (const f32x4*)g, (f32x4*)da, 0);
-  if (dt && R > 0)
-    hipLaunchKernelGGL(mulg_segsum_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, s, (const f32x4*)g, (const f32x4*)a, order, ptr, R,
-                       F / 4, (f32x4*)dt);
-  return launched();
+  return mdx_op_mul_gather_bwd_t(g, a, t, idx, order, ptr, M, R, F, da, dt, 0, stream);
 }

@@ -26,6 +26,10 @@ class TrainGraph:
 
 
 def cat(*xs):
+    """feature blocks side by side.  Half storage: the result feeds a Linear, which rounds its operand to float16 anyway, so fp32
+    blocks (time / distance smearing, one-hot inputs) join float16 blocks as float16."""
+    if any(x.dtype == torch.float16 for x in xs):
+        xs = [x if x.dtype == torch.float16 else x.to(torch.float16) for x in xs]
     return torch.cat(xs, dim=-1)
 
 
@@ -139,7 +143,8 @@ def moldiff_forward(model, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_
     n_half = h_edge.shape[0] // 2
     pred_node = mlp(model.node_decoder, h_node)
     pred_half = mlp(model.edge_decoder, T.add(h_edge[:n_half].contiguous(), h_edge[n_half:].contiguous()))
-    return {'pred_node': pred_node, 'pred_pos': pos, 'pred_halfedge': pred_half}
+    # the loss tail (log_softmax, posteriors, KL) is fp32 like autocast's own fp32 list
+    return {'pred_node': pred_node.float(), 'pred_pos': pos, 'pred_halfedge': pred_half.float()}
 
 
 def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge, t):
@@ -155,4 +160,4 @@ def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge
     he = T.add(h_edge[:n_half].contiguous(), h_edge[n_half:].contiguous())
     li, ri = T.IndexPlan(edge_index[0, :n_half], g.N), T.IndexPlan(edge_index[1, :n_half], g.N)
     hn = T.add(T.gather(h_node, li), T.gather(h_node, ri))
-    return mlp(model.edge_decoder, cat(he, hn))
+    return mlp(model.edge_decoder, cat(he, hn)).float()       # logits enter the cross-entropy in fp32

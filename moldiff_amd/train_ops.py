@@ -34,8 +34,12 @@ def _c(t):
 #     (fp32 accumulation), so do its data / weight / bias gradients; products of two such results (gates, pairwise products) are
 #     half too; LayerNorm, softmax, the posteriors, the loss and every segment sum stay fp32.  Tensors live in fp32 containers
 #     holding half-representable values.
+#   store = True ('fp16'): those half VALUES also live in float16 CONTAINERS (every Linear / LayerNorm / product result and its
+#     gradient) -- the operators are memory-bound, so this halves what limits them; 'fp16_f32store' keeps fp32 containers (round 3's
+#     first cut; the two differ only where the half container rounds a LayerNorm output or a residual sum one operator earlier).
 _AMP = None
-KINDS = {'f32': None, 'bf16': (1, False), 'fp16': (2, True), 'bf16_autocast': (1, True)}
+KINDS = {'f32': None, 'bf16': (1, False, False), 'fp16': (2, True, True), 'fp16_f32store': (2, True, False),
+         'bf16_autocast': (1, True, False)}
 
 
 class precision:
@@ -64,17 +68,56 @@ def _round_kind():
     return _AMP[0] if (_AMP is not None and _AMP[1]) else 0
 
 
-def sgemm_nt(a, b, bias=None, splits=1, addend=None, keep32=False):
+def _store_dtype():
+    """container of a Linear / LayerNorm / product result in the current mode"""
+    return torch.float16 if (_AMP is not None and _AMP[2]) else torch.float32
+
+
+def _t(t):
+    """device tensor, contiguous, in its own container type (fp32 or float16); anything else is converted to fp32"""
+    _lib._need_gpu(t)
+    t = t.detach()
+    if t.dtype not in (torch.float32, torch.float16):
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _h(t):
+    return 1 if (t is not None and t.dtype == torch.float16) else 0
+
+
+def _same(a, b):
+    """two operands of an element-wise operator in one container type (mixed -> fp32)"""
+    a, b = _t(a), _t(b)
+    if a.dtype != b.dtype or (a.dtype == torch.float16 and (a.numel() % 4 or a.shape[-1] % 4)):   # half kernels are 4-wide
+        a, b = a.float(), b.float()
+    return a, b
+
+
+def _t4(t):
+    """like _t, but a float16 tensor whose rows are not a multiple of 4 wide goes through fp32 (the half kernels are 4-wide)"""
+    t = _t(t)
+    return t.float() if (t.dtype == torch.float16 and t.shape[-1] % 4) else t
+
+
+def sgemm_nt(a, b, bias=None, splits=1, addend=None, keep32=False, out_dtype=None):
     """a (M,K) @ b (N,K)^T + bias + addend -> (M,N).  Rows of a / b may be strided (column slices of a wider matrix).
-    keep32: in an autocast mode, do not round the result (it is a partial sum that enters another Linear as its addend)."""
+    keep32: in an autocast mode, do not round the result (it is a partial sum that enters another Linear as its addend).
+    a / addend may be fp32 or float16 containers (mixed precision only); out_dtype: container of the result (default: the mode's)."""
     M, K = a.shape
     N = b.shape[0]
-    assert a.stride(1) == 1 and b.stride(1) == 1
-    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    assert a.stride(1) == 1 and b.stride(1) == 1 and b.dtype == torch.float32
     if _AMP is not None and splits <= 1:
-        check(_L().mdx_op_xgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0,
-                                   ptr(out), N, M, N, K, _AMP[0], int(_AMP[1] and not keep32), stream()))
+        if out_dtype is None:
+            out_dtype = torch.float32 if keep32 else _store_dtype()
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+        rnd = int((_AMP[1] and not keep32) or out_dtype == torch.float16)
+        check(_L().mdx_op_xgemm_nt_t(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend),
+                                     addend.stride(0) if addend is not None else 0, ptr(out), N, M, N, K, _AMP[0], rnd,
+                                     _h(a) | (_h(addend) << 1) | (_h(out) << 2), stream()))
         return out
+    assert a.dtype == torch.float32 and (addend is None or addend.dtype == torch.float32)
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     part = torch.empty(splits * M * N, dtype=torch.float32, device=a.device) if splits > 1 else None
     check(_L().mdx_op_sgemm_nt(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), ptr(addend), N if addend is not None else 0, ptr(out),
                                N, M, N, K, splits, ptr(part), stream()))
@@ -86,7 +129,7 @@ ROWS_MIN = 16384   # from this many rows on a Linear runs on the row-owner kerne
 
 def linear_rows_ok(a, n, k, addend=None):
     """Can `a` (M,k) @ W -> (M,n) take the row-owner kernel?  Shape built, enough rows, 16-byte aligned rows, fp32 mode."""
-    return (_AMP is None and a.shape[0] >= ROWS_MIN and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+    return (_AMP is None and a.dtype == torch.float32 and a.shape[0] >= ROWS_MIN and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
             and (addend is None or (addend.stride(1) == 1 and addend.stride(0) % 4 == 0 and addend.data_ptr() % 16 == 0))
             and _L().mdx_op_linear_rows_supported(n, k) == 1)
 
@@ -114,9 +157,10 @@ def sgemm_tn(g, x, splits, want_bias=False):
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
     part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
     if _AMP is not None:
-        check(_L().mdx_op_xgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), _AMP[0],
-                                   int(_AMP[1]), stream()))
+        check(_L().mdx_op_xgemm_tn_t(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), _AMP[0],
+                                     int(_AMP[1]), _h(g) | (_h(x) << 1), stream()))
     else:
+        assert g.dtype == torch.float32 and x.dtype == torch.float32
         check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), stream()))
     return (out, db) if want_bias else out
 
@@ -146,10 +190,10 @@ def _splits_for(rows, n, k):
 
 
 def _rows(t):
-    """fp32 device matrix whose rows are contiguous (row stride arbitrary: column slices of a weight stay views)."""
+    """device matrix (fp32 or float16 container) whose rows are contiguous (row stride arbitrary: column slices of a weight stay views)."""
     _lib._need_gpu(t)
     t = t.detach()
-    if t.dtype != torch.float32:
+    if t.dtype not in (torch.float32, torch.float16):
         t = t.float()
     return t if t.stride(-1) == 1 else t.contiguous()
 
@@ -158,10 +202,17 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, addend, keep32):
         xc, wc = _rows(x), _rows(w)
+        if _AMP is None and xc.dtype != torch.float32:
+            xc = xc.float()
         ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.has_addend = b is not None, addend is not None
+        ctx.x_dtype = x.dtype
+        ctx.addend_dtype = addend.dtype if addend is not None else None
         ctx.prec = _AMP     # the backward of this layer runs in the forward's precision
-        bc, ac = (_c(b) if b is not None else None), (_c(addend) if addend is not None else None)
+        bc = _c(b) if b is not None else None
+        ac = None
+        if addend is not None:
+            ac = _rows(addend) if _AMP is not None else _c(addend)
         if linear_rows_ok(xc, wc.shape[0], wc.shape[1], ac):
             return linear_rows(xc, wc, False, bc, ac)
         return sgemm_nt(xc, wc, bc, addend=ac, keep32=keep32)
@@ -169,21 +220,26 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gy = _c(gy)
+        gy = _t(gy) if ctx.prec is not None else _c(gy)
         gx = gw = gb = None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         with precision(ctx.prec):
             if ctx.needs_input_grad[0]:
                 if linear_rows_ok(gy, w.shape[1], w.shape[0]):
                     gx = linear_rows(gy, w, True)                     # (M,N) @ (N,K), the weight read transposed by the pack
-                else:
-                    gx = sgemm_nt(gy, transpose(w))                   # (M,N) @ (K,N)^T
+                else:                                                 # (M,N) @ (K,N)^T; the gradient lives in x's container type
+                    gx = sgemm_nt(gy, transpose(w), out_dtype=x.dtype if ctx.prec is not None else None)
+                if gx.dtype != ctx.x_dtype:
+                    gx = gx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
                 gw, gb = r if want_b else (r, None)
             elif want_b:
-                gb = colreduce(gy)
-        return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None), None
+                gb = colreduce(gy.float() if gy.dtype != torch.float32 else gy)
+        ga = None
+        if ctx.has_addend and ctx.needs_input_grad[3]:
+            ga = gy if gy.dtype == ctx.addend_dtype else gy.to(ctx.addend_dtype)
+        return gx, gw, gb, ga, None
 
 
 def linear(x, w, b=None, addend=None, keep32=False):
@@ -197,11 +253,15 @@ def linear(x, w, b=None, addend=None, keep32=False):
 class _LnRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, relu):
-        xc, g, b = _c(x), _c(gamma), _c(beta)
+        xc, g, b = _t(x), _c(gamma), _c(beta)
         M, F = xc.shape
-        y = torch.empty_like(xc)
+        ctx.x_dtype = x.dtype
+        if F not in (32, 64, 128, 256):     # the half kernels cover the widths the networks use
+            xc = xc.float()
+        # the only consumers of a LayerNorm result are Linears, which round their operand to half anyway: a half container is exact
+        y = torch.empty(M, F, dtype=(_store_dtype() if (_AMP is not None and F in (32, 64, 128, 256)) else torch.float32), device=xc.device)
         stats = torch.empty(M, 2, dtype=torch.float32, device=xc.device)
-        check(_L().mdx_op_ln_relu_fwd(ptr(xc), ptr(g), ptr(b), M, F, int(relu), ptr(y), ptr(stats), stream()))
+        check(_L().mdx_op_ln_relu_fwd_t(ptr(xc), ptr(g), ptr(b), M, F, int(relu), ptr(y), ptr(stats), _h(xc) | (_h(y) << 1), stream()))
         ctx.save_for_backward(xc, g, b, stats)
         ctx.relu = int(relu)
         return y
@@ -209,13 +269,16 @@ class _LnRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, g, b, stats = ctx.saved_tensors
-        gy = _c(gy)
+        gy = _t(gy)
         M, F = x.shape
+        if F not in (32, 64, 128, 256):
+            gy = gy.float()
         dx = torch.empty_like(x)
         dgb = torch.empty(2 * F, dtype=torch.float32, device=x.device)
         ws = torch.empty(_L().mdx_op_ln_relu_bwd_ws(M, F) // 4 + 1, dtype=torch.float32, device=x.device)
-        check(_L().mdx_op_ln_relu_bwd(ptr(gy), ptr(x), ptr(stats), ptr(g), ptr(b), M, F, ctx.relu, ptr(dx), ptr(dgb), ptr(ws), stream()))
-        return dx, dgb[:F], dgb[F:], None
+        check(_L().mdx_op_ln_relu_bwd_t(ptr(gy), ptr(x), ptr(stats), ptr(g), ptr(b), M, F, ctx.relu, ptr(dx), ptr(dgb), ptr(ws),
+                                        _h(gy) | (_h(x) << 1) | (_h(dx) << 2), stream()))
+        return (dx if dx.dtype == ctx.x_dtype else dx.to(ctx.x_dtype)), dgb[:F], dgb[F:], None
 
 
 def ln_relu(x, gamma, beta, relu=True):
@@ -225,11 +288,12 @@ def ln_relu(x, gamma, beta, relu=True):
 class _Ew(torch.autograd.Function):
     @staticmethod
     def forward(ctx, op, a, b):
-        ac, bc = _c(a), _c(b)
+        ctx.dtypes = (a.dtype, b.dtype)
+        ac, bc = _same(a, b)
         assert ac.shape == bc.shape, (ac.shape, bc.shape)
         out = torch.empty_like(ac)
         rk = _round_kind() if op in (MUL, GATE) else 0     # autocast: a product of two half tensors is a half tensor
-        check(_L().mdx_op_ew_fwd(op | (rk << 8), ptr(ac), ptr(bc), ptr(out), ac.numel(), stream()))
+        check(_L().mdx_op_ew_fwd_t(op | (rk << 8), ptr(ac), ptr(bc), ptr(out), ac.numel(), _h(ac) | (_h(bc) << 1) | (_h(out) << 2), stream()))
         ctx.op = op
         ctx.save_for_backward(ac, bc)
         return out
@@ -237,10 +301,15 @@ class _Ew(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        g = _c(g)
+        g = _t(g)
         da = torch.empty_like(a) if ctx.needs_input_grad[1] else None
         db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
-        check(_L().mdx_op_ew_bwd(ctx.op, ptr(a), ptr(b), ptr(g), ptr(da), ptr(db), a.numel(), stream()))
+        check(_L().mdx_op_ew_bwd_t(ctx.op, ptr(a), ptr(b), ptr(g), ptr(da), ptr(db), a.numel(),
+                                   _h(a) | (_h(b) << 1) | (_h(g) << 2) | (_h(da) << 3) | (_h(db) << 4), stream()))
+        if da is not None and da.dtype != ctx.dtypes[0]:
+            da = da.to(ctx.dtypes[0])
+        if db is not None and db.dtype != ctx.dtypes[1]:
+            db = db.to(ctx.dtypes[1])
         return None, da, db
 
 
@@ -275,40 +344,46 @@ class IndexPlan:
         self.ptr[1:] = torch.cumsum(counts, 0)
 
 
-def _gather_raw(x, plan):
+def _gather_raw(x, plan, out_dtype=None):
     M, F = plan.index.numel(), x.shape[1]
-    y = torch.empty(M, F, dtype=torch.float32, device=x.device)
-    check(_L().mdx_op_gather_rows(ptr(x), ptr(plan.index), M, F, ptr(y), stream()))
+    y = torch.empty(M, F, dtype=out_dtype or x.dtype, device=x.device)
+    check(_L().mdx_op_gather_rows_t(ptr(x), ptr(plan.index), M, F, ptr(y), _h(x) | (_h(y) << 1), stream()))
     return y
 
 
-def _segsum_raw(src, plan):
+def _segsum_raw(src, plan, out_dtype=torch.float32):
     F = src.shape[1]
-    out = torch.empty(plan.n, F, dtype=torch.float32, device=src.device)
-    check(_L().mdx_op_segsum_rows(ptr(src), ptr(plan.order), ptr(plan.ptr), plan.n, F, ptr(out), stream()))
+    out = torch.empty(plan.n, F, dtype=out_dtype, device=src.device)
+    check(_L().mdx_op_segsum_rows_t(ptr(src), ptr(plan.order), ptr(plan.ptr), plan.n, F, ptr(out), _h(src) | (_h(out) << 1), stream()))
     return out
 
 
 class _Gather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, plan):
-        ctx.plan = plan
-        return _gather_raw(_c(x), plan)
+        ctx.plan, ctx.dtype = plan, x.dtype
+        return _gather_raw(_t4(x), plan)
 
     @staticmethod
     def backward(ctx, g):
-        return _segsum_raw(_c(g), ctx.plan), None
+        g = _t4(g)
+        half = ctx.dtype == torch.float16 and g.shape[-1] % 4 == 0
+        r = _segsum_raw(g, ctx.plan, torch.float16 if half else torch.float32)
+        return (r if r.dtype == ctx.dtype else r.to(ctx.dtype)), None
 
 
 class _SegSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, plan):
-        ctx.plan = plan
-        return _segsum_raw(_c(src), plan)
+        ctx.plan, ctx.dtype = plan, src.dtype
+        return _segsum_raw(_t4(src), plan)            # sums are fp32 whatever the rows' container
 
     @staticmethod
     def backward(ctx, g):
-        return _gather_raw(_c(g), ctx.plan), None
+        g = _t4(g)
+        half = ctx.dtype == torch.float16 and g.shape[-1] % 4 == 0
+        r = _gather_raw(g, ctx.plan, torch.float16 if half else torch.float32)
+        return (r if r.dtype == ctx.dtype else r.to(ctx.dtype)), None
 
 
 def gather(x, plan):
@@ -324,10 +399,12 @@ def scatter_sum(src, plan):
 class _MulGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, table, plan):
-        ac, tc = _c(a), _c(table)
+        ctx.dtypes = (a.dtype, table.dtype)
+        ac, tc = _same(a, table)
         M, F = ac.shape
         y = torch.empty_like(ac)
-        check(_L().mdx_op_mul_gather_fwd(ptr(ac), ptr(tc), ptr(plan.index), M, F | (_round_kind() << 16), ptr(y), stream()))
+        check(_L().mdx_op_mul_gather_fwd_t(ptr(ac), ptr(tc), ptr(plan.index), M, F | (_round_kind() << 16), ptr(y),
+                                           _h(ac) | (_h(tc) << 1) | (_h(y) << 2), stream()))
         ctx.plan = plan
         ctx.save_for_backward(ac, tc)
         return y
@@ -335,12 +412,16 @@ class _MulGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, t = ctx.saved_tensors
-        g, plan = _c(g), ctx.plan
+        g, plan = _t(g), ctx.plan
         M, F = a.shape
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         dt = torch.empty_like(t) if ctx.needs_input_grad[1] else None
-        check(_L().mdx_op_mul_gather_bwd(ptr(g), ptr(a), ptr(t), ptr(plan.index), ptr(plan.order), ptr(plan.ptr), M, plan.n, F, ptr(da),
-                                         ptr(dt), stream()))
+        check(_L().mdx_op_mul_gather_bwd_t(ptr(g), ptr(a), ptr(t), ptr(plan.index), ptr(plan.order), ptr(plan.ptr), M, plan.n, F, ptr(da),
+                                           ptr(dt), _h(g) | (_h(a) << 1) | (_h(t) << 2) | (_h(da) << 3) | (_h(dt) << 4), stream()))
+        if da is not None and da.dtype != ctx.dtypes[0]:
+            da = da.to(ctx.dtypes[0])
+        if dt is not None and dt.dtype != ctx.dtypes[1]:
+            dt = dt.to(ctx.dtypes[1])
         return da, dt, None
 
 
@@ -413,7 +494,7 @@ class _Force(torch.autograd.Function):
         out = torch.empty_like(rc)
         check(_L().mdx_op_force_fwd(ptr(wc), ptr(rc), ptr(dc), dc.numel(), ptr(out), stream()))
         ctx.save_for_backward(wc, rc, dc)
-        ctx.wshape = w.shape
+        ctx.wshape, ctx.wdtype = w.shape, w.dtype
         return out
 
     @staticmethod
@@ -421,7 +502,7 @@ class _Force(torch.autograd.Function):
         w, rel, d = ctx.saved_tensors
         gw, grel, gd = torch.empty_like(w), torch.empty_like(rel), torch.empty_like(d)
         check(_L().mdx_op_force_bwd(ptr(w), ptr(rel), ptr(d), ptr(_c(g)), d.numel(), ptr(gw), ptr(grel), ptr(gd), stream()))
-        return gw.reshape(ctx.wshape), grel, gd
+        return gw.reshape(ctx.wshape).to(ctx.wdtype), grel, gd
 
 
 def force(w, rel, dist):

@@ -199,3 +199,42 @@ def test_mul_gather_matches_mul_of_gather():
     y2.backward(gy)
     assert torch.equal(y, y2) and torch.equal(a.grad, a2.grad)
     assert _rel(t.grad, t2.grad) < 2e-6
+
+
+def test_half_storage_operators_equal_their_fp32_container_twins():
+    """Half storage (round 3): in the mixed-precision mode every Linear / LayerNorm / product result is a float16 VALUE; `precision('fp16')`
+    keeps it in a float16 container, `precision('fp16_f32store')` in an fp32 one.  On float16-representable inputs each typed operator
+    (`mdx_op_*_t`) must return what its fp32-container twin returns, rounded to float16 where the container is float16 -- forward and
+    backward, on ragged row counts."""
+    from moldiff_amd import train_ops as T
+    g = U.rng(31)
+    dev = 'cuda:0'
+    M, Nn = 1003, 77
+    h = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32)).to(dev).half()
+    idx = torch.from_numpy(g.integers(0, Nn, M)).to(dev)
+    plan = T.IndexPlan(idx, Nn)
+    x, w, b = h(M, 64), h(128, 64).float(), h(128).float()
+    gam, bet = (1 + 0.1 * h(128)).float(), (0.1 * h(128)).float()
+    tab, a2 = h(Nn, 128), h(M, 128)
+    gout = h(M, 128)
+
+    def run(mode, half):
+        cast = (lambda t: t) if half else (lambda t: t.float())
+        xs = [cast(t).clone().requires_grad_(True) for t in (x, tab, a2)]
+        ws = [t.clone().requires_grad_(True) for t in (w, b, gam, bet)]
+        with T.precision(mode):
+            y = T.linear(xs[0], ws[0], ws[1])                       # (M,128) Linear: half operands, rounded result
+            y = T.ln_relu(y, ws[2], ws[3], True)
+            y = T.mul_gather(y, xs[1], plan)                        # product with a gathered per-node row
+            y = T.gate(y, xs[2])
+            y = T.add(y, T.gather(T.scatter_sum(y, plan).to(y.dtype), plan))
+            y.backward(cast(gout))
+        return [y.detach().float()] + [t.grad.float() for t in xs + ws]
+
+    half, full = run('fp16', True), run('fp16_f32store', False)
+    names = ['out', 'dx', 'dtab', 'da2', 'dW', 'db', 'dgamma', 'dbeta']
+    for n, p, q in zip(names, half, full):
+        scale = float(q.abs().max())
+        # identical arithmetic; the half container rounds the LayerNorm output and the residual sum one operator earlier
+        assert float((p - q).abs().max()) <= 4e-3 * scale, (n, float((p - q).abs().max()), scale)
+    assert half[0].shape == (M, 128)

@@ -8,7 +8,7 @@ S=float(z['scale'])
 for nm,kind in (('full','MolDiff'),('simple','MolDiff_simple')):
     args,t,noise,want=_case(nm,'cuda')
     m=U.moldiff(kind,'cuda')
-    for tag,mode in (('fp16','fp16'),('bf16','bf16_autocast'),('fp16','f32'),('bf16','bf16')):
+    for tag,mode in (('fp16','fp16'),('fp16','fp16_f32store'),('fp16','f32')):
         m.zero_grad(set_to_none=True)
         with train_ops.precision(mode):
             got=m.get_loss(*args,time_step=t,noise=noise)
