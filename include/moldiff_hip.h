@@ -335,6 +335,16 @@ int mdx_op_mul_gather_fwd_t(const void* a, const void* t, const int64_t* idx, in
 int mdx_op_mul_gather_bwd_t(const void* g, const void* a, const void* t, const int64_t* idx, const int64_t* order, const int64_t* ptr,
                             int64_t M, int64_t R, int32_t F, void* da, void* dtab, int32_t dt, void* stream);
 
+/* Deferred gradient reduction: mdx_op_sgemm_tn / mdx_op_xgemm_tn(_t) with dW == NULL (db != NULL still requests the bias partials)
+ * and mdx_op_ln_relu_bwd(_t) with dgb == NULL leave their split partials in the caller's buffer (layout: mdx_op_wgrad_layout -> number
+ * of partials S and the float offset of the [S][N] bias partials; LayerNorm: mdx_op_ln_relu_bwd_rows(M) rows of 2F floats in ws).
+ * mdx_op_reduce_deferred sums every record of a device table in ONE launch and ADDS it to its destination (a parameter's slot in a flat
+ * gradient buffer): record = 8 x int64 {P, dst, S, rows, cols, ld, pstride, rkind | first_block << 8}; total_blocks = sum of
+ * ceil(rows * cols / 32).  Same fixed summation order as the per-layer reduction kernels. */
+int mdx_op_wgrad_layout(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t half, int64_t* S, int64_t* bias_off);
+int64_t mdx_op_ln_relu_bwd_rows(int64_t M);
+int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks, void* stream);
+
 /* One optimisation step with torch.cuda.amp.GradScaler semantics and ALL of its state on the device (no host round trip):
  * g = gradient of (S x loss).  state (16 floats): [0] loss scale S, [1] growth tracker, [2] optimizer steps taken, [3] steps skipped,
  * [4] unscaled squared gradient norm of this step (inf / nan if a gradient overflowed); [5..8] internal.  Finite: clip to max_norm

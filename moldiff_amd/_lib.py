@@ -25,7 +25,8 @@ EXPORTS = [
     'mdx_profile_enable', 'mdx_profile_read', 'mdx_profile_kernel_name',
     'mdx_op_sgemm_nt', 'mdx_op_sgemm_tn', 'mdx_op_hgemm_nt', 'mdx_op_hgemm_tn', 'mdx_op_xgemm_nt', 'mdx_op_xgemm_tn', 'mdx_op_amp_adamw',
     'mdx_op_xgemm_nt_t', 'mdx_op_xgemm_tn_t', 'mdx_op_ln_relu_fwd_t', 'mdx_op_ln_relu_bwd_t', 'mdx_op_ew_fwd_t', 'mdx_op_ew_bwd_t',
-    'mdx_op_gather_rows_t', 'mdx_op_segsum_rows_t', 'mdx_op_mul_gather_fwd_t', 'mdx_op_mul_gather_bwd_t', 'mdx_op_transpose', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
+    'mdx_op_gather_rows_t', 'mdx_op_segsum_rows_t', 'mdx_op_mul_gather_fwd_t', 'mdx_op_mul_gather_bwd_t',
+    'mdx_op_wgrad_layout', 'mdx_op_ln_relu_bwd_rows', 'mdx_op_reduce_deferred', 'mdx_op_transpose', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_mul_gather_fwd', 'mdx_op_mul_gather_bwd', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
 ]
@@ -137,6 +138,10 @@ def lib():
         L.mdx_op_segsum_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
         L.mdx_op_mul_gather_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
         L.mdx_op_mul_gather_bwd.argtypes = [c_void_p] * 6 + [c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_wgrad_layout.argtypes = [c_int64, c_int64, c_int64, c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]
+        L.mdx_op_ln_relu_bwd_rows.argtypes = [c_int64]
+        L.mdx_op_ln_relu_bwd_rows.restype = c_int64
+        L.mdx_op_reduce_deferred.argtypes = [c_void_p, c_int32, c_int64, c_void_p]
         # half-storage forms: the fp32 signature with an int32 `dt` mask in front of the stream
         for name in ('xgemm_nt', 'xgemm_tn', 'ln_relu_fwd', 'ln_relu_bwd', 'ew_fwd', 'ew_bwd', 'gather_rows', 'segsum_rows', 'mul_gather_fwd',
                      'mul_gather_bwd'):

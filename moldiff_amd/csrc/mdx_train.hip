@@ -1366,7 +1366,7 @@ extern "C" int mdx_op_ln_relu_bwd_t(const void* dyv, const void* xv, const float
                                     int32_t F, int32_t relu, void* dxv, float* dgb, float* ws, int32_t dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (F <= 0 || F > 64 * LN_MAXJ) return bad("ln_relu: feature count must be in 1..1024");
-  if (M <= 0) return hipMemsetAsync(dgb, 0, (size_t)F * 8, s) == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "memset");
+  if (M <= 0) return !dgb || hipMemsetAsync(dgb, 0, (size_t)F * 8, s) == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "memset");
   if (!ws) return bad("ln_relu_bwd: workspace required");
   const TP dy{dyv, dt & 1}, x{xv, (dt >> 1) & 1};
   const TPW dx{dxv, (dt >> 2) & 1};
@@ -1388,8 +1388,9 @@ extern "C" int mdx_op_ln_relu_bwd_t(const void* dyv, const void* xv, const float
     hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, (const float*)dyv, (const float*)xv, stats, gamma, beta,
                        (int)M, F, relu, RPW, (float*)dxv, ws);
   }
-  // [dgamma | dbeta] = sum over the nwp per-wave partial rows, fixed-order parallel reduction
-  launch_reduce_partials(ws, nwp, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)nwp * 2 * F, s);
+  // [dgamma | dbeta] = sum over the nwp per-wave partial rows, fixed-order parallel reduction (dgb == NULL: deferred, the partial
+  // rows stay in ws for mdx_op_reduce_deferred)
+  if (dgb) launch_reduce_partials(ws, nwp, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)nwp * 2 * F, s);
   return launched();
 }
 extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
@@ -1556,7 +1557,7 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
                                int64_t N, int64_t K, int32_t splits, float* partial, void* stream) {
   if (N <= 0 || K <= 0) return MDX_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (!G || !X || !dW || !partial) return bad("sgemm_tn: null operand / partial buffer");
+  if (!G || !X || !partial) return bad("sgemm_tn: null operand / partial buffer");
   if (splits < 1) splits = 1;
   int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
   mper = (mper + W_MC - 1) / W_MC * W_MC;
@@ -1567,6 +1568,7 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
   hipLaunchKernelGGL(sgemm_tn_split_kernel, grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+  if (!dW) return launched();  // deferred: the partials stay where mdx_op_wgrad_layout says, mdx_op_reduce_deferred sums them later
   if (db && S <= RED_CHUNK) {  // both reductions in one launch
     const unsigned gxw = (unsigned)(((size_t)N * K + 31) / 32), gxb = (unsigned)((N + 31) / 32);
     hipLaunchKernelGGL(reduce_partials2_kernel, dim3(gxw + gxb), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K, dW, (int)ldw,
@@ -1575,6 +1577,66 @@ extern "C" int mdx_op_sgemm_tn(const float* G, int64_t ldg, const float* X, int6
     launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s);
     if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s);
   }
+  return launched();
+}
+
+// ---- deferred gradient reduction (round 3) ----------------------------------------------------------------------------------------
+// A training step has ~260 weight gradients and ~150 LayerNorm parameter gradients; each used to end in its own 7 us reduction launch
+// (plus torch's accumulation kernels on the way into the flat gradient buffer).  With dW == NULL (LayerNorm: dgb == NULL) the
+// operators leave their split partials in the caller's buffer; ONE launch of mdx_op_reduce_deferred per step then sums every record
+// in the fixed order of the dedicated kernels and ADDS the result to its destination -- the parameter's slot of the flat gradient
+// buffer.  Record (8 x int64): P, dst, S (partials), rows, cols, ld (dst row stride), pstride (floats between consecutive partials),
+// rkind (0 fp32, 1 bfloat16, 2 float16 rounding of the sum, mixed precision) | first_block << 8.
+extern "C" int mdx_op_wgrad_layout(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t half, int64_t* S_out, int64_t* bias_off) {
+  if (splits < 1) splits = 1;
+  const int mc = half ? HW_MC : W_MC;
+  int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
+  mper = (mper + mc - 1) / mc * mc;
+  const int64_t S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
+  const int64_t nc = (S + RED_CHUNK - 1) / RED_CHUNK;
+  if (S_out) *S_out = S;
+  if (bias_off) *bias_off = (S + nc) * N * K;   // floats from `partial` to the [S][N] bias partials
+  return MDX_OK;
+}
+extern "C" int64_t mdx_op_ln_relu_bwd_rows(int64_t M) {  // partial rows mdx_op_ln_relu_bwd leaves in ws ([rows][2F])
+  const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW;
+  return (nw + 3) / 4 * 4;
+}
+namespace {
+__global__ __launch_bounds__(256) void reduce_deferred_kernel(const int64_t* __restrict__ desc, int n) {
+  __shared__ float sh[8][32];
+  // binary search: last record whose first block is <= blockIdx.x
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int64_t)(desc[8 * mid + 7] >> 8) <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* d = desc + 8 * lo;
+  const float* P = reinterpret_cast<const float*>(d[0]);
+  float* dst = reinterpret_cast<float*>(d[1]);
+  const int S = (int)d[2], cols = (int)d[4], ld = (int)d[5];
+  const size_t total = (size_t)d[3] * cols, pstride = (size_t)d[6];
+  const int rkind = (int)(d[7] & 255);
+  const int o = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const size_t i = ((size_t)blockIdx.x - (size_t)(d[7] >> 8)) * 32 + o;
+  float s = 0.f;
+  if (i < total)
+    for (int k = z; k < S; k += 8) s += P[(size_t)k * pstride + i];
+  sh[z][o] = s;
+  __syncthreads();
+  if (z == 0 && i < total) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += sh[k][o];
+    const size_t row = i / cols, col = i % cols;
+    dst[row * ld + col] += round_kind(r, rkind);
+  }
+}
+}  // namespace
+extern "C" int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks, void* stream) {
+  if (n <= 0 || total_blocks <= 0) return MDX_OK;
+  if (!desc) return bad("reduce_deferred: null record table");
+  hipLaunchKernelGGL(reduce_deferred_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, desc, (int)n);
   return launched();
 }
 
@@ -1633,7 +1695,7 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
                                  void* stream) {
   if (N <= 0 || K <= 0) return MDX_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (!Gv || !Xv || !dW || !partial) return bad("xgemm_tn: null operand / partial buffer");
+  if (!Gv || !Xv || !partial) return bad("xgemm_tn: null operand / partial buffer");
   const TP G{Gv, dt & 1}, X{Xv, (dt >> 1) & 1};
   if (half_kind != 1 && half_kind != 2) return bad("xgemm_tn: half_kind must be 1 (bfloat16) or 2 (float16)");
   if (splits < 1) splits = 1;
@@ -1649,6 +1711,7 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
   else
     hipLaunchKernelGGL((hgemm_tn_split_kernel<1>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
   const int rkind = round_out ? half_kind : 0;
+  if (!dW) return launched();  // deferred reduction (mdx_op_reduce_deferred)
   if (db && S <= RED_CHUNK) {  // both reductions in one launch
     const unsigned gxw = (unsigned)(((size_t)N * K + 31) / 32), gxb = (unsigned)((N + 31) / 32);
     hipLaunchKernelGGL(reduce_partials2_kernel, dim3(gxw + gxb), dim3(256), 0, s, (const float*)partial, S, (int)N, (int)K, dW, (int)ldw,

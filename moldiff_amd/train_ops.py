@@ -100,6 +100,62 @@ def _t4(t):
     return t.float() if (t.dtype == torch.float16 and t.shape[-1] % 4) else t
 
 
+# ---- deferred parameter gradients (round 3) ----------------------------------------------------------------------------------
+# While a `grad_sink` is active (Trainer.step), a Linear / LayerNorm whose parameters live in the sink's flat parameter buffer does
+# not hand its weight / bias / affine gradients to autograd: it leaves the split partials of its weight-gradient GEMM (LayerNorm: its
+# per-wave partial rows) where they are, records {partials, destination slot in the flat GRADIENT buffer, sizes} and returns None.
+# `flush_grad_sink()` -- called once after backward -- sums every record in ONE launch (`mdx_op_reduce_deferred`, same fixed order as
+# the per-layer reduction kernels) straight into the flat gradient buffer.  That replaces ~660 reduction launches and ~540 of torch's
+# accumulation / slice-gradient kernels per step.  Without a sink everything goes through autograd as before.
+_SINK = None
+
+
+class grad_sink:
+    def __init__(self, flat):
+        self.flat = flat
+
+    def __enter__(self):
+        global _SINK
+        f = self.flat
+        self.prev = _SINK
+        _SINK = {'data': f.data.data_ptr(), 'grad': f.grad.data_ptr(), 'nbytes': f.data.numel() * 4, 'recs': [], 'keep': [], 'blocks': 0,
+                 'device': f.data.device}
+        return self
+
+    def __exit__(self, *exc):
+        global _SINK
+        if _SINK is not None and _SINK['recs']:
+            flush_grad_sink()
+        _SINK = self.prev
+
+
+def _sink_dst(t):
+    """address of `t`'s slot in the flat gradient buffer when t (a parameter or a view of one) lives in the sink's parameter buffer"""
+    if _SINK is None or t is None:
+        return None
+    off = t.data_ptr() - _SINK['data']
+    return _SINK['grad'] + off if 0 <= off < _SINK['nbytes'] else None
+
+
+def _sink_record(part_ptr, dst, S, rows, cols, ld, pstride, rkind, keep):
+    sk = _SINK
+    sk['recs'].append((part_ptr, dst, S, rows, cols, ld, pstride, rkind | (sk['blocks'] << 8)))
+    sk['blocks'] += (rows * cols + 31) // 32
+    sk['keep'].append(keep)
+
+
+def flush_grad_sink():
+    """one launch: every recorded gradient summed into its slot of the flat gradient buffer"""
+    sk = _SINK
+    if sk is None or not sk['recs']:
+        return
+    desc = torch.tensor(sk['recs'], dtype=torch.int64).to(sk['device'], non_blocking=True)
+    check(_L().mdx_op_reduce_deferred(ptr(desc), len(sk['recs']), sk['blocks'], stream()))
+    sk['keep'].append(desc)
+    # the partial buffers may be reused once the launch above has been enqueued (stream order); drop the references
+    sk['recs'], sk['keep'], sk['blocks'] = [], [], 0
+
+
 def sgemm_nt(a, b, bias=None, splits=1, addend=None, keep32=False, out_dtype=None):
     """a (M,K) @ b (N,K)^T + bias + addend -> (M,N).  Rows of a / b may be strided (column slices of a wider matrix).
     keep32: in an autocast mode, do not round the result (it is a partial sum that enters another Linear as its addend).
@@ -147,15 +203,33 @@ def linear_rows(a, w, trans_w, bias=None, addend=None):
     return out
 
 
-def sgemm_tn(g, x, splits, want_bias=False):
+def sgemm_tn(g, x, splits, want_bias=False, defer=None):
     """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors; with want_bias also the
-    column sums of g (the bias gradient) from the same pass -> (dW, db)."""
+    column sums of g (the bias gradient) from the same pass -> (dW, db).
+    defer = (dst_w, ldw, dst_b): leave the split partials for `flush_grad_sink` (destinations in the flat gradient buffer) -> None."""
     M, N = g.shape
     K = x.shape[1]
     splits = max(1, int(splits))
+    part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
+    if defer is not None:
+        dst_w, ldw, dst_b = defer
+        import ctypes
+        S, boff = ctypes.c_int64(), ctypes.c_int64()
+        check(_L().mdx_op_wgrad_layout(M, N, K, splits, 1 if _AMP is not None else 0, ctypes.byref(S), ctypes.byref(boff)))
+        wb = ptr(part) if want_bias else None        # any non-null pointer = "also write the bias partials"
+        if _AMP is not None:
+            check(_L().mdx_op_xgemm_tn_t(ptr(g), g.stride(0), ptr(x), x.stride(0), None, K, wb, M, N, K, splits, ptr(part), _AMP[0],
+                                         int(_AMP[1]), _h(g) | (_h(x) << 1), stream()))
+            rk = _AMP[0] if _AMP[1] else 0
+        else:
+            check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), None, K, wb, M, N, K, splits, ptr(part), stream()))
+            rk = 0
+        _sink_record(part.data_ptr(), dst_w, S.value, N, K, ldw, N * K, rk, part)
+        if want_bias:
+            _sink_record(part.data_ptr() + 4 * boff.value, dst_b, S.value, 1, N, N, N, rk, part)
+        return None
     out = torch.empty(N, K, dtype=torch.float32, device=g.device)
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
-    part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
     if _AMP is not None:
         check(_L().mdx_op_xgemm_tn_t(ptr(g), g.stride(0), ptr(x), x.stride(0), ptr(out), K, ptr(db), M, N, K, splits, ptr(part), _AMP[0],
                                      int(_AMP[1]), _h(g) | (_h(x) << 1), stream()))
@@ -206,6 +280,7 @@ class _Linear(torch.autograd.Function):
             xc = xc.float()
         ctx.save_for_backward(xc, wc)
         ctx.has_bias, ctx.has_addend = b is not None, addend is not None
+        ctx.b_ref = b.detach() if b is not None else None      # (a view of the parameter: only its address is used, see grad_sink)
         ctx.x_dtype = x.dtype
         ctx.addend_dtype = addend.dtype if addend is not None else None
         ctx.prec = _AMP     # the backward of this layer runs in the forward's precision
@@ -232,8 +307,14 @@ class _Linear(torch.autograd.Function):
                 if gx.dtype != ctx.x_dtype:
                     gx = gx.to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
-                r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
-                gw, gb = r if want_b else (r, None)
+                dst_w = _sink_dst(w)
+                dst_b = _sink_dst(ctx.b_ref) if want_b else None
+                if dst_w is not None and (not want_b or dst_b is not None):
+                    sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b,
+                             defer=(dst_w, w.stride(0), dst_b))              # summed into the flat gradient buffer at flush time
+                else:
+                    r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
+                    gw, gb = r if want_b else (r, None)
             elif want_b:
                 gb = colreduce(gy.float() if gy.dtype != torch.float32 else gy)
         ga = None
@@ -264,6 +345,7 @@ class _LnRelu(torch.autograd.Function):
         check(_L().mdx_op_ln_relu_fwd_t(ptr(xc), ptr(g), ptr(b), M, F, int(relu), ptr(y), ptr(stats), _h(xc) | (_h(y) << 1), stream()))
         ctx.save_for_backward(xc, g, b, stats)
         ctx.relu = int(relu)
+        ctx.gb_ref = (gamma.detach(), beta.detach())
         return y
 
     @staticmethod
@@ -274,11 +356,19 @@ class _LnRelu(torch.autograd.Function):
         if F not in (32, 64, 128, 256):
             gy = gy.float()
         dx = torch.empty_like(x)
-        dgb = torch.empty(2 * F, dtype=torch.float32, device=x.device)
         ws = torch.empty(_L().mdx_op_ln_relu_bwd_ws(M, F) // 4 + 1, dtype=torch.float32, device=x.device)
+        dst_g, dst_b = _sink_dst(ctx.gb_ref[0]), _sink_dst(ctx.gb_ref[1])
+        defer = dst_g is not None and dst_b is not None and M > 0 and ws.data_ptr() % 16 == 0
+        dgb = None if defer else torch.empty(2 * F, dtype=torch.float32, device=x.device)
         check(_L().mdx_op_ln_relu_bwd_t(ptr(gy), ptr(x), ptr(stats), ptr(g), ptr(b), M, F, ctx.relu, ptr(dx), ptr(dgb), ptr(ws),
                                         _h(gy) | (_h(x) << 1) | (_h(dx) << 2), stream()))
-        return (dx if dx.dtype == ctx.x_dtype else dx.to(ctx.x_dtype)), dgb[:F], dgb[F:], None
+        dx = dx if dx.dtype == ctx.x_dtype else dx.to(ctx.x_dtype)
+        if defer:       # [dgamma | dbeta] partial rows stay in ws: summed into the flat gradient buffer at flush time
+            rows = int(_L().mdx_op_ln_relu_bwd_rows(M))
+            _sink_record(ws.data_ptr(), dst_g, rows, 1, F, F, 2 * F, 0, ws)
+            _sink_record(ws.data_ptr() + 4 * F, dst_b, rows, 1, F, F, 2 * F, 0, ws)
+            return dx, None, None, None
+        return dx, dgb[:F], dgb[F:], None
 
 
 def ln_relu(x, gamma, beta, relu=True):

@@ -152,7 +152,9 @@ class Trainer:
         call, state on the device).  Returns the pre-clip global gradient norm of the UNSCALED gradient (0-d device tensor, like
         clip_grad_norm_ after scaler.unscale_; inf / nan on a skipped step)."""
         L = _lib.lib()
+        from . import train_ops
         (loss * self.state[0]).backward()
+        train_ops.flush_grad_sink()      # weight / LayerNorm gradients recorded during backward -> flat gradient buffer, one launch
         allreduce_mean_(self.flat.grad, self.group)
         f = self.flat
         max_norm = float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0
@@ -166,9 +168,12 @@ class Trainer:
         """zero_grad -> model.get_loss(*batch) -> backward_and_step.  Returns the loss dict plus 'grad_norm'."""
         from . import train_ops
         self.zero_grad()
-        with train_ops.precision(self.precision):
-            out = self.model.get_loss(*batch, **kw)
-        gn = self.backward_and_step(out['loss'])
+        # grad_sink: parameter gradients of the HIP layer operators bypass autograd's accumulation and are reduced straight into the
+        # flat gradient buffer by one launch (train_ops.flush_grad_sink)
+        with train_ops.grad_sink(self.flat):
+            with train_ops.precision(self.precision):
+                out = self.model.get_loss(*batch, **kw)
+            gn = self.backward_and_step(out['loss'])
         res = {k: v.detach() for k, v in out.items()}
         res['grad_norm'] = gn
         return res

@@ -265,3 +265,36 @@ def test_fp16_loss_scale_follows_grad_scaler():
     assert tr.steps == 4 and tr.skipped == 1
     for p, r in zip(ps, ref):
         assert U.maxdiff(p, r) <= 2e-6 * max(1.0, float(r.abs().max()))
+
+
+@pytest.mark.parametrize('precision', ['f32', 'fp16'])
+def test_deferred_gradient_sink_equals_autograd_accumulation(precision):
+    """Trainer.step routes every weight / bias / LayerNorm gradient of the HIP operators around autograd: the split partials are
+    summed into the flat gradient buffer by ONE launch (train_ops.grad_sink / mdx_op_reduce_deferred).  Same fixed summation order as
+    the per-layer reductions, so the flat gradient must equal what plain `loss.backward()` accumulates -- bit for bit in fp32."""
+    import copy
+    from moldiff_amd import train_ops
+    base = U.moldiff('MolDiff', DEV)
+    m = copy.deepcopy(base)
+    for mod in m.modules():
+        if hasattr(mod, '_eng'):
+            mod._eng, mod._eng_sig = None, None
+    tr = Trainer(m, lr=0.0, max_grad_norm=None, precision=precision, init_scale=1.0)   # lr 0: the weights stay put
+    batch = _tiny_batch(21, sizes=(7, 12, 5, 9, 16))
+    t = torch.tensor([5, 310, 640, 880, 999], device=DEV)
+    g = U.rng(22)
+    N, Eh = batch[1].shape[0], batch[3].shape[0]
+    noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))).to(DEV), u_node=U.t32(g.random((N, 8))).to(DEV),
+                 u_halfedge=U.t32(g.random((Eh, 6))).to(DEV))
+    tr.step(*batch, time_step=t, noise=noise)
+    sunk = tr.flat.grad.clone()
+    tr.zero_grad()
+    with train_ops.precision(precision):
+        loss = m.get_loss(*batch, time_step=t, noise=noise)['loss']
+    loss.backward()                                   # no sink: autograd's own accumulation
+    plain = tr.flat.grad.clone()
+    assert float(plain.abs().max()) > 0
+    if precision == 'f32':
+        assert torch.equal(sunk, plain)
+    else:
+        assert float((sunk - plain).abs().max()) <= 1e-6 * float(plain.abs().max())
