@@ -461,53 +461,68 @@ __global__ __launch_bounds__(256) void hgemm3_nt_kernel(const float* __restrict_
 // bf16 weight gradient: 64 rows of G and X per step are transposed into LDS ([column][row], so that the 8 consecutive
 // contraction values a lane needs are one 16-byte read); otherwise the structure of sgemm_tn_split_kernel.
 constexpr int HW_MC = 64;
-template <int HT>
+// Workgroup tile TNW (columns of G) x TKW (columns of X), 64 or 128 each (round 3: 128 where the layer is that wide -- four times the
+// MFMAs per staged byte and per barrier of the 64 x 64 tile, half the passes over G and X).  Wave w owns the (TNW/2) x (TKW/2) quadrant.
+template <int HT, int TNW, int TKW>
 __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg, const TP X, int ldx,
                                                               int M, int N, int K, int mper, float* __restrict__ P,
                                                               float* __restrict__ Pb) {
-  __shared__ __attribute__((aligned(16))) uint16_t Gt[W_T * H_LD];
-  __shared__ __attribute__((aligned(16))) uint16_t Xt[W_T * H_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Gt[TNW * H_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Xt[TKW * H_LD];
+  constexpr int IN = TNW / 32, IK = TKW / 32;      // 16 x 16 tiles per wave along n / k
+  constexpr int NBG = TNW / 64, NBX = TKW / 64;    // 4 x 4 staging blocks per thread and step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.y * W_T, k0 = blockIdx.x * W_T;
+  const int n0 = blockIdx.y * TNW, k0 = blockIdx.x * TKW;
   const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
-  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;
+  const int wn = (wave >> 1) * (TNW / 2), wk = (wave & 1) * (TKW / 2);
   const bool vecg = tp_vec_ok(G.p, G.h, ldg) && ((n0 & 3) == 0);
   const bool vecx = tp_vec_ok(X.p, X.h, ldx) && ((k0 & 3) == 0);
-  f32x4 acc[2][2];
-  acc_zero<2, 2>(acc);
-  const bool do_bias = Pb && blockIdx.x == 0 && tid < W_T;
+  f32x4 acc[IN][IK];
+  acc_zero<IN, IK>(acc);
+  const bool do_bias = Pb && blockIdx.x == 0 && tid < TNW;
   float bsum = 0.f;
-  // One 4x4 block per thread and step: rows 4 (tid >> 4) + j, columns 4 (tid & 15) ..+3 of the 64 x 64 tile of G and of X.  The block
-  // is transposed in registers and leaves as four 8-byte LDS stores per matrix ([column][4 consecutive rows]) -- round 2 wrote sixteen
-  // 2-byte stores per matrix and thread, which (with the conversions) bound this kernel, not its traffic.
-  f32x4 rg[4], rx[4];
+  // 4 x 4 blocks: block b of a W-wide tile = rows 4 (b / (W/4)) ..+3, columns 4 (b % (W/4)) ..+3; transposed in registers, they leave
+  // as four 8-byte LDS stores ([column][4 consecutive rows]) -- round 2 wrote sixteen 2-byte stores per block, which (with the
+  // conversions) bound this kernel, not its traffic.
+  f32x4 rg[NBG][4], rx[NBX][4];
   auto fetch = [&](int m0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = 4 * (tid >> 4) + j, c4 = (tid & 15) * 4;
-      const int gm = m0 + row;
-      rg[j] = load4_guard_t(G, (size_t)gm * ldg + n0, c4, N - n0, gm < mend, vecg);
-      rx[j] = load4_guard_t(X, (size_t)gm * ldx + k0, c4, K - k0, gm < mend, vecx);
+    for (int u = 0; u < NBG; ++u) {
+      const int bq = tid + 256 * u, r4 = 4 * (bq / (TNW / 4)), c4 = 4 * (bq % (TNW / 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rg[u][j] = load4_guard_t(G, (size_t)(m0 + r4 + j) * ldg + n0, c4, N - n0, m0 + r4 + j < mend, vecg);
+    }
+#pragma unroll
+    for (int u = 0; u < NBX; ++u) {
+      const int bq = tid + 256 * u, r4 = 4 * (bq / (TKW / 4)), c4 = 4 * (bq % (TKW / 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rx[u][j] = load4_guard_t(X, (size_t)(m0 + r4 + j) * ldx + k0, c4, K - k0, m0 + r4 + j < mend, vecx);
+    }
+  };
+  auto stage = [&](uint16_t* dst, const f32x4 (&r)[4], int r4, int c4) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint2 v = {(uint32_t)HalfT<HT>::cvt(r[0][e]) | ((uint32_t)HalfT<HT>::cvt(r[1][e]) << 16),
+                       (uint32_t)HalfT<HT>::cvt(r[2][e]) | ((uint32_t)HalfT<HT>::cvt(r[3][e]) << 16)};
+      *reinterpret_cast<uint2*>(dst + (c4 + e) * H_LD + r4) = v;
     }
   };
   if (mbeg < mend) fetch(mbeg);
   for (int m0 = mbeg; m0 < mend; m0 += HW_MC) {
-    {
-      const int r4 = 4 * (tid >> 4), c4 = (tid & 15) * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint2 vg = {(uint32_t)HalfT<HT>::cvt(rg[0][e]) | ((uint32_t)HalfT<HT>::cvt(rg[1][e]) << 16),
-                          (uint32_t)HalfT<HT>::cvt(rg[2][e]) | ((uint32_t)HalfT<HT>::cvt(rg[3][e]) << 16)};
-        const uint2 vx = {(uint32_t)HalfT<HT>::cvt(rx[0][e]) | ((uint32_t)HalfT<HT>::cvt(rx[1][e]) << 16),
-                          (uint32_t)HalfT<HT>::cvt(rx[2][e]) | ((uint32_t)HalfT<HT>::cvt(rx[3][e]) << 16)};
-        *reinterpret_cast<uint2*>(Gt + (c4 + e) * H_LD + r4) = vg;
-        *reinterpret_cast<uint2*>(Xt + (c4 + e) * H_LD + r4) = vx;
-      }
+    for (int u = 0; u < NBG; ++u) {
+      const int bq = tid + 256 * u;
+      stage(Gt, rg[u], 4 * (bq / (TNW / 4)), 4 * (bq % (TNW / 4)));
+    }
+#pragma unroll
+    for (int u = 0; u < NBX; ++u) {
+      const int bq = tid + 256 * u;
+      stage(Xt, rx[u], 4 * (bq / (TKW / 4)), 4 * (bq % (TKW / 4)));
     }
     __syncthreads();
     if (m0 + HW_MC < mend) fetch(m0 + HW_MC);
-    if (do_bias) {  // bias gradient partial: column tid of the staged (bf16-rounded) G tile, fp32 sum
+    if (do_bias) {  // bias gradient partial: column tid of the staged (half-rounded) G tile, fp32 sum
       float sacc = 0.f;
 #pragma unroll 8
       for (int r = 0; r < HW_MC; ++r) sacc += HalfT<HT>::back(Gt[tid * H_LD + r]);
@@ -515,25 +530,24 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg
     }
 #pragma unroll
     for (int ks = 0; ks < HW_MC / 32; ++ks) {
-      typename HalfT<HT>::v8 a[2], b[2];
+      typename HalfT<HT>::v8 a[IN], b[IK];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = lds_h8<HT>(Gt + (wn + 16 * i + c) * H_LD + 32 * ks + 8 * q);
-        b[i] = lds_h8<HT>(Xt + (wk + 16 * i + c) * H_LD + 32 * ks + 8 * q);
-      }
+      for (int i = 0; i < IN; ++i) a[i] = lds_h8<HT>(Gt + (wn + 16 * i + c) * H_LD + 32 * ks + 8 * q);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < IK; ++j) b[j] = lds_h8<HT>(Xt + (wk + 16 * j + c) * H_LD + 32 * ks + 8 * q);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = HalfT<HT>::mfma(a[i], b[j], acc[i][j]);
+      for (int i = 0; i < IN; ++i)
+#pragma unroll
+        for (int j = 0; j < IK; ++j) acc[i][j] = HalfT<HT>::mfma(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
   if (do_bias && n0 + tid < N) Pb[(size_t)blockIdx.z * N + n0 + tid] = bsum;
   float* out = P + (size_t)blockIdx.z * N * K;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IN; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < IK; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn + 16 * i + 4 * q + r, k = k0 + wk + 16 * j + c;
@@ -1702,14 +1716,24 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
   int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
   mper = (mper + HW_MC - 1) / HW_MC * HW_MC;
   const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
-  dim3 grid((unsigned)((K + W_T - 1) / W_T), (unsigned)((N + W_T - 1) / W_T), (unsigned)S);
+  static const int wide = [] { const char* e = getenv("MDX_WGRAD_TILE"); return e ? atoi(e) : 64; }();   // 128: wide tiles (A/B)
+  const int tnw = (wide >= 128 && N >= 128) ? 128 : 64, tkw = (wide >= 128 && K >= 128) ? 128 : 64;
+  dim3 grid((unsigned)((K + tkw - 1) / tkw), (unsigned)((N + tnw - 1) / tnw), (unsigned)S);
   const size_t nc = (size_t)(S + RED_CHUNK - 1) / RED_CHUNK;
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
-  if (half_kind == 1)
-    hipLaunchKernelGGL((hgemm_tn_split_kernel<0>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
-  else
-    hipLaunchKernelGGL((hgemm_tn_split_kernel<1>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb);
+#define MDX_XTN(HTv, A_, B_) \
+  hipLaunchKernelGGL((hgemm_tn_split_kernel<HTv, A_, B_>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb)
+#define MDX_XTN2(HTv)                                   \
+  do {                                                  \
+    if (tnw == 128 && tkw == 128) MDX_XTN(HTv, 128, 128); \
+    else if (tnw == 128) MDX_XTN(HTv, 128, 64);         \
+    else if (tkw == 128) MDX_XTN(HTv, 64, 128);         \
+    else MDX_XTN(HTv, 64, 64);                          \
+  } while (0)
+  if (half_kind == 1) MDX_XTN2(0); else MDX_XTN2(1);
+#undef MDX_XTN2
+#undef MDX_XTN
   const int rkind = round_out ? half_kind : 0;
   if (!dW) return launched();  // deferred reduction (mdx_op_reduce_deferred)
   if (db && S <= RED_CHUNK) {  // both reductions in one launch

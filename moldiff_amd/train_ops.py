@@ -259,7 +259,11 @@ def colreduce(x, y=None):
 
 def _splits_for(rows, n, k):
     # weight gradient = contraction over `rows`: enough row ranges to put ~1024 workgroups on the chip (flat between 512 and 4096) (each loops over its rows in 32-row steps, so many short loops hide the load latency better than few long ones), each >= 128 rows
-    tiles = ((n + 63) // 64) * ((k + 63) // 64)
+    import os
+    wide = os.environ.get('MDX_WGRAD_TILE') == '128' and os.environ.get('MDX_WGRAD_SPLITS') != 'old'
+    tn = 128 if (wide and _AMP is not None and n >= 128) else 64
+    tk = 128 if (wide and _AMP is not None and k >= 128) else 64
+    tiles = ((n + tn - 1) // tn) * ((k + tk - 1) // tk)
     return max(1, min(rows // 128, (1024 + tiles - 1) // tiles))
 
 
