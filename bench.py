@@ -452,6 +452,12 @@ def aggregation_line(N, E, prof, sizes=None, agg=True):
     sums the BondFFN-left rows through the by-right index list."""
     c, ms = prof['aggregate']
     avg = ms / max(c, 1)
+    if agg and c == 0:
+        return {'bound': 'hbm', 'kernel': 'none: the reduction left after edge kernel A\'s in-kernel segment sums (combine ~2.5 partial rows per '
+                                          'node, by-right BondFFN sum) runs inside node_kernel (its MID stage and a second set of workgroups); '
+                                          'MDX_NO_NODE_AGG=1 restores the separate seg_reduce_block2_kernel (16 us per launch). The '
+                                          'scatter/gather primitive by itself: see segment_sum', 'achieved': None, 'peak': PEAK_HBM,
+                'unit': 'GB/s', 'frac': None, 'launches': 0}
     if agg and sizes is not None:
         P = partial_rows(sizes)
         nbytes = P * (1024.0 + 256.0) + E * (256.0 + 4.0) + N * 1536.0

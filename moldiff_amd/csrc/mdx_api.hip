@@ -758,6 +758,7 @@ struct ProfSlot {
   long long count = 0;
 };
 bool use_agg();  // below
+bool use_node_agg();
 unsigned g_prof_mask = 0;  // bit k: kernel k is timed
 ProfSlot g_prof[PK_COUNT];
 
@@ -813,7 +814,7 @@ extern "C" const char* mdx_profile_kernel_name(int32_t kernel) {
     case PK_EDGE_A: return ro ? (use_agg() ? "edge_a2_kernel<15>" : "edge_a2_kernel<7>") : "edge_a_kernel";
     case PK_EDGE_B: return ro ? "edge_b2_kernel" : "edge_b_kernel";
     case PK_NODE: return "node_kernel";
-    case PK_AGGR: return ro && use_agg() ? "seg_reduce_block2_kernel" : "seg_reduce_block_kernel";
+    case PK_AGGR: return ro && use_node_agg() ? "" : ro && use_agg() ? "seg_reduce_block2_kernel" : "seg_reduce_block_kernel";   // "": fused into node_kernel
     case PK_EDGE_BWD: return ro ? "edge_bwd2_kernel" : "edge_bwd_kernel";
     default: return "";
   }
@@ -857,6 +858,14 @@ bool use_agg() {
   static const bool v = [] {
     const char* e = getenv("MDX_NO_AGG");
     return mdx_use_rowowner() && !(e && e[0] == '1');
+  }();
+  return v;
+}
+// the reduction that is left after the in-kernel sums runs inside the node kernel (MDX_NO_NODE_AGG=1: seg_reduce_block2_kernel, A/B)
+bool use_node_agg() {
+  static const bool v = [] {
+    const char* e = getenv("MDX_NO_NODE_AGG");
+    return use_agg() && !(e && e[0] == '1');
   }();
   return v;
 }
@@ -926,7 +935,10 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
       ProfScope ps(PK_EDGE_A, s);
       LCHK(launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0), NTcur), s));
     }
-    {
+    // round 3: with the in-kernel sums the reduction that is left (combine ~2.5 partial rows per node, the by-right BondFFN sum) is
+    // done by the node kernel itself for its 16 nodes -- one launch fewer per block (MDX_NO_NODE_AGG=1: separate kernel, A/B)
+    const bool node_agg = use_node_agg();
+    if (!(agg && node_agg)) {
       ProfScope ps(PK_AGGR, s);
       if (agg)
         launch_seg_reduce_block2(w.P, w.PR, w.FL, g->pbase, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
@@ -936,7 +948,15 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
     const bool pre = i + 1 < nb;
     const bool split = overlap && pre;
     int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (pre && !split ? ND_PRE : 0);
-    { ProfScope ps(PK_NODE, s); launch_node(make_nd(m, g, w, i, pre ? i + 1 : -1, nflags, NTcur, NTnxt), s); }
+    {
+      ProfScope ps(PK_NODE, s);
+      NodeArgs na = make_nd(m, g, w, i, pre ? i + 1 : -1, nflags, NTcur, NTnxt);
+      if (agg && node_agg) {
+        na.P = w.P; na.PR = w.PR; na.FL = w.FL; na.pbase = g->pbase; na.col_ptr = g->col_ptr; na.col_eids = g->col_eids;
+        na.SL = w.SL; na.SR = w.SR;
+      }
+      launch_node(na, s);
+    }
     if (split) HIPCHK(hipEventRecord(g->ev_mid, s));
     {
       ProfScope ps(PK_EDGE_B, s);

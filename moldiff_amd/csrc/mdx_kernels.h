@@ -153,6 +153,12 @@ struct NodeArgs {
   float *Lf, *Rf;        // (N,64)
   float* H;              // (N,256) out: node_net(x) for the next block
   float* NT;             // (N,960) out
+  // fused reduction (round 3, P != nullptr): the MID stage sums each node's partial rows of P itself instead of reading `aggr`, and the
+  // workgroup also writes its 16 nodes' SR (partial rows of PR) and SL (indexed sum over FL) -- what seg_reduce_block2_kernel did in a
+  // launch of its own between edge kernel A and this kernel
+  const float *P, *PR, *FL;
+  const int *pbase, *col_ptr, *col_eids;
+  float *SL, *SR;
   NodeW wmid, wpre;
 };
 #define ND_MID 1

@@ -27,6 +27,28 @@ constexpr int OFF_RED = OFF_S + TN * LD64;
 constexpr int OFF_RED2 = OFF_RED + 4 * TN;
 constexpr int NODE_LDS_FLOATS = OFF_RED2 + 4 * TN;
 
+// sum over the run ptr[v] .. ptr[v+1] of row i (or eids[i]) of src, this lane's four features: 4 independent loads in flight,
+// summed in CSR order
+template <int C>
+__device__ __forceinline__ f32x4 seg_sum(const float* __restrict__ src, const int* __restrict__ ptr, const int* __restrict__ eids,
+                                         int v, int c4) {
+  const int j0 = ptr[v], j1 = ptr[v + 1];
+  f32x4 s0 = splat4(0.f);
+  int j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    const int i0 = eids ? eids[j] : j, i1 = eids ? eids[j + 1] : j + 1, i2 = eids ? eids[j + 2] : j + 2,
+              i3 = eids ? eids[j + 3] : j + 3;
+    const f32x4 a0 = ldg4(src + (size_t)i0 * C + 4 * c4), a1 = ldg4(src + (size_t)i1 * C + 4 * c4),
+                a2 = ldg4(src + (size_t)i2 * C + 4 * c4), a3 = ldg4(src + (size_t)i3 * C + 4 * c4);
+    s0 = (((s0 + a0) + a1) + a2) + a3;
+  }
+  for (; j < j1; ++j) {
+    const int i0 = eids ? eids[j] : j;
+    s0 = s0 + ldg4(src + (size_t)i0 * C + 4 * c4);
+  }
+  return s0;
+}
+
 __device__ __forceinline__ void mlp_small(const MlpW& w, const float* Hn, float* S, float* red, float* red2, float* out,
                                           int v0, int N, int wave, int lane) {
   // 256 -> 64 (LN, ReLU) -> 64 ; each wave owns one 16-feature tile
@@ -56,8 +78,22 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
   float* red2 = smem + OFF_RED2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int v0 = blockIdx.x * TN;
   const int N = a.N;
+  const int ntile = (N + TN - 1) / TN;
+  if ((int)blockIdx.x >= ntile) {
+    // Fused reduction, second role: the workgroups past the tile range compute the BondFFN sums edge kernel B needs (SR from the
+    // partial rows of PR, SL through the by-right index list over FL), one (node, 4 features) per thread.  393 tiles leave 119 of the
+    // chip's 512 workgroup slots free, so these run beside the tiles' GEMM chains instead of in front of them (as a prologue of every
+    // tile they cost 10 us per launch).
+    static_assert(TN * 16 <= MDX_WG, "one thread per (node, float4) of a 64-wide row");
+    const int v = ((int)blockIdx.x - ntile) * TN + (tid >> 4), c4 = tid & 15;
+    if ((tid >> 4) < TN && v < N) {
+      stg4(a.SR + (size_t)v * 64 + 4 * c4, seg_sum<64>(a.PR, a.pbase, nullptr, v, c4));
+      stg4(a.SL + (size_t)v * 64 + 4 * c4, seg_sum<64>(a.FL, a.col_ptr, a.col_eids, v, c4));
+    }
+    return;
+  }
+  const int v0 = blockIdx.x * TN;
   const int ft0 = 4 * wave;
   bool valid[NT_];
   int vi[NT_];
@@ -75,7 +111,9 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
 #pragma unroll
       for (int et = 0; et < NT_; ++et) {
         const int f = 16 * (ft0 + ft) + 4 * q;
-        z[ft][et] = ldg4(a.NTin + (size_t)vi[et] * MDX_NTW + MDX_NT_C + f) + ldg4(a.aggr + (size_t)vi[et] * MDX_ND + f);
+        const f32x4 ag = a.P ? seg_sum<256>(a.P, a.pbase, nullptr, vi[et], 4 * (ft0 + ft) + q)   // the node's partial rows, in order
+                             : ldg4(a.aggr + (size_t)vi[et] * MDX_ND + f);
+        z[ft][et] = ldg4(a.NTin + (size_t)vi[et] * MDX_NTW + MDX_NT_C + f) + ag;
       }
     layernorm_relu<4, NT_, 4>(z, a.wmid.lng, a.wmid.lnb, ft0, red, red2, wave, lane, true);
     acc_to_lds<4, NT_>(z, X, LD256, 0, ft0, lane);
@@ -145,28 +183,6 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
 // Segmented sum.  C = 256: one wave per node (64 lanes x float4);  C = 64: 16 lanes per node;
 // C = 3: one lane per (node, component).  Sequential in CSR order => bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-// sum over the run ptr[v] .. ptr[v+1] of row i (or eids[i]) of src, this lane's four features: 4 independent loads in flight,
-// summed in CSR order
-template <int C>
-__device__ __forceinline__ f32x4 seg_sum(const float* __restrict__ src, const int* __restrict__ ptr, const int* __restrict__ eids,
-                                         int v, int c4) {
-  const int j0 = ptr[v], j1 = ptr[v + 1];
-  f32x4 s0 = splat4(0.f);
-  int j = j0;
-  for (; j + 4 <= j1; j += 4) {
-    const int i0 = eids ? eids[j] : j, i1 = eids ? eids[j + 1] : j + 1, i2 = eids ? eids[j + 2] : j + 2,
-              i3 = eids ? eids[j + 3] : j + 3;
-    const f32x4 a0 = ldg4(src + (size_t)i0 * C + 4 * c4), a1 = ldg4(src + (size_t)i1 * C + 4 * c4),
-                a2 = ldg4(src + (size_t)i2 * C + 4 * c4), a3 = ldg4(src + (size_t)i3 * C + 4 * c4);
-    s0 = (((s0 + a0) + a1) + a2) + a3;
-  }
-  for (; j < j1; ++j) {
-    const int i0 = eids ? eids[j] : j;
-    s0 = s0 + ldg4(src + (size_t)i0 * C + 4 * c4);
-  }
-  return s0;
-}
-
 template <int C>
 __global__ __launch_bounds__(MDX_WG) void seg_reduce_kernel(const float* __restrict__ src, const int* __restrict__ ptr,
                                                             const int* __restrict__ eids, float* __restrict__ out,
@@ -259,28 +275,51 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce3_kernel(const float* __rest
 // Embedding: h_node = [x_n W_n^T | smear(t)],  h_edge = [x_e W_e^T | smear(t)]  (internal edge order),
 // plus the per-row time arrays t/T used by the gates.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void embed_node_thread(const EmbedArgs& a, int i) {
-  if (i >= a.N * MDX_ND) return;
-  const int v = i / MDX_ND, f = i - v * MDX_ND;
-  const int64_t t = a.t[a.node_graph[v]];
-  float out;
-  if (f < a.nd_emb) {
-    float s = 0.f;
-    for (int k = 0; k < a.Kn; ++k) s = fmaf(a.xn[(size_t)v * a.Kn + k], a.Wn[f * a.Kn + k], s);
-    out = s;
-  } else {
-    const int k = f - a.nd_emb;
-    const float x = fminf(fmaxf((float)t, 0.f), (float)a.T) - a.toff[k];
-    out = expf(a.tcoef[k] * (x * x));
+// Node rows: 64 threads per atom, four features each (one 16-byte store per thread); the embedder's weight sits transposed in LDS
+// ([k][feature]); each feature is the same fmaf chain over k as the one-thread-per-element version, so the result has the same bits.
+constexpr int EMB_NODE_REPS = 4;
+__device__ __forceinline__ void embed_node_block(const EmbedArgs& a, int blk, float* WT) {
+  const int tid = threadIdx.x;
+  const int Kn = a.Kn;
+  for (int i = tid; i < Kn * MDX_ND; i += MDX_WG) {
+    const int k = i / MDX_ND, f = i - k * MDX_ND;
+    WT[i] = f < a.nd_emb ? a.Wn[f * Kn + k] : 0.f;
   }
-  a.Hn[i] = out;
-  if (f == 0) a.tn[v] = (float)t / (float)a.T;
+  __syncthreads();
+  const int f0 = 4 * (tid & 63);
+#pragma unroll 1
+  for (int rep = 0; rep < EMB_NODE_REPS; ++rep) {   // 4 atoms per pass: the staged weight serves 16 atoms per workgroup
+    const int v = (blk * EMB_NODE_REPS + rep) * (MDX_WG / 64) + (tid >> 6);
+    if (v >= a.N) return;
+    const int64_t t = a.t[a.node_graph[v]];
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = k < Kn ? a.xn[(size_t)v * Kn + k] : 0.f;
+    f32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = f0 + j;
+      if (f < a.nd_emb) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < Kn) s = fmaf(x[k], WT[k * MDX_ND + f], s);
+        out[j] = s;
+      } else {
+        const int k = f - a.nd_emb;
+        const float u = fminf(fmaxf((float)t, 0.f), (float)a.T) - a.toff[k];
+        out[j] = expf(a.tcoef[k] * (u * u));
+      }
+    }
+    stg4(a.Hn + (size_t)v * MDX_ND + f0, out);
+    if (f0 == 0) a.tn[v] = (float)t / (float)a.T;
+  }
 }
 
 // Edge rows: 16 threads per edge, four features each (one 16-byte store per thread; round 2's one-thread-per-element version
 // spent 95 us per step on 40 MB of output).  The embedder's weight sits transposed in LDS ([k][feature]); each feature is the
 // same fmaf chain over k as before, so the result has the same bits.
-constexpr int EMB_KMAX = 16;  // Ke (MolDiff: 6) or 2 Kn (bond predictor: 16)
+constexpr int EMB_KMAX = 16;  // Ke (MolDiff: 6) or 2 Kn (bond predictor: 16); the node embedder has Kn <= 8
 __device__ __forceinline__ void embed_edge_block(const EmbedArgs& a, int blk, float* WT) {
   const int tid = threadIdx.x;
   const int K = a.xe ? a.Ke : 2 * a.Kn;
@@ -324,11 +363,12 @@ __device__ __forceinline__ void embed_edge_block(const EmbedArgs& a, int blk, fl
   if (f0 == 0) a.te[e] = (float)t / (float)a.T;
 }
 
-// one launch for both: the first nb_node workgroups embed atoms (one thread per element), the rest edges
+// one launch for both: the first nb_node workgroups embed atoms (4 per workgroup), the rest edges (16 per workgroup)
 __global__ __launch_bounds__(MDX_WG) void embed_kernel(const EmbedArgs a, const int nb_node) {
-  __shared__ float WT[EMB_KMAX * MDX_ED];
+  __shared__ float WT[8 * MDX_ND];   // >= EMB_KMAX * MDX_ED
+  static_assert(8 * MDX_ND >= EMB_KMAX * MDX_ED, "one staging buffer for both embedders");
   if ((int)blockIdx.x < nb_node)
-    embed_node_thread(a, blockIdx.x * MDX_WG + threadIdx.x);
+    embed_node_block(a, blockIdx.x, WT);
   else
     embed_edge_block(a, blockIdx.x - nb_node, WT);
 }
@@ -337,15 +377,14 @@ __global__ __launch_bounds__(MDX_WG) void embed_kernel(const EmbedArgs a, const 
 // Decoders: node_decoder MLP(256 -> 256 -> Kn), edge_decoder MLP(64 -> 64 -> Ke) on He[h] + He[Eh + h].
 // Second layers are zero-padded to 16 outputs on the host.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MDX_WG, 2) void decode_node_kernel(const DecodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void decode_node_body(const DecodeArgs& a, float* smem, const int block) {
   float* Hn = smem + OFF_HN;
   float* X = smem + OFF_X;
   float* red = smem + OFF_RED;
   float* red2 = smem + OFF_RED2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int v0 = blockIdx.x * TN, N = a.N, ft0 = 4 * wave;
+  const int v0 = block * TN, N = a.N, ft0 = 4 * wave;
   for (int i = tid; i < TN * 64; i += MDX_WG) {
     const int row = i >> 6, c4 = i & 63;
     const int v = v0 + row;
@@ -379,15 +418,14 @@ constexpr int DOFF_B = DOFF_A + DTE * LD64;
 constexpr int DOFF_RED = DOFF_B + DTE * LD64;
 constexpr int DEC_EDGE_LDS_FLOATS = DOFF_RED + 8 * DTE;
 
-__global__ __launch_bounds__(MDX_WG, 2) void decode_edge_kernel(const DecodeArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[DEC_EDGE_LDS_FLOATS];
+__device__ __forceinline__ void decode_edge_body(const DecodeArgs& a, float* smem, const int block) {
   float* A = smem + DOFF_A;
   float* B = smem + DOFF_B;
   float* red = smem + DOFF_RED;
   float* red2 = red + 4 * DTE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int h0 = blockIdx.x * DTE, Eh = a.Eh;
+  const int h0 = block * DTE, Eh = a.Eh;
   for (int i = tid; i < DTE * 16; i += MDX_WG) {
     const int row = i >> 4, c4 = i & 15;
     const int h = h0 + row;
@@ -417,6 +455,17 @@ __global__ __launch_bounds__(MDX_WG, 2) void decode_edge_kernel(const DecodeArgs
   }
 }
 
+// Both decoders in ONE launch (round 3): the first nb_node workgroups decode atoms, the rest half-edges -- the two are independent and
+// each too small to fill the chip (16 + 20 us one after the other).
+constexpr int DEC_LDS_FLOATS = NODE_LDS_FLOATS > DEC_EDGE_LDS_FLOATS ? NODE_LDS_FLOATS : DEC_EDGE_LDS_FLOATS;
+__global__ __launch_bounds__(MDX_WG, 2) void decode_kernel(const DecodeArgs a, const int nb_node) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < nb_node)
+    decode_node_body(a, smem, blockIdx.x);
+  else
+    decode_edge_body(a, smem, blockIdx.x - nb_node);
+}
+
 }  // namespace
 
 void launch_node(const NodeArgs& a, hipStream_t s) {
@@ -426,7 +475,10 @@ void launch_node(const NodeArgs& a, hipStream_t s) {
     hipFuncSetAttribute((const void*)node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_FLOATS * 4);
     attr = true;
   }
-  hipLaunchKernelGGL(node_kernel, dim3((a.N + TN - 1) / TN), dim3(MDX_WG), NODE_LDS_FLOATS * 4, s, a);
+  const int ntile = (a.N + TN - 1) / TN;
+  // fused reduction: a second set of workgroups (ids >= ntile) computes the BondFFN sums beside the tiles
+  const int grid = ((a.flags & ND_MID) && a.P) ? 2 * ntile : ntile;
+  hipLaunchKernelGGL(node_kernel, dim3(grid), dim3(MDX_WG), NODE_LDS_FLOATS * 4, s, a);
 }
 
 void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float* out, const float* addend, int N, int C,
@@ -456,7 +508,8 @@ void launch_seg_reduce_block2(const float* P, const float* PR, const float* FL, 
 }
 
 void launch_embed(const EmbedArgs& a, hipStream_t s) {
-  const int nbn = a.N > 0 ? (int)(((size_t)a.N * MDX_ND + MDX_WG - 1) / MDX_WG) : 0;
+  const int apb = (MDX_WG / 64) * EMB_NODE_REPS;   // atoms per workgroup
+  const int nbn = a.N > 0 ? (int)((a.N + apb - 1) / apb) : 0;
   const int nbe = a.E > 0 ? (int)((a.E + MDX_WG / 16 - 1) / (MDX_WG / 16)) : 0;  // 16 edges per workgroup
   if (nbn + nbe > 0) hipLaunchKernelGGL(embed_kernel, dim3(nbn + nbe), dim3(MDX_WG), 0, s, a, nbn);
 }
@@ -464,11 +517,10 @@ void launch_embed(const EmbedArgs& a, hipStream_t s) {
 void launch_decode(const DecodeArgs& a, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)decode_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_FLOATS * 4);
+    hipFuncSetAttribute((const void*)decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
     attr = true;
   }
-  if (a.N > 0 && a.pred_node)
-    hipLaunchKernelGGL(decode_node_kernel, dim3((a.N + TN - 1) / TN), dim3(MDX_WG), NODE_LDS_FLOATS * 4, s, a);
-  if (a.Eh > 0 && a.pred_halfedge)
-    hipLaunchKernelGGL(decode_edge_kernel, dim3((a.Eh + DTE - 1) / DTE), dim3(MDX_WG), 0, s, a);
+  const int nbn = (a.N > 0 && a.pred_node) ? (a.N + TN - 1) / TN : 0;
+  const int nbe = (a.Eh > 0 && a.pred_halfedge) ? (a.Eh + DTE - 1) / DTE : 0;
+  if (nbn + nbe > 0) hipLaunchKernelGGL(decode_kernel, dim3(nbn + nbe), dim3(MDX_WG), DEC_LDS_FLOATS * 4, s, a, nbn);
 }
