@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -498,6 +499,7 @@ extern "C" int mdx_model_finalize(mdx_model_t m) {
 // ------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------
+constexpr int MDX_WQ_SETS = 4, MDX_WQ_SET_INTS = 512 * 32;  // mdx_row.h: MDX_WQ_PAIRS lines of MDX_WQ_STRIDE ints per set
 struct mdx_graph_s {
   int64_t N = 0, E = 0, Eh = 0, B = 0;
   int32_t* dev = nullptr;   // one int32 slab
@@ -512,6 +514,11 @@ struct mdx_graph_s {
   // run_blocks' side stream: the next block's per-node PRE stage runs beside edge kernel B of the current block (see there)
   hipStream_t side = nullptr;
   hipEvent_t ev_mid = nullptr, ev_pre = nullptr;
+  // work-queue counter sets of the persistent edge kernels, one per launching stream (wq_for)
+  int* wq = nullptr;
+  hipStream_t wq_stream[MDX_WQ_SETS] = {};
+  int wq_n = 0;
+  std::mutex wq_mu;
 };
 
 namespace {
@@ -652,6 +659,7 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   std::vector<int32_t> half_of_int(E);
   for (int64_t i = 0; i < E; ++i) half_of_int[i] = Eh > 0 ? (int32_t)(p.int2ref[i] % Eh) : 0;
   const size_t o_hoi = add(half_of_int);
+  const size_t o_wq = add(std::vector<int32_t>((size_t)MDX_WQ_SET_INTS * MDX_WQ_SETS, 0));  // work-queue counters: all zero between launches
   if (hipMalloc((void**)&g->dev, slab.size() * 4) != hipSuccess ||
       hipMemcpy(g->dev, slab.data(), slab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
     delete g;
@@ -672,6 +680,7 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   g->node_ptr = g->dev + o_np;
   g->he_ptr = g->dev + o_hp;
   g->units = g->dev + o_un; g->epo = g->dev + o_epo; g->pbase = g->dev + o_pb;
+  g->wq = g->dev + o_wq;
   *out = g;
   return MDX_OK;
 }
@@ -884,6 +893,32 @@ EdgeBArgs make_eb(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i
   return a;
 }
 
+// Work-queue counters of the persistent edge kernels (mdx_row.h, WorkQ): a set per stream that launches on this graph, because
+// launches that share a set must be ordered (the guidance chain runs on a second stream beside the denoiser).  A fifth stream
+// gets none: its launches use the static split.  MDX_STATIC_SPLIT=1 turns the queues off (A/B).
+int* wq_for(const mdx_graph_s* gc, hipStream_t s) {
+  static const bool off = [] {
+    const char* e = getenv("MDX_STATIC_SPLIT");
+    return e && e[0] == '1';
+  }();
+  mdx_graph_s* g = const_cast<mdx_graph_s*>(gc);
+  if (off || !g->wq) return nullptr;
+  std::lock_guard<std::mutex> lk(g->wq_mu);
+  for (int i = 0; i < g->wq_n; ++i)
+    if (g->wq_stream[i] == s) return g->wq + (size_t)MDX_WQ_SET_INTS * i;
+  if (g->wq_n == MDX_WQ_SETS) return nullptr;
+  g->wq_stream[g->wq_n] = s;
+  return g->wq + (size_t)MDX_WQ_SET_INTS * g->wq_n++;
+}
+int run_ea(const mdx_graph_s* g, EdgeAArgs a, hipStream_t s) {
+  a.wq = wq_for(g, s);
+  return launch_edge_a(a, s);
+}
+int run_eb(const mdx_graph_s* g, EdgeBArgs a, hipStream_t s) {
+  a.wq = wq_for(g, s);
+  return launch_edge_b(a, s);
+}
+
 NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int imid, int ipre, int flags,
                  const float* NTin = nullptr, float* NTout = nullptr) {
   NodeArgs a{};
@@ -933,7 +968,7 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
     const bool agg = use_agg();
     {
       ProfScope ps(PK_EDGE_A, s);
-      LCHK(launch_edge_a(make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0), NTcur), s));
+      LCHK(run_ea(g, make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0), NTcur), s));
     }
     // round 3: with the in-kernel sums the reduction that is left (combine ~2.5 partial rows per node, the by-right BondFFN sum) is
     // done by the node kernel itself for its 16 nodes -- one launch fewer per block (MDX_NO_NODE_AGG=1: separate kernel, A/B)
@@ -960,7 +995,7 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
     if (split) HIPCHK(hipEventRecord(g->ev_mid, s));
     {
       ProfScope ps(PK_EDGE_B, s);
-      LCHK(launch_edge_b(make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s));
+      LCHK(run_eb(g, make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s));
     }
     if (split) {
       HIPCHK(hipStreamWaitEvent(g->side, g->ev_mid, 0));
@@ -1018,7 +1053,7 @@ extern "C" int mdx_node_block(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   // NodeBlock's gate sees node_time[col]: per-edge time = node_time[right]
   gather_rows(node_time, g->right, w.te, g->E, 1, s);
   launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
-  LCHK(launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_NODE), s));
+  LCHK(run_ea(g, make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_NODE), s));
   launch_seg_reduce(w.M, g->row_ptr, nullptr, w.aggr, nullptr, (int)g->N, 256, s);
   NodeArgs na = make_nd(m, g, w, i, -1, ND_MID | ND_DELTA);
   na.dHn = out;
@@ -1038,10 +1073,10 @@ extern "C" int mdx_edge_block(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   gather_rows(h_bond, g->int2ref, w.HeA, g->E, 64, s);
   gather_rows(bond_time, g->int2ref, w.te, g->E, 1, s);
   launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
-  LCHK(launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s));
+  LCHK(run_ea(g, make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s));
   launch_seg_reduce(w.FL, g->col_ptr, g->col_eids, w.SL, nullptr, (int)g->N, 64, s);
   launch_seg_reduce(w.FR, g->row_ptr, nullptr, w.SR, nullptr, (int)g->N, 64, s);
-  LCHK(launch_edge_b(make_eb(m, g, w, i, nullptr, w.HeA, w.HeB, EB_EDGE | EB_DELTA), s));
+  LCHK(run_eb(g, make_eb(m, g, w, i, nullptr, w.HeA, w.HeB, EB_EDGE | EB_DELTA), s));
   gather_rows(w.HeB, g->ref2int, out, g->E, 64, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
@@ -1061,7 +1096,7 @@ extern "C" int mdx_bond_ffn(mdx_model_t m, mdx_graph_t g, int32_t i, int32_t sid
   gather_rows(bond_feat, g->int2ref, w.HeA, g->E, 64, s);
   gather_rows(time, g->int2ref, w.te, g->E, 1, s);
   launch_node(make_nd(m, g, w, -1, i, ND_PRE), s);
-  LCHK(launch_edge_a(make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s));
+  LCHK(run_ea(g, make_ea(m, g, w, i, nullptr, w.HeA, w.HeA, EA_FFN), s));
   gather_rows(side ? w.FR : w.FL, g->ref2int, out, g->E, 64, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
@@ -1086,7 +1121,7 @@ extern "C" int mdx_pos_update(mdx_model_t m, mdx_graph_t g, int32_t i, const flo
   EdgeBArgs eb = make_eb(m, g, w, i, nullptr, w.HeA, nullptr, EB_POS);
   eb.rel_in = w.M;
   eb.dist_in = w.FL;
-  LCHK(launch_edge_b(eb, s));
+  LCHK(run_eb(g, eb, s));
   launch_seg_reduce(w.Fe, g->row_ptr, nullptr, out, nullptr, (int)g->N, 3, s);
   HIPCHK(hipGetLastError());
   return MDX_OK;
@@ -1353,7 +1388,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
         ea_args.tHE = tp.b[i].HE;
         ea_args.M = tp.b[i].M;  // the backward reads the gated message back (with EA_AGG it is no longer the reduction's input)
       }
-      { ProfScope ps(PK_EDGE_A, s); LCHK(launch_edge_a(ea_args, s)); }
+      { ProfScope ps(PK_EDGE_A, s); LCHK(run_ea(g, ea_args, s)); }
     }
     if (use_agg())
       launch_seg_reduce_block2(wi.P, wi.PR, wi.FL, g->pbase, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
@@ -1364,11 +1399,11 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
     } else {  // no tape: fuse the next block's PRE into this node launch (tables double-buffered like run_blocks)
       float* NTn = (wr.NT == w.NT) ? w.NT2 : w.NT;
       launch_node(make_nd(m, g, wi, i, i + 1 < nb ? i + 1 : -1, ND_MID | (i + 1 < nb ? ND_PRE : 0), wi.NT, NTn), s);
-      LCHK(launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
+      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
       wr.NT = NTn;
       continue;
     }
-    LCHK(launch_edge_b(make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
+    LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
   }
   if (tape) {
     HIPCHK(hipMemcpyAsync(tp.HnF, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
@@ -1415,7 +1450,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     EdgeTailBwdArgs et{};
     et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
     et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
-    et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT;
+    et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT; et.wq = wq_for(g, s);
     if (mdx_use_rowowner()) launch_edge_tail_bwd2(et, s); else launch_edge_tail_bwd(et, s);
     launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
@@ -1423,7 +1458,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
-    eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i];
+    eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = et.wq;
     { ProfScope ps(PK_EDGE_BWD, s); if (mdx_use_rowowner()) launch_edge_bwd2(eb, s); else launch_edge_bwd(eb, s); }
     {
       SegBwdArgs sr{};

@@ -35,7 +35,7 @@ namespace {
 constexpr int BW_FO = 32 + 7 * 256, BW_FS = 640;
 constexpr int BW_CONST_FLOATS = BW_FO + 2 * BW_FS;
 
-__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBwdArgs a, const int nunits) {
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBwdArgs a, const int nunits, const WorkQ wq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
@@ -76,20 +76,35 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBw
   }
   __syncthreads();
 
-  const int nslots = gridDim.x * 4;
-  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  const int per = (nunits + nslots - 1) / nslots;
-  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
-  if (ubeg >= uend) return;
+  // units of this wave: drawn from its pair's counter (mdx_row.h, WorkQ), or a contiguous range of the static split
+  const bool dyn = wq.ctr != nullptr;
+  WorkPair wp{};
+  int ubeg, uend;
+  if (dyn) {
+    wp = wq_pair(wq);
+    uend = wp.end;
+    ubeg = wp.beg + wq_take(wq_request(wp.line, lane));
+  } else {
+    const int nslots = gridDim.x * 4;
+    const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int per = (nunits + nslots - 1) / nslots;
+    ubeg = slot0 * per;
+    uend = min(nunits, ubeg + per);
+  }
+  if (ubeg >= uend) {
+    if (dyn) wq_leave(wp, lane);
+    return;
+  }
 
   const float* wfirst = a.wt.s.WmT;
   WRing ring;
   ring_prime(ring, W(wfirst));
 
 #pragma unroll 1
-  for (int unit = ubeg; unit < uend; ++unit) {
+  for (int unit = ubeg;;) {
     int q = q0;
     asm volatile("" : "+v"(q));  // opaque per iteration (no address hoisting out of the persistent loop)
+    const int ureq = dyn ? wq_request(wp.line, lane) : 0;  // the next unit, consumed at the end of this one
     STAMPW(46);
     STAMPW(0);
     const RowTile t = load_tile(a.l, a.r, a.te, unit * ROWS, E, c);
@@ -313,29 +328,47 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBw
     }
     STAMPW(40);
     STAMPW(47);
+    unit = dyn ? wp.beg + wq_take(ureq) : unit + 1;
+    if (unit >= uend) break;
   }
+  if (dyn) wq_leave(wp, lane);
 }
 
 // EdgeBlock tail backward (reference models/graph.py:286-294 through autograd), row-owner: He'' = He' + out(relu(LN(u))),
 // u = self_ffn(He') + SL[l] + SR[r] + nfl[l] + nfr[r].  In: dL/dHe''.  Out: GU = dL/du (reduced per node by the caller) and
 // GHEP = dL/dHe'' + self_ffn^T dL/du (the part of dL/dHe' that does not go through the BondFFNs).  Same math as
 // mdx_bondpred.hip's edge_tail_bwd_kernel (tile design, MDX_TILE_KERNELS=1).
-__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_tail_bwd2_kernel(const EdgeTailBwdArgs a, const int nunits) {
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_tail_bwd2_kernel(const EdgeTailBwdArgs a, const int nunits, const WorkQ wq) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
   const unsigned lane_off = 16u * lane;
   auto W = [&](const float* p) { return make_ws(p, lane_off); };
-  const int nslots = gridDim.x * 4;
-  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  const int per = (nunits + nslots - 1) / nslots;
-  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
-  if (ubeg >= uend) return;
+  // units of this wave: drawn from its pair's counter (mdx_row.h, WorkQ), or a contiguous range of the static split
+  const bool dyn = wq.ctr != nullptr;
+  WorkPair wp{};
+  int ubeg, uend;
+  if (dyn) {
+    wp = wq_pair(wq);
+    uend = wp.end;
+    ubeg = wp.beg + wq_take(wq_request(wp.line, lane));
+  } else {
+    const int nslots = gridDim.x * 4;
+    const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int per = (nunits + nslots - 1) / nslots;
+    ubeg = slot0 * per;
+    uend = min(nunits, ubeg + per);
+  }
+  if (ubeg >= uend) {
+    if (dyn) wq_leave(wp, lane);
+    return;
+  }
   WRing ring;
   ring_prime(ring, W(a.w.s.Wself));
 #pragma unroll 1
-  for (int unit = ubeg; unit < uend; ++unit) {
+  for (int unit = ubeg;;) {
     int q = q0;
     asm volatile("" : "+v"(q));
+    const int ureq = dyn ? wq_request(wp.line, lane) : 0;
     const RowTile t = load_tile(a.l, a.r, a.te, unit * ROWS, a.E, c);
     f32x4 hep[4][RR], g[4][RR], u[4][RR];
     row_gather<4, RR>(hep, a.Hep, t.row, 64, q);
@@ -363,7 +396,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_tail_bwd2_kernel(const E
     row_store<4, RR>(gy, a.GU, t.row, t.valid, 64, q);
     rgemm<4, 4, RR>(g, gy, W(a.sWselfT), ring, W(a.w.s.Wself));
     row_store<4, RR>(g, a.GHEP, t.row, t.valid, 64, q);
+    unit = dyn ? wp.beg + wq_take(ureq) : unit + 1;
+    if (unit >= uend) break;
   }
+  if (dyn) wq_leave(wp, lane);
 }
 
 }  // namespace
@@ -371,7 +407,8 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_tail_bwd2_kernel(const E
 void launch_edge_tail_bwd2(const EdgeTailBwdArgs& a, hipStream_t s) {
   if (a.E <= 0) return;
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_tail_bwd2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS)), dim3(MDX_WG), 0, s, a, nunits);
+  const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
+  hipLaunchKernelGGL(edge_tail_bwd2_kernel, dim3(grid), dim3(MDX_WG), 0, s, a, nunits, make_workq(a.wq, nunits, grid, mdx_num_cus()));
 }
 
 void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s) {
@@ -383,5 +420,6 @@ void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s) {
     attr = true;
   }
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_bwd2_kernel, dim3(std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS)), dim3(MDX_WG), lds, s, a, nunits);
+  const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
+  hipLaunchKernelGGL(edge_bwd2_kernel, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, make_workq(a.wq, nunits, grid, mdx_num_cus()));
 }

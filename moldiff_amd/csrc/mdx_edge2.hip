@@ -89,6 +89,24 @@ inline EdgePlan make_plan(int nunits, int nslots, bool can_split) {
   return p;
 }
 
+// Work queue of the full kernel (mdx_row.h, WorkQ): a pair of workgroups hands out its units in order; the last few of them
+// (tail8 eighths of a unit per wave) are cut by section so that the waves, which arrive at the end of the list up to one unit
+// apart, finish close together: first the message-path halves of those units (0.72 of a unit), then their BondFFN halves
+// (0.31).  Largest pieces first: the spread at the end is bounded by the smallest piece.
+struct WorkQA {
+  WorkQ q;
+  int tail8;
+};
+// item i of a pair's list -> unit (relative to the XCD's first) and mode
+__device__ __forceinline__ int wq_item(int i, int cnt, int nt, int& mode) {
+  if (i < cnt) {
+    mode = i < cnt - nt ? 15 : 5;
+    return i;
+  }
+  mode = 10;
+  return i - nt;
+}
+
 // rows of the He tile + edge length of one unit: loaded one unit ahead by the persistent loop
 struct Prolog {
   RowTile t;
@@ -116,7 +134,7 @@ __device__ __forceinline__ void prolog_rows(Prolog& p, const EdgeAArgs& a, int q
 // FLAGS (EA_*) is a template parameter: with run-time section flags every section sits behind a branch and the values that
 // cross it (He', the tile, the weight ring) get spilled around the control flow.
 template <int FLAGS>
-__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArgs a, const EdgePlan plan) {
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArgs a, const EdgePlan plan, const WorkQA wq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
@@ -172,28 +190,43 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   __syncthreads();  // the only barrier of the kernel: constants visible to every wave
 
   // persistent wave; slots are XCD-contiguous so that neighbouring units (same molecule -> same node rows) share an L2
+  // (static split; with a work queue the wave draws its items from its pair's counter instead)
+  const bool dyn = wq.q.ctr != nullptr;
   const int slot = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  const int nitems = plan_items(plan, slot);
-  if (nitems <= 0) return;
+  WorkPair wp{};
+  int nitems, xcnt = 0, xnt = 0, mode, mode_next, unit;
+  if (dyn) {
+    wp = wq_pair(wq.q);
+    xcnt = wp.end - wp.beg;
+    xnt = min(xcnt, wp.waves * wq.tail8 >> 3);
+    const int i0 = wq_take(wq_request(wp.line, lane));
+    nitems = i0 < xcnt + xnt ? 1 : 0;
+    unit = wp.beg + wq_item(i0, xcnt, xnt, mode);
+  } else {
+    nitems = plan_items(plan, slot);
+    unit = plan_item(plan, slot, 0, mode);
+  }
+  if (nitems <= 0) {
+    if (dyn) wq_leave(wp, lane);
+    return;
+  }
 
   // first stream of a unit (the tail of every unit primes it again for the next one)
   const float* wfirst = do_emb ? a.w.s.Wemb : do_node ? a.w.s.Wg1e : a.w.s.ffn[0].Wbl;
   WRing ring;
   ring_prime(ring, W(wfirst));
   Prolog pr;
-  int mode, mode_next;
-  int unit = plan_item(plan, slot, 0, mode);
   pr.t = tile_of(unit);
   prolog_rows(pr, a, q0);
 
 #pragma unroll 1
-  for (int it = 0; it < nitems; ++it) {
+  for (int it = 0;; ++it) {
     int q = q0;
     asm volatile("" : "+v"(q));  // opaque per iteration: lane-dependent address parts stay next to their loads instead of
                                  // being hoisted out of the persistent loop into (spilled) registers
     const RowTile t = pr.t;
     const int ucnt = do_agg ? __builtin_amdgcn_readfirstlane(t.cnt) : 0;
-    const int unext = plan_item(plan, slot, min(it + 1, nitems - 1), mode_next);
+    const int ureq = dyn ? wq_request(wp.line, lane) : 0;  // the next item, consumed where its tile is requested
     const bool inode = do_node && (mode & 1), iffn = do_ffn && (mode & 10);
     const int sfirst = (mode & 2) ? 0 : 1, slast = (mode & 8) ? 1 : 0;  // BondFFN sections of this item (wave-uniform)
     STAMP(46);
@@ -291,6 +324,17 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
     }
     // next unit's tile: indices, He rows and edge lengths are requested here, ahead of the BondFFN sections, and arrive under
     // their GEMMs (requested inside a section they would sit behind that section's run-time condition: spills)
+    int unext;
+    bool more;
+    if (dyn) {
+      const int i = wq_take(ureq);
+      more = i < xcnt + xnt;
+      mode_next = mode;
+      unext = more ? wp.beg + wq_item(i, xcnt, xnt, mode_next) : unit;  // last item: the look-ahead repeats this unit's rows
+    } else {
+      more = it + 1 < nitems;
+      unext = plan_item(plan, slot, min(it + 1, nitems - 1), mode_next);
+    }
     pr.t = tile_of(unext);
     prolog_rows(pr, a, q);
 
@@ -353,9 +397,11 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
     }
     STAMP(40);
     STAMP(47);
+    if (!more) break;
     unit = unext;
     mode = mode_next;
   }
+  if (dyn) wq_leave(wp, lane);
 }
 
 }  // namespace
@@ -392,7 +438,17 @@ static void launch_a2(const EdgeAArgs& a, hipStream_t s) {
   constexpr bool all = (FLAGS & ~EA_AGG) == (EA_EMB | EA_NODE | EA_FFN);
   static const bool nosplit = getenv("MDX_NO_TAIL_SPLIT") != nullptr;
   const EdgePlan plan = make_plan(nunits, grid * 4, all && !nosplit);
-  hipLaunchKernelGGL(edge_a2_kernel<FLAGS>, dim3(grid), dim3(MDX_WG), lds, s, a, plan);
+  WorkQA wq{};
+  wq.q = make_workq(a.wq, nunits, grid, mdx_num_cus());
+  if (a.wq && all && !nosplit) {
+    // units cut by section at the end of each pair's list: MDX_WQ_TAIL eighths of a unit per wave (default 10)
+    static const int tail8 = [] {
+      const char* e = getenv("MDX_WQ_TAIL");
+      return e ? atoi(e) : 10;
+    }();
+    wq.tail8 = tail8;
+  }
+  hipLaunchKernelGGL(edge_a2_kernel<FLAGS>, dim3(grid), dim3(MDX_WG), lds, s, a, plan, wq);
 }
 
 int launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {

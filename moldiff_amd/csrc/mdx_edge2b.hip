@@ -33,7 +33,7 @@ struct PrologB {
 };
 
 template <int FLAGS>
-__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArgs a, const int nunits) {
+__global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArgs a, const int nunits, const WorkQ wq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q0 = lane >> 4;
@@ -57,11 +57,25 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArg
   }
   __syncthreads();
 
-  const int nslots = gridDim.x * 4;
-  const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  const int per = (nunits + nslots - 1) / nslots;
-  const int ubeg = slot0 * per, uend = min(nunits, ubeg + per);
-  if (ubeg >= uend) return;
+  // units of this wave: drawn from its pair's counter (mdx_row.h, WorkQ), or a contiguous range of the static split
+  const bool dyn = wq.ctr != nullptr;
+  WorkPair wp{};
+  int ubeg, uend;
+  if (dyn) {
+    wp = wq_pair(wq);
+    uend = wp.end;
+    ubeg = wp.beg + wq_take(wq_request(wp.line, lane));
+  } else {
+    const int nslots = gridDim.x * 4;
+    const int slot0 = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    const int per = (nunits + nslots - 1) / nslots;
+    ubeg = slot0 * per;
+    uend = min(nunits, ubeg + per);
+  }
+  if (ubeg >= uend) {
+    if (dyn) wq_leave(wp, lane);
+    return;
+  }
 
   const float* wfirst = do_edge ? a.w.s.Wself : a.w.s.Wbl;
   WRing ring;
@@ -71,11 +85,11 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArg
   row_gather<4, RR>(pr.he, a.Hep, pr.t.row, 64, q0);
 
 #pragma unroll 1
-  for (int unit = ubeg; unit < uend; ++unit) {
+  for (int unit = ubeg;;) {
     int q = q0;
     asm volatile("" : "+v"(q));  // see edge_a2_kernel
     const RowTile t = pr.t;
-    const int unext = min(unit + 1, uend - 1);
+    const int ureq = dyn ? wq_request(wp.line, lane) : 0;  // consumed where the next tile is loaded
     STAMPB(46);
     STAMPB(0);
     f32x4 he[4][RR];  // He' on entry, He'' after the EdgeBlock tail
@@ -134,6 +148,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArg
         }
       row_store<4, RR>(he, a.He_out, t.row, t.valid, 64, q);
     }
+    int unext = dyn ? wp.beg + wq_take(ureq) : unit + 1;
+    const bool more = unext < uend;
+    if (!more) unext = unit;  // last unit of the wave: the look-ahead loads repeat this unit's rows
     pr.t = load_tile(a.l, a.r, a.te, unext * ROWS, E, c);  // next unit's indices travel under the PosUpdate GEMMs
 
     // ---- PosUpdate: w = inter((W_bl He'') * (W_nl a)) * sigmoid(gate([He'' | a | t])), a = Lf[l] * Rf[r]; Fe = w rel / d / (d+1) ----
@@ -196,7 +213,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArg
     }
     STAMPB(40);
     STAMPB(47);
+    if (!more) break;
+    unit = unext;
   }
+  if (dyn) wq_leave(wp, lane);
 }
 
 }  // namespace
@@ -204,8 +224,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_b2_kernel(const EdgeBArg
 template <int FLAGS>
 static void launch_b2(const EdgeBArgs& a, hipStream_t s) {
   const int nunits = (a.E + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL(edge_b2_kernel<FLAGS>, dim3(std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS)), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a,
-                     nunits);
+  const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
+  hipLaunchKernelGGL(edge_b2_kernel<FLAGS>, dim3(grid), dim3(MDX_WG), EB_CONST_FLOATS * 4, s, a, nunits,
+                     make_workq(a.wq, nunits, grid, mdx_num_cus()));
 }
 
 int launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {

@@ -119,6 +119,7 @@ struct EdgeAArgs {
   int nunits;
   const int* epo;         // (E) partial-row offset of each edge's left node: row = epo[e] + unit
   float *P, *PR;
+  int* wq;                 // work-queue counters of the launch's stream (mdx_row.h WorkQ), nullptr = static unit split
   EdgeAW w;
 };
 #define EA_EMB 1
@@ -138,6 +139,7 @@ struct EdgeBArgs {
   float* He_out;           // (E,64): He' + EdgeBlock(...)  (or just EdgeBlock(...) when EB_DELTA)
   const float *Lf, *Rf;    // (N,64) PosUpdate per-node MLP outputs
   float* Fe;               // (E,3) per-edge force
+  int* wq;                 // work-queue counters of the launch's stream (mdx_row.h WorkQ), nullptr = static unit split
   EdgeBW w;
 };
 #define EB_EDGE 1   // run the EdgeBlock tail
@@ -198,6 +200,7 @@ struct EdgeTailBwdArgs {
   const float *Hep, *gHe;      // (E,64): He'_i (tape), dL/dHe_{i+1}
   const float *SL, *SR, *NT;   // tape
   float *GU, *GHEP;            // (E,64): dL/du ; gHe + self_ffn^T dL/du
+  int* wq;                     // see EdgeAArgs
   EdgeBW w;
   const float *WselfT, *WoutT;
   const float *sWselfT, *sWoutT;  // the same as stream packs (row-owner kernel, mdx_bwd2.hip)
@@ -219,6 +222,7 @@ struct EdgeBwdArgs {
   float *GH, *GGX;             // (E,256) per-edge gradient payloads reduced by right endpoint
   float* GNL[2];               // (E,128): left -> reduced by left, right -> by right
   float* GGXS[2];              // (E,32)
+  int* wq;                 // work-queue counters of the launch's stream (mdx_row.h WorkQ), nullptr = static unit split
   EdgeAW w;
   EdgeBwdW wt;
 };

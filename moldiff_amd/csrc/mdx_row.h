@@ -416,3 +416,70 @@ __device__ __forceinline__ const float* lds_put(float* base, const float* __rest
   if (4 * tid < N) sts4(base + OFF + 4 * tid, ldg4(src + 4 * tid));
   return base + OFF;
 }
+
+// ---- work distribution of the persistent kernels ------------------------------------------------------------------------
+// A CU holds two workgroups of a row-owner kernel, i.e. every SIMD two waves, and the instruction arbiter serves the OLDER wave
+// first: on the bench workload the units of the first-dispatched half of the grid (one workgroup per CU) take 140 / 46 / 195 us
+// (kernel A / B / guidance backward) while those of the second half take 213 / 70 / 315 us (tools/trace_edge2.py,
+// profiles/r3_trace_*).  With a static equal split the first half finishes after ~75 % of the kernel and idles while the second
+// runs on alone at well under the two-wave throughput.  So workgroup b of the first half and workgroup b + #CUs of the second
+// form a PAIR that shares one contiguous unit range and draws from it through a counter: whatever the two rates are, the pair
+// finishes together.  (One counter per XCD or per grid balances just as well on paper but measured 10-25 % SLOWER than the
+// static split: ~10^4 returning device-scope atomics per launch on 8 addresses serialise at the memory side, and a wave's
+// consecutive units end up on different CUs, away from the node rows its L1 already holds.  Per pair: 8 waves and ~40 atomics
+// per counter, each counter on its own 128-byte line, a pair walks ~40 consecutive units.)
+// One relaxed device-scope atomic per unit, requested one unit ahead so that its latency sits under the current unit.  Which
+// wave computes a unit does not enter any result (every unit owns its output rows).
+// The counters live in device memory that is all zero between launches: every wave counts itself out in the pair's second word
+// and the last one of the pair clears both for the next launch on the stream (launches sharing a set must be stream-ordered).
+constexpr int MDX_WQ_STRIDE = 32;  // ints per pair: [0] next unit (relative to the pair's first), [1] waves that have left
+struct WorkQ {
+  int* ctr;     // MDX_WQ_PAIRS lines of MDX_WQ_STRIDE ints; nullptr: static split
+  int npairs;   // min(grid, #CUs): workgroup b belongs to pair b % npairs
+  int nunits;
+};
+constexpr int MDX_WQ_PAIRS = 512;  // lines per counter set (>= #CUs)
+
+inline WorkQ make_workq(int* ctr, int nunits, int grid, int ncus) {
+  WorkQ w{};
+  static const int cap = [] {  // MDX_WQ_NPAIRS: fewer, larger sharing groups (A/B experiments)
+    const char* e = getenv("MDX_WQ_NPAIRS");
+    return e ? atoi(e) : MDX_WQ_PAIRS;
+  }();
+  w.npairs = std::max(1, std::min(std::min(grid, ncus), std::min(cap, MDX_WQ_PAIRS)));
+  w.ctr = ctr;
+  w.nunits = nunits;
+  return w;
+}
+
+// the pair's view: its counter line, its unit range [beg, end) and its wave count
+struct WorkPair {
+  int* line;
+  int beg, end, waves;
+};
+__device__ __forceinline__ WorkPair wq_pair(const WorkQ& w) {
+  const int p = blockIdx.x % w.npairs;
+  const int ri = xcd_remap(p, w.npairs);  // ranges in XCD order: neighbouring units (same molecule, same node rows) share an L2
+  const int q = w.nunits / w.npairs, r = w.nunits % w.npairs;
+  WorkPair k;
+  k.line = w.ctr + (size_t)MDX_WQ_STRIDE * p;
+  k.beg = ri * q + min(ri, r);
+  k.end = k.beg + q + (ri < r ? 1 : 0);
+  k.waves = (blockDim.x >> 6) * (gridDim.x / w.npairs + (p < (int)(gridDim.x % w.npairs) ? 1 : 0));
+  return k;
+}
+
+// request (a VGPR that is only read by wq_take: the atomic's latency stays off the critical path) and wave-uniform result
+__device__ __forceinline__ int wq_request(int* line, int lane) {
+  int v = 0;
+  if (lane == 0) v = __hip_atomic_fetch_add(line, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+__device__ __forceinline__ int wq_take(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void wq_leave(const WorkPair& k, int lane) {
+  if (lane == 0 && __hip_atomic_fetch_add(k.line + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k.waves - 1) {
+    __hip_atomic_store(k.line, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(k.line + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}

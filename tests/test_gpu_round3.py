@@ -254,3 +254,19 @@ def test_config1_whole_chain_agrees_with_the_oracle_statistically():
     # itself (mean / median).  "Within 1 %" needs trained weights (unavailable offline); what can be asserted with 64 chaotic
     # molecules is a two-sample test at molecule level: |difference of the per-molecule means| <= 3.5 standard errors.
     assert na > 0 and nb > 0 and abs(float(pa.mean()) - float(pb.mean())) <= 3.5 * se
+
+
+@pytest.mark.parametrize('sizes', [[5, 9, 4], [23] * 30 + [44, 4, 31, 17] * 5])
+def test_work_queue_results_equal_the_static_split(sizes):
+    """The persistent edge kernels draw their 16-edge units from per-workgroup-pair counters (csrc/mdx_row.h, WorkQ); which wave
+    computes a unit must not enter any result.  Three guided steps (denoiser, predictor forward with tape, backward) on two samplers
+    in a row, once with the queues and once with the static split (MDX_STATIC_SPLIT=1): identical bytes.  The small batch has fewer
+    units than waves, the larger one (~23,000 directed edges) fills the grid so that workgroups pair up."""
+    digests = []
+    for static in ('0', '1'):
+        env = dict(os.environ, MDX_STATIC_SPLIT=static)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'wq_probe.py'), ','.join(str(s) for s in sizes)], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        digests.append([ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith('WQ_DIGEST')])
+    assert len(digests[0]) == 1 and digests[0] == digests[1]

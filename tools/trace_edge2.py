@@ -107,6 +107,14 @@ def report(which, buf, nunits, phases, last, ROWS=ROWS):
     tr = buf.cpu().numpy().reshape(nunits, 48).astype(np.int64)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     np.save(os.path.join(ROOT, 'gpurun_out', f'trace_edge2_{which}.npy'), tr)
+    # units cut by section (kernel A's tail) are stamped by two waves on CUs whose shader clocks are not synchronised: keep the
+    # units whose stamps are monotonic, i.e. come from one wave
+    span = tr[:, last] - tr[:, 0]
+    ok = (span > 0) & (span < 10_000_000) & (tr[:, 47] > tr[:, 46])
+    for _, a, b, _ in phases:
+        ok &= tr[:, b] >= tr[:, a]
+    print(f'{int(ok.sum())} of {nunits} units traced by a single wave (the others are cut by section between two waves)')
+    tr = tr[ok]
     clk, wall0, wall1 = tr[:, :46], tr[:, 46], tr[:, 47]
     scale = (clk[:, last] - clk[:, 0]).sum() / ((wall1 - wall0).sum() / 100.0)   # shader clocks per us
     dur = (clk[:, last] - clk[:, 0]) / scale
