@@ -258,6 +258,10 @@ size_t mdx_op_linear_rows_ws(int64_t N, int64_t K);
 int mdx_op_linear_rows(const float* X, int64_t ldx, const float* W, int64_t ldw, int32_t transW, const float* bias, const float* addend,
                        int64_t ldd, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, float* pack_ws, void* stream);
 int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream);
+/* n contiguous row-major matrices transposed by one launch (every weight of a model once per optimisation step: the grad_input
+ * GEMMs read W^T).  desc (device): 4 int64 per matrix {src pointer, dst pointer, R, C}; dst receives (C,R) contiguous.
+ * max_tiles = the largest matrix's count of 32 x 32 tiles (sizes the launch). */
+int mdx_op_transpose_batch(const int64_t* desc, int64_t n, int64_t max_tiles, void* stream);
 int mdx_op_colreduce(const float* X, const float* Y, int64_t ld, int64_t M, int64_t N, float* out, float* ws, void* stream);
 /* y = relu?(LayerNorm(x) * gamma + beta) over F <= 1024 features (nn.LayerNorm eps 1e-5, models/common.py MLP);
  * stats (M,2) receives (mean, rstd) for the backward.  Backward: dx (M,F), dgb (2F) = [dgamma | dbeta]; ws =

@@ -555,6 +555,115 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg
       }
 }
 
+// float16 weight gradient on float16 CONTAINERS (half storage, round 3): P[z][n][k] = sum_{m in split z} G[m][n] * X[m][k].
+// The contraction runs over ROWS, so an MFMA operand (8 contraction values of one column per lane) is a column walk through a
+// row-major tile.  hgemm_tn_split_kernel transposes 4 x 4 blocks in registers while staging and is bound by those instructions
+// (a 256 x 256 gradient over 154,666 rows: 204 us against 32 us of operand streaming).  Here the tiles go global -> LDS as they
+// are (16-byte copies, no conversion, no shuffles) and the operands come out of ds_read_b64_tr_b16, gfx950's LDS transpose
+// read: within a group of 16 lanes, lane p supplies the address of 4 consecutive halves and lane i receives element i % 4 of the
+// loads of lanes 4 j + i / 4 (j = 0..3).  With lane p pointing at row 4 g + p / 4, columns 4 (p % 4).. of a 16-column subtile, lane i
+// of group g gets rows 4 g .. 4 g + 3 of column i -- two such reads (rows +0 and +16) are the 8 contraction values of a
+// 16x16x32 MFMA operand.  Which 8 of the 32 rows a lane group holds is irrelevant as long as both operands agree.
+// LDS image: [16-column subtile][64 rows][16 halves] (32-byte rows: the conflict-free layout for the transpose read; a group's
+// four rows are 128 bytes, the wave's four groups 512 consecutive bytes).  Staging lanes 8 s .. 8 s + 7 write 128 consecutive
+// bytes of subtile s (4 rows x 32 bytes): conflict-free 16-byte stores.
+typedef __fp16 fh4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 f16x4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x8_t lds_tr8(const _Float16* p) {
+  typedef __attribute__((address_space(3))) fh4_t* lds_ptr;
+  const fh4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_ptr)(p));
+  const fh4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_ptr)(p + 16 * 16));
+  return __builtin_shufflevector(__builtin_bit_cast(f16x4v_t, lo), __builtin_bit_cast(f16x4v_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int TNW, int TKW>
+__global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __restrict__ G, int ldg, const _Float16* __restrict__ X, int ldx,
+                                                           int M, int N, int K, int mper, float* __restrict__ P,
+                                                           float* __restrict__ Pb) {
+  constexpr int SUB = HW_MC * 16;                  // halves per 16-column subtile
+  __shared__ __attribute__((aligned(16))) _Float16 Gt[(TNW / 16) * SUB];
+  __shared__ __attribute__((aligned(16))) _Float16 Xt[(TKW / 16) * SUB];
+  constexpr int IN = TNW / 32, IK = TKW / 32;      // 16 x 16 tiles per wave along n / k
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * TNW, k0 = blockIdx.x * TKW;
+  const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
+  const int wn = (wave >> 1) * (TNW / 2), wk = (wave & 1) * (TKW / 2);
+  f32x4 acc[IN][IK];
+  acc_zero<IN, IK>(acc);
+  const bool do_bias = Pb && blockIdx.x == 0 && tid < TNW;
+  float bsum = 0.f;
+  // staging: W / 32 16-byte pieces per thread and tile; lanes 8 s .. 8 s + 7 of a wave fill 4 rows of subtile s
+  uint4 rg[TNW / 32], rx[TKW / 32];
+  auto piece = [&](int W, int u, int& row, int& col) {   // u-th piece of this thread in a W-column tile
+    const int nsub = W / 16, sel = lane >> 3;
+    row = 4 * (8 / nsub) * (wave + 4 * u) + 4 * (sel / nsub) + ((lane >> 1) & 3);
+    col = 16 * (sel % nsub) + 8 * (lane & 1);
+  };
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int u = 0; u < TNW / 32; ++u) {
+      int row, col;
+      piece(TNW, u, row, col);
+      rg[u] = m0 + row < mend ? *reinterpret_cast<const uint4*>(G + (size_t)(m0 + row) * ldg + n0 + col) : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < TKW / 32; ++u) {
+      int row, col;
+      piece(TKW, u, row, col);
+      rx[u] = m0 + row < mend ? *reinterpret_cast<const uint4*>(X + (size_t)(m0 + row) * ldx + k0 + col) : uint4{0, 0, 0, 0};
+    }
+  };
+  if (mbeg < mend) fetch(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += HW_MC) {
+#pragma unroll
+    for (int u = 0; u < TNW / 32; ++u) {
+      int row, col;
+      piece(TNW, u, row, col);
+      *reinterpret_cast<uint4*>(Gt + (col >> 4) * SUB + row * 16 + (col & 15)) = rg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < TKW / 32; ++u) {
+      int row, col;
+      piece(TKW, u, row, col);
+      *reinterpret_cast<uint4*>(Xt + (col >> 4) * SUB + row * 16 + (col & 15)) = rx[u];
+    }
+    __syncthreads();
+    if (m0 + HW_MC < mend) fetch(m0 + HW_MC);
+    if (do_bias) {  // bias gradient partial: column tid of the staged G tile, fp32 sum in row order
+      float sacc = 0.f;
+      const _Float16* col = Gt + (tid >> 4) * SUB + (tid & 15);
+#pragma unroll 8
+      for (int r = 0; r < HW_MC; ++r) sacc += (float)col[r * 16];
+      bsum += sacc;
+    }
+    const int lrow = (4 * q + (c >> 2)) * 16 + 4 * (c & 3);   // this lane's address inside a 32-row block of a subtile
+#pragma unroll
+    for (int ks = 0; ks < HW_MC / 32; ++ks) {
+      f16x8_t a[IN], b[IK];
+#pragma unroll
+      for (int i = 0; i < IN; ++i) a[i] = lds_tr8(Gt + ((wn >> 4) + i) * SUB + 32 * 16 * ks + lrow);
+#pragma unroll
+      for (int j = 0; j < IK; ++j) b[j] = lds_tr8(Xt + ((wk >> 4) + j) * SUB + 32 * 16 * ks + lrow);
+#pragma unroll
+      for (int i = 0; i < IN; ++i)
+#pragma unroll
+        for (int j = 0; j < IK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (do_bias && n0 + tid < N) Pb[(size_t)blockIdx.z * N + n0 + tid] = bsum;
+  float* out = P + (size_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < IN; ++i)
+#pragma unroll
+    for (int j = 0; j < IK; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + 16 * i + 4 * q + r, k = k0 + wk + 16 * j + c;
+        if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
+}
+
 // Weight gradient without transposes: P[z][n][k] = sum_{m in split z} G[m][n] * X[m][k]   (G = dY (M,N), X (M,K) row-major).
 // Workgroup tile 64 (n) x 64 (k); 32 rows of G and X are staged per step in their memory layout [m][cols] (coalesced
 // 16-byte loads); the MFMA contraction index runs over m, so operands are read from LDS as scalars down a column
@@ -1322,6 +1431,40 @@ extern "C" int mdx_op_sgemm_nt(const float* A, int64_t lda, const float* B, int6
   return launched();
 }
 
+// Every weight matrix of a model transposed by ONE launch (the dgrad GEMMs read W^T; a step used to spend ~240 small launches
+// on it).  desc: 4 int64 per matrix {src, dst, R, C} (row-major, contiguous); blockIdx.y = matrix, blockIdx.x = 32 x 32 tile.
+__global__ void transpose_batch_kernel(const long long* __restrict__ desc) {
+  __shared__ float t[32][33];
+  const long long* d = desc + 4 * (size_t)blockIdx.y;
+  const float* in = reinterpret_cast<const float*>(d[0]);
+  float* out = reinterpret_cast<float*>(d[1]);
+  const int R = (int)d[2], Cn = (int)d[3];
+  const int tc = (Cn + 31) / 32, tr = (R + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int tile = blockIdx.x; tile < tc * tr; tile += gridDim.x) {
+    const int r0 = (tile / tc) * 32, c0 = (tile % tc) * 32;
+    for (int j = ty; j < 32; j += 8) {
+      const int r = r0 + j, cc = c0 + tx;
+      t[j][tx] = (r < R && cc < Cn) ? in[(size_t)r * Cn + cc] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int cc = c0 + j, r = r0 + tx;
+      if (cc < Cn && r < R) out[(size_t)cc * R + r] = t[tx][j];
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int mdx_op_transpose_batch(const int64_t* desc, int64_t n, int64_t max_tiles, void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (!desc) return bad("transpose_batch: null descriptor table");
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(max_tiles, 64));
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(desc));
+  return launched();
+}
+
 extern "C" int mdx_op_transpose(const float* in, int64_t ldi, int64_t R, int64_t Cn, float* out, int64_t ldo, void* stream) {
   if (R <= 0 || Cn <= 0) return MDX_OK;
   if (!in || !out) return bad("transpose: null operand");
@@ -1722,6 +1865,21 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
   const size_t nc = (size_t)(S + RED_CHUNK - 1) / RED_CHUNK;
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
+  // float16 containers on both sides, tile-aligned widths: the transpose-read kernel (no conversion, no register transposes)
+  static const bool no_tr = [] { const char* e = getenv("MDX_WGRAD_TR"); return e && e[0] == '0'; }();
+  if (!no_tr && half_kind == 2 && G.h && X.h && N % 64 == 0 && K % 64 == 0 && ldg % 8 == 0 && ldx % 8 == 0 &&
+      (reinterpret_cast<uintptr_t>(Gv) & 15) == 0 && (reinterpret_cast<uintptr_t>(Xv) & 15) == 0) {
+    const int tn = N % 128 == 0 ? 128 : 64, tk = K % 128 == 0 ? 128 : 64;
+    dim3 gtr((unsigned)(K / tk), (unsigned)(N / tn), (unsigned)S);
+    const _Float16 *Gh = reinterpret_cast<const _Float16*>(Gv), *Xh = reinterpret_cast<const _Float16*>(Xv);
+#define MDX_XTR(A_, B_) \
+  hipLaunchKernelGGL((hgemm_tn_tr_kernel<A_, B_>), gtr, dim3(256), 0, s, Gh, (int)ldg, Xh, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb)
+    if (tn == 128 && tk == 128) MDX_XTR(128, 128);
+    else if (tn == 128) MDX_XTR(128, 64);
+    else if (tk == 128) MDX_XTR(64, 128);
+    else MDX_XTR(64, 64);
+#undef MDX_XTR
+  } else {
 #define MDX_XTN(HTv, A_, B_) \
   hipLaunchKernelGGL((hgemm_tn_split_kernel<HTv, A_, B_>), grid, dim3(256), 0, s, G, (int)ldg, X, (int)ldx, (int)M, (int)N, (int)K, mper, partial, pb)
 #define MDX_XTN2(HTv)                                   \
@@ -1734,6 +1892,7 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
   if (half_kind == 1) MDX_XTN2(0); else MDX_XTN2(1);
 #undef MDX_XTN2
 #undef MDX_XTN
+  }
   const int rkind = round_out ? half_kind : 0;
   if (!dW) return launched();  // deferred reduction (mdx_op_reduce_deferred)
   if (db && S <= RED_CHUNK) {  // both reductions in one launch

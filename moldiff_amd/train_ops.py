@@ -239,9 +239,72 @@ def sgemm_tn(g, x, splits, want_bias=False, defer=None):
     return (out, db) if want_bias else out
 
 
+# Transposed weights of the step (Trainer.refresh_transposed): the flat parameter buffer's 2-D tensors, each transposed at its own
+# offset of a second flat buffer by ONE launch per step.  A weight W (N,K) or a column slice W[:, a:b] of it (the hoisted layers
+# split their weights by columns, train_graph.py) then has its transpose as a VIEW: rows a..b of W^T (K,N).
+_WT = None
+
+
+class TransposedParams:
+    def __init__(self, flat):
+        self.base, self.nbytes = flat.data.data_ptr(), 4 * flat.numel
+        self.buf = torch.empty_like(flat.data)
+        self.entries, desc, off, tiles = {}, [], 0, 1
+        for p in flat.params:
+            n = p.numel()
+            if p.dim() == 2 and p.shape[0] % 4 == 0:     # W^T rows are R = shape[0] floats: 16-byte aligned rows for the GEMM loads
+                R, C = p.shape
+                self.entries[4 * off] = (off, R, C)
+                desc += [self.base + 4 * off, self.buf.data_ptr() + 4 * off, R, C]
+                tiles = max(tiles, ((R + 31) // 32) * ((C + 31) // 32))
+            off += n
+        self.offsets = sorted(self.entries)
+        self.n, self.tiles = len(desc) // 4, tiles
+        self.desc = torch.tensor(desc, dtype=torch.int64, device=flat.data.device)
+
+    def refresh(self):
+        check(_L().mdx_op_transpose_batch(ptr(self.desc), self.n, self.tiles, stream()))
+
+    def view(self, w):
+        """W^T of a parameter matrix or of a column slice of one, as a view into the transposed buffer; None if `w` is neither."""
+        import bisect
+        rel = w.data_ptr() - self.base
+        if rel < 0 or rel >= self.nbytes or w.dim() != 2 or w.dtype != torch.float32 or w.stride(1) != 1:
+            return None
+        i = bisect.bisect_right(self.offsets, rel) - 1
+        if i < 0:
+            return None
+        off, R, C = self.entries[self.offsets[i]]
+        col = rel // 4 - off
+        if col < 0 or col >= C or w.stride(0) != C or w.shape[0] != R or col + w.shape[1] > C:
+            return None
+        if (self.buf.data_ptr() + 4 * (off + col * R)) % 16:
+            return None                                 # the GEMM's 16-byte operand loads want aligned rows
+        return self.buf[off:off + R * C].view(C, R)[col:col + w.shape[1]]
+
+
+class transposed_params:
+    """context: the dgrad GEMMs inside take W^T from `tp` (a TransposedParams refreshed for the current weights)"""
+
+    def __init__(self, tp):
+        self.tp = tp
+
+    def __enter__(self):
+        global _WT
+        self.prev, _WT = _WT, self.tp
+
+    def __exit__(self, *a):
+        global _WT
+        _WT = self.prev
+
+
 def transpose(x, pad=4):
     """(R,C) -> contiguous-rows (C,R) view whose leading dimension is padded to a multiple of `pad` floats (so that the
     SGEMM's 16-byte loads stay aligned for any R)."""
+    if _WT is not None:
+        v = _WT.view(x)
+        if v is not None:
+            return v
     R, C = x.shape
     ld = (R + pad - 1) // pad * pad
     buf = torch.empty(C, ld, dtype=torch.float32, device=x.device)
@@ -257,9 +320,16 @@ def colreduce(x, y=None):
     return out
 
 
-def _splits_for(rows, n, k):
-    # weight gradient = contraction over `rows`: enough row ranges to put ~1024 workgroups on the chip (flat between 512 and 4096) (each loops over its rows in 32-row steps, so many short loops hide the load latency better than few long ones), each >= 128 rows
+def _splits_for(rows, n, k, half=False):
+    """row ranges of a weight gradient (the contraction runs over `rows`): enough of them to fill the chip with workgroups, each >= 128
+    rows.  fp32 / converting kernels: 64 x 64 tiles, ~1024 workgroups (flat between 512 and 4096; each loops over its rows in short
+    steps, many short loops hide the load latency better than few long ones).  float16 containers with tile-aligned widths take the
+    transpose-read kernel (csrc hgemm_tn_tr_kernel): 128-wide tiles where the layer allows, ~768 workgroups."""
     import os
+    if half and n % 64 == 0 and k % 64 == 0 and os.environ.get('MDX_WGRAD_TR') != '0':
+        tiles = (n // (128 if n % 128 == 0 else 64)) * (k // (128 if k % 128 == 0 else 64))
+        target = int(os.environ.get('MDX_WGRAD_TR_WGS', 768))
+        return max(1, min(rows // 128, (target + tiles - 1) // tiles))
     wide = os.environ.get('MDX_WGRAD_TILE') == '128' and os.environ.get('MDX_WGRAD_SPLITS') != 'old'
     tn = 128 if (wide and _AMP is not None and n >= 128) else 64
     tk = 128 if (wide and _AMP is not None and k >= 128) else 64
@@ -314,10 +384,10 @@ class _Linear(torch.autograd.Function):
                 dst_w = _sink_dst(w)
                 dst_b = _sink_dst(ctx.b_ref) if want_b else None
                 if dst_w is not None and (not want_b or dst_b is not None):
-                    sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b,
+                    sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1], _h(gy) and _h(x) and _AMP is not None and _AMP[0] == 2), want_bias=want_b,
                              defer=(dst_w, w.stride(0), dst_b))              # summed into the flat gradient buffer at flush time
                 else:
-                    r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1]), want_bias=want_b)
+                    r = sgemm_tn(gy, x, _splits_for(x.shape[0], gy.shape[1], x.shape[1], _h(gy) and _h(x) and _AMP is not None and _AMP[0] == 2), want_bias=want_b)
                     gw, gb = r if want_b else (r, None)
             elif want_b:
                 gb = colreduce(gy.float() if gy.dtype != torch.float32 else gy)

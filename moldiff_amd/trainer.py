@@ -116,6 +116,8 @@ class Trainer:
         self.growth = (float(growth_factor), float(backoff_factor), int(growth_interval)) if scaled else (1.0, 1.0, 0)
         self.state = torch.zeros(16, dtype=torch.float32, device=dev)     # mdx_op_amp_adamw: [scale, tracker, steps, skipped, norm2, ...]
         self.state[0] = float(init_scale if init_scale is not None else (65536.0 if scaled else 1.0))
+        # W^T of every weight for the grad_input GEMMs: one launch per step instead of one per layer (train_ops.TransposedParams)
+        self.wt = train_ops.TransposedParams(self.flat)
         self.sync_replicas()
 
     @property
@@ -170,7 +172,8 @@ class Trainer:
         self.zero_grad()
         # grad_sink: parameter gradients of the HIP layer operators bypass autograd's accumulation and are reduced straight into the
         # flat gradient buffer by one launch (train_ops.flush_grad_sink)
-        with train_ops.grad_sink(self.flat):
+        self.wt.refresh()
+        with train_ops.grad_sink(self.flat), train_ops.transposed_params(self.wt):
             with train_ops.precision(self.precision):
                 out = self.model.get_loss(*batch, **kw)
             gn = self.backward_and_step(out['loss'])

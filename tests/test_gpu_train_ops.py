@@ -238,3 +238,40 @@ def test_half_storage_operators_equal_their_fp32_container_twins():
         # identical arithmetic; the half container rounds the LayerNorm output and the residual sum one operator earlier
         assert float((p - q).abs().max()) <= 4e-3 * scale, (n, float((p - q).abs().max()), scale)
     assert half[0].shape == (M, 128)
+
+
+@pytest.mark.parametrize('M,N,K,splits', [(64, 64, 64, 1), (1003, 64, 128, 5), (20011, 128, 64, 37), (50021, 256, 256, 192),
+                                          (7001, 128, 256, 40), (333, 960, 256, 2)])
+def test_float16_weight_gradient_by_lds_transpose_reads(M, N, K, splits):
+    """dW = dY^T X on float16 containers (csrc hgemm_tn_tr_kernel: tiles copied to LDS as they are, MFMA operands fetched with the
+    LDS transpose read ds_read_b64_tr_b16) against the fp64 product of the same float16 values: the kernel multiplies exactly and
+    accumulates in fp32, so with the output rounding switched off (round_out = 0 through the C ABI) the error is fp32 summation
+    error.  Asymmetric random operands (a transposed or permuted operand would show), ragged row counts (the last 64-row step is
+    padded with zeros), the bias gradient from the same pass.  Through train_ops (autocast semantics: the gradient of a weight that
+    autocast cast to half is itself rounded to half) the result is that product rounded to float16, and equals the fp32-container
+    twin (the converting kernel) up to one rounding boundary."""
+    from moldiff_amd import _lib
+    g = U.rng(41)
+    dy = torch.from_numpy(g.standard_normal((M, N)).astype(np.float32)).to(DEV).half()
+    x = torch.from_numpy((g.standard_normal((M, K)) * np.linspace(0.5, 2.0, K)).astype(np.float32)).to(DEV).half()
+    ref = dy.double().t() @ x.double()
+    refb = dy.double().sum(0)
+    tol = 2e-6 * float((dy.double().abs().t() @ x.double().abs()).max())
+    # exact-product check: C ABI, float16 containers on both sides (dt = 3), float16 MFMA (half_kind = 2), no output rounding
+    L = _lib.lib()
+    part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=DEV)
+    dw = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    db = torch.empty(N, dtype=torch.float32, device=DEV)
+    _lib.check(L.mdx_op_xgemm_tn_t(_lib.ptr(dy), dy.stride(0), _lib.ptr(x), x.stride(0), _lib.ptr(dw), K, _lib.ptr(db), M, N, K, splits,
+                                   _lib.ptr(part), 2, 0, 3, _lib.stream()))
+    assert float((dw.double() - ref).abs().max()) <= tol
+    assert float((db.double() - refb).abs().max()) <= 2e-6 * float(dy.double().abs().sum(0).max())
+    # operator level: rounded to float16 like autocast's weight gradient; twin = fp32 containers (converting kernel)
+    with T.precision('fp16'):
+        dwh, dbh = T.sgemm_tn(dy, x, splits, want_bias=True)
+    with T.precision('fp16_f32store'):
+        dw2, db2 = T.sgemm_tn(dy.float(), x.float(), splits, want_bias=True)
+    half_ulp = ref.abs() * 2.0 ** -10 + 2.0 ** -24
+    assert bool(((dwh.double() - ref).abs() <= half_ulp + tol).all())
+    assert bool(((dwh.double() - dw2.double()).abs() <= half_ulp + tol).all())
+    assert torch.equal(dbh, db2)                       # same values, same row order

@@ -298,3 +298,35 @@ def test_deferred_gradient_sink_equals_autograd_accumulation(precision):
         assert torch.equal(sunk, plain)
     else:
         assert float((sunk - plain).abs().max()) <= 1e-6 * float(plain.abs().max())
+
+
+def test_batched_weight_transposes_are_exact_views():
+    """Trainer.step transposes every weight matrix once per step with ONE launch (mdx_op_transpose_batch) and the grad_input GEMMs
+    take W^T -- of a whole weight or of a column slice of one (the hoisted layers split their weights by columns) -- as a view into
+    that buffer.  Every view must equal the transpose torch computes, after a step that changed the weights."""
+    import copy
+    m = copy.deepcopy(U.moldiff('MolDiff', DEV))
+    tr = Trainer(m, lr=1e-3, precision='fp16', init_scale=1.0)
+    batch = _tiny_batch(31, sizes=(6, 11, 8))
+    tr.step(*batch)
+    tr.step(*batch)
+    tr.wt.refresh()
+    torch.cuda.synchronize()
+    assert tr.wt.n > 100
+    seen = 0
+    for p in tr.flat.params:
+        if p.dim() != 2:
+            continue
+        v = tr.wt.view(p.data)
+        if p.shape[0] % 4:
+            assert v is None
+            continue
+        if v is None:      # unaligned offset inside the flat buffer: the per-call transpose serves it
+            continue
+        assert torch.equal(v, p.data.t())
+        if p.shape[1] >= 16:
+            s = p.data[:, 4:12]
+            vs = tr.wt.view(s)
+            assert vs is not None and torch.equal(vs, s.t())
+        seen += 1
+    assert seen > 100
