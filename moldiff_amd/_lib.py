@@ -167,23 +167,43 @@ def check(rc):
 
 
 def _need_gpu(*tensors):
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError('moldiff_amd runs on a ROCm device only (got a CPU tensor); there is no CPU fallback. '
                                'The CPU oracle lives in oracle/ and is test infrastructure.')
         # the library allocates and launches on the CURRENT HIP device and stream: tensors of another device would be addressed
         # from the wrong GPU's queue (memory fault or unordered execution), so say so instead
-        if t is not None and t.device.index is not None and t.device.index != torch.cuda.current_device():
-            raise RuntimeError(f'tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: call '
-                               'torch.cuda.set_device(...) first (one process per GPU)')
+        if cur is None:
+            cur = _current_device()
+        if t.get_device() != cur:
+            raise RuntimeError(f'tensor on {t.device} but the current device is cuda:{cur}: call torch.cuda.set_device(...) first '
+                               '(one process per GPU)')
+
+
+# These two run a few thousand times per training step (every operator call): the raw torch._C entry points cost ~1 us, the
+# torch.cuda wrappers (lazy-init check, Stream object construction) ~9 us -- on a step of ~1,500 operators that was 15 % of the
+# host time of a step that the host, not the GPU, bounds.
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _current_device():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
 
 
 def ptr(t):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+    """address of a tensor's first element as a plain int (None = NULL): every pointer parameter is declared c_void_p in `argtypes`,
+    which converts both, and no c_void_p object is built per argument"""
+    return t.data_ptr() if t is not None else None
 
 
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def f32c(t):

@@ -371,6 +371,118 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const TP A, int lda, cons
   }
 }
 
+// Row-owner float16 Linear for MANY rows (round 3): Y (M,N) = X (M,K) W^T + bias + addend with X in a float16 container, K <= 256,
+// N <= 256.  hgemm_nt_kernel walks a short K loop per 128-row tile with two barriers per 64-wide chunk and one chunk in flight per
+// workgroup: at these widths it is bound by that latency chain (256 -> 256 on 154,666 rows: 84 us against 32 us of traffic).  Here
+// the whole weight sits in LDS as float16 for the lifetime of a persistent workgroup (8 waves, one per CU), every wave owns 16-row
+// tiles and needs nobody else: the MFMA's activation operand -- 8 consecutive k of one row per lane -- is a plain 16-byte global
+// load in exactly that layout (no LDS round trip, no barrier in the loop), the next tile's rows are requested before the current
+// tile's MFMAs, weight fragments are conflict-free 16-byte LDS reads.  X is read once, Y written once.
+// Same products, same accumulation order per output as hgemm_nt_kernel (k ascending in chunks of 32): bit-identical results.
+template <int KT, int FT, bool ROUND>
+__global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                             const float* __restrict__ bias, const TP addend, int ldd, const TPW C,
+                                                             int ldc, int M) {
+  constexpr int K = 32 * KT, N = 16 * FT, LD = K + 8;
+  extern __shared__ __attribute__((aligned(16))) uint16_t hr_smem[];
+  uint16_t* Ws = hr_smem;                                   // [N][LD] float16
+  float* bs = reinterpret_cast<float*>(hr_smem + N * LD);   // [N]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  for (int i = tid; i < N * (K / 4); i += blockDim.x) {
+    const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
+    const f32x4 v = load4_guard(B + (size_t)n * ldb, k4, K, true, vecb);
+    const uint2 h = {(uint32_t)HalfT<1>::cvt(v[0]) | ((uint32_t)HalfT<1>::cvt(v[1]) << 16),
+                     (uint32_t)HalfT<1>::cvt(v[2]) | ((uint32_t)HalfT<1>::cvt(v[3]) << 16)};
+    *reinterpret_cast<uint2*>(Ws + n * LD + k4) = h;
+  }
+  for (int i = tid; i < N; i += blockDim.x) bs[i] = bias ? bias[i] : 0.f;
+  __syncthreads();  // the only barrier
+
+  const int nw = gridDim.x * (blockDim.x >> 6), ntiles = (M + 15) >> 4;
+  int tile = blockIdx.x * (blockDim.x >> 6) + wave;
+  uint4 x[KT], xn[KT];
+  auto load = [&](uint4 (&d)[KT], int t) {
+    const int row = min(16 * t + c, M - 1);   // clamped: loads stay inside the matrix, stores are predicated
+    const _Float16* p = A + (size_t)row * lda + 8 * q;
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) d[ks] = *reinterpret_cast<const uint4*>(p + 32 * ks);
+  };
+  if (tile < ntiles) load(x, tile);
+  const bool veco = tp_vec_ok(C.p, C.h, ldc), vecd = addend.p && tp_vec_ok(addend.p, addend.h, ldd);
+  const uint16_t* wl = Ws + c * LD + 8 * q;
+#pragma unroll 1
+  for (; tile < ntiles; tile += nw) {
+    if (tile + nw < ntiles) load(xn, tile + nw);
+    f32x4 acc[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) acc[ft] = splat4(0.f);
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+      const f16x8_t b = __builtin_bit_cast(f16x8_t, x[ks]);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+        acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds_h8<1>(wl + 16 * ft * LD + 32 * ks), b, acc[ft], 0, 0, 0);
+      // one k-step's weight fragments at a time (hoisting all FT x KT reads ahead of the MFMAs spills; the other wave of the SIMD
+      // covers the read latency and the kernel streams rows, it does not live on the matrix pipe)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int row = 16 * tile + c;
+    if (row < M) {
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        const int col = 16 * ft + 4 * q;
+        f32x4 v = acc[ft] + lds4(bs + col);
+        if (addend.p) {
+          if (vecd) {
+            v = v + ld4(addend, (size_t)row * ldd + col);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += ld1(addend, (size_t)row * ldd + col + r);
+          }
+        }
+        if (ROUND) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = round_half<1>(v[r]);
+        }
+        const size_t o = (size_t)row * ldc + col;
+        if (veco) {
+          st4(C, o, v);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st1(C, o + r, v[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) x[ks] = xn[ks];
+  }
+}
+
+}  // namespace
+int mdx_num_cus();  // mdx_edge2.hip
+namespace {
+template <int KT, int FT, bool ROUND>
+static void launch_hgemm_nt_rows(const _Float16* A, int lda, const float* B, int ldb, const float* bias, const TP& addend, int ldd,
+                                 const TPW& C, int ldc, int M, hipStream_t s) {
+  constexpr int lds = 16 * FT * (32 * KT + 8) * 2 + 16 * FT * 4;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)hgemm_nt_rows_kernel<KT, FT, ROUND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  static int per_cu = 0;   // resident workgroups per CU: one where the weight fills the LDS, more for the narrow layers
+  if (!per_cu) {
+    int nb = 0;
+    per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hgemm_nt_rows_kernel<KT, FT, ROUND>, 512, lds) == hipSuccess && nb > 0)
+                 ? std::min(nb, 4) : 1;
+  }
+  const int ntiles = (M + 15) / 16;
+  const int grid = std::max(1, std::min(mdx_num_cus() * per_cu, (ntiles + 7) / 8));
+  hipLaunchKernelGGL((hgemm_nt_rows_kernel<KT, FT, ROUND>), dim3(grid), dim3(512), lds, s, A, lda, B, ldb, bias, addend, ldd, C, ldc, M);
+}
+
 #ifdef MDX_EXPERIMENTAL
 // EXPERIMENT (tools/ubench_bf16x3.py): fp32 product emulated with three-way bf16 splits x = h + m + l (each piece
 // exactly representable, so x is reproduced to 24 bits); six of the nine cross products (h*h, h*m, m*h, m*m, h*l, l*h;
@@ -1813,6 +1925,32 @@ extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, in
   const TPW C{Cv, (dt >> 2) & 1};
   if (half_kind != 1 && half_kind != 2) return bad("xgemm_nt: half_kind must be 1 (bfloat16) or 2 (float16)");
   hipStream_t s = (hipStream_t)stream;
+  // float16 rows, widths the row-owner kernel is instantiated for: whole weight resident in LDS, no K loop over barriers
+  static const bool no_rows = [] { const char* e = getenv("MDX_HGEMM_ROWS"); return e && e[0] == '0'; }();
+  const int kt = (int)(K / 32), ftn = (int)(N / 16);
+  if (!no_rows && half_kind == 2 && A.h && M >= 1024 && K % 32 == 0 && N % 16 == 0 && (kt == 1 || kt == 2 || kt == 4 || kt == 8) &&
+      (ftn == 2 || ftn == 4 || ftn == 8 || ftn == 16) && (lda & 7) == 0 && (reinterpret_cast<uintptr_t>(Av) & 15) == 0) {
+    const _Float16* Ah = reinterpret_cast<const _Float16*>(Av);
+#define MDX_HR(KTv, FTv)                                                                                                     \
+  do {                                                                                                                       \
+    if (round_out) launch_hgemm_nt_rows<KTv, FTv, true>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s); \
+    else launch_hgemm_nt_rows<KTv, FTv, false>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s);   \
+  } while (0)
+#define MDX_HR_F(KTv)                      \
+  do {                                     \
+    if (ftn == 2) MDX_HR(KTv, 2);          \
+    else if (ftn == 4) MDX_HR(KTv, 4);     \
+    else if (ftn == 8) MDX_HR(KTv, 8);     \
+    else MDX_HR(KTv, 16);                  \
+  } while (0)
+    if (kt == 1) MDX_HR_F(1);
+    else if (kt == 2) MDX_HR_F(2);
+    else if (kt == 4) MDX_HR_F(4);
+    else MDX_HR_F(8);
+#undef MDX_HR_F
+#undef MDX_HR
+    return launched();
+  }
   // measured on the training step (ms per step, fp16 mode): TN <= 64: 52.0, <= 128: 51.5, <= 256: 54.7 (one workgroup per CU) -- the
   // re-reads of A were L2 hits all along; the kernel is bound by its short K loop (one 64-wide chunk in flight per workgroup)
   static const int tn_max = [] { const char* e = getenv("MDX_HGEMM_TN_MAX"); return e ? atoi(e) : 128; }();

@@ -85,8 +85,48 @@ def extract(coef, t, batch, ndim=2):
     raise NotImplementedError('ndim > 3')
 
 
-def index_to_log_onehot(x, num_classes):
-    assert x.max().item() < num_classes, f'Error: {x.max().item()} >= {num_classes}'
+class deferred_class_checks:
+    """Context: the class-range assert of `index_to_log_onehot` (models/diffusion.py:54) reads a device value, i.e. makes the host
+    wait for the GPU -- twice at the top of every training step, where it keeps the host from issuing the step while the previous
+    one still runs.  Inside this context the maxima are kept on the device; `finish()` starts ONE asynchronous copy of them to pinned
+    memory and returns a callable that raises the same AssertionError when called later (Trainer.step: at the start of the next
+    step, when the copy has long completed)."""
+    _active = None
+
+    def __enter__(self):
+        self.prev, deferred_class_checks._active = deferred_class_checks._active, self
+        self.items = []
+        return self
+
+    def __exit__(self, *a):
+        deferred_class_checks._active = self.prev
+
+    def finish(self):
+        if not self.items:
+            return None
+        dev = torch.stack([m for m, _ in self.items])
+        limits = [k for _, k in self.items]
+        host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def verify():
+            ev.synchronize()
+            for m, k in zip(host.tolist(), limits):
+                assert m < k, f'Error: {m} >= {k}'
+        return verify
+
+
+def index_to_log_onehot(x, num_classes, checked=True):
+    """log of the one-hot encoding, clamped at log(1e-30).  checked: the reference's assert on the class range (models/diffusion.py:54),
+    a host-device synchronisation; callers whose ids come out of an argmax over `num_classes` logits pass False (in range by
+    construction), and inside `deferred_class_checks` the comparison is postponed instead of skipped."""
+    if checked and x.numel():
+        if deferred_class_checks._active is not None and x.is_cuda:
+            deferred_class_checks._active.items.append((x.max(), num_classes))
+        else:
+            assert x.max().item() < num_classes, f'Error: {x.max().item()} >= {num_classes}'
     return torch.log(F.one_hot(x, num_classes).float().clamp(min=1e-30))
 
 

@@ -154,6 +154,7 @@ def main(argv=None):
                 lr = torch.tensor([trainer.lr], dtype=torch.float64, device=device)
                 torch.distributed.broadcast(lr, 0)        # rank 0's scheduler decides the learning rate for everyone
                 trainer.lr = float(lr.item())
+    trainer.check_deferred()      # the last step's class-range check (Trainer.step postpones it by one step)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -102,6 +102,8 @@ class Trainer:
         if precision not in train_ops.KINDS:
             raise ValueError(precision)
         self.model, self.group = model, group
+        self._mods = None
+        self._deferred = None
         # 'f32' | 'bf16' (GEMM operands only) | 'fp16' (the reference's autocast + GradScaler semantics) | 'bf16_autocast'
         self.precision = precision
         self.flat = FlatParams(model)
@@ -142,7 +144,9 @@ class Trainer:
     def _stale(self):
         # the fused sampling/validation engine caches a packed copy of the weights keyed on tensor versions; the optimizer
         # kernel writes through raw pointers, so drop that cache explicitly
-        for mod in self.model.modules():
+        if self._mods is None:
+            self._mods = list(self.model.modules())     # (walking the module tree costs ~0.7 ms per step)
+        for mod in self._mods:
             if hasattr(mod, '_eng_sig'):
                 mod._eng_sig = None
 
@@ -172,14 +176,24 @@ class Trainer:
         self.zero_grad()
         # grad_sink: parameter gradients of the HIP layer operators bypass autograd's accumulation and are reduced straight into the
         # flat gradient buffer by one launch (train_ops.flush_grad_sink)
+        from .diffusion import deferred_class_checks
+        self.check_deferred()        # the previous step's class-range assert (its values reached the host long ago)
         self.wt.refresh()
         with train_ops.grad_sink(self.flat), train_ops.transposed_params(self.wt):
-            with train_ops.precision(self.precision):
+            with train_ops.precision(self.precision), deferred_class_checks() as chk:
                 out = self.model.get_loss(*batch, **kw)
+            self._deferred = chk.finish()
             gn = self.backward_and_step(out['loss'])
         res = {k: v.detach() for k, v in out.items()}
         res['grad_norm'] = gn
         return res
+
+    def check_deferred(self):
+        """Raise the class-range AssertionError (models/diffusion.py:54) of the last step's batch, if any: Trainer.step postpones that
+        check by one step instead of waiting for the GPU at the top of every step (diffusion.deferred_class_checks)."""
+        verify, self._deferred = self._deferred, None
+        if verify is not None:
+            verify()
 
     def state_dict(self):
         return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr, 'amp_state': self.state.clone()}

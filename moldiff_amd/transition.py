@@ -95,7 +95,7 @@ class GeneralCategoricalTransition(nn.Module):
     def q_v_posterior(self, log_v0, log_vt, t, batch, v0_prob):
         """log q(v_{t-1} | v_t, v_0); `log_v0` holds log-probabilities when `v0_prob` else is arg-maxed."""
         if not v0_prob:
-            log_v0 = index_to_log_onehot(log_v0.argmax(dim=-1), self.num_classes)
+            log_v0 = index_to_log_onehot(log_v0.argmax(dim=-1), self.num_classes, checked=False)
         if log_v0.ndim != 2:
             raise NotImplementedError('ndim not supported')
         return _lib.cat_posterior(self.q_mats, self.transpopse_q_onestep_mats, log_v0, log_vt, t, batch)
@@ -120,7 +120,7 @@ class GeneralCategoricalTransition(nn.Module):
     def q_vt_sample(self, log_v0, t, batch, u=None):
         logits = self.q_vt_pred(log_v0, t, batch)
         cls = _lib.gumbel_argmax(logits, torch.rand_like(logits) if u is None else u)
-        return cls, index_to_log_onehot(cls, self.num_classes)
+        return cls, index_to_log_onehot(cls, self.num_classes, checked=False)   # ids from an argmax over num_classes logits
 
     def add_noise(self, v, time_step, batch, u=None):
         log_v0 = index_to_log_onehot(v, self.num_classes)
@@ -144,4 +144,4 @@ class GeneralCategoricalTransition(nn.Module):
         if u is None:
             u = torch.rand_like(logits)
         cls = (logits - torch.log(-torch.log(u + 1e-30) + 1e-30)).argmax(dim=-1)
-        return cls, self.onehot_encode(cls), index_to_log_onehot(cls, self.num_classes) if n > 0 else torch.zeros(0, self.num_classes, device=dev)
+        return cls, self.onehot_encode(cls), index_to_log_onehot(cls, self.num_classes, checked=False) if n > 0 else torch.zeros(0, self.num_classes, device=dev)

@@ -275,3 +275,35 @@ def test_float16_weight_gradient_by_lds_transpose_reads(M, N, K, splits):
     assert bool(((dwh.double() - ref).abs() <= half_ulp + tol).all())
     assert bool(((dwh.double() - dw2.double()).abs() <= half_ulp + tol).all())
     assert torch.equal(dbh, db2)                       # same values, same row order
+
+
+@pytest.mark.parametrize('K,N', [(64, 64), (64, 256), (256, 256), (256, 64), (128, 128), (32, 64), (64, 32), (128, 256)])
+def test_float16_linear_on_many_rows_is_the_row_owner_kernel_and_equals_the_tile_kernel(K, N):
+    """Y = X W^T + b + addend on float16 rows: from 1,024 rows on (and K, N among the instantiated widths) the operator runs
+    csrc hgemm_nt_rows_kernel -- whole weight resident in LDS, every wave streams its own 16-row tiles straight from HBM into MFMA
+    operand registers -- below that hgemm_nt_kernel (LDS tiles, K loop).  Same products, same accumulation order: the rows of a big
+    call must equal, bit for bit, the same rows computed by a small call; and both the fp64 result rounded to float16.  Ragged row
+    count, float16 and fp32 addends, fp32 output container (keep32), and the grad_input form (W^T view, float16 result)."""
+    g = U.rng(43)
+    M = 5003
+    h = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32)).to(DEV).half()
+    x, w, b = h(M, K), (h(N, K) * 0.2).float(), h(N).float()
+    lo, hi = 2000, 2900
+    for addend, keep32 in ((None, False), (h(M, N), False), (h(M, N).float(), True)):
+        with T.precision('fp16'):
+            big = T.sgemm_nt(x, w, b, addend=addend, keep32=keep32)
+            small = T.sgemm_nt(x[lo:hi], w, b, addend=None if addend is None else addend[lo:hi], keep32=keep32)
+            tail = T.sgemm_nt(x[M - 7:], w, b, addend=None if addend is None else addend[M - 7:], keep32=keep32)
+        assert big.dtype == (torch.float32 if keep32 else torch.float16)
+        assert torch.equal(big[lo:hi], small) and torch.equal(big[M - 7:], tail)
+        ref = x.double() @ w.half().double().t() + b.double() + (0 if addend is None else addend.double())
+        err = (big.double() - ref).abs()
+        bound = (ref.abs() * 2.0 ** -10 + 1e-3) if not keep32 else (2e-6 * (x.double().abs() @ w.half().double().abs().t() + 1))
+        assert bool((err <= bound).all()), float((err - bound).max())
+    gy = h(M, N)
+    with T.precision('fp16'):
+        gx = T.sgemm_nt(gy, w.t().contiguous(), out_dtype=torch.float16)          # grad_input: (M,N) @ (N,K)
+        gxs = T.sgemm_nt(gy[lo:hi], w.t().contiguous(), out_dtype=torch.float16)
+    assert gx.dtype == torch.float16 and torch.equal(gx[lo:hi], gxs)
+    ref = gy.double() @ w.half().double()
+    assert bool(((gx.double() - ref).abs() <= ref.abs() * 2.0 ** -10 + 1e-3).all())

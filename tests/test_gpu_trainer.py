@@ -330,3 +330,31 @@ def test_batched_weight_transposes_are_exact_views():
             assert vs is not None and torch.equal(vs, s.t())
         seen += 1
     assert seen > 100
+
+
+def test_class_range_assert_is_postponed_not_dropped():
+    """models/diffusion.py:54 asserts the class range of the clean batch (a host-device synchronisation).  model.get_loss keeps it
+    where the reference has it; Trainer.step keeps the maxima on the device, copies them asynchronously and raises the same
+    AssertionError one call later (next step or check_deferred) -- the host no longer waits for the GPU at the top of every step.
+    (The out-of-range id itself is never fed to F.one_hot on the device here: that would be a device-side fault.)"""
+    import copy
+    from moldiff_amd import diffusion as D
+    m = copy.deepcopy(U.moldiff('MolDiff', DEV))
+    batch = list(_tiny_batch(33, sizes=(6, 9)))
+    bad = list(batch)
+    bad[0] = batch[0].clone()
+    bad[0][3] = 8                               # node classes are 0..7
+    with pytest.raises(AssertionError, match='8 >= 8'):
+        m.get_loss(*bad)                         # synchronous, before anything touches the id
+    tr = Trainer(m, lr=0.0, precision='f32')
+    tr.step(*batch)
+    assert tr._deferred is not None              # node and bond classes of the batch were recorded ...
+    tr.check_deferred()                          # ... and are in range
+    assert tr._deferred is None
+    with D.deferred_class_checks() as chk:       # the postponed form of the assert, on values that are out of range
+        ok = D.index_to_log_onehot(batch[0], 8)
+        chk.items.append((bad[0].max(), 8))
+    assert len(chk.items) == 2 and torch.equal(ok, D.index_to_log_onehot(batch[0], 8))
+    verify = chk.finish()
+    with pytest.raises(AssertionError, match='8 >= 8'):
+        verify()
