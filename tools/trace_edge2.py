@@ -21,7 +21,7 @@ import moldiff_amd._lib as _lib  # noqa: E402
 _lib.LIB_PATH = os.path.join(ROOT, 'moldiff_amd', 'libmoldiff_hip_trace2.so')
 import bench  # noqa: E402
 
-ROWS = 32
+ROWS = 16
 PH_A = [('tile load + He + smear', 0, 1, 0), ('emb GEMM 80->64', 1, 2, 2 * 80 * 64), ('He store + gate init gathers', 2, 3, 0),
         ('gate GEMM1 64->256', 3, 4, 2 * 64 * 256), ('LN + bias', 4, 5, 0), ('gate GEMM2 256->256', 5, 6, 2 * 256 * 256),
         ('sigmoid + park + bias', 6, 7, 0), ('en GEMM1 64->256', 7, 8, 2 * 64 * 256), ('LN + bias', 8, 9, 0),
@@ -90,7 +90,7 @@ def main():
         sm.step(i)
     torch.cuda.synchronize()
     E = 2 * ph['halfedge_index'].shape[1]
-    rows = int(os.environ.get('MDX_ROWS', 16 if which == 'a' else 32))   # rows per wave the kernel was built with
+    rows = int(os.environ.get('MDX_ROWS', 16))   # rows per wave the kernels are built with (MDX_RR = 1)
     nunits = (E + rows - 1) // rows
     if which == 'a' and os.environ.get('MDX_NO_AGG') != '1':   # EA_AGG: units are aligned to each molecule's first edge
         nunits = int(sum((int(n) * (int(n) - 1) + 15) // 16 for n in sizes))
