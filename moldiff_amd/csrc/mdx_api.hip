@@ -862,6 +862,14 @@ EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i
   return a;
 }
 
+// BondFFN intermediates on the guidance tape (round 3; MDX_BWD_RECOMPUTE=1: the backward recomputes them as in round 2, A/B)
+bool ffn_tape() {
+  static const bool v = [] {
+    const char* e = getenv("MDX_BWD_RECOMPUTE");
+    return mdx_use_rowowner() && !(e && e[0] == '1');
+  }();
+  return v;
+}
 // Edge kernel A with its segment sums fused (round 3) unless the tile kernels (no EA_AGG) or MDX_NO_AGG=1 (A/B) are selected
 bool use_agg() {
   static const bool v = [] {
@@ -1309,6 +1317,7 @@ namespace {
 struct TapeBlock {
   float *Hep, *Hn, *H, *NT, *aggr, *SL, *SR;
   float *SG, *HE, *M;  // (E,256): sigmoid(gate), edge_net output, gated message -- read back by edge_bwd instead of recomputed
+  float *BL[2], *H1[2], *O[2];  // BondFFN intermediates (EdgeAArgs tBL / tH1 / tO), left and right: 2.5 KB per edge and block
 };
 struct Tape {
   std::vector<TapeBlock> b;
@@ -1331,6 +1340,7 @@ size_t tape_layout(int64_t N, int64_t E, int nb, char* base, Tape* t) {
     k.Hep = take(e * 64); k.Hn = take(n * MDX_ND); k.H = take(n * MDX_ND); k.NT = take(n * MDX_NTW);
     k.aggr = take(n * MDX_ND); k.SL = take(n * 64); k.SR = take(n * 64);
     k.SG = take(e * MDX_ND); k.HE = take(e * MDX_ND); k.M = take(e * MDX_ND);
+    for (int sd = 0; sd < 2; ++sd) { k.BL[sd] = take(e * 128); k.H1[sd] = take(e * 128); k.O[sd] = take(e * 64); }
   }
   tp.HeF = take(e * 64); tp.HnF = take(n * MDX_ND); tp.te = take(e);
   tp.GGX = take(e * MDX_ND); tp.GNL0 = take(e * 128); tp.GNL1 = take(e * 128); tp.GGXS0 = take(e * 32);
@@ -1384,9 +1394,12 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
     {
       EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN | (use_agg() ? EA_AGG : 0), wi.NT);
       if (tape) {
+        if (mdx_use_rowowner()) ea_args.flags |= EA_TAPE;  // (a template flag of the row-owner kernel; the tile kernel tests the pointers)
         ea_args.tSG = tp.b[i].SG;
         ea_args.tHE = tp.b[i].HE;
         ea_args.M = tp.b[i].M;  // the backward reads the gated message back (with EA_AGG it is no longer the reduction's input)
+        if (ffn_tape())
+          for (int sd = 0; sd < 2; ++sd) { ea_args.tBL[sd] = tp.b[i].BL[sd]; ea_args.tH1[sd] = tp.b[i].H1[sd]; ea_args.tO[sd] = tp.b[i].O[sd]; }
       }
       { ProfScope ps(PK_EDGE_A, s); LCHK(run_ea(g, ea_args, s)); }
     }
@@ -1457,6 +1470,8 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
     eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
+    if (ffn_tape())
+      for (int sd = 0; sd < 2; ++sd) { eb.BL[sd] = k.BL[sd]; eb.H1[sd] = k.H1[sd]; eb.O[sd] = k.O[sd]; }
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = et.wq;
     { ProfScope ps(PK_EDGE_BWD, s); if (mdx_use_rowowner()) launch_edge_bwd2(eb, s); else launch_edge_bwd(eb, s); }

@@ -35,6 +35,9 @@ namespace {
 constexpr int BW_FO = 32 + 7 * 256, BW_FS = 640;
 constexpr int BW_CONST_FLOATS = BW_FO + 2 * BW_FS;
 
+// TAPE: the BondFFN intermediates (W_bl He', the inter MLP's pre-LayerNorm activation and its output) come from the forward's tape
+// instead of three recomputed GEMMs per side -- the kernel is bound by the matrix pipe, the 2.5 KB per edge of reads are not.
+template <bool TAPE>
 __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBwdArgs a, const int nunits, const WorkQ wq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBw
       }
       row_store<16, RR>(u, a.GGX, t.row, t.valid, MDX_ND, q);
       STAMPW(12);
-      rgemm<16, 4, RR>(ghe, u, W(a.wt.s.Wg1eT), ring, W(a.w.s.ffn[0].Wbl));
+      rgemm<16, 4, RR>(ghe, u, W(a.wt.s.Wg1eT), ring, W(TAPE ? a.w.s.ffn[0].Wg1e : a.w.s.ffn[0].Wbl));
       STAMPW(13);
     }
 
@@ -211,6 +214,40 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBw
       // section) instead of 128 registers
       f32x4 xh1[8][RR], o[4][RR], sgt[4][RR], xhg[2][RR];
       float rstd1[RR], rstdg[RR];
+      if constexpr (TAPE) {  // forward values from the tape; only the gate (two small GEMMs) is recomputed
+        {
+          f32x4 blv[8][RR], nlv[8][RR];
+          row_gather<8, RR>(blv, a.BL[s], t.row, 128, q);
+          row_gather<8, RR>(nlv, a.NT + nlcol, idx, MDX_NTW, q);
+#pragma unroll
+          for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+            for (int rt = 0; rt < RR; ++rt) {
+              park[(ft * RR + rt) * 64] = blv[ft][rt];
+              park[((8 + ft) * RR + rt) * 64] = nlv[ft][rt];
+            }
+        }
+        row_gather<8, RR>(xh1, a.H1[s], t.row, 128, q);
+        row_gather<4, RR>(o, a.O[s], t.row, 64, q);
+        row_gather<2, RR>(xhg, a.NT + gxcol, idx, MDX_NTW, q);
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+          const f32x4 b = lds4(f_bg1[s] + 16 * ft + 4 * q), wt = lds4(f_wtg1[s] + 16 * ft + 4 * q);
+#pragma unroll
+          for (int rt = 0; rt < RR; ++rt) xhg[ft][rt] = (b + xhg[ft][rt]) + splat4(t.tt[rt]) * wt;
+        }
+        rgemm<4, 2, RR>(xhg, hep, W(ws.Wg1e), ring, W(ws.Wg2));
+        row_ln_xhat<8, RR>(xh1, rstd1);
+        row_ln_xhat<2, RR>(xhg, rstdg);
+        f32x4 g1[2][RR];
+        row_ln_apply_relu<2, RR>(g1, xhg, f_gg[s], f_gb[s], q);
+        row_bias<4, RR>(sgt, f_bg2[s], q);
+        rgemm<2, 4, RR>(sgt, g1, W(ws.Wg2), ring, W(wts.Wi2T));
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+          for (int rt = 0; rt < RR; ++rt) sgt[ft][rt] = row_sigmoid4(sgt[ft][rt]);
+      } else
       {  // forward recompute
         f32x4 tmp[8][RR];
         {
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2_kernel(const EdgeBw
         rgemm<4, 2, RR>(ggg, sgt, W(wts.Wg2T), ring, W(wts.Wg1eT));
         row_ln_relu_bwd<2, RR>(ggg, xhg, rstdg, f_gg[s], f_gb[s], q);
         row_store<2, RR>(ggg, a.GGXS[s], t.row, t.valid, 32, q);
-        rgemm<2, 4, RR>(ghe, ggg, W(wts.Wg1eT), ring, W(s == 0 ? a.w.s.ffn[1].Wbl : a.wt.s.WembHT));
+        rgemm<2, 4, RR>(ghe, ggg, W(wts.Wg1eT), ring, W(s == 0 ? (TAPE ? a.w.s.ffn[1].Wg1e : a.w.s.ffn[1].Wbl) : a.wt.s.WembHT));
       }
     });
 
@@ -416,10 +453,15 @@ void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s) {
   static bool attr = false;
   constexpr int lds = (4 * PARK_FLOATS + BW_CONST_FLOATS) * 4;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)edge_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)edge_bwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)edge_bwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   const int nunits = (a.E + ROWS - 1) / ROWS;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
-  hipLaunchKernelGGL(edge_bwd2_kernel, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, make_workq(a.wq, nunits, grid, mdx_num_cus()));
+  const WorkQ wq = make_workq(a.wq, nunits, grid, mdx_num_cus());
+  if (a.BL[0] && a.BL[1] && a.H1[0] && a.H1[1] && a.O[0] && a.O[1])
+    hipLaunchKernelGGL(edge_bwd2_kernel<true>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
+  else
+    hipLaunchKernelGGL(edge_bwd2_kernel<false>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
 }

@@ -140,6 +140,11 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   const int c = lane & 15, q0 = lane >> 4;
   const int E = a.E;
   constexpr bool do_emb = FLAGS & EA_EMB, do_node = FLAGS & EA_NODE, do_ffn = FLAGS & EA_FFN, do_agg = FLAGS & EA_AGG;
+#ifdef MDX_TAPE_RUNTIME   // A/B build: tape stores behind their run-time pointer tests in every instantiation (round 2's form)
+  constexpr bool do_tape = true;
+#else
+  constexpr bool do_tape = FLAGS & EA_TAPE;  // the guidance tape's stores: compiled out of the denoiser's instantiation
+#endif
   static_assert(!do_agg || RR == 1, "the in-kernel segment sums are written for one 16-row tile per wave");
   // rows of unit u: graph-aligned units from the plan's table (EA_AGG) or 16 consecutive rows of the batch
   auto tile_of = [&](int u) {
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
 #pragma unroll
         for (int rt = 0; rt < RR; ++rt) {
           const f32x4 sg = row_sigmoid4(z[ft][rt]);
-          if (a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
+          if (do_tape && a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
           park[(ft * RR + rt) * 64] = sg;
         }
       // edge_net
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       STAMP(9);
       rgemm<16, 16, RR>(z, y, W(a.w.s.W2), ring, W(a.w.s.Wm));
       STAMP(10);
-      if (a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
+      if (do_tape && a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
       row_gather<16, RR>(y, a.H, t.ri, MDX_ND, q);
       mul_inplace<16>(z, y);
       // msg_net, gated
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       if constexpr (do_agg) {
         // aggr[v] = sum over v's edge run of M (models/graph.py:50), the part of it that lies in this unit: segmented sum over
         // the tile's rows, one partial row per left node stored by the last row of its segment
-        if (a.M) row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
+        if (do_tape && a.M) row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
         seg_sum_store<16>(y, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.P);
       } else {
         row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
@@ -360,6 +365,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         STAMP(14 + 10 * s);
         rgemm<4, 8, RR>(bl, hep, W(ws.Wbl), ring, W(ws.Wg1e));
         STAMP(15 + 10 * s);
+        if (do_tape && a.tBL[s]) row_store<8, RR>(bl, a.tBL[s], t.row, t.valid, 128, q);
         mul_inplace<8>(bl, nl);
         rgemm<4, 2, RR>(g1, hep, W(ws.Wg1e), ring, W(ws.W1));
         STAMP(16 + 10 * s);
@@ -369,12 +375,14 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         STAMP(17 + 10 * s);
         rgemm<8, 8, RR>(h, bl, W(ws.W1), ring, W(ws.W2));
         STAMP(18 + 10 * s);
+        if (do_tape && a.tH1[s]) row_store<8, RR>(h, a.tH1[s], t.row, t.valid, 128, q);
         row_layernorm<8, RR>(h, f_ig[s], f_ibe[s], q);
         f32x4 o[4][RR], g2[4][RR];
         row_bias<4, RR>(o, f_ib2[s], q);
         STAMP(19 + 10 * s);
         rgemm<8, 4, RR>(o, h, W(ws.W2), ring, W(ws.Wg2));
         STAMP(20 + 10 * s);
+        if (do_tape && a.tO[s]) row_store<4, RR>(o, a.tO[s], t.row, t.valid, 64, q);
         row_bias<4, RR>(g2, f_bg2[s], q);
         rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, W(s < slast ? a.w.s.ffn[1].Wbl : wfirst));
         STAMP(21 + 10 * s);
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
           for (int rt = 0; rt < RR; ++rt) o[ft][rt] = o[ft][rt] * row_sigmoid4(g2[ft][rt]);
         if constexpr (do_agg) {
           if (s == 1) {  // SR[v] = sum over v's edge run of bond_ffn_right (graph.py:283): same segments as M
-            if (a.F[1]) row_store<4, RR>(o, a.F[1], t.row, t.valid, 64, q);
+            if (do_tape && a.F[1]) row_store<4, RR>(o, a.F[1], t.row, t.valid, 64, q);
             seg_sum_store<4>(o, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.PR);
           } else {
             row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
@@ -435,7 +443,7 @@ static void launch_a2(const EdgeAArgs& a, hipStream_t s) {
   const int nunits = (FLAGS & EA_AGG) ? a.nunits : (a.E + ROWS - 1) / ROWS;
   if (nunits <= 0) return;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
-  constexpr bool all = (FLAGS & ~EA_AGG) == (EA_EMB | EA_NODE | EA_FFN);
+  constexpr bool all = (FLAGS & ~(EA_AGG | EA_TAPE)) == (EA_EMB | EA_NODE | EA_FFN);
   static const bool nosplit = getenv("MDX_NO_TAIL_SPLIT") != nullptr;
   const EdgePlan plan = make_plan(nunits, grid * 4, all && !nosplit);
   WorkQA wq{};
@@ -455,6 +463,8 @@ int launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
   if (a.E <= 0) return MDX_OK;
   switch (a.flags) {
     case EA_EMB | EA_NODE | EA_FFN | EA_AGG: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_AGG>(a, s); return MDX_OK;  // product path
+    case EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE>(a, s); return MDX_OK;  // + guidance tape
+    case EA_EMB | EA_NODE | EA_FFN | EA_TAPE: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_TAPE>(a, s); return MDX_OK;
     case EA_EMB | EA_NODE | EA_FFN: launch_a2<EA_EMB | EA_NODE | EA_FFN>(a, s); return MDX_OK;  // a block with M / FR in HBM
     case EA_NODE: launch_a2<EA_NODE>(a, s); return MDX_OK;                                    // NodeBlock.forward
     case EA_FFN: launch_a2<EA_FFN>(a, s); return MDX_OK;                                      // EdgeBlock.forward

@@ -109,6 +109,10 @@ struct EdgeAArgs {
   float* M;               // (E,256) gated messages
   float* F[2];            // (E,64) bond_ffn_left / right outputs
   float *tSG, *tHE;       // optional tape for the guidance backward: sigmoid(gate) and edge_net output, (E,256) each
+  // optional tape of the BondFFNs (round 3; both kernels are bound by the matrix pipe, not by HBM, so the backward reads these back
+  // instead of recomputing three GEMMs per side): W_bl He' (E,128), the inter MLP's pre-LayerNorm activation (E,128), its output
+  // before the gate (E,64); [0] = left, [1] = right
+  float *tBL[2], *tH1[2], *tO[2];
   // EA_AGG (round 3): the segment sums over each left node's edge run happen INSIDE the kernel.  Units are aligned to each
   // graph's first edge (units[2u] = first edge, units[2u+1] = rows of unit u, <= 16) so that where a node's run is cut -- and with
   // it the association of its sum -- depends on the molecule only, never on its position in the batch.  A unit emits one partial
@@ -126,6 +130,7 @@ struct EdgeAArgs {
 #define EA_NODE 2
 #define EA_FFN 4
 #define EA_AGG 8
+#define EA_TAPE 16  // the launch writes the guidance tape (tSG, tHE, M, F[1] with EA_AGG, tBL / tH1 / tO): a template flag of the row-owner kernel
 
 struct EdgeBArgs {
   int E, flags;
@@ -216,6 +221,7 @@ struct EdgeBwdArgs {
   const float *Hep, *GHEP;     // (E,64)
   const float *H, *NT;         // tape node tables of this block
   const float *SG, *HE, *M;    // tape (E,256): sigmoid(gate), edge_net output, gated message (M = msg_net(he*h[r]) * SG)
+  const float *BL[2], *H1[2], *O[2];  // BondFFN tape (EdgeAArgs tBL / tH1 / tO); all null = recompute (tile kernels, A/B)
   const float* GNT;            // (N,960) gradient table: C cols = dL/d(aggr), NFL cols = A_l, NFR cols = A_r
   float* gHe_out;              // (E,64) dL/dHe_i
   float* gdist;                // (E) accumulated over blocks

@@ -320,17 +320,28 @@ def colreduce(x, y=None):
     return out
 
 
+_ENV = None
+
+
+def _env():
+    """the A/B knobs of the weight-gradient split, read once (this runs for every weight gradient of every step)"""
+    global _ENV
+    if _ENV is None:
+        import os
+        _ENV = (os.environ.get('MDX_WGRAD_TR') != '0', int(os.environ.get('MDX_WGRAD_TR_WGS', 768)),
+                os.environ.get('MDX_WGRAD_TILE') == '128' and os.environ.get('MDX_WGRAD_SPLITS') != 'old')
+    return _ENV
+
+
 def _splits_for(rows, n, k, half=False):
     """row ranges of a weight gradient (the contraction runs over `rows`): enough of them to fill the chip with workgroups, each >= 128
     rows.  fp32 / converting kernels: 64 x 64 tiles, ~1024 workgroups (flat between 512 and 4096; each loops over its rows in short
     steps, many short loops hide the load latency better than few long ones).  float16 containers with tile-aligned widths take the
     transpose-read kernel (csrc hgemm_tn_tr_kernel): 128-wide tiles where the layer allows, ~768 workgroups."""
-    import os
-    if half and n % 64 == 0 and k % 64 == 0 and os.environ.get('MDX_WGRAD_TR') != '0':
+    use_tr, target, wide = _env()
+    if half and use_tr and n % 64 == 0 and k % 64 == 0:
         tiles = (n // (128 if n % 128 == 0 else 64)) * (k // (128 if k % 128 == 0 else 64))
-        target = int(os.environ.get('MDX_WGRAD_TR_WGS', 768))
         return max(1, min(rows // 128, (target + tiles - 1) // tiles))
-    wide = os.environ.get('MDX_WGRAD_TILE') == '128' and os.environ.get('MDX_WGRAD_SPLITS') != 'old'
     tn = 128 if (wide and _AMP is not None and n >= 128) else 64
     tk = 128 if (wide and _AMP is not None and k >= 128) else 64
     tiles = ((n + tn - 1) // tn) * ((k + tk - 1) // tk)
