@@ -44,7 +44,10 @@ T_STEPS = 1000
 _ORIG_ARGV = list(sys.argv[1:])   # main_train() strips --train before parsing; a self-launch must pass it on
 FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIGN.md / SURVEY Appendix D)
 FLOP_EDGE_B = 221184        # edge kernel B (EdgeBlock tail + PosUpdate): 2 * (2*64*64 + 2*64*256 + 2*64*32 + 256*256)
-FLOP_EDGE_BWD = 829440      # per directed edge per launch of the guidance backward's edge kernel
+# per directed edge per launch of the guidance backward's edge kernel: EXECUTED flops.  Round 3 reads the
+# BondFFN intermediates from the tape instead of recomputing W_bl (64->128), W_1 (128->128) and W_2 (128->64) on both sides:
+# 829,440 - 2 * 2 * (64*128 + 128*128 + 128*64) = 698,368 (MDX_BWD_RECOMPUTE=1 brings the recompute back)
+FLOP_EDGE_BWD = 829440 if os.environ.get('MDX_BWD_RECOMPUTE') == '1' else 698368
 EDGE_A_NAME = ('edge_a2_kernel<15> (row-owner fused per-edge MLP chain + in-kernel segment sums of its messages, 16 rows x 2 waves per '
                'SIMD, v_mfma_f32_16x16x4_f32)')
 EDGE_B_NAME = 'edge_b2_kernel (row-owner EdgeBlock tail + PosUpdate, v_mfma_f32_16x16x4_f32)'
@@ -679,7 +682,7 @@ def main():
             el3, prof3 = run_chain(sm3, 20, 3, barrier)
             ra = roofline_mfma('edge_a', EDGE_A_NAME + ' (14 launches per guided step: 6 denoiser + 8 predictor blocks)', FLOP_EDGE_A,
                                2 * sm3.Eh, prof3)
-            rb = roofline_mfma('edge_bwd', 'edge_bwd2_kernel (row-owner guidance backward: residual recompute + dgrad chain, '
+            rb = roofline_mfma('edge_bwd', 'edge_bwd2_kernel<true> (row-owner guidance backward: dgrad chain over the forward tape, first-layer recompute only, '
                                'v_mfma_f32_16x16x4_f32)', FLOP_EDGE_BWD, 2 * sm3.Eh, prof3)
             tot_a, tot_b = prof3['edge_a'][1], prof3['edge_bwd'][1]
             line2['roofline'] = dict(ra if tot_a >= tot_b else rb,

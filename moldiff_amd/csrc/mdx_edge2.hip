@@ -140,11 +140,11 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   const int c = lane & 15, q0 = lane >> 4;
   const int E = a.E;
   constexpr bool do_emb = FLAGS & EA_EMB, do_node = FLAGS & EA_NODE, do_ffn = FLAGS & EA_FFN, do_agg = FLAGS & EA_AGG;
-#ifdef MDX_TAPE_RUNTIME   // A/B build: tape stores behind their run-time pointer tests in every instantiation (round 2's form)
-  constexpr bool do_tape = true;
-#else
-  constexpr bool do_tape = FLAGS & EA_TAPE;  // the guidance tape's stores: compiled out of the denoiser's instantiation
-#endif
+  // The BondFFN tape stores (round 3) are compiled into the tape instantiation only.  Round 2's three stores (tSG, tHE, M / F[1]
+  // with EA_AGG) stay behind their run-time pointer tests in every instantiation: compiling them out of the denoiser's kernel as
+  // well measured 0.8 % SLOWER on the same box (6.94 vs 6.89 ms per step; the register allocation of a 256-VGPR kernel is that
+  // sensitive -- 5 spilled registers instead of 4), so the form that measured best ships.
+  constexpr bool do_tape = FLAGS & EA_TAPE;
   static_assert(!do_agg || RR == 1, "the in-kernel segment sums are written for one 16-row tile per wave");
   // rows of unit u: graph-aligned units from the plan's table (EA_AGG) or 16 consecutive rows of the batch
   auto tile_of = [&](int u) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
 #pragma unroll
         for (int rt = 0; rt < RR; ++rt) {
           const f32x4 sg = row_sigmoid4(z[ft][rt]);
-          if (do_tape && a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
+          if (a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
           park[(ft * RR + rt) * 64] = sg;
         }
       // edge_net
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       STAMP(9);
       rgemm<16, 16, RR>(z, y, W(a.w.s.W2), ring, W(a.w.s.Wm));
       STAMP(10);
-      if (do_tape && a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
+      if (a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
       row_gather<16, RR>(y, a.H, t.ri, MDX_ND, q);
       mul_inplace<16>(z, y);
       // msg_net, gated
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       if constexpr (do_agg) {
         // aggr[v] = sum over v's edge run of M (models/graph.py:50), the part of it that lies in this unit: segmented sum over
         // the tile's rows, one partial row per left node stored by the last row of its segment
-        if (do_tape && a.M) row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
+        if (a.M) row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
         seg_sum_store<16>(y, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.P);
       } else {
         row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
           for (int rt = 0; rt < RR; ++rt) o[ft][rt] = o[ft][rt] * row_sigmoid4(g2[ft][rt]);
         if constexpr (do_agg) {
           if (s == 1) {  // SR[v] = sum over v's edge run of bond_ffn_right (graph.py:283): same segments as M
-            if (do_tape && a.F[1]) row_store<4, RR>(o, a.F[1], t.row, t.valid, 64, q);
+            if (a.F[1]) row_store<4, RR>(o, a.F[1], t.row, t.valid, 64, q);
             seg_sum_store<4>(o, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.PR);
           } else {
             row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
