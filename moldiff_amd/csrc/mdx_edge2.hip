@@ -145,6 +145,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   // well measured 0.8 % SLOWER on the same box (6.94 vs 6.89 ms per step; the register allocation of a 256-VGPR kernel is that
   // sensitive -- 5 spilled registers instead of 4), so the form that measured best ships.
   constexpr bool do_tape = FLAGS & EA_TAPE;
+  // the tape is read back by the backward a whole forward later: streaming (non-temporal) stores keep its 870 MB per launch from
+  // displacing weights and node rows in L2 (guided step 26.00 -> 25.90 ms)
+  constexpr bool TAPE_NT = do_tape;
+#define TAPE_ST(p, v) do { if (TAPE_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else stg4(p, v); } while (0)
   static_assert(!do_agg || RR == 1, "the in-kernel segment sums are written for one 16-row tile per wave");
   // rows of unit u: graph-aligned units from the plan's table (EA_AGG) or 16 consecutive rows of the batch
   auto tile_of = [&](int u) {
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
 #pragma unroll
         for (int rt = 0; rt < RR; ++rt) {
           const f32x4 sg = row_sigmoid4(z[ft][rt]);
-          if (a.tSG && t.valid[rt]) stg4(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
+          if (a.tSG && t.valid[rt]) TAPE_ST(a.tSG + (size_t)t.row[rt] * MDX_ND + 16 * ft + 4 * q, sg);
           park[(ft * RR + rt) * 64] = sg;
         }
       // edge_net
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       STAMP(9);
       rgemm<16, 16, RR>(z, y, W(a.w.s.W2), ring, W(a.w.s.Wm));
       STAMP(10);
-      if (a.tHE) row_store<16, RR>(z, a.tHE, t.row, t.valid, MDX_ND, q);
+      if (a.tHE) row_store<16, RR, TAPE_NT>(z, a.tHE, t.row, t.valid, MDX_ND, q);
       row_gather<16, RR>(y, a.H, t.ri, MDX_ND, q);
       mul_inplace<16>(z, y);
       // msg_net, gated
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
       if constexpr (do_agg) {
         // aggr[v] = sum over v's edge run of M (models/graph.py:50), the part of it that lies in this unit: segmented sum over
         // the tile's rows, one partial row per left node stored by the last row of its segment
-        if (a.M) row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
+        if (a.M) row_store<16, RR, TAPE_NT>(y, a.M, t.row, t.valid, MDX_ND, q);  // the guidance tape keeps M itself
         seg_sum_store<16>(y, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.P);
       } else {
         row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         STAMP(14 + 10 * s);
         rgemm<4, 8, RR>(bl, hep, W(ws.Wbl), ring, W(ws.Wg1e));
         STAMP(15 + 10 * s);
-        if (do_tape && a.tBL[s]) row_store<8, RR>(bl, a.tBL[s], t.row, t.valid, 128, q);
+        if (do_tape && a.tBL[s]) row_store<8, RR, TAPE_NT>(bl, a.tBL[s], t.row, t.valid, 128, q);
         mul_inplace<8>(bl, nl);
         rgemm<4, 2, RR>(g1, hep, W(ws.Wg1e), ring, W(ws.W1));
         STAMP(16 + 10 * s);
@@ -375,14 +379,14 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         STAMP(17 + 10 * s);
         rgemm<8, 8, RR>(h, bl, W(ws.W1), ring, W(ws.W2));
         STAMP(18 + 10 * s);
-        if (do_tape && a.tH1[s]) row_store<8, RR>(h, a.tH1[s], t.row, t.valid, 128, q);
+        if (do_tape && a.tH1[s]) row_store<8, RR, TAPE_NT>(h, a.tH1[s], t.row, t.valid, 128, q);
         row_layernorm<8, RR>(h, f_ig[s], f_ibe[s], q);
         f32x4 o[4][RR], g2[4][RR];
         row_bias<4, RR>(o, f_ib2[s], q);
         STAMP(19 + 10 * s);
         rgemm<8, 4, RR>(o, h, W(ws.W2), ring, W(ws.Wg2));
         STAMP(20 + 10 * s);
-        if (do_tape && a.tO[s]) row_store<4, RR>(o, a.tO[s], t.row, t.valid, 64, q);
+        if (do_tape && a.tO[s]) row_store<4, RR, TAPE_NT>(o, a.tO[s], t.row, t.valid, 64, q);
         row_bias<4, RR>(g2, f_bg2[s], q);
         rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, W(s < slast ? a.w.s.ffn[1].Wbl : wfirst));
         STAMP(21 + 10 * s);

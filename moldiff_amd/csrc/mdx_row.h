@@ -149,7 +149,9 @@ __device__ __forceinline__ void row_gather(f32x4 (&v)[FT][R], const float* __res
   }
 }
 
-template <int FT, int R>
+// NT: non-temporal (streaming) stores -- for data nobody reads back soon (the guidance tape), so that it does not displace weights
+// and node rows in L2
+template <int FT, int R, bool NT = false>
 __device__ __forceinline__ void row_store(const f32x4 (&v)[FT][R], float* __restrict__ base, const int (&row)[R],
                                           const bool (&valid)[R], int ld, int q) {
 #pragma unroll
@@ -157,7 +159,10 @@ __device__ __forceinline__ void row_store(const f32x4 (&v)[FT][R], float* __rest
     if (!valid[rt] || (MDX_ABL & 1)) continue;
     float* p = base + (size_t)row[rt] * ld + 4 * q;
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) stg4(p + 16 * ft, v[ft][rt]);
+    for (int ft = 0; ft < FT; ++ft) {
+      if (NT) __builtin_nontemporal_store(v[ft][rt], reinterpret_cast<f32x4*>(p + 16 * ft));
+      else stg4(p + 16 * ft, v[ft][rt]);
+    }
   }
 }
 
