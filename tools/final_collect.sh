@@ -1,3 +1,9 @@
+#!/bin/bash
+# usage (GPU box, via gpurun): bash tools/final_collect.sh   -> gpurun_out/r3_* (copy into profiles/)
+# Everything profiles/r3_* holds, taken at one HEAD on one box: tools/collect_profiles.sh (bench line, rocprofv3 kernel statistics,
+# PMC passes, training benches), the batch sweep, the training GEMM micro-benchmark and host profile, the phase traces of the three
+# row-owner edge kernels (needs moldiff_amd/libmoldiff_hip_trace2.so: tools/build_variant.sh trace2 -DMDX_TRACE2 mdx_edge2.hip
+# mdx_edge2b.hip mdx_bwd2.hip) and the work-queue A/B.
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
