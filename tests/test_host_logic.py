@@ -314,3 +314,51 @@ def test_lazy_one_hot_dtype_changes_and_masks_take_the_dense_path():
     assert not isinstance(picked, LazyOneHot) and torch.equal(picked, dense[full_mask])
     row_mask = torch.tensor([[True, False, True], [False, True, False]])   # (2,3): frame x row -> still compact
     assert isinstance(t[row_mask], LazyOneHot) and torch.equal(t[row_mask].dense(), dense[row_mask])
+
+
+def test_transposed_parameter_views_cover_weights_and_their_column_slices():
+    """train_ops.TransposedParams (the grad_input GEMMs' W^T, transposed once per step on the device): pure bookkeeping over the flat
+    parameter buffer -- a weight or a column slice of one maps to a row range of its transpose, everything else to None (the
+    per-call transpose then serves it).  The device kernel is emulated with torch here."""
+    import torch
+    from moldiff_amd import train_ops as T
+    from moldiff_amd.trainer import FlatParams
+    net = torch.nn.Sequential(torch.nn.Linear(80, 64), torch.nn.LayerNorm(64), torch.nn.Linear(64, 256), torch.nn.Linear(256, 5))
+    flat = FlatParams(net)
+    tp = T.TransposedParams(flat)
+    assert tp.n == 2                                              # the (5, 256) weight has rows of 5 floats: not 16-byte aligned
+    for off, (o, R, C) in tp.entries.items():
+        tp.buf[o:o + R * C] = flat.data[o:o + R * C].view(R, C).t().contiguous().view(-1)
+    w = net[0].weight
+    assert torch.equal(tp.view(w), w.t()) and tp.view(w).stride() == (64, 1)
+    v = tp.view(w[:, 16:48])
+    assert v is not None and torch.equal(v, w[:, 16:48].t()) and v.data_ptr() == tp.view(w).data_ptr() + 4 * 16 * 64
+    assert tp.view(w[8:16]) is None                               # row slices are not views of the transpose
+    assert tp.view(net[3].weight) is None and tp.view(net[1].weight) is None and tp.view(torch.zeros(64, 80)) is None
+    w2 = net[2].weight                                            # its offset inside the flat buffer decides the alignment
+    v2 = tp.view(w2)
+    assert v2 is None or torch.equal(v2, w2.t())
+
+
+def test_class_range_assert_is_synchronous_on_the_api_and_recorded_inside_the_deferred_context():
+    import pytest
+    import torch
+    from moldiff_amd import diffusion as D
+    x = torch.tensor([0, 3, 7])
+    assert D.index_to_log_onehot(x, 8).shape == (3, 8)
+    with pytest.raises(AssertionError, match='8 >= 8'):
+        D.index_to_log_onehot(torch.tensor([1, 8]), 9 - 1)
+    with D.deferred_class_checks() as chk:      # CPU tensors are checked on the spot even inside the context (nothing to wait for)
+        with pytest.raises(AssertionError):
+            D.index_to_log_onehot(torch.tensor([9]), 8)
+        assert chk.items == [] and chk.finish() is None
+    assert D.index_to_log_onehot(torch.tensor([2]), 3, checked=False).argmax() == 2
+
+
+def test_weight_gradient_row_ranges():
+    from moldiff_amd import train_ops as T
+    assert T._splits_for(154666, 256, 256, True) == 192           # 4 tiles of 128 x 128 -> ~768 workgroups
+    assert T._splits_for(154666, 64, 64, True) == 768
+    assert T._splits_for(154666, 64, 80, True) == T._splits_for(154666, 64, 80, False)   # 80 is not tile-aligned: converting kernel
+    assert T._splits_for(300, 256, 256, True) == 2                # never fewer than 128 rows per range
+    assert T._splits_for(100, 64, 64) == 1
