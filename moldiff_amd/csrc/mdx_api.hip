@@ -1390,7 +1390,10 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
       Hep = k.Hep;
       HIPCHK(hipMemcpyAsync(k.Hn, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
     }
-    if (i == 0 || tape) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
+    // tape + in-kernel sums: the reduction, MID of this block and PRE of the next are ONE node launch as in run_blocks (round 3; it
+    // used to be three plus the reduction kernel), with every output pointed straight at its tape buffer
+    const bool fused_tape = tape && use_agg() && use_node_agg();
+    if (i == 0 || (tape && !fused_tape)) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
     {
       EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN | (use_agg() ? EA_AGG : 0), wi.NT);
       if (tape) {
@@ -1402,6 +1405,16 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
           for (int sd = 0; sd < 2; ++sd) { ea_args.tBL[sd] = tp.b[i].BL[sd]; ea_args.tH1[sd] = tp.b[i].H1[sd]; ea_args.tO[sd] = tp.b[i].O[sd]; }
       }
       { ProfScope ps(PK_EDGE_A, s); LCHK(run_ea(g, ea_args, s)); }
+    }
+    if (fused_tape) {
+      const bool pre = i + 1 < nb;
+      NodeArgs na = make_nd(m, g, wi, i, pre ? i + 1 : -1, ND_MID | (pre ? ND_PRE : 0), wi.NT, pre ? tp.b[i + 1].NT : nullptr);
+      if (pre) na.H = tp.b[i + 1].H;
+      na.P = wi.P; na.PR = wi.PR; na.FL = wi.FL; na.pbase = g->pbase; na.col_ptr = g->col_ptr; na.col_eids = g->col_eids;
+      na.SL = wi.SL; na.SR = wi.SR; na.aggr_out = wi.aggr;
+      launch_node(na, s);
+      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
+      continue;
     }
     if (use_agg())
       launch_seg_reduce_block2(wi.P, wi.PR, wi.FL, g->pbase, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);

@@ -166,6 +166,7 @@ struct NodeArgs {
   const float *P, *PR, *FL;
   const int *pbase, *col_ptr, *col_eids;
   float *SL, *SR;
+  float* aggr_out;       // optional (N,256), fused reduction only: the summed messages, kept for the guidance tape
   NodeW wmid, wpre;
 };
 #define ND_MID 1

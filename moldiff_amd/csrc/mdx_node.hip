@@ -113,6 +113,7 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
         const int f = 16 * (ft0 + ft) + 4 * q;
         const f32x4 ag = a.P ? seg_sum<256>(a.P, a.pbase, nullptr, vi[et], 4 * (ft0 + ft) + q)   // the node's partial rows, in order
                              : ldg4(a.aggr + (size_t)vi[et] * MDX_ND + f);
+        if (a.aggr_out && valid[et]) stg4(a.aggr_out + (size_t)vi[et] * MDX_ND + f, ag);
         z[ft][et] = ldg4(a.NTin + (size_t)vi[et] * MDX_NTW + MDX_NT_C + f) + ag;
       }
     layernorm_relu<4, NT_, 4>(z, a.wmid.lng, a.wmid.lnb, ft0, red, red2, wave, lane, true);
