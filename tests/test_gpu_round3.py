@@ -270,3 +270,33 @@ def test_work_queue_results_equal_the_static_split(sizes):
         assert r.returncode == 0, r.stderr[-3000:]
         digests.append([ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith('WQ_DIGEST')])
     assert len(digests[0]) == 1 and digests[0] == digests[1]
+
+
+def test_work_queue_counter_sets_per_stream_and_static_fallback():
+    """A graph object owns four work-queue counter sets, one per launching stream (launches that share a set must be stream-ordered);
+    a fifth stream gets none and its launches use the static split.  The same forward on six streams in turn, on one cached graph:
+    identical results every time (which wave computes a unit never enters a result), and again on the first stream afterwards
+    (its counters were left all zero)."""
+    m = U.moldiff('MolDiff', DEV)
+    bn, hei, bh, ei, be = U.graph_from_sizes([23] * 30 + [44, 4, 31, 17] * 5, DEV)
+    g = U.rng(5)
+    N, Eh = len(bn), len(bh)
+    xn = F.one_hot(torch.from_numpy(g.integers(0, 8, N)), 8).float().to(DEV)
+    xh = F.one_hot(torch.from_numpy(g.integers(0, 6, Eh)), 6).float().to(DEV)
+    pos = (U.t32(g.standard_normal((N, 3), dtype=np.float32)) * 2.5).to(DEV)
+    t = torch.from_numpy(g.integers(0, 1000, 50)).to(DEV)
+    he = torch.cat([xh, xh])
+
+    def run():
+        out = m(xn, pos, bn, he, ei, be, t)
+        return [out[k].clone() for k in ('pred_node', 'pred_pos', 'pred_halfedge')]
+
+    ref = run()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    for s in streams + streams[:2]:
+        with torch.cuda.stream(s):
+            got = run()
+        s.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    assert all(torch.equal(a, b) for a, b in zip(run(), ref))
