@@ -203,6 +203,22 @@ def linear_rows(a, w, trans_w, bias=None, addend=None):
     return out
 
 
+_LAYOUTS = {}
+
+
+def _wgrad_layout(M, N, K, splits, half):
+    """(row ranges actually used, offset of the bias partials) of a weight-gradient call: a pure function of its arguments, asked of the
+    library once per shape (it used to be a call per weight gradient per step)"""
+    key = (M, N, K, splits, half)
+    r = _LAYOUTS.get(key)
+    if r is None:
+        import ctypes
+        S, boff = ctypes.c_int64(), ctypes.c_int64()
+        check(_L().mdx_op_wgrad_layout(M, N, K, splits, half, ctypes.byref(S), ctypes.byref(boff)))
+        r = _LAYOUTS[key] = (S.value, boff.value)
+    return r
+
+
 def sgemm_tn(g, x, splits, want_bias=False, defer=None):
     """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors; with want_bias also the
     column sums of g (the bias gradient) from the same pass -> (dW, db).
@@ -213,9 +229,7 @@ def sgemm_tn(g, x, splits, want_bias=False, defer=None):
     part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
     if defer is not None:
         dst_w, ldw, dst_b = defer
-        import ctypes
-        S, boff = ctypes.c_int64(), ctypes.c_int64()
-        check(_L().mdx_op_wgrad_layout(M, N, K, splits, 1 if _AMP is not None else 0, ctypes.byref(S), ctypes.byref(boff)))
+        S, boff = _wgrad_layout(M, N, K, splits, 1 if _AMP is not None else 0)
         wb = ptr(part) if want_bias else None        # any non-null pointer = "also write the bias partials"
         if _AMP is not None:
             check(_L().mdx_op_xgemm_tn_t(ptr(g), g.stride(0), ptr(x), x.stride(0), None, K, wb, M, N, K, splits, ptr(part), _AMP[0],
@@ -224,9 +238,9 @@ def sgemm_tn(g, x, splits, want_bias=False, defer=None):
         else:
             check(_L().mdx_op_sgemm_tn(ptr(g), g.stride(0), ptr(x), x.stride(0), None, K, wb, M, N, K, splits, ptr(part), stream()))
             rk = 0
-        _sink_record(part.data_ptr(), dst_w, S.value, N, K, ldw, N * K, rk, part)
+        _sink_record(part.data_ptr(), dst_w, S, N, K, ldw, N * K, rk, part)
         if want_bias:
-            _sink_record(part.data_ptr() + 4 * boff.value, dst_b, S.value, 1, N, N, N, rk, part)
+            _sink_record(part.data_ptr() + 4 * boff, dst_b, S, 1, N, N, N, rk, part)
         return None
     out = torch.empty(N, K, dtype=torch.float32, device=g.device)
     db = torch.empty(N, dtype=torch.float32, device=g.device) if want_bias else None
