@@ -1401,8 +1401,10 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
         ea_args.tSG = tp.b[i].SG;
         ea_args.tHE = tp.b[i].HE;
         ea_args.M = tp.b[i].M;  // the backward reads the gated message back (with EA_AGG it is no longer the reduction's input)
-        if (ffn_tape())
+        if (ffn_tape()) {
           for (int sd = 0; sd < 2; ++sd) { ea_args.tBL[sd] = tp.b[i].BL[sd]; ea_args.tH1[sd] = tp.b[i].H1[sd]; ea_args.tO[sd] = tp.b[i].O[sd]; }
+          if (use_agg()) ea_args.flags |= EA_TAPE_FFN;   // (ffn_tape() implies the row-owner kernels)
+        }
       }
       { ProfScope ps(PK_EDGE_A, s); LCHK(run_ea(g, ea_args, s)); }
     }

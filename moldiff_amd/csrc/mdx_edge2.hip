@@ -145,6 +145,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
   // well measured 0.8 % SLOWER on the same box (6.94 vs 6.89 ms per step; the register allocation of a 256-VGPR kernel is that
   // sensitive -- 5 spilled registers instead of 4), so the form that measured best ships.
   constexpr bool do_tape = FLAGS & EA_TAPE;
+  constexpr bool do_tape_ffn = FLAGS & EA_TAPE_FFN;  // unconditional stores: no pointer tests inside the BondFFN sections
   // the tape is read back by the backward a whole forward later: streaming (non-temporal) stores keep its 870 MB per launch from
   // displacing weights and node rows in L2 (guided step 26.00 -> 25.90 ms)
   constexpr bool TAPE_NT = do_tape;
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         STAMP(14 + 10 * s);
         rgemm<4, 8, RR>(bl, hep, W(ws.Wbl), ring, W(ws.Wg1e));
         STAMP(15 + 10 * s);
-        if (do_tape && a.tBL[s]) row_store<8, RR, TAPE_NT>(bl, a.tBL[s], t.row, t.valid, 128, q);
+        if constexpr (do_tape_ffn) row_store<8, RR, TAPE_NT>(bl, a.tBL[s], t.row, t.valid, 128, q);
         mul_inplace<8>(bl, nl);
         rgemm<4, 2, RR>(g1, hep, W(ws.Wg1e), ring, W(ws.W1));
         STAMP(16 + 10 * s);
@@ -379,14 +380,14 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2_kernel(const EdgeAArg
         STAMP(17 + 10 * s);
         rgemm<8, 8, RR>(h, bl, W(ws.W1), ring, W(ws.W2));
         STAMP(18 + 10 * s);
-        if (do_tape && a.tH1[s]) row_store<8, RR, TAPE_NT>(h, a.tH1[s], t.row, t.valid, 128, q);
+        if constexpr (do_tape_ffn) row_store<8, RR, TAPE_NT>(h, a.tH1[s], t.row, t.valid, 128, q);
         row_layernorm<8, RR>(h, f_ig[s], f_ibe[s], q);
         f32x4 o[4][RR], g2[4][RR];
         row_bias<4, RR>(o, f_ib2[s], q);
         STAMP(19 + 10 * s);
         rgemm<8, 4, RR>(o, h, W(ws.W2), ring, W(ws.Wg2));
         STAMP(20 + 10 * s);
-        if (do_tape && a.tO[s]) row_store<4, RR, TAPE_NT>(o, a.tO[s], t.row, t.valid, 64, q);
+        if constexpr (do_tape_ffn) row_store<4, RR, TAPE_NT>(o, a.tO[s], t.row, t.valid, 64, q);
         row_bias<4, RR>(g2, f_bg2[s], q);
         rgemm<2, 4, RR>(g2, g1, W(ws.Wg2), ring, W(s < slast ? a.w.s.ffn[1].Wbl : wfirst));
         STAMP(21 + 10 * s);
@@ -447,7 +448,7 @@ static void launch_a2(const EdgeAArgs& a, hipStream_t s) {
   const int nunits = (FLAGS & EA_AGG) ? a.nunits : (a.E + ROWS - 1) / ROWS;
   if (nunits <= 0) return;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
-  constexpr bool all = (FLAGS & ~(EA_AGG | EA_TAPE)) == (EA_EMB | EA_NODE | EA_FFN);
+  constexpr bool all = (FLAGS & ~(EA_AGG | EA_TAPE | EA_TAPE_FFN)) == (EA_EMB | EA_NODE | EA_FFN);
   static const bool nosplit = getenv("MDX_NO_TAIL_SPLIT") != nullptr;
   const EdgePlan plan = make_plan(nunits, grid * 4, all && !nosplit);
   WorkQA wq{};
@@ -468,6 +469,8 @@ int launch_edge_a2(const EdgeAArgs& a, hipStream_t s) {
   switch (a.flags) {
     case EA_EMB | EA_NODE | EA_FFN | EA_AGG: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_AGG>(a, s); return MDX_OK;  // product path
     case EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE>(a, s); return MDX_OK;  // + guidance tape
+    case EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE | EA_TAPE_FFN:
+      launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE | EA_TAPE_FFN>(a, s); return MDX_OK;                     // + BondFFN tape
     case EA_EMB | EA_NODE | EA_FFN | EA_TAPE: launch_a2<EA_EMB | EA_NODE | EA_FFN | EA_TAPE>(a, s); return MDX_OK;
     case EA_EMB | EA_NODE | EA_FFN: launch_a2<EA_EMB | EA_NODE | EA_FFN>(a, s); return MDX_OK;  // a block with M / FR in HBM
     case EA_NODE: launch_a2<EA_NODE>(a, s); return MDX_OK;                                    // NodeBlock.forward

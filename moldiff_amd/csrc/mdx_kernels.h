@@ -130,6 +130,7 @@ struct EdgeAArgs {
 #define EA_NODE 2
 #define EA_FFN 4
 #define EA_AGG 8
+#define EA_TAPE_FFN 32  // + the BondFFN intermediates (tBL / tH1 / tO all non-null); implies EA_TAPE
 #define EA_TAPE 16  // the launch writes the guidance tape (tSG, tHE, M, F[1] with EA_AGG, tBL / tH1 / tO): a template flag of the row-owner kernel
 
 struct EdgeBArgs {
