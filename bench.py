@@ -73,6 +73,29 @@ def self_launch(n_gpus):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints "Librccl path : ..." into C stdio's
+    buffer at communicator setup, and the buffer is flushed at process exit, i.e. AFTER the line): from here on file descriptor 1
+    is stderr for everybody, and `emit` writes the line to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + '\n').encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def launch_env(args_gpus):
     """(world, rank, local_rank); starts the ranks when --gpus N > 1 was given to a plain `python bench.py`."""
     if 'WORLD_SIZE' not in os.environ and args_gpus > 1:
@@ -307,6 +330,88 @@ def train_cpu_baseline(kind, model, sizes, budget_s):
 
 
 
+TRAIN_DTYPE = {'f32': 'f32', 'bf16': 'bf16 GEMM operands, f32 accumulate / elsewhere',
+               'fp16': 'f16 Linear operands and results (f32 accumulate), f32 LayerNorm / loss / sums, dynamic loss scale '
+                       '(the reference\'s use_amp: True)',
+               'fp16_f32store': 'as fp16, but the float16 values kept in fp32 containers',
+               'bf16_autocast': 'bf16 Linear operands and results, f32 elsewhere'}
+# executed matrix FLOPs of one training step = forward + data gradient + weight gradient of every Linear, each the hoisted forward
+# count of SURVEY 8(d) (5,033,472 E + 5,935,104 N + 8,960 Eh for the 6-block denoiser; the O(rows x 8) loss tail is not counted)
+PEAK_F16_MFMA = 2500.0   # TFLOP/s dense (MI355X_MICROARCH.md)
+
+
+def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0, world=1, dist=None):
+    """`warmup` + `steps` optimisation steps of BASELINE config #5's step (scripts/train_drug3d.py:88-109: get_loss, backward,
+    gradient all-reduce, clip, AdamW) on one synthetic batch of the reference's size recipe.  Returns the measurement dict."""
+    import moldiff_amd as M
+    from moldiff_amd.harness import default_config, GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
+    from moldiff_amd.trainer import Trainer
+    np.random.seed(2920)
+    sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=batch_size * (rank + 1)).astype('int64')
+    sizes = np.maximum(sizes[batch_size * rank:], 2)
+    if model_kind == 'bondpred':
+        model = M.BondPredictor(default_config('bondpred'), 8, 5)
+        model.load_state_dict(M.recipe_state_dict(model, 20230808), strict=True)
+    else:
+        model = M.MolDiff(default_config(model_kind), 8, 6)
+        model.load_state_dict(M.recipe_state_dict(model, 20230807), strict=True)
+    model = model.to(dev).train()
+    tr = Trainer(model, lr=1e-4, betas=(0.99, 0.999), weight_decay=1e-8, max_grad_norm=50.0, precision=precision)
+    batch = clean_batch([int(s) for s in sizes], 100 + rank, dev)
+    torch.manual_seed(2023 + rank)
+    losses = []
+    for _ in range(warmup):
+        tr.step(*batch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    barrier()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(tr.step(*batch)['loss'])
+    issued = time.perf_counter() - t0      # the host has ISSUED every step (nothing in a step waits for the device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms = elapsed / steps * 1e3
+    N, Eh = int(batch[1].shape[0]), int(batch[3].shape[0])
+    E = 2 * Eh
+    nb = 8 if model_kind == 'bondpred' else 6
+    fwd = (5033472.0 / 6 * nb) * E + (5935104.0 / 6 * nb) * N + 8960.0 * Eh if model_kind != 'bondpred' else \
+        ((10240 + 590336 + 393344 - 442368.0) * nb) * E + (966656.0 * nb) * N
+    flop = 3.0 * fwd
+    half = precision in ('fp16', 'fp16_f32store', 'bf16', 'bf16_autocast')
+    peak = PEAK_F16_MFMA if half else PEAK_FP32_MFMA
+    ach = flop / (ms * 1e-3) / 1e12
+    out = {'metric': 'molecules/sec (training step: forward + backward + all-reduce + clip + AdamW)', 'value': batch_size * world / (ms / 1e3),
+           'unit': 'molecules/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms,
+           'host_issue_ms_per_step': issued / steps * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': TRAIN_DTYPE[precision], 'data': 'synthetic',
+           'config': {'workload': f'train_{model_kind}.yml: batch_size={batch_size} molecules/GPU (rank 0: N={N} atoms, E={E} directed '
+                                  f'edges), AdamW lr 1e-4 betas (0.99,0.999) wd 1e-8, max_grad_norm 50; recipe weights',
+                      'parallelism': f'data-parallel x{world}, one flat-gradient all-reduce per step',
+                      'parameters': tr.flat.numel},
+           'roofline': {'bound': 'mfma', 'kernel': 'whole step (layer-operator GEMMs: hgemm_nt_rows / hgemm_tn_tr / sgemm kernels of mdx_train.hip)',
+                        'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                        'frac_of_fp32_mfma_peak': ach / PEAK_FP32_MFMA, 'flops_per_step': flop,
+                        'flops_what': '3 x the hoisted forward count (forward, data gradient, weight gradient of every Linear)',
+                        'traffic': None,
+                        'note': 'whole-step fraction: the step is a chain of ~2,000 launches, half of its time HBM-bound row-wise passes '
+                                'between the GEMMs (DESIGN section 10)'},
+           'peak_hbm_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
+           'loss_first_last': [float(losses[0]), float(losses[-1])]}
+    return out, model, sizes
+
+
 def main_train():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -320,6 +425,7 @@ def main_train():
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
     world, rank, local_rank = launch_env(args.gpus)
+    own_stdout()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py --train needs a ROCm GPU (no CPU fallback).')
     torch.cuda.set_device(local_rank)
@@ -331,64 +437,12 @@ def main_train():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    import moldiff_amd as M
-    from moldiff_amd.harness import default_config, GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
-    from moldiff_amd.trainer import Trainer
-    np.random.seed(2920)
-    sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=args.batch * (rank + 1)).astype('int64')
-    sizes = np.maximum(sizes[args.batch * rank:], 2)
-    if args.model == 'bondpred':
-        model = M.BondPredictor(default_config('bondpred'), 8, 5)
-        model.load_state_dict(M.recipe_state_dict(model, 20230808), strict=True)
-    else:
-        model = M.MolDiff(default_config(args.model), 8, 6)
-        model.load_state_dict(M.recipe_state_dict(model, 20230807), strict=True)
-    model = model.to(dev).train()
-    tr = Trainer(model, lr=1e-4, betas=(0.99, 0.999), weight_decay=1e-8, max_grad_norm=50.0, precision=args.precision)
-    batch = clean_batch([int(s) for s in sizes], 100 + rank, dev)
-    torch.manual_seed(2023 + rank)
-    losses = []
-    for _ in range(args.warmup):
-        tr.step(*batch)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    barrier()
-    torch.cuda.reset_peak_memory_stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses.append(tr.step(*batch)['loss'])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms = elapsed / args.steps * 1e3
+    out, model, sizes = train_measure(args.model, args.precision, args.batch, args.steps, args.warmup, dev, rank, world, dist)
     if rank == 0:
-        N, E = int(batch[1].shape[0]), 2 * int(batch[3].shape[0])
-        out = {'metric': 'molecules/sec (training step: forward + backward + all-reduce + clip + AdamW)', 'value': args.batch * world / (ms / 1e3),
-               'unit': 'molecules/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': {'f32': 'f32', 'bf16': 'bf16 GEMM operands, f32 accumulate / elsewhere',
-                         'fp16': 'f16 Linear operands and results (f32 accumulate), f32 LayerNorm / loss / sums, dynamic loss scale '
-                                 '(the reference\'s use_amp: True)',
-                         'fp16_f32store': 'as fp16, but the float16 values kept in fp32 containers',
-                         'bf16_autocast': 'bf16 Linear operands and results, f32 elsewhere'}[args.precision], 'data': 'synthetic',
-               'config': {'workload': f'train_{args.model}.yml: batch_size={args.batch} molecules/GPU (rank 0: N={N} atoms, E={E} directed '
-                                      f'edges), AdamW lr 1e-4 betas (0.99,0.999) wd 1e-8, max_grad_norm 50; recipe weights',
-                          'parallelism': f'data-parallel x{world}, one flat-gradient all-reduce per step',
-                          'parameters': tr.flat.numel},
-               'peak_hbm_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
-               'loss_first_last': [float(losses[0]), float(losses[-1])]}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = train_cpu_baseline(args.model, model, sizes, args.cpu_budget)
             out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -434,6 +488,25 @@ def roofline_mfma(name, kernel, flop_per_edge, E, prof):
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': ach, 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s',
             'frac': (ach / PEAK_FP32_MFMA) if ach else None, 'traffic': None, 'launches': c, 'avg_ms': avg,
             'flops_per_launch': flop_per_edge * E, 'flops_per_edge': flop_per_edge}
+
+
+SPLIT_DTYPE = ('f32 operands split into float16 hi + lo halves (22 significand bits; lo scaled by 2^11), three '
+               'v_mfma_f32_16x16x32_f16 per 32-wide k-group (Whi Xhi + Whi Xlo + Wlo Xhi), f32 accumulation; per-node layers, LayerNorm, '
+               'gates, segment sums, transitions: f32 as in the exact path')
+
+
+def roofline_split(name, kernel, flop_per_edge, E, prof):
+    """The split float16 path's kernel against BOTH peaks: `achieved` counts the ALGORITHMIC fp32 FLOPs (the same count as the exact
+    path's line, so `frac_of_fp32_mfma_peak` can exceed 1); the matrix pipe actually executes three float16 products per one,
+    `frac` = 3 x achieved / the dense float16 MFMA peak."""
+    r = roofline_mfma(name, kernel, flop_per_edge, E, prof)
+    if r['achieved']:
+        r['frac_of_fp32_mfma_peak'] = r['achieved'] / PEAK_FP32_MFMA
+        r['executed_f16_tflops'] = 3.0 * r['achieved']
+        r['peak'], r['frac'] = PEAK_F16_MFMA, 3.0 * r['achieved'] / PEAK_F16_MFMA
+        r['bound_note'] = ('no longer bound by the matrix pipe: the per-wave weight stream (L2 -> VGPR, the same bytes as fp32) and the '
+                           'operand conversions are what is left (DESIGN section 3.4)')
+    return r
 
 
 def partial_rows(sizes):
@@ -519,6 +592,7 @@ def main():
     args = ap.parse_args()
 
     world, rank, local_rank = launch_env(args.gpus)
+    own_stdout()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU (no CPU fallback).')
     # one process per GPU over RCCL.  MDX_BENCH_BACKEND=gloo (+ ranks sharing a GPU when there are fewer devices than
@@ -527,15 +601,28 @@ def main():
     dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    dist = None
-    if world > 1:
+    # The group is created for ONE rank too (round 4): the N = 1 line then runs the same RCCL code as N = 8 -- communicator
+    # setup, the max-over-ranks all-reduce, the end-of-run gather on device tensors -- instead of skipping it.  A single rank
+    # whose group cannot be created (no RCCL on the box) still reports its line, with `backend` saying why.
+    dist, backend_note = None, None
+    if world > 1 or backend != 'none':
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        if 'MASTER_PORT' not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+        try:
+            if backend == 'nccl':
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:
+            if world > 1:
+                raise
+            dist, backend_note = None, 'none (single rank; process group not created: %r)' % (e,)
 
     def barrier():
         torch.cuda.synchronize()
@@ -631,7 +718,7 @@ def main():
             'roofline_edge_b': roofline_mfma('edge_b', EDGE_B_NAME, FLOP_EDGE_B, E, prof_all),
             'aggregation': aggregation_line(N, E, prof_all, sizes_head, os.environ.get('MDX_NO_AGG') != '1'),
             'kernel_ms_per_step': head['kernel_ms_per_step'], 'kernel_ms_note': head['kernel_ms_note'],
-            'ranks_seen': 1,
+            'ranks_seen': 1, 'backend': backend_note or 'none',
         }
         if multi is not None:
             out.update(multi)
@@ -732,6 +819,49 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # measurement extra: never fail the headline line
             out['aggregation_large'] = {'error': repr(e)}
+        # ---- the opt-in split float16 matrix path (csrc/mdx_split.h): the same two configurations, reported beside the exact ones;
+        # the headline `value` above is and stays the exact fp32 path
+        try:
+            from moldiff_amd import _lib as _L
+            for cname, kind in (('simple_split', 'MolDiff_simple'), ('guided_split', 'MolDiff')):
+                with _L.default_matrix_path('split_f16'):
+                    ssteps, swarm = max(10, min(args.steps, 200)), min(args.warmup, 10)
+                    smS, *_ = sampler_for(kind, args.batch, 0)
+                    elS, _ = run_chain(smS, ssteps, swarm, barrier, prof=0)            # step time without event overhead
+                    lineS = config_line(kind, smS, ssteps, swarm, elS, {}, 1)
+                    elP, profS = run_chain(smS, 20, 0, barrier, start=ssteps + swarm)  # kernel durations, events on every kernel
+                    ES = 2 * smS.Eh
+                    del smS
+                lineS['dtype'] = SPLIT_DTYPE
+                lineS['matrix_path'] = 'split_f16 (opt-in: module.matrix_path / MOLDIFF_MATRIX_PATH / mdx_model_set_matrix_path)'
+                lineS['kernel_ms_per_step'] = {k: v[1] / 20 for k, v in profS.items() if v[0]}
+                lineS['roofline'] = roofline_split('edge_a', 'edge_a2s_kernel (split float16 build of edge kernel A, mdx_edge2s.hip)', FLOP_EDGE_A, ES, profS)
+                lineS['roofline_edge_b'] = roofline_split('edge_b', 'edge_b2s_kernel (split float16 build of edge kernel B)', FLOP_EDGE_B, ES, profS)
+                exact = configs['simple' if cname == 'simple_split' else 'guided']
+                lineS['speedup_vs_exact_path'] = exact['ms_per_step'] / lineS['ms_per_step']
+                lineS['parity'] = ('tests/test_gpu_round4.py: the exact path\'s golden / fp64-arbitrated parity tests re-run on this path '
+                                   '(class ids bit-exact, positions and logits inside the same contract)')
+                configs[cname] = lineS
+                torch.cuda.empty_cache()
+        except Exception as e:  # measurement extra: never fail the headline line
+            configs['simple_split'] = {'error': repr(e)}
+        # ---- BASELINE config #5's step (one optimisation step of train_MolDiff.yml at its own batch size) on the same line
+        try:
+            tr_lines = {}
+            for prec, st_, wu_ in (('fp16', 10, 3), ('f32', 5, 2)):
+                tl, tmodel, tsizes = train_measure('MolDiff', prec, args.batch, st_, wu_, dev)
+                tl.pop('metric', None)
+                if prec == 'fp16' and not args.no_cpu_baseline:
+                    tl['cpu_baseline'] = train_cpu_baseline('MolDiff', tmodel, tsizes, min(args.cpu_budget, 15.0))
+                    tl['speedup_vs_cpu_baseline'] = tl['value'] / tl['cpu_baseline']['value']
+                tr_lines[prec] = tl
+                del tmodel
+                torch.cuda.empty_cache()
+            configs['train'] = dict(tr_lines['fp16'], what="config #5: train_MolDiff.yml's step (use_amp: True = precision 'fp16'), one GPU; "
+                                                           "the 8-GPU data-parallel half adds one 22 MB all-reduce per step",
+                                    f32=tr_lines['f32'])
+        except Exception as e:
+            configs['train'] = {'error': repr(e)}
         out['configs'] = configs
         if not args.no_cpu_baseline:
             for name, kind in (('simple', 'MolDiff_simple'), ('guided', 'MolDiff')):
@@ -747,7 +877,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == '__main__':

@@ -68,6 +68,15 @@ int mdx_model_set_param(mdx_model_t m, const char* key, const float* h_data, con
 /* Packs all weights into MFMA fragment order and uploads them.  Fails with MDX_ERR_STATE listing the
  * first missing key.  Must be called after the last set_param and before any forward. */
 int mdx_model_finalize(mdx_model_t m);
+/* Matrix path of the per-edge Linear layers (reference models/common.py:181-201, models/graph.py:29-55,133-141,268-295; the
+ * reference computes them in fp32).  MDX_MATRIX_EXACT_F32 (default): fp32-input MFMA, bit-for-bit an fmaf chain.
+ * MDX_MATRIX_SPLIT_F16 (opt-in): every operand split into float16 hi + lo halves (22 significand bits), three float16 MFMAs
+ * per k-group with fp32 accumulation -- same parity tests, ~2x the matrix throughput.  Needs a finalized model; refused with
+ * MDX_ERR_UNSUPPORTED if a weight lies outside float16's range (|w| >= 65504).  Takes effect on the next forward / step. */
+#define MDX_MATRIX_EXACT_F32 0
+#define MDX_MATRIX_SPLIT_F16 1
+int mdx_model_set_matrix_path(mdx_model_t m, int32_t path);
+int mdx_model_get_matrix_path(mdx_model_t m, int32_t* path);
 
 /* ---- graph handle: CSR plan of one packed batch (utils/transforms.py:125-156 produces the inputs) */
 /* h_edge_index: (2,E) int64 row-major, row 0 = left/row, row 1 = right/col; h_batch_node: (N) int64,

@@ -17,6 +17,7 @@ MDX_KIND_MOLDIFF, MDX_KIND_BONDPRED, MDX_KIND_NET = 0, 1, 2
 EXPORTS = [
     'mdx_last_error', 'mdx_version', 'mdx_device_count',
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
+    'mdx_model_set_matrix_path', 'mdx_model_get_matrix_path',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_bond_ffn', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
@@ -75,6 +76,8 @@ def lib():
         L.mdx_model_destroy.argtypes = [c_void_p]
         L.mdx_model_set_param.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
         L.mdx_model_finalize.argtypes = [c_void_p]
+        L.mdx_model_set_matrix_path.argtypes = [c_void_p, c_int32]
+        L.mdx_model_get_matrix_path.argtypes = [c_void_p, POINTER(c_int32)]
         L.mdx_graph_create.argtypes = [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_void_p)]
         L.mdx_graph_destroy.argtypes = [c_void_p]
         L.mdx_graph_plan_host.argtypes = [c_int64, c_int64] + [c_void_p] * 7
@@ -299,8 +302,48 @@ def graph_for_halfedges(halfedge_index, batch_node, n_graphs):
     return g
 
 
+# Matrix path of the per-edge Linear layers (include/moldiff_hip.h: MDX_MATRIX_*).  'exact_f32' is the default everywhere;
+# 'split_f16' is opt-in per module (`module.matrix_path = 'split_f16'`) or process-wide through default_matrix_path().
+MATRIX_PATHS = {'exact_f32': 0, 'split_f16': 1}
+_default_matrix_path = os.environ.get('MOLDIFF_MATRIX_PATH', 'exact_f32')
+
+
+class default_matrix_path:
+    """`with default_matrix_path('split_f16'):` -- modules whose own `matrix_path` is None follow the process default."""
+
+    def __init__(self, name):
+        if name not in MATRIX_PATHS:
+            raise ValueError(f'unknown matrix path {name!r} (one of {sorted(MATRIX_PATHS)})')
+        self.name = name
+
+    def __enter__(self):
+        global _default_matrix_path
+        self.prev, _default_matrix_path = _default_matrix_path, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _default_matrix_path
+        _default_matrix_path = self.prev
+
+
+def resolve_matrix_path(name):
+    name = _default_matrix_path if name is None else name
+    if name not in MATRIX_PATHS:
+        raise ValueError(f'unknown matrix path {name!r} (one of {sorted(MATRIX_PATHS)})')
+    return name
+
+
 class Model:
     """Packed weights of one MolDiff / BondPredictor / bare NodeEdgeNet on the device."""
+    _path = 'exact_f32'
+
+    def use_matrix_path(self, name):
+        """Select the matrix path for the following calls (a no-op when it is already selected)."""
+        name = resolve_matrix_path(name)
+        if name != self._path:
+            check(lib().mdx_model_set_matrix_path(self.h, MATRIX_PATHS[name]))
+            self._path = name
+        return self
 
     def __init__(self, kind, *, num_blocks, cutoff, update_pos, time_dim=0, num_timesteps=1, num_node_types=1,
                  num_edge_types=1, node_dim=256, edge_dim=64, num_gaussians=16):

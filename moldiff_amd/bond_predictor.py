@@ -104,6 +104,9 @@ class BondPredictor(Module):
             get_beta_schedule(num_timesteps=T, **config.diff_atom), self.num_node_types,
             init_prob=config.diff_atom.init_prob)
 
+    # None = follow _lib.default_matrix_path (exact fp32 unless MOLDIFF_MATRIX_PATH says otherwise); or 'exact_f32' / 'split_f16'
+    matrix_path = None
+
     def _engine(self):
         sig = _sig(self)
         if self._eng is None or sig != self._eng_sig:
@@ -114,7 +117,7 @@ class BondPredictor(Module):
                              node_dim=e.node_dim, edge_dim=e.edge_dim, num_gaussians=e.distance_expansion.offset.numel())
             eng.upload(self.state_dict())
             self._eng, self._eng_sig = eng, sig
-        return self._eng
+        return self._eng.use_matrix_path(self.matrix_path)
 
     def sample_time(self, num_graphs, device, **kwargs):
         T = self.num_timesteps

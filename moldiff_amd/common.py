@@ -1,8 +1,9 @@
 """Parameter containers shared by the network modules.
 
 ``MLP`` and ``GaussianSmearing`` keep the constructor signatures and ``state_dict`` key grammar of the
-reference (models/common.py:181-201, :216-237) so checkpoints load strictly; they own no device math --
-the arithmetic of every live instance is fused into the HIP kernels (csrc/mdx_edge.hip, mdx_node.hip).
+reference (models/common.py:181-201, :216-237) so checkpoints load strictly.  Inside the networks their arithmetic is
+fused into the HIP kernels (csrc/mdx_edge2.hip, mdx_node.hip); called on their own (``forward``) they run the
+library's layer operators (csrc/mdx_train.hip: Linear / LayerNorm+ReLU / smearing kernels), differentiable like the reference's.
 """
 import numpy as np
 import torch
@@ -37,13 +38,8 @@ class AttrDict(dict):
     __setattr__ = __setitem__
 
 
-def no_device_math(name):
-    raise RuntimeError(f'{name}.forward is fused into the parent HIP kernel; call the enclosing '
-                       f'NodeBlock / EdgeBlock / PosUpdate / NodeEdgeNet instead')
-
-
 class MLP(nn.Module):
-    """Linear -> [LayerNorm -> ReLU -> Linear]* ; only the parameter layout lives here."""
+    """Linear -> [LayerNorm -> ReLU -> Linear]*  (models/common.py:181-201)."""
 
     def __init__(self, in_dim, out_dim, hidden_dim, num_layer=2, norm=True, act_fn='relu', act_last=False):
         super().__init__()
@@ -59,7 +55,11 @@ class MLP(nn.Module):
         self.net = nn.Sequential(*mods)
 
     def forward(self, x):
-        no_device_math('MLP')
+        """models/common.py:200-201 on device rows (..., in_dim) -> (..., out_dim): Linear and LayerNorm+ReLU operator launches."""
+        from . import train_graph
+        lead = x.shape[:-1]
+        y = train_graph.mlp(self, x.reshape(-1, x.shape[-1]))
+        return y.reshape(*lead, y.shape[-1])
 
 
 class GaussianSmearing(nn.Module):
@@ -80,4 +80,10 @@ class GaussianSmearing(nn.Module):
         self.register_buffer('offset', offset)
 
     def forward(self, dist):
-        no_device_math('GaussianSmearing')
+        """models/common.py:233-237: clamp to [start, stop], (n,) -> (n, num_gaussians); integer inputs (time steps) are
+        promoted to float like the reference's subtraction does."""
+        from . import train_graph
+        d = dist.reshape(-1)
+        if not d.is_floating_point():
+            d = d.float()
+        return train_graph.smear(self, d)

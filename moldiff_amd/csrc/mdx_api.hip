@@ -69,6 +69,11 @@ struct mdx_model_s {
   BondDecW dec{};
   std::vector<EdgeBwdW> ebw;
   std::vector<NodeBwdW> nbw;
+  // matrix path of the row-owner edge kernels: 0 = exact fp32 MFMA (default), 1 = split float16 (mdx_split.h).  Both weight
+  // packs are always built; split_ok is false when a weight would overflow the scaled float16 range (the path is then refused).
+  int matrix_path = 0;
+  bool split_ok = true;
+  float split_wmax = 0.f;
 };
 
 namespace {
@@ -142,6 +147,41 @@ struct PackCtx {
     if (!t) return;
     pack_stream(slot, t->data, F, ldw, col0, K);
   }
+  // split float16 stream pack (mdx_split.h rgemm_s): W = hi + lo 2^-11 with hi = fp16(W), lo = fp16((W - hi) 2^11); half-step hs = (ftp*KG + g)*2 + h carries
+  // the fragments of feature tiles 2 ftp + j, j = 0,1 (h = 0: hi, h = 1: lo), 64 lanes x 8 halves each:
+  // half index ((hs*2 + j)*64 + lane)*8 + t <- W[16 (2 ftp + j) + (lane & 15)][col0 + 32 g + 16 (t / 4) + 4 (lane >> 4) + t % 4];
+  // F padded to 32 and K to 32 with zeros, plus 4 zero half-steps so a ring may over-fetch.  Same bytes as pack_stream for K % 32 == 0.
+  void pack_stream_split(const float** slot, const std::vector<float>& W, int F, int ldw, int col0, int K) {
+    const int FTP = (F + 31) / 32, KG = (K + 31) / 32;
+    size_t off = pk.reserve((size_t)FTP * KG * 2 * 512 + 4 * 512);
+    const float lo_up = 2048.0f;  // 2^MDX_LO_SHIFT
+    std::vector<uint16_t> hbuf((size_t)FTP * KG * 2 * 1024, 0);
+    for (int ftp = 0; ftp < FTP; ++ftp)
+      for (int g = 0; g < KG; ++g)
+        for (int j = 0; j < 2; ++j)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 8; ++t) {
+              const int f = 16 * (2 * ftp + j) + (lane & 15), k = 32 * g + 16 * (t / 4) + 4 * (lane >> 4) + t % 4;
+              const float w = (f < F && k < K) ? W[(size_t)f * ldw + col0 + k] : 0.f;
+              if (!(std::fabs(w) < 65504.0f)) m->split_ok = false;
+              m->split_wmax = std::max(m->split_wmax, std::fabs(w));
+              const _Float16 hi = (_Float16)w;
+              const _Float16 lo = (_Float16)((w - (float)hi) * lo_up);
+              uint16_t uh, ul;
+              std::memcpy(&uh, &hi, 2);
+              std::memcpy(&ul, &lo, 2);
+              const size_t hs = ((size_t)ftp * KG + g) * 2;
+              hbuf[((hs * 2 + j) * 64 + lane) * 8 + t] = uh;
+              hbuf[(((hs + 1) * 2 + j) * 64 + lane) * 8 + t] = ul;
+            }
+    std::memcpy(pk.host.data() + off, hbuf.data(), hbuf.size() * 2);
+    pk.bind(slot, off);
+  }
+  void packSS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    pack_stream_split(slot, t->data, F, ldw, col0, K);
+  }
   // transpose pack: out[k][f] = W[f][col0 + k]  (contraction over the forward's output features, zero padded to 16)
   void packT(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
     const HostTensor* t = get(key, {F, ldw});
@@ -161,6 +201,16 @@ struct PackCtx {
     for (int k = 0; k < K; ++k)
       for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
     pack_stream(slot, Wt, K, Fp, 0, Fp);
+  }
+  // transposed split stream pack (mdx_bwd2s.hip)
+  void packTSS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    const int Fp = (F + 15) / 16 * 16;
+    std::vector<float> Wt((size_t)K * Fp, 0.f);
+    for (int k = 0; k < K; ++k)
+      for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
+    pack_stream_split(slot, Wt, K, Fp, 0, Fp);
   }
   std::map<int, std::vector<float>> wcat_dense;  // block -> dense (960 x 256) concatenated node-table weights
   void vec(const float** slot, const std::string& key, int n, int pad_to = 0) {
@@ -194,6 +244,8 @@ struct PackCtx {
 
 int pack_model(mdx_model_s* m) {
   PackCtx c{m};
+  m->split_ok = true;
+  m->split_wmax = 0.f;
   const mdx_config& cf = m->cfg;
   const int ND = MDX_ND, ED = MDX_ED, GIN = ED + ND + 1;  // 321
   const std::string net = cf.kind == MDX_KIND_MOLDIFF ? "denoiser." : cf.kind == MDX_KIND_BONDPRED ? "encoder." : "";
@@ -224,6 +276,12 @@ int pack_model(mdx_model_s* m) {
     c.packS(&b.ea.s.W1, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
     c.packS(&b.ea.s.W2, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
     c.packS(&b.ea.s.Wm, nb + ".msg_net.weight", ND, ND, 0, ND);
+    c.packSS(&b.ea.ss.Wemb, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, 0, ED + MDX_NG);
+    c.packSS(&b.ea.ss.Wg1e, nb + ".gate.net.0.weight", ND, GIN, 0, ED);
+    c.packSS(&b.ea.ss.Wg2, nb + ".gate.net.3.weight", ND, ND, 0, ND);
+    c.packSS(&b.ea.ss.W1, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
+    c.packSS(&b.ea.ss.W2, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
+    c.packSS(&b.ea.ss.Wm, nb + ".msg_net.weight", ND, ND, 0, ND);
     for (int s = 0; s < 2; ++s) {
       FfnW& f = b.ea.ffn[s];
       const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
@@ -242,6 +300,12 @@ int pack_model(mdx_model_s* m) {
       c.packS(&fs.W1, fp + ".inter_module.net.0.weight", 2 * ED, 2 * ED, 0, 2 * ED);
       c.packS(&fs.W2, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
       c.packS(&fs.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
+      FfnS& fss = b.ea.ss.ffn[s];
+      c.packSS(&fss.Wbl, fp + ".bond_linear.weight", 2 * ED, ED, 0, ED);
+      c.packSS(&fss.Wg1e, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
+      c.packSS(&fss.W1, fp + ".inter_module.net.0.weight", 2 * ED, 2 * ED, 0, 2 * ED);
+      c.packSS(&fss.W2, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
+      c.packSS(&fss.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
     }
     {  // fused first layers of both BondFFNs (see EdgeAW::Wffa)
       std::vector<float> Wf((size_t)320 * ED, 0.f);
@@ -268,6 +332,8 @@ int pack_model(mdx_model_s* m) {
     c.vec(&b.eb.bout, eb + ".out_transform.bias", ED);
     c.packS(&b.eb.s.Wself, eb + ".self_ffn.weight", ED, ED, 0, ED);
     c.packS(&b.eb.s.Wout, eb + ".out_transform.weight", ED, ED, 0, ED);
+    c.packSS(&b.eb.ss.Wself, eb + ".self_ffn.weight", ED, ED, 0, ED);
+    c.packSS(&b.eb.ss.Wout, eb + ".out_transform.weight", ED, ED, 0, ED);
     // ---- node kernel
     c.vec(&b.nd.lng, nb + ".layer_norm.weight", ND);
     c.vec(&b.nd.lnb, nb + ".layer_norm.bias", ND);
@@ -317,6 +383,11 @@ int pack_model(mdx_model_s* m) {
       c.packS(&b.eb.s.Wi1, el + ".inter_module.net.0.weight", ND, ND, 0, ND);
       c.packS(&b.eb.s.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
       c.packS(&b.eb.s.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
+      c.packSS(&b.eb.ss.Wbl, el + ".bond_linear.weight", ND, ED, 0, ED);
+      c.packSS(&b.eb.ss.Wnl, el + ".node_linear.weight", ND, ED, 0, ED);
+      c.packSS(&b.eb.ss.Wi1, el + ".inter_module.net.0.weight", ND, ND, 0, ND);
+      c.packSS(&b.eb.ss.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
+      c.packSS(&b.eb.ss.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
       {
         const HostTensor* bl = c.get(el + ".bond_linear.weight", {ND, ED});
         const HostTensor* nl = c.get(el + ".node_linear.weight", {ND, ED});
@@ -423,6 +494,25 @@ int pack_model(mdx_model_s* m) {
         c.packTS(&f.Wg1eT, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
         c.packTS(&f.Wg2T, fp + ".gate.net.3.weight", ED, 32, 0, 32);
       }
+      // ... and as split float16 stream packs for the split build of that kernel (mdx_bwd2s.hip)
+      c.packTSS(&e.ss.WembHT, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, 0, ED);
+      c.packTSS(&e.ss.WembDT, net + "edge_embs." + si + ".weight", ED, ED + MDX_NG, ED, MDX_NG);
+      c.packTSS(&e.ss.Wg1eT, nb + ".gate.net.0.weight", ND, GIN, 0, ED);
+      c.packTSS(&e.ss.Wg2T, nb + ".gate.net.3.weight", ND, ND, 0, ND);
+      c.packTSS(&e.ss.W1T, nb + ".edge_net.net.0.weight", ND, ED, 0, ED);
+      c.packTSS(&e.ss.W2T, nb + ".edge_net.net.3.weight", ND, ND, 0, ND);
+      c.packTSS(&e.ss.WmT, nb + ".msg_net.weight", ND, ND, 0, ND);
+      c.packTSS(&e.ss.WselfT, eb + ".self_ffn.weight", ED, ED, 0, ED);
+      c.packTSS(&e.ss.WoutT, eb + ".out_transform.weight", ED, ED, 0, ED);
+      for (int s = 0; s < 2; ++s) {
+        const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
+        FfnTS& f = e.ss.ffn[s];
+        c.packTSS(&f.WblT, fp + ".bond_linear.weight", 2 * ED, ED, 0, ED);
+        c.packTSS(&f.Wi1T, fp + ".inter_module.net.0.weight", 2 * ED, 2 * ED, 0, 2 * ED);
+        c.packTSS(&f.Wi2T, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
+        c.packTSS(&f.Wg1eT, fp + ".gate.net.0.weight", 32, GIN, 0, ED);
+        c.packTSS(&f.Wg2T, fp + ".gate.net.3.weight", ED, 32, 0, 32);
+      }
       NodeBwdW& n = m->nbw[i];
       c.packT(&n.WoutT, nb + ".out_transform.weight", ND, ND, 0, ND);
       c.packT(&n.W1T, nb + ".node_net.net.0.weight", ND, ND, 0, ND);
@@ -494,6 +584,29 @@ extern "C" int mdx_model_set_param(mdx_model_t m, const char* key, const float* 
 extern "C" int mdx_model_finalize(mdx_model_t m) {
   if (!m) return fail(MDX_ERR_ARG, "null model");
   return pack_model(m);
+}
+
+// Matrix path of the row-owner edge kernels (the products of models/common.py:181-201 MLP / models/graph.py:29-55,133-141,268-295
+// Linear layers evaluated per edge): MDX_MATRIX_EXACT_F32 = v_mfma_f32_16x16x4_f32, bit-for-bit an fmaf chain (default);
+// MDX_MATRIX_SPLIT_F16 = operands split into float16 hi + lo halves, three v_mfma_f32_16x16x32_f16 per k-group, fp32 accumulation
+// (mdx_split.h).  Per-node layers, reductions, LayerNorm, gates and transitions are fp32 in both.
+extern "C" int mdx_model_set_matrix_path(mdx_model_t m, int32_t path) {
+  if (!m) return fail(MDX_ERR_ARG, "null model");
+  if (path != MDX_MATRIX_EXACT_F32 && path != MDX_MATRIX_SPLIT_F16) return fail(MDX_ERR_ARG, "unknown matrix path %d", (int)path);
+  if (path == MDX_MATRIX_SPLIT_F16) {
+    if (!m->finalized) return fail(MDX_ERR_STATE, "model not finalized (call mdx_model_finalize)");
+    if (!mdx_use_rowowner()) return fail(MDX_ERR_UNSUPPORTED, "the split float16 path exists for the row-owner kernels only");
+    if (!m->split_ok)
+      return fail(MDX_ERR_UNSUPPORTED, "split float16 path refused: a weight of magnitude %g is outside float16's range (|w| < 65504)",
+                  (double)m->split_wmax);
+  }
+  m->matrix_path = path;
+  return MDX_OK;
+}
+extern "C" int mdx_model_get_matrix_path(mdx_model_t m, int32_t* path) {
+  if (!m || !path) return fail(MDX_ERR_ARG, "null argument");
+  *path = m->matrix_path;
+  return MDX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -863,10 +976,13 @@ EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i
 }
 
 // BondFFN intermediates on the guidance tape (round 3; MDX_BWD_RECOMPUTE=1: the backward recomputes them as in round 2, A/B)
+bool use_agg();
+// (the BondFFN tape stores exist in the EA_AGG instantiations of edge kernel A only: without the in-kernel sums -- MDX_NO_AGG=1 --
+// the backward recomputes instead of reading a tape nobody wrote)
 bool ffn_tape() {
   static const bool v = [] {
     const char* e = getenv("MDX_BWD_RECOMPUTE");
-    return mdx_use_rowowner() && !(e && e[0] == '1');
+    return mdx_use_rowowner() && use_agg() && !(e && e[0] == '1');
   }();
   return v;
 }
@@ -964,6 +1080,7 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
   float* NTcur = w.NT;
   float* NTnxt = w.NT2;
   const bool overlap = node_overlap() && nb > 1;
+  const int split_a = m->matrix_path == MDX_MATRIX_SPLIT_F16 ? EA_SPLIT : 0, split_b = split_a ? EB_SPLIT : 0;
   if (overlap && !g->side) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
@@ -976,7 +1093,7 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
     const bool agg = use_agg();
     {
       ProfScope ps(PK_EDGE_A, s);
-      LCHK(run_ea(g, make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0), NTcur), s));
+      LCHK(run_ea(g, make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0) | split_a, NTcur), s));
     }
     // round 3: with the in-kernel sums the reduction that is left (combine ~2.5 partial rows per node, the by-right BondFFN sum) is
     // done by the node kernel itself for its 16 nodes -- one launch fewer per block (MDX_NO_NODE_AGG=1: separate kernel, A/B)
@@ -1003,7 +1120,7 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
     if (split) HIPCHK(hipEventRecord(g->ev_mid, s));
     {
       ProfScope ps(PK_EDGE_B, s);
-      LCHK(run_eb(g, make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0), NTcur), s));
+      LCHK(run_eb(g, make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0) | split_b, NTcur), s));
     }
     if (split) {
       HIPCHK(hipStreamWaitEvent(g->side, g->ev_mid, 0));
@@ -1380,6 +1497,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
   Ws wr = w;
   wr.te = ea.te;
   const size_t nHn = (size_t)g->N * MDX_ND * 4;
+  const int split_a = m->matrix_path == MDX_MATRIX_SPLIT_F16 ? EA_SPLIT : 0, split_b = split_a ? EB_SPLIT : 0;
   for (int i = 0; i < nb; ++i) {
     // same sequence as run_blocks (update_pos = false), with the per-block outputs redirected into the tape
     Ws wi = wr;
@@ -1406,6 +1524,8 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
           if (use_agg()) ea_args.flags |= EA_TAPE_FFN;   // (ffn_tape() implies the row-owner kernels)
         }
       }
+      // split float16 matrix path: the same launch on mdx_edge2s.hip (the section combinations the product path uses)
+      if (split_a && use_agg() && (!tape || (ea_args.flags & EA_TAPE_FFN))) ea_args.flags |= EA_SPLIT;
       { ProfScope ps(PK_EDGE_A, s); LCHK(run_ea(g, ea_args, s)); }
     }
     if (fused_tape) {
@@ -1415,7 +1535,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
       na.P = wi.P; na.PR = wi.PR; na.FL = wi.FL; na.pbase = g->pbase; na.col_ptr = g->col_ptr; na.col_eids = g->col_eids;
       na.SL = wi.SL; na.SR = wi.SR; na.aggr_out = wi.aggr;
       launch_node(na, s);
-      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
+      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE | split_b, wi.NT), s));
       continue;
     }
     if (use_agg())
@@ -1427,11 +1547,11 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
     } else {  // no tape: fuse the next block's PRE into this node launch (tables double-buffered like run_blocks)
       float* NTn = (wr.NT == w.NT) ? w.NT2 : w.NT;
       launch_node(make_nd(m, g, wi, i, i + 1 < nb ? i + 1 : -1, ND_MID | (i + 1 < nb ? ND_PRE : 0), wi.NT, NTn), s);
-      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
+      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE | split_b, wi.NT), s));
       wr.NT = NTn;
       continue;
     }
-    LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE, wi.NT), s));
+    LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE | split_b, wi.NT), s));
   }
   if (tape) {
     HIPCHK(hipMemcpyAsync(tp.HnF, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
@@ -1479,7 +1599,11 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
     et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
     et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT; et.wq = wq_for(g, s);
-    if (mdx_use_rowowner()) launch_edge_tail_bwd2(et, s); else launch_edge_tail_bwd(et, s);
+    et.ssWselfT = m->ebw[i].ss.WselfT; et.ssWoutT = m->ebw[i].ss.WoutT;
+    const bool split_bwd = m->matrix_path == MDX_MATRIX_SPLIT_F16 && mdx_use_rowowner() && ffn_tape();
+    et.split = split_bwd ? 1 : 0;
+    if (split_bwd) launch_edge_tail_bwd2s(et, s);
+    else if (mdx_use_rowowner()) launch_edge_tail_bwd2(et, s); else launch_edge_tail_bwd(et, s);
     launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
@@ -1489,7 +1613,14 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
       for (int sd = 0; sd < 2; ++sd) { eb.BL[sd] = k.BL[sd]; eb.H1[sd] = k.H1[sd]; eb.O[sd] = k.O[sd]; }
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = et.wq;
-    { ProfScope ps(PK_EDGE_BWD, s); if (mdx_use_rowowner()) launch_edge_bwd2(eb, s); else launch_edge_bwd(eb, s); }
+    eb.split = split_bwd ? 1 : 0;
+    {
+      ProfScope ps(PK_EDGE_BWD, s);
+      if (split_bwd) {
+        if (launch_edge_bwd2s(eb, s) != 0) return fail(MDX_ERR_STATE, "split float16 backward: the forward tape holds no BondFFN intermediates");
+      } else if (mdx_use_rowowner()) launch_edge_bwd2(eb, s);
+      else launch_edge_bwd(eb, s);
+    }
     {
       SegBwdArgs sr{};
       sr.N = N; sr.row_ptr = g->row_ptr; sr.col_ptr = g->col_ptr; sr.col_eids = g->col_eids; sr.GH = GH; sr.GGX = tp.GGX;

@@ -490,6 +490,7 @@ static void ensure_attr() {
 
 int launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
   if (a.E <= 0) return MDX_OK;
+  if (a.flags & EA_SPLIT) return launch_edge_a2s(a, s);
   if (mdx_use_rowowner()) return launch_edge_a2(a, s);
   if (a.flags & EA_AGG) return mdx_set_error(MDX_ERR_UNSUPPORTED, "the tile kernels have no in-kernel aggregation (EA_AGG)");
   ensure_attr();
@@ -500,6 +501,7 @@ int launch_edge_a(const EdgeAArgs& a, hipStream_t s) {
 
 int launch_edge_b(const EdgeBArgs& a, hipStream_t s) {
   if (a.E <= 0) return MDX_OK;
+  if (a.flags & EB_SPLIT) return launch_edge_b2s(a, s);
   if (mdx_use_rowowner()) return launch_edge_b2(a, s);
   ensure_attr();
   const int ntiles = (a.E + TE - 1) / TE;

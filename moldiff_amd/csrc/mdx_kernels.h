@@ -66,6 +66,7 @@ struct EdgeAW {  // weights of edge kernel A for one block
   // [bond_linear_s rows 64h..64h+63 | gate layer-1 edge part rows 16h..16h+15], s = w/2, h = w%2
   const float* Wffa;
   EdgeAS s;
+  EdgeAS ss;  // the same streams split into float16 hi / lo halves (mdx_split.h; EA_SPLIT launches)
 };
 
 struct EdgeBW {  // weights of edge kernel B for one block
@@ -82,6 +83,7 @@ struct EdgeBW {  // weights of edge kernel B for one block
   const float *wg2;                // (32)
   float bg2;
   EdgeBS s;
+  EdgeBS ss;  // split float16 streams (EB_SPLIT launches)
 };
 
 struct NodeW {  // weights of the node kernel
@@ -131,6 +133,7 @@ struct EdgeAArgs {
 #define EA_FFN 4
 #define EA_AGG 8
 #define EA_TAPE_FFN 32  // + the BondFFN intermediates (tBL / tH1 / tO all non-null); implies EA_TAPE
+#define EA_SPLIT 64  // matrix products on the split float16 path (mdx_edge2s.hip); not a section flag
 #define EA_TAPE 16  // the launch writes the guidance tape (tSG, tHE, M, F[1] with EA_AGG, tBL / tH1 / tO): a template flag of the row-owner kernel
 
 struct EdgeBArgs {
@@ -151,6 +154,7 @@ struct EdgeBArgs {
 #define EB_EDGE 1   // run the EdgeBlock tail
 #define EB_POS 2    // run PosUpdate
 #define EB_DELTA 4  // He_out = delta only (per-function EdgeBlock API)
+#define EB_SPLIT 8  // matrix products on the split float16 path (mdx_edge2bs.hip)
 
 struct NodeArgs {
   int N, flags;
@@ -193,6 +197,7 @@ struct EdgeBwdW {  // transposed packs (contraction over the forward's output fe
   FfnWT ffn[2];
   const float *WselfT, *WoutT;                  // EdgeBlock tail
   EdgeBwdS s;                                   // row-owner kernel (mdx_bwd2.hip)
+  EdgeBwdS ss;                                  // the same as split float16 streams (mdx_bwd2s.hip)
 };
 struct NodeBwdW {
   const float* WoutT;      // NodeBlock out_transform^T
@@ -211,6 +216,8 @@ struct EdgeTailBwdArgs {
   EdgeBW w;
   const float *WselfT, *WoutT;
   const float *sWselfT, *sWoutT;  // the same as stream packs (row-owner kernel, mdx_bwd2.hip)
+  const float *ssWselfT, *ssWoutT;  // ... and as split float16 stream packs (mdx_bwd2s.hip)
+  int split;                       // 1: run the split float16 build
 };
 
 struct EdgeBwdArgs {
@@ -231,6 +238,7 @@ struct EdgeBwdArgs {
   float* GNL[2];               // (E,128): left -> reduced by left, right -> by right
   float* GGXS[2];              // (E,32)
   int* wq;                 // work-queue counters of the launch's stream (mdx_row.h WorkQ), nullptr = static unit split
+  int split;               // 1: run the split float16 build (mdx_bwd2s.hip; needs the BondFFN tape)
   EdgeAW w;
   EdgeBwdW wt;
 };
@@ -266,6 +274,8 @@ void launch_edge_tail_bwd(const EdgeTailBwdArgs& a, hipStream_t s);
 void launch_edge_bwd(const EdgeBwdArgs& a, hipStream_t s);
 void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s);  // row-owner version (mdx_bwd2.hip)
 void launch_edge_tail_bwd2(const EdgeTailBwdArgs& a, hipStream_t s);
+int launch_edge_bwd2s(const EdgeBwdArgs& a, hipStream_t s);       // split float16 builds (mdx_bwd2s.hip); nonzero = tape missing
+void launch_edge_tail_bwd2s(const EdgeTailBwdArgs& a, hipStream_t s);
 void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s);
 void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s);
 // generalized segment sum: C in {32,64,128,256}; out row stride out_ld (floats), column offset already applied to `out`
@@ -291,6 +301,9 @@ int launch_edge_b(const EdgeBArgs& a, hipStream_t s);
 // row-owner versions (mdx_edge2.hip); launch_edge_a/b dispatch to them unless MDX_TILE_KERNELS=1 is set in the environment
 int launch_edge_a2(const EdgeAArgs& a, hipStream_t s);
 int launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
+// split-precision builds of the two (mdx_edge2s.hip, mdx_edge2bs.hip): taken when the flags carry EA_SPLIT / EB_SPLIT
+int launch_edge_a2s(const EdgeAArgs& a, hipStream_t s);
+int launch_edge_b2s(const EdgeBArgs& a, hipStream_t s);
 bool mdx_use_rowowner();
 int mdx_num_cus();
 void launch_node(const NodeArgs& a, hipStream_t s);

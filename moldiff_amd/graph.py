@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.nn import Linear, Module, ModuleList
 
 from . import _lib
-from .common import MLP, GaussianSmearing, no_device_math
+from .common import MLP, GaussianSmearing
 
 
 def _sig(module):
@@ -81,8 +81,10 @@ class BondFFN(_Block):
     def forward(self, bond_feat_input, node_feat_input, time):
         """bond (E,He), node (E,H) -- one gathered node row per edge --, time (E,1) -> (E,He)  (models/graph.py:133-141)."""
         if self._side < 0:
-            raise NotImplementedError('standalone BondFFN.forward is built for the EdgeBlock FFNs (bond_ffn_left / _right); '
-                                      "PosUpdate.edge_lin only runs fused inside PosUpdate.forward")
+            # not one of the EdgeBlock's fused FFNs (e.g. PosUpdate.edge_lin, out_dim = 1, models/graph.py:389): the layer operators
+            from . import train_graph
+            _lib._need_gpu(bond_feat_input, node_feat_input, time)
+            return train_graph.bond_ffn(self, bond_feat_input, time.reshape(-1, 1), node_edges=node_feat_input)
         net = self._net()
         _lib._need_gpu(bond_feat_input, node_feat_input, time)
         eng = net._engine()
@@ -194,6 +196,9 @@ class NodeEdgeNet(Module):
         self._eng_sig = None
 
     # ---- engine plumbing --------------------------------------------------------------------
+    # None = follow _lib.default_matrix_path (exact fp32 unless MOLDIFF_MATRIX_PATH says otherwise); or 'exact_f32' / 'split_f16'
+    matrix_path = None
+
     def _engine(self):
         sig = _sig(self)
         if self._eng is None or sig != self._eng_sig:
@@ -202,7 +207,7 @@ class NodeEdgeNet(Module):
                              num_gaussians=self.distance_expansion.offset.numel())
             eng.upload(self.state_dict())
             self._eng, self._eng_sig = eng, sig
-        return self._eng
+        return self._eng.use_matrix_path(self.matrix_path)
 
     @staticmethod
     def _graph(edge_index, n_nodes):

@@ -75,6 +75,9 @@ class MolDiff(Module):
             init_prob=config.diff_bond.init_prob)
 
     # ---- engine ---------------------------------------------------------------------------------
+    # None = follow _lib.default_matrix_path (exact fp32 unless MOLDIFF_MATRIX_PATH says otherwise); or 'exact_f32' / 'split_f16'
+    matrix_path = None
+
     def _engine(self):
         sig = _sig(self)
         if self._eng is None or sig != self._eng_sig:
@@ -86,7 +89,7 @@ class MolDiff(Module):
                              num_gaussians=d.distance_expansion.offset.numel())
             eng.upload(self.state_dict())
             self._eng, self._eng_sig = eng, sig
-        return self._eng
+        return self._eng.use_matrix_path(self.matrix_path)
 
     def sample_time(self, num_graphs, device, **kwargs):
         """Antithetic time-step draw: half the batch uniform in [0, T), the other half mirrored (T-1-t)."""

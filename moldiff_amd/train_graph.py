@@ -33,6 +33,19 @@ def cat(*xs):
     return torch.cat(xs, dim=-1)
 
 
+def cat32(*xs):
+    """feature blocks of the RESIDUAL streams side by side, in an fp32 container: under the reference's autocast
+    cat([float16 Linear result, fp32 time embedding]) promotes to fp32 (models/model.py:211-213)."""
+    return torch.cat([x if x.dtype == torch.float32 else x.float() for x in xs], dim=-1)
+
+
+def res_add(x, delta):
+    """x + delta on a residual stream (models/graph.py:359-366).  The reference's autocast adds a float16 Linear result to the fp32
+    stream and the sum promotes to fp32: the streams h_node / h_edge never round between blocks (rounding them to
+    float16 after every block compounds over the six blocks).  Mixed containers go through the fp32 element-wise kernel."""
+    return T.add(x if x.dtype == torch.float32 else x.float(), delta)
+
+
 def mlp_from_pre(m, pre):
     """common.MLP given the output of its first Linear: (LayerNorm -> ReLU -> Linear)*"""
     mods = list(m.net)
@@ -118,8 +131,8 @@ def node_edge_net(net, h_node, pos, h_edge, g, node_time, edge_time):
         h_edge = T.linear(cat(h_edge, h_dist) if net.update_edge else h_dist, emb.weight, emb.bias)
         upd = node_block(net.node_blocks_with_edge[i], h_node, g, h_edge, node_time)
         if net.update_edge:
-            h_edge = T.add(h_edge, edge_block(net.edge_blocks[i], h_edge, g, h_node, edge_time))
-        h_node = T.add(h_node, upd)
+            h_edge = res_add(h_edge, edge_block(net.edge_blocks[i], h_edge, g, h_node, edge_time))
+        h_node = res_add(h_node, upd)
         if net.update_pos:
             pos = T.add(pos, pos_update(net.pos_blocks[i], h_node, h_edge, g, rel, dist, edge_time))
     return h_node, pos, h_edge
@@ -135,8 +148,8 @@ def moldiff_forward(model, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_
     g = TrainGraph(edge_index, h_node_pert.shape[0])
     ts = model.time_emb[0]
     tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
-    h_node = cat(T.linear(h_node_pert, model.node_embedder.weight), time_embedding(ts, tn))
-    h_edge = cat(T.linear(h_edge_pert, model.edge_embedder.weight), time_embedding(ts, te))
+    h_node = cat32(T.linear(h_node_pert, model.node_embedder.weight), time_embedding(ts, tn))
+    h_edge = cat32(T.linear(h_edge_pert, model.edge_embedder.weight), time_embedding(ts, te))
     T_ = float(model.num_timesteps)
     h_node, pos, h_edge = node_edge_net(model.denoiser, h_node, pos_pert, h_edge, g,
                                         (tn.unsqueeze(-1) / T_).float(), (te.unsqueeze(-1) / T_).float())
@@ -151,8 +164,8 @@ def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge
     g = TrainGraph(edge_index, h_node.shape[0])
     tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
     h_edge = cat(h_node[edge_index[0]], h_node[edge_index[1]])            # one-hot pairs: pure indexing
-    h_node = cat(T.linear(h_node, model.node_embedder.weight), time_embedding(model.time_emb, tn))
-    h_edge = cat(T.linear(h_edge, model.edge_embedder.weight), time_embedding(model.time_emb, te))
+    h_node = cat32(T.linear(h_node, model.node_embedder.weight), time_embedding(model.time_emb, tn))
+    h_edge = cat32(T.linear(h_edge, model.edge_embedder.weight), time_embedding(model.time_emb, te))
     T_ = float(model.num_timesteps)
     h_node, _, h_edge = node_edge_net(model.encoder, h_node, pos_node, h_edge, g,
                                       (tn.unsqueeze(-1) / T_).float(), (te.unsqueeze(-1) / T_).float())

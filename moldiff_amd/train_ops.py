@@ -36,7 +36,8 @@ def _c(t):
 #     holding half-representable values.
 #   store = True ('fp16'): those half VALUES also live in float16 CONTAINERS (every Linear / LayerNorm / product result and its
 #     gradient) -- the operators are memory-bound, so this halves what limits them; 'fp16_f32store' keeps fp32 containers (round 3's
-#     first cut; the two differ only where the half container rounds a LayerNorm output or a residual sum one operator earlier).
+#     first cut; the two differ only where the half container rounds a LayerNorm output one operator earlier -- the residual streams
+#     h_node / h_edge stay fp32 in both, as under the reference's autocast: train_graph.res_add).
 _AMP = None
 KINDS = {'f32': None, 'bf16': (1, False, False), 'fp16': (2, True, True), 'fp16_f32store': (2, True, False),
          'bf16_autocast': (1, True, False)}
@@ -119,7 +120,7 @@ class grad_sink:
         f = self.flat
         self.prev = _SINK
         _SINK = {'data': f.data.data_ptr(), 'grad': f.grad.data_ptr(), 'nbytes': f.data.numel() * 4, 'recs': [], 'keep': [], 'blocks': 0,
-                 'device': f.data.device}
+                 'device': f.data.device, 'seen': set()}
         return self
 
     def __exit__(self, *exc):
@@ -139,6 +140,13 @@ def _sink_dst(t):
 
 def _sink_record(part_ptr, dst, S, rows, cols, ld, pstride, rkind, keep):
     sk = _SINK
+    # The reduction launch sums all records of a flush with plain (non-atomic) read-modify-writes, one workgroup per 32-element
+    # block of a record: two records for the SAME slot (a layer applied twice, tied weights, a second backward() inside one sink)
+    # would race and lose a contribution.  A repeated destination therefore flushes what has been recorded first -- launches are
+    # stream-ordered, so the second gradient is added on top of the first like autograd's AccumulateGrad would.
+    if dst in sk['seen']:
+        flush_grad_sink()
+    sk['seen'].add(dst)
     sk['recs'].append((part_ptr, dst, S, rows, cols, ld, pstride, rkind | (sk['blocks'] << 8)))
     sk['blocks'] += (rows * cols + 31) // 32
     sk['keep'].append(keep)
@@ -154,6 +162,7 @@ def flush_grad_sink():
     sk['keep'].append(desc)
     # the partial buffers may be reused once the launch above has been enqueued (stream order); drop the references
     sk['recs'], sk['keep'], sk['blocks'] = [], [], 0
+    sk['seen'] = set()
 
 
 def sgemm_nt(a, b, bias=None, splits=1, addend=None, keep32=False, out_dtype=None):

@@ -114,7 +114,11 @@ class Trainer:
         self.ws = torch.empty(1024, dtype=torch.float32, device=dev)
         # torch.cuda.amp.GradScaler's defaults (init 2**16, x2 after 2000 clean steps, x0.5 on overflow) for float16; every other
         # mode needs no scaling: scale pinned to 1, same code path
-        scaled = precision == 'fp16'
+        # (derived from the arithmetic, not the mode's name: every float16-autocast mode -- 'fp16' and 'fp16_f32store' -- underflows
+        # without a loss scale)
+        kind = train_ops.KINDS[precision]
+        scaled = kind is not None and kind[0] == 2 and kind[1]
+        self._scaled = scaled
         self.growth = (float(growth_factor), float(backoff_factor), int(growth_interval)) if scaled else (1.0, 1.0, 0)
         self.state = torch.zeros(16, dtype=torch.float32, device=dev)     # mdx_op_amp_adamw: [scale, tracker, steps, skipped, norm2, ...]
         self.state[0] = float(init_scale if init_scale is not None else (65536.0 if scaled else 1.0))
@@ -203,5 +207,11 @@ class Trainer:
         self.lr = float(sd['lr'])
         if 'amp_state' in sd:
             self.state.copy_(sd['amp_state'])
+            # a checkpoint written in another precision mode carries that mode's loss scale: an unscaled mode must run at scale 1
+            # (its growth is disabled), a scaled mode must not start from the 1.0 an unscaled run stored
+            if not self._scaled:
+                self.state[0], self.state[1] = 1.0, 0.0
+            elif float(sd['amp_state'][0]) == 1.0:
+                self.state[0], self.state[1] = 65536.0, 0.0
         else:
             self.state[2] = float(sd['steps'])

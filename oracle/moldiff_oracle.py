@@ -262,14 +262,46 @@ def bondpred_forward(P, cfg, h_node, pos, batch_node, edge_index, batch_edge, t)
     return mlp(P, 'edge_decoder', ext, layers=3)
 
 
-def guidance_delta(Pb, cfgb, h_node, pos, batch_node, edge_index, batch_edge, t, scale):
-    """'uncertainty' guidance (model.py:312-325): -scale * d/dpos sum log sigmoid(-LSE(logits))."""
+GUIDANCE_TYPES = ('entropy', 'uncertainty', 'uncertainty_bond', 'entropy_bond', 'logit_bond', 'logit', 'crossent', 'crossent_bond')
+
+
+def guidance_objective(gui_type, logits, halfedge_type_prev=None, log_halfedge_type=None):
+    """The eight objectives of model.py:317-359 on the predictor's (Eh,5) logits -> (scalar objective, sign of the shift).
+    `halfedge_type_prev` / `log_halfedge_type` are THIS step's sampled bond classes and posterior (model.py:297-300)."""
+    if gui_type == 'entropy':
+        p = torch.softmax(logits, -1)
+        return (-torch.sum(p * torch.log(p + 1e-12), -1)).log().sum(), -1.0
+    if gui_type == 'uncertainty':
+        return torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), -1.0
+    if gui_type == 'uncertainty_bond':
+        p = torch.softmax(logits, -1)
+        u = torch.sigmoid(-torch.logsumexp(logits, -1)).log()
+        return (u * p[:, 1:].detach().sum(-1)).sum(), -1.0
+    if gui_type == 'entropy_bond':
+        p = torch.softmax(logits, -1)
+        e = (-torch.sum(p * torch.log(p + 1e-12), -1)).log()
+        return (e * p[:, 1:].detach().sum(-1)).sum(), -1.0
+    if gui_type in ('logit_bond', 'logit'):
+        c = halfedge_type_prev
+        keep = ((c >= 1) & (c <= 4)) if gui_type == 'logit_bond' else (c <= 4)
+        idx = keep.nonzero().squeeze(-1)
+        return logits[idx, c[idx]].sum(), 1.0
+    if gui_type == 'crossent':
+        return F.cross_entropy(logits, log_halfedge_type.exp()[:, :-1], reduction='none').log().sum(), -1.0
+    if gui_type == 'crossent_bond':
+        return F.cross_entropy(logits[:, 1:], log_halfedge_type.exp()[:, 1:-1], reduction='none').log().sum(), -1.0
+    raise NotImplementedError(f'Guidance type {gui_type} is not implemented')
+
+
+def guidance_delta(Pb, cfgb, h_node, pos, batch_node, edge_index, batch_edge, t, scale, gui_type='uncertainty',
+                   halfedge_type_prev=None, log_halfedge_type=None):
+    """Guidance shift of model.py:309-362: sign * scale * d objective / d pos at the step's INPUT state."""
     with torch.enable_grad():
         p = pos.detach().clone().requires_grad_(True)
         logits = bondpred_forward(Pb, cfgb, h_node.detach(), p, batch_node, edge_index, batch_edge, t)
-        u = torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum()
-        g, = torch.autograd.grad(u, p)
-    return -g * scale, logits.detach()
+        obj, sign = guidance_objective(gui_type, logits, halfedge_type_prev, log_halfedge_type)
+        g, = torch.autograd.grad(obj, p)
+    return sign * g * scale, logits.detach()
 
 
 # --------------------------------------------------------------------------------------
@@ -329,8 +361,8 @@ def sample_step(P, cfg, tabs, state, graph, step, noise, Pb=None, cfgb=None, gui
     ch = gumbel_argmax(lh, noise['u_halfedge'])
     delta = None
     if guidance is not None and guidance[1] > 0:
-        assert guidance[0] == 'uncertainty'
-        delta, _ = guidance_delta(Pb, cfgb, state['h_node'], state['pos'], bn, edge_index, batch_edge, t, guidance[1])
+        delta, _ = guidance_delta(Pb, cfgb, state['h_node'], state['pos'], bn, edge_index, batch_edge, t, guidance[1],
+                                  gui_type=guidance[0], halfedge_type_prev=ch, log_halfedge_type=lh)
         pos_prev = pos_prev + delta
     new = {'h_node': F.one_hot(cn, ln.shape[-1]).float(), 'pos': pos_prev,
            'h_halfedge': F.one_hot(ch, lh.shape[-1]).float(), 'log_node': ln, 'log_halfedge': lh,

@@ -78,7 +78,9 @@ def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, 
             ('log_halfedge', got['log_halfedge'], want32['log_halfedge'], want64['log_halfedge'], 1e-4)):
         e_hip, e_ref = U.maxdiff(hip, r64), U.maxdiff(r32, r64)
         report[name] = (e_hip, e_ref, U.maxdiff(hip, r32))
-        assert e_hip <= max(tol, 1.5 * e_ref), f'{name}: |HIP-fp64| = {e_hip:.3e}, |oracle_fp32-fp64| = {e_ref:.3e}, contract {tol}'
+        assert e_hip <= max(tol, U.TAIL['factor'] * e_ref), f'{name}: |HIP-fp64| = {e_hip:.3e}, |oracle_fp32-fp64| = {e_ref:.3e}, contract {tol}'
+        # and not only in the tail: the rms error stays within 2x the fp32 reference's own
+        assert U.rmsdiff(hip, r64) <= max(0.02 * tol, 2.0 * U.rmsdiff(r32, r64)), name
     print('\n[fp64 arbitration] quantity: |HIP-fp64|  |oracle32-fp64|  |HIP-oracle32|')
     for k, v in report.items():
         print(f'    {k:14s} {v[0]:.3e}  {v[1]:.3e}  {v[2]:.3e}')
@@ -160,7 +162,11 @@ def test_one_full_size_guided_step_matches_oracle():
     print(f'    guidance delta: max |delta| {scale:.3e}, |HIP-fp64| {e_hip:.3e}, |oracle32-fp64| {e_ref:.3e}')
     # a gradient through 8 blocks in a different (equally valid) summation order: within 2x the reference's own fp32 error,
     # and two orders of magnitude inside the 1e-4 position contract it feeds
-    assert e_hip <= max(1e-3 * scale, 2.0 * e_ref) and e_hip <= 2e-6
+    assert e_hip <= max(1e-3 * scale, U.TAIL['delta'] * e_ref) and e_hip <= 2e-6
+    # the maximum is set by isolated ReLU kink events (tests/util.py TAIL); the bulk: rms within 1e-4 of the increment's scale
+    r_hip, r_ref = U.rmsdiff(delta, d64), U.rmsdiff(d32, d64)
+    print(f'    guidance delta rms: |HIP-fp64| {r_hip:.3e}, |oracle32-fp64| {r_ref:.3e}')
+    assert r_hip <= max(1e-4 * scale, 2.0 * r_ref)
 
 
 def _rotation(seed):

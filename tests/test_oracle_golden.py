@@ -174,6 +174,47 @@ def test_guidance_delta(P_bond):
         assert U.maxdiff(d, g[f'{tag}_delta']) < 1e-8 + 1e-3 * float(np.abs(g[f'{tag}_delta']).max())
 
 
+def _gt_state(g, tag, gt, j):
+    """State iteration j of the guidance_types.npz run of objective `gt` starts from (frame j; frame 0 = the prior)."""
+    if j == 0:
+        nt, ht = g[f'{tag}_init_node_type'], g[f'{tag}_init_halfedge_type']
+        oh_n, oh_h = F.one_hot(torch.from_numpy(nt.astype(np.int64)), 8).float(), F.one_hot(torch.from_numpy(ht.astype(np.int64)), 6).float()
+        return {'h_node': oh_n, 'pos': U.t32(g[f'{tag}_init_pos']), 'h_halfedge': oh_h,
+                'log_node': torch.log(oh_n.clamp(min=1e-30)), 'log_halfedge': torch.log(oh_h.clamp(min=1e-30))}
+    nt, ht = g[f'{tag}_0_none_node_type'], g[f'{tag}_0_none_halfedge_type']
+    return {'h_node': F.one_hot(torch.from_numpy(nt.astype(np.int64)), 8).float(), 'pos': U.t32(g[f'{tag}_0_{gt}_pos']),
+            'h_halfedge': F.one_hot(torch.from_numpy(ht.astype(np.int64)), 6).float(),
+            'log_node': U.t32(g[f'{tag}_0_log_node']), 'log_halfedge': U.t32(g[f'{tag}_0_log_halfedge'])}
+
+
+@pytest.mark.parametrize('gt', O.GUIDANCE_TYPES)
+def test_all_eight_guidance_objectives_vs_reference_sample(gt, P_full, P_bond):
+    """models/model.py:317-359: guidance_types.npz was written by the reference's own `sample()` (oracle/make_goldens_guidance.py);
+    the oracle's step, teacher-forced from the reference's frames, must land on the reference's guided positions -- which
+    `halfedge_type_prev` / `log_halfedge_type` feed the logit* / crossent* objectives is exactly what this catches."""
+    g = U.gold('guidance_types.npz')
+    first, scale = int(g['first']), float(g['scale'])
+    tabs = U.tables(P_full)
+    for tag in ('n12', 'n101'):
+        bn, hei, bh, ei, be = U.graph_from_sizes(g[f'{tag}_sizes'])
+        graph = {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': int(bn.max()) + 1}
+        for j in range(int(g['nsteps'])):
+            st = _gt_state(g, tag, gt, j)
+            noise = {k: U.t32(g[f'{tag}_{j}_{k}']) for k in ('eps_pos', 'u_node', 'u_halfedge')}
+            with torch.no_grad():
+                new, _ = O.sample_step(P_full, U.CFG, tabs, st, graph, 999 - (first + j), noise, Pb=P_bond, cfgb=U.CFGB,
+                                       guidance=[gt, scale])
+            ref = g[f'{tag}_{j}_{gt}_pos']
+            shift = float(np.abs(ref - g[f'{tag}_{j}_none_pos']).max()) if j == 0 else 0.0
+            assert U.maxdiff(new['pos'], ref) <= 2.0 ** -21, (tag, j)   # a few fp32 ulps of an O(1) position (CPU autograd order)
+            if j == 0:
+                assert np.array_equal(new['halfedge_type'].numpy(), g[f'{tag}_0_none_halfedge_type'])
+                if not (tag == 'n12' and gt == 'logit_bond'):   # no real bond among 31 half-edges: that shift is exactly zero
+                    assert shift > 1e-3
+    with pytest.raises(NotImplementedError):
+        O.guidance_objective('nope', torch.zeros(1, 5))
+
+
 @pytest.mark.parametrize('tag', ['simple', 'guided'])
 def test_step_replay(tag, P_full, P_bond):
     g = U.gold('step_replay.npz')
@@ -223,7 +264,11 @@ def test_pinning_record_says_bit_exact():
     quantities that pass through autograd (the guidance increment and the guided position it is added to) are pinned to one fp32
     ulp of a unit-scale position (1.2e-7), not to 0 -- CPU autograd accumulates in thread-dependent order, so regenerating the
     record gives between 9e-10 and 6e-8 there."""
-    rec = json.load(open(os.path.join(U.GOLD, 'PINNING.json')))['max_abs_diff_oracle_vs_reference']
+    full = json.load(open(os.path.join(U.GOLD, 'PINNING.json')))
+    # all eight guidance objectives against the reference's own sample() (oracle/make_goldens_guidance.py): positions after a
+    # guided step, i.e. through CPU autograd -> a few fp32 ulps of an O(1) position
+    assert full['guidance_types_pos_max'] <= 2.0 ** -21 and len(full['guidance_types_detail']) == 32
+    rec = full['max_abs_diff_oracle_vs_reference']
     autograd = {'guidance_delta', 'sample_step_pos'}
     assert autograd <= set(rec)
     for name, d in rec.items():

@@ -70,3 +70,28 @@ def tables(P):
     return {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')},
             'node': {k: P['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
             'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
+
+
+# Tail factor of the fp64-arbitrated bounds  |HIP - fp64| <= max(contract, TAIL * |oracle_fp32 - fp64|).  1.5 for the exact fp32 path.
+# The MAXIMUM over atoms is a tail statistic: for positions it is set by a few ill-conditioned atoms (pairs ~0.1 apart), for the
+# guidance gradient by isolated ReLU kink events (a pre-activation that one fp32 evaluation puts 1e-8 on the other side of zero
+# than fp64 changes that atom's gradient discretely -- profiles/r4_split_delta_diag.txt).  Two fp32 arithmetics with the same error
+# DISTRIBUTION therefore differ in their maxima by small factors either way; the split float16 path's tests use 3.0 where the
+# committed fixture needs it, and always assert the rms as well.
+TAIL = {'factor': 1.5, 'delta': 2.0}    # 'delta': the guidance increment's own clause (test_gpu_fullsize.py)
+
+
+class tail_factor:
+    def __init__(self, f, key='factor'):
+        self.f, self.key = f, key
+
+    def __enter__(self):
+        self.prev, TAIL[self.key] = TAIL[self.key], self.f
+
+    def __exit__(self, *exc):
+        TAIL[self.key] = self.prev
+
+
+def rmsdiff(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).pow(2).mean().sqrt()) if a.numel() else 0.0
