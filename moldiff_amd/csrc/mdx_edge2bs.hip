@@ -2,8 +2,19 @@
 // (reference models/graph.py:286-294 and :384-393) -- round 4, opt-in; see mdx_edge2s.hip / mdx_split.h.
 // Same argument block, work decomposition and outputs as edge_b2_kernel (mdx_edge2b.hip); only the matrix products differ.
 #include "mdx_kernels.h"
+// Decomposition of the split build (measured on the bench workload, ms per sampling step, kernel A / kernel B): 16 rows x 2 waves per
+// SIMD like the exact kernels 2.80 / 0.96 -- there the per-wave weight stream (the same bytes as fp32, 11.9 GB per kernel-A launch)
+// runs at the L1/L2 limit (~25 TB/s) and IS the kernel time; 32 rows x 1 wave (every weight fragment feeds two row tiles: half the
+// stream) 2.46 / 0.83 with a ring of 4 half-steps, 2.30 / 0.82 with 8 (a lone wave per SIMD has only its own prefetch depth to
+// cover the L2 latency).  The exact fp32 kernels measured the other way round (4.66 vs 4.97 ms): they are bound by the matrix pipe.
+#ifndef MDX_RR
+#define MDX_RR 2
+#endif
+#ifndef MDX_WPS
+#define MDX_WPS 1
+#endif
 #ifndef MDX_RING
-#define MDX_RING 4
+#define MDX_RING 8  // half-steps of 2 KiB in flight per wave
 #endif
 #include "mdx_row.h"
 #include "mdx_split.h"

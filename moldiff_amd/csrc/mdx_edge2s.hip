@@ -7,8 +7,19 @@
 // (mdx_split.h: three products per k-group, fp32 accumulation, ~22 significand bits per operand).  Everything that is not a
 // matrix product (smearing, biases, LayerNorm, gates, segment sums, stores) is the fp32 code of the exact kernel.
 #include "mdx_kernels.h"
+// Decomposition of the split build (measured on the bench workload, ms per sampling step, kernel A / kernel B): 16 rows x 2 waves per
+// SIMD like the exact kernels 2.80 / 0.96 -- there the per-wave weight stream (the same bytes as fp32, 11.9 GB per kernel-A launch)
+// runs at the L1/L2 limit (~25 TB/s) and IS the kernel time; 32 rows x 1 wave (every weight fragment feeds two row tiles: half the
+// stream) 2.46 / 0.83 with a ring of 4 half-steps, 2.30 / 0.82 with 8 (a lone wave per SIMD has only its own prefetch depth to
+// cover the L2 latency).  The exact fp32 kernels measured the other way round (4.66 vs 4.97 ms): they are bound by the matrix pipe.
+#ifndef MDX_RR
+#define MDX_RR 2
+#endif
+#ifndef MDX_WPS
+#define MDX_WPS 1
+#endif
 #ifndef MDX_RING
-#define MDX_RING 4  // half-steps of 2 KiB in flight per wave (= the exact kernel's ring in bytes)
+#define MDX_RING 8  // half-steps of 2 KiB in flight per wave
 #endif
 #include "mdx_row.h"
 #include "mdx_split.h"
@@ -30,11 +41,29 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
   constexpr bool do_tape_ffn = FLAGS & EA_TAPE_FFN;
   constexpr bool TAPE_NT = do_tape;
 #define TAPE_ST(p, v) do { if (TAPE_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else stg4(p, v); } while (0)
-  static_assert(!do_agg || RR == 1, "the in-kernel segment sums are written for one 16-row tile per wave");
+  // Work item u of an EA_AGG launch = the RR consecutive graph-aligned 16-row units RR u .. RR u + RR - 1 of the plan's table, one
+  // per row tile (a wave with two row tiles shares every weight fragment between two units: half the weight stream per edge).
+  // Each row tile keeps its own unit's rows, row count and partial-row index, so the partial rows -- and every result -- are the
+  // same whatever RR is.
+  int ucnt_next[RR];
   auto tile_of = [&](int u) {
     if constexpr (do_agg) {
-      const int2 ue = reinterpret_cast<const int2*>(a.units)[u];
-      return load_tile_u(a.l, a.r, a.te, a.epo, ue.x, ue.y, E, c);
+      RowTile t;
+#pragma unroll
+      for (int rt = 0; rt < RR; ++rt) {
+        const int uu = min(RR * u + rt, a.nunits - 1);
+        const int2 ue = reinterpret_cast<const int2*>(a.units)[uu];
+        const int cnt = (RR * u + rt < a.nunits) ? ue.y : 0;
+        ucnt_next[rt] = cnt;
+        t.valid[rt] = c < cnt;
+        t.row[rt] = t.valid[rt] ? ue.x + c : ue.x;  // clamped to the unit's first row (always a row of the same graph)
+        t.li[rt] = a.l[t.row[rt]];
+        t.ri[rt] = a.r[t.row[rt]];
+        t.tt[rt] = a.te[t.row[rt]];
+        t.pf[rt] = a.epo[t.row[rt]];
+      }
+      t.cnt = ucnt_next[0];
+      return t;
     } else {
       return load_tile(a.l, a.r, a.te, u * ROWS, E, c);
     }
@@ -111,7 +140,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
     int q = q0;
     asm volatile("" : "+v"(q));
     const RowTile t = pr.t;
-    const int ucnt = do_agg ? __builtin_amdgcn_readfirstlane(t.cnt) : 0;
+    int ucnt[RR];
+#pragma unroll
+    for (int rt = 0; rt < RR; ++rt) ucnt[rt] = do_agg ? __builtin_amdgcn_readfirstlane(ucnt_next[rt]) : 0;
     const int ureq = dyn ? wq_request(wp.line, lane) : 0;
     const bool inode = do_node && (mode & 1), iffn = do_ffn && (mode & 10);
     const int sfirst = (mode & 2) ? 0 : 1, slast = (mode & 8) ? 1 : 0;
@@ -204,7 +235,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
         for (int rt = 0; rt < RR; ++rt) y[ft][rt] = y[ft][rt] * park[(ft * RR + rt) * 64];
       if constexpr (do_agg) {
         if (a.M) row_store<16, RR, TAPE_NT>(y, a.M, t.row, t.valid, MDX_ND, q);
-        seg_sum_store<16>(y, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.P);
+        static_for<0, RR>([&](auto rc) {
+          constexpr int rt = decltype(rc)::value;
+          seg_sum_store<16, RR, rt>(y, smem + (size_t)wave * PARK_FLOATS, lane, ucnt[rt], t.li[rt], t.pf[rt] + RR * unit + rt, a.P);
+        });
       } else {
         row_store<16, RR>(y, a.M, t.row, t.valid, MDX_ND, q);
       }
@@ -277,7 +311,10 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
         if constexpr (do_agg) {
           if (s == 1) {
             if (a.F[1]) row_store<4, RR>(o, a.F[1], t.row, t.valid, 64, q);
-            seg_sum_store<4>(o, smem + (size_t)wave * PARK_FLOATS, lane, ucnt, t.li[0], t.pf[0] + unit, a.PR);
+            static_for<0, RR>([&](auto rc) {
+              constexpr int rt = decltype(rc)::value;
+              seg_sum_store<4, RR, rt>(o, smem + (size_t)wave * PARK_FLOATS, lane, ucnt[rt], t.li[rt], t.pf[rt] + RR * unit + rt, a.PR);
+            });
           } else {
             row_store<4, RR>(o, a.F[s], t.row, t.valid, 64, q);
           }
@@ -304,7 +341,7 @@ static void launch_a2s(const EdgeAArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)edge_a2s_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
-  const int nunits = (FLAGS & EA_AGG) ? a.nunits : (a.E + ROWS - 1) / ROWS;
+  const int nunits = (FLAGS & EA_AGG) ? (a.nunits + RR - 1) / RR : (a.E + ROWS - 1) / ROWS;   // work items (RR units each)
   if (nunits <= 0) return;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
   constexpr bool all = (FLAGS & ~(EA_AGG | EA_TAPE | EA_TAPE_FFN)) == (EA_EMB | EA_NODE | EA_FFN);

@@ -353,8 +353,8 @@ __device__ __forceinline__ RowTile load_tile_u(const int* __restrict__ l, const 
 // (on this core VALU time is additive to MFMA time; a DPP scan of the 64 accumulator registers costs ~1,000 VALU issues per
 // unit, this ~50).  XOR swizzle of the 16-byte column by the row: writes (16 rows x 4 adjacent columns per instruction) and reads
 // (one row, 64 or 16 adjacent columns) are both bank-conflict free without padding, so the 16 KiB sigmoid parking area is reused.
-template <int FT>
-__device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][1], float* wbuf, int lane, int cnt, int key, int prow,
+template <int FT, int R = 1, int RT = 0>   // (R, RT: the tile is row tile RT of a wave that owns R of them)
+__device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][R], float* wbuf, int lane, int cnt, int key, int prow,
                                               float* __restrict__ out) {
   constexpr int C4 = 4 * FT;  // 16-byte columns per row
   static_assert(C4 == 64 || C4 == 16, "256- or 64-wide rows");
@@ -370,7 +370,7 @@ __device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][1], float* wb
 #pragma unroll
     for (int j = 0; j < 4; ++j) a4[j] = lo + (((unsigned)j ^ cc) << 6);
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) *reinterpret_cast<f32x4*>(base + a4[ft & 3] + 256 * (ft >> 2)) = y[ft][0];
+    for (int ft = 0; ft < FT; ++ft) *reinterpret_cast<f32x4*>(base + a4[ft & 3] + 256 * (ft >> 2)) = y[ft][RT];
   }
   // lanes read what OTHER lanes of the wave wrote: DS operations of a wave execute in order, the compiler only has to keep them so
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -125,6 +125,11 @@ def index_to_log_onehot(x, num_classes, checked=True):
     if checked and x.numel():
         if deferred_class_checks._active is not None and x.is_cuda:
             deferred_class_checks._active.items.append((x.max(), num_classes))
+            # one_hot on an out-of-range id trips a device-side assert long before the postponed check would report it: encode
+            # the clamped ids, so that the reference's AssertionError (one step later) is what the caller sees.  In a multi-rank run
+            # the rank that raises leaves its peers in that step's gradient all-reduce until the collective's watchdog ends them
+            # (an invalid-data error path; checking before the collective would need the host round trip this context avoids).
+            x = x.clamp(max=num_classes - 1)
         else:
             assert x.max().item() < num_classes, f'Error: {x.max().item()} >= {num_classes}'
     return torch.log(F.one_hot(x, num_classes).float().clamp(min=1e-30))

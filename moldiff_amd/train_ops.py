@@ -36,8 +36,8 @@ def _c(t):
 #     holding half-representable values.
 #   store = True ('fp16'): those half VALUES also live in float16 CONTAINERS (every Linear / LayerNorm / product result and its
 #     gradient) -- the operators are memory-bound, so this halves what limits them; 'fp16_f32store' keeps fp32 containers (round 3's
-#     first cut; the two differ only where the half container rounds a LayerNorm output one operator earlier -- the residual streams
-#     h_node / h_edge stay fp32 in both, as under the reference's autocast: train_graph.res_add).
+#     first cut; the two differ only where the half container rounds a LayerNorm output one operator earlier -- the node residual stream
+#     stays fp32 in both, as under the reference's autocast: train_graph.res_add).
 _AMP = None
 KINDS = {'f32': None, 'bf16': (1, False, False), 'fp16': (2, True, True), 'fp16_f32store': (2, True, False),
          'bf16_autocast': (1, True, False)}

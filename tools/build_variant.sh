@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../moldiff_amd/csrc"
 make -j8 >/dev/null
 mkdir -p /tmp/mdxv_$NAME
 OBJS=""
-for o in mdx_api.o mdx_edge.o mdx_edge2.o mdx_edge2b.o mdx_bwd2.o mdx_linear_rows.o mdx_node.o mdx_transition.o mdx_bondpred.o mdx_decode.o mdx_train.o; do
+for o in $(sed -n "s/^OBJS *= *//p" Makefile); do
   src=${o%.o}.hip
   if echo " $FILES " | grep -q " $src "; then
     /opt/rocm/bin/hipcc $FLAGS -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -c $src -o /tmp/mdxv_$NAME/$o
