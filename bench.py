@@ -720,6 +720,13 @@ def main():
             'kernel_ms_per_step': head['kernel_ms_per_step'], 'kernel_ms_note': head['kernel_ms_note'],
             'ranks_seen': 1, 'backend': backend_note or 'none',
         }
+        from moldiff_amd import _lib as _lp
+        if _lp.resolve_matrix_path(None) != 'exact_f32':
+            # MOLDIFF_MATRIX_PATH selected the opt-in split path for the WHOLE run (profiling / A-B use; never the driver's command):
+            # say so on the line instead of reporting split numbers under the exact path's labels
+            out['dtype'], out['matrix_path'] = SPLIT_DTYPE, _lp.resolve_matrix_path(None)
+            out['roofline'] = roofline_split('edge_a', 'edge_a2s_kernel (split float16 build of edge kernel A)', FLOP_EDGE_A, E, prof)
+            out['roofline_edge_b'] = roofline_split('edge_b', 'edge_b2s_kernel (split float16 build of edge kernel B)', FLOP_EDGE_B, E, prof_all)
         if multi is not None:
             out.update(multi)
             # a complete 1000-step run of every rank plus the gather, i.e. what the entry point's batch loop costs
