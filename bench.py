@@ -46,8 +46,8 @@ FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIG
 FLOP_EDGE_B = 221184        # edge kernel B (EdgeBlock tail + PosUpdate): 2 * (2*64*64 + 2*64*256 + 2*64*32 + 256*256)
 # per directed edge per launch of the guidance backward's edge kernel: EXECUTED flops.  Round 3 reads the
 # BondFFN intermediates from the tape instead of recomputing W_bl (64->128), W_1 (128->128) and W_2 (128->64) on both sides:
-# 829,440 - 2 * 2 * (64*128 + 128*128 + 128*64) = 698,368 (MDX_BWD_RECOMPUTE=1 brings the recompute back)
-FLOP_EDGE_BWD = 829440 if os.environ.get('MDX_BWD_RECOMPUTE') == '1' else 698368
+# 829,440 - 2 * 2 * (64*128 + 128*128 + 128*64) = 698,368
+FLOP_EDGE_BWD = 698368
 EDGE_A_NAME = ('edge_a2_kernel<15> (row-owner fused per-edge MLP chain + in-kernel segment sums of its messages, 16 rows x 2 waves per '
                'SIMD, v_mfma_f32_16x16x4_f32)')
 EDGE_B_NAME = 'edge_b2_kernel (row-owner EdgeBlock tail + PosUpdate, v_mfma_f32_16x16x4_f32)'
@@ -531,7 +531,7 @@ def aggregation_line(N, E, prof, sizes=None, agg=True):
     if agg and c == 0:
         return {'bound': 'hbm', 'kernel': 'none: the reduction left after edge kernel A\'s in-kernel segment sums (combine ~2.5 partial rows per '
                                           'node, by-right BondFFN sum) runs inside node_kernel (its MID stage and a second set of workgroups); '
-                                          'MDX_NO_NODE_AGG=1 restores the separate seg_reduce_block2_kernel (16 us per launch). The '
+                                          '(as a launch of its own, seg_reduce_block2_kernel, it took 16 us). The '
                                           'scatter/gather primitive by itself: see segment_sum', 'achieved': None, 'peak': PEAK_HBM,
                 'unit': 'GB/s', 'frac': None, 'launches': 0}
     if agg and sizes is not None:
@@ -716,7 +716,7 @@ def main():
                        'parallelism': f'independent streams x{world}', 'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
             'roofline': roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, E, prof),
             'roofline_edge_b': roofline_mfma('edge_b', EDGE_B_NAME, FLOP_EDGE_B, E, prof_all),
-            'aggregation': aggregation_line(N, E, prof_all, sizes_head, os.environ.get('MDX_NO_AGG') != '1'),
+            'aggregation': aggregation_line(N, E, prof_all, sizes_head, True),
             'kernel_ms_per_step': head['kernel_ms_per_step'], 'kernel_ms_note': head['kernel_ms_note'],
             'ranks_seen': 1, 'backend': backend_note or 'none',
         }
@@ -818,7 +818,7 @@ def main():
             smb.init()
             elb, profb = run_chain(smb, 5, 2, barrier)
             szb = torch.bincount(phb['batch_node'], minlength=big).cpu().numpy()
-            out['aggregation_large'] = dict(aggregation_line(smb.N, 2 * smb.Eh, profb, szb, os.environ.get('MDX_NO_AGG') != '1'), molecules=big,
+            out['aggregation_large'] = dict(aggregation_line(smb.N, 2 * smb.Eh, profb, szb, True), molecules=big,
                                             ms_per_step=elb / 5 * 1e3, molecules_per_sec=big / (elb / 5 * T_STEPS))
             out['aggregation_large']['segment_sum'] = segment_sum_line(smb, dev)
             out['aggregation_large']['roofline_edge_a'] = roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, 2 * smb.Eh, profb)['frac']

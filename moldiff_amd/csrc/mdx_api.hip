@@ -307,22 +307,6 @@ int pack_model(mdx_model_s* m) {
       c.packSS(&fss.W2, fp + ".inter_module.net.3.weight", ED, 2 * ED, 0, 2 * ED);
       c.packSS(&fss.Wg2, fp + ".gate.net.3.weight", ED, 32, 0, 32);
     }
-    {  // fused first layers of both BondFFNs (see EdgeAW::Wffa)
-      std::vector<float> Wf((size_t)320 * ED, 0.f);
-      bool ok = true;
-      for (int wv = 0; wv < 4 && ok; ++wv) {
-        const int s = wv >> 1, h = wv & 1;
-        const std::string fp = eb + (s ? ".bond_ffn_right" : ".bond_ffn_left");
-        const HostTensor* bl = c.get(fp + ".bond_linear.weight", {2 * ED, ED});
-        const HostTensor* g1 = c.get(fp + ".gate.net.0.weight", {32, GIN});
-        if (!bl || !g1) { ok = false; break; }
-        for (int r = 0; r < 64; ++r)
-          for (int k = 0; k < ED; ++k) Wf[(size_t)(80 * wv + r) * ED + k] = bl->data[(size_t)(64 * h + r) * ED + k];
-        for (int r = 0; r < 16; ++r)
-          for (int k = 0; k < ED; ++k) Wf[(size_t)(80 * wv + 64 + r) * ED + k] = g1->data[(size_t)(16 * h + r) * GIN + k];
-      }
-      if (ok) c.pack_dense(&b.ea.Wffa, Wf, 320, ED, 0, ED);
-    }
     // ---- edge kernel B
     c.packA(&b.eb.Wself, eb + ".self_ffn.weight", ED, ED, 0, ED);
     c.vec(&b.eb.bself, eb + ".self_ffn.bias", ED);
@@ -388,29 +372,6 @@ int pack_model(mdx_model_s* m) {
       c.packSS(&b.eb.ss.Wi1, el + ".inter_module.net.0.weight", ND, ND, 0, ND);
       c.packSS(&b.eb.ss.Wg1h, el + ".gate.net.0.weight", 32, 2 * ED + 1, 0, ED);
       c.packSS(&b.eb.ss.Wg1a, el + ".gate.net.0.weight", 32, 2 * ED + 1, ED, ED);
-      {
-        const HostTensor* bl = c.get(el + ".bond_linear.weight", {ND, ED});
-        const HostTensor* nl = c.get(el + ".node_linear.weight", {ND, ED});
-        const HostTensor* g1 = c.get(el + ".gate.net.0.weight", {32, 2 * ED + 1});
-        if (bl && nl && g1) {
-          std::vector<float> Wb((size_t)320 * ED, 0.f), Wn((size_t)320 * ED, 0.f);
-          for (int wv = 0; wv < 4; ++wv) {
-            for (int r = 0; r < 64; ++r)
-              for (int k = 0; k < ED; ++k) {
-                Wb[(size_t)(80 * wv + r) * ED + k] = bl->data[(size_t)(64 * wv + r) * ED + k];
-                Wn[(size_t)(80 * wv + r) * ED + k] = nl->data[(size_t)(64 * wv + r) * ED + k];
-              }
-            if (wv < 2)
-              for (int r = 0; r < 16; ++r)
-                for (int k = 0; k < ED; ++k) {
-                  Wb[(size_t)(80 * wv + 64 + r) * ED + k] = g1->data[(size_t)(16 * wv + r) * (2 * ED + 1) + k];
-                  Wn[(size_t)(80 * wv + 64 + r) * ED + k] = g1->data[(size_t)(16 * wv + r) * (2 * ED + 1) + ED + k];
-                }
-          }
-          c.pack_dense(&b.eb.WblG, Wb, 320, ED, 0, ED);
-          c.pack_dense(&b.eb.WnlG, Wn, 320, ED, 0, ED);
-        }
-      }
       c.vec(&b.eb.bg1, el + ".gate.net.0.bias", 32);
       c.column(&b.eb.wtg1, el + ".gate.net.0.weight", 32, 2 * ED + 1, 2 * ED);
       c.vec(&b.eb.gg, el + ".gate.net.1.weight", 32);
@@ -595,7 +556,6 @@ extern "C" int mdx_model_set_matrix_path(mdx_model_t m, int32_t path) {
   if (path != MDX_MATRIX_EXACT_F32 && path != MDX_MATRIX_SPLIT_F16) return fail(MDX_ERR_ARG, "unknown matrix path %d", (int)path);
   if (path == MDX_MATRIX_SPLIT_F16) {
     if (!m->finalized) return fail(MDX_ERR_STATE, "model not finalized (call mdx_model_finalize)");
-    if (!mdx_use_rowowner()) return fail(MDX_ERR_UNSUPPORTED, "the split float16 path exists for the row-owner kernels only");
     if (!m->split_ok)
       return fail(MDX_ERR_UNSUPPORTED, "split float16 path refused: a weight of magnitude %g is outside float16's range (|w| < 65504)",
                   (double)m->split_wmax);
@@ -624,9 +584,6 @@ struct mdx_graph_s {
   const int32_t *units = nullptr, *epo = nullptr, *pbase = nullptr;
   int64_t nunits = 0, nparts = 0;
   hipEvent_t ev_in = nullptr, ev_done = nullptr;  // stream hand-offs of mdx_sample_step_full's concurrent guidance chain
-  // run_blocks' side stream: the next block's per-node PRE stage runs beside edge kernel B of the current block (see there)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_mid = nullptr, ev_pre = nullptr;
   // work-queue counter sets of the persistent edge kernels, one per launching stream (wq_for)
   int* wq = nullptr;
   hipStream_t wq_stream[MDX_WQ_SETS] = {};
@@ -804,9 +761,6 @@ extern "C" int mdx_graph_destroy(mdx_graph_t g) {
   if (g->mol_ids) hipFree(g->mol_ids);
   if (g->ev_in) hipEventDestroy(g->ev_in);
   if (g->ev_done) hipEventDestroy(g->ev_done);
-  if (g->ev_mid) hipEventDestroy(g->ev_mid);
-  if (g->ev_pre) hipEventDestroy(g->ev_pre);
-  if (g->side) hipStreamDestroy(g->side);
   delete g;
   return MDX_OK;
 }
@@ -879,8 +833,6 @@ struct ProfSlot {
   double total_ms = 0.0;
   long long count = 0;
 };
-bool use_agg();  // below
-bool use_node_agg();
 unsigned g_prof_mask = 0;  // bit k: kernel k is timed
 ProfSlot g_prof[PK_COUNT];
 
@@ -931,13 +883,12 @@ extern "C" int mdx_profile_enable(int32_t on) {
 // name of the kernel function slot `kernel` brackets in THIS build (bench.py checks a committed PMC summary against it before
 // quoting its traffic figure)
 extern "C" const char* mdx_profile_kernel_name(int32_t kernel) {
-  const bool ro = mdx_use_rowowner();
   switch (kernel) {
-    case PK_EDGE_A: return ro ? (use_agg() ? "edge_a2_kernel<15>" : "edge_a2_kernel<7>") : "edge_a_kernel";
-    case PK_EDGE_B: return ro ? "edge_b2_kernel" : "edge_b_kernel";
+    case PK_EDGE_A: return "edge_a2_kernel<15>";
+    case PK_EDGE_B: return "edge_b2_kernel";
     case PK_NODE: return "node_kernel";
-    case PK_AGGR: return ro && use_node_agg() ? "" : ro && use_agg() ? "seg_reduce_block2_kernel" : "seg_reduce_block_kernel";   // "": fused into node_kernel
-    case PK_EDGE_BWD: return ro ? "edge_bwd2_kernel" : "edge_bwd_kernel";
+    case PK_AGGR: return "";   // the reduction left after edge kernel A's in-kernel sums runs inside node_kernel
+    case PK_EDGE_BWD: return "edge_bwd2_kernel";
     default: return "";
   }
 }
@@ -975,33 +926,6 @@ EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i
   return a;
 }
 
-// BondFFN intermediates on the guidance tape (round 3; MDX_BWD_RECOMPUTE=1: the backward recomputes them as in round 2, A/B)
-bool use_agg();
-// (the BondFFN tape stores exist in the EA_AGG instantiations of edge kernel A only: without the in-kernel sums -- MDX_NO_AGG=1 --
-// the backward recomputes instead of reading a tape nobody wrote)
-bool ffn_tape() {
-  static const bool v = [] {
-    const char* e = getenv("MDX_BWD_RECOMPUTE");
-    return mdx_use_rowowner() && use_agg() && !(e && e[0] == '1');
-  }();
-  return v;
-}
-// Edge kernel A with its segment sums fused (round 3) unless the tile kernels (no EA_AGG) or MDX_NO_AGG=1 (A/B) are selected
-bool use_agg() {
-  static const bool v = [] {
-    const char* e = getenv("MDX_NO_AGG");
-    return mdx_use_rowowner() && !(e && e[0] == '1');
-  }();
-  return v;
-}
-// the reduction that is left after the in-kernel sums runs inside the node kernel (MDX_NO_NODE_AGG=1: seg_reduce_block2_kernel, A/B)
-bool use_node_agg() {
-  static const bool v = [] {
-    const char* e = getenv("MDX_NO_NODE_AGG");
-    return use_agg() && !(e && e[0] == '1');
-  }();
-  return v;
-}
 #define LCHK(x)                    \
   do {                             \
     const int rc_ = (x);           \
@@ -1054,21 +978,8 @@ NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int im
 }
 
 // Runs all blocks.  In: w.Hn, w.HeA (internal order), pos_in, w.tn / w.te.  Out: w.Hn, He (returned pointer), pos (returned).
-// Experiment kept behind MDX_NODE_OVERLAP=1 (round 3, measured NEGATIVE, default off).  Edge kernel B runs 4.72 rounds of 16-edge
-// units on 2,048 persistent waves as 5: in its last round 28 % of the wave slots retire early.  The next block's PRE stage (node_net +
-// the 960-wide hoisted table: 78 % of the node kernel's work) depends only on the node state the MID stage has just written, and edge
-// kernel B reads none of its outputs, so PRE can go to a low-priority side stream behind kernel B's launch in the hope that its
-// workgroups back-fill the CUs kernel B's early finishers free.  They do not wait for that: the dispatcher interleaves both kernels
-// from the start, kernel B's statically partitioned persistent waves lose CU slots and it takes 2.01 ms per step instead of 1.69
-// (step: 7.41 vs 6.99 ms).  A stream priority is a hint the workgroup dispatcher does not honour here.
-bool node_overlap() {
-  static const bool v = [] {
-    const char* e = getenv("MDX_NODE_OVERLAP");
-    return e && e[0] == '1';
-  }();
-  return v;
-}
-
+// (Round 3 tried the next block's PRE stage on a low-priority side stream behind edge kernel B, to back-fill the CUs its early
+// finishers free: the dispatcher interleaves both kernels from the start and the step got slower, 7.41 vs 6.99 ms; removed.)
 int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* pos_in, const float** He_final,
                const float** pos_final, hipStream_t s, float* pos_out = nullptr) {
   const int nb = m->cfg.num_blocks;
@@ -1079,53 +990,26 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
   // after the node kernel has already produced block i+1's table.
   float* NTcur = w.NT;
   float* NTnxt = w.NT2;
-  const bool overlap = node_overlap() && nb > 1;
   const int split_a = m->matrix_path == MDX_MATRIX_SPLIT_F16 ? EA_SPLIT : 0, split_b = split_a ? EB_SPLIT : 0;
-  if (overlap && !g->side) {
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
-    HIPCHK(hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, lo));
-    HIPCHK(hipEventCreateWithFlags(&g->ev_mid, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&g->ev_pre, hipEventDisableTiming));
-  }
   launch_node(make_nd(m, g, w, -1, 0, ND_PRE, nullptr, NTcur), s);
   for (int i = 0; i < nb; ++i) {
-    const bool agg = use_agg();
     {
       ProfScope ps(PK_EDGE_A, s);
-      LCHK(run_ea(g, make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | (agg ? EA_AGG : 0) | split_a, NTcur), s));
+      LCHK(run_ea(g, make_ea(m, g, w, i, pos, w.HeA, w.HeB, EA_EMB | EA_NODE | EA_FFN | EA_AGG | split_a, NTcur), s));
     }
-    // round 3: with the in-kernel sums the reduction that is left (combine ~2.5 partial rows per node, the by-right BondFFN sum) is
-    // done by the node kernel itself for its 16 nodes -- one launch fewer per block (MDX_NO_NODE_AGG=1: separate kernel, A/B)
-    const bool node_agg = use_node_agg();
-    if (!(agg && node_agg)) {
-      ProfScope ps(PK_AGGR, s);
-      if (agg)
-        launch_seg_reduce_block2(w.P, w.PR, w.FL, g->pbase, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
-      else
-        launch_seg_reduce_block(w.M, w.FL, w.FR, g->row_ptr, g->col_ptr, g->col_eids, w.aggr, w.SL, w.SR, (int)g->N, s);
-    }
+    // The reduction that is left after edge kernel A's in-kernel sums (combine ~2.5 partial rows per node, the by-right BondFFN sum)
+    // is done by the node kernel itself for its 16 nodes: MID of this block + PRE of the next in one launch.
     const bool pre = i + 1 < nb;
-    const bool split = overlap && pre;
-    int nflags = ND_MID | (upos ? ND_POSMLP : 0) | (pre && !split ? ND_PRE : 0);
     {
       ProfScope ps(PK_NODE, s);
-      NodeArgs na = make_nd(m, g, w, i, pre ? i + 1 : -1, nflags, NTcur, NTnxt);
-      if (agg && node_agg) {
-        na.P = w.P; na.PR = w.PR; na.FL = w.FL; na.pbase = g->pbase; na.col_ptr = g->col_ptr; na.col_eids = g->col_eids;
-        na.SL = w.SL; na.SR = w.SR;
-      }
+      NodeArgs na = make_nd(m, g, w, i, pre ? i + 1 : -1, ND_MID | (upos ? ND_POSMLP : 0) | (pre ? ND_PRE : 0), NTcur, NTnxt);
+      na.P = w.P; na.PR = w.PR; na.FL = w.FL; na.pbase = g->pbase; na.col_ptr = g->col_ptr; na.col_eids = g->col_eids;
+      na.SL = w.SL; na.SR = w.SR;
       launch_node(na, s);
     }
-    if (split) HIPCHK(hipEventRecord(g->ev_mid, s));
     {
       ProfScope ps(PK_EDGE_B, s);
       LCHK(run_eb(g, make_eb(m, g, w, i, pos, w.HeB, w.HeA, EB_EDGE | (upos ? EB_POS : 0) | split_b, NTcur), s));
-    }
-    if (split) {
-      HIPCHK(hipStreamWaitEvent(g->side, g->ev_mid, 0));
-      launch_node(make_nd(m, g, w, -1, i + 1, ND_PRE, NTcur, NTnxt), g->side);
-      HIPCHK(hipEventRecord(g->ev_pre, g->side));
     }
     if (upos) {
       if (pos_out && i + 1 == nb) pos_next = pos_out;  // the last update lands in the caller's buffer (no copy afterwards)
@@ -1133,7 +1017,6 @@ int run_blocks(const mdx_model_s* m, mdx_graph_s* g, const Ws& w, const float* p
       pos = pos_next;
       pos_next = (pos_next == w.posA) ? w.posB : w.posA;
     }
-    if (split) HIPCHK(hipStreamWaitEvent(s, g->ev_pre, 0));
     std::swap(NTcur, NTnxt);
   }
   *He_final = w.HeA;
@@ -1510,22 +1393,18 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
     }
     // tape + in-kernel sums: the reduction, MID of this block and PRE of the next are ONE node launch as in run_blocks (round 3; it
     // used to be three plus the reduction kernel), with every output pointed straight at its tape buffer
-    const bool fused_tape = tape && use_agg() && use_node_agg();
-    if (i == 0 || (tape && !fused_tape)) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
+    const bool fused_tape = tape != nullptr;
+    if (i == 0) launch_node(make_nd(m, g, wi, -1, i, ND_PRE, nullptr, wi.NT), s);
     {
-      EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN | (use_agg() ? EA_AGG : 0), wi.NT);
-      if (tape) {
-        if (mdx_use_rowowner()) ea_args.flags |= EA_TAPE;  // (a template flag of the row-owner kernel; the tile kernel tests the pointers)
+      EdgeAArgs ea_args = make_ea(m, g, wi, i, pos, wr.HeA, Hep, EA_EMB | EA_NODE | EA_FFN | EA_AGG, wi.NT);
+      if (tape) {  // the launch also writes the guidance tape (template flags of the kernel)
+        ea_args.flags |= EA_TAPE | EA_TAPE_FFN;
         ea_args.tSG = tp.b[i].SG;
         ea_args.tHE = tp.b[i].HE;
         ea_args.M = tp.b[i].M;  // the backward reads the gated message back (with EA_AGG it is no longer the reduction's input)
-        if (ffn_tape()) {
-          for (int sd = 0; sd < 2; ++sd) { ea_args.tBL[sd] = tp.b[i].BL[sd]; ea_args.tH1[sd] = tp.b[i].H1[sd]; ea_args.tO[sd] = tp.b[i].O[sd]; }
-          if (use_agg()) ea_args.flags |= EA_TAPE_FFN;   // (ffn_tape() implies the row-owner kernels)
-        }
+        for (int sd = 0; sd < 2; ++sd) { ea_args.tBL[sd] = tp.b[i].BL[sd]; ea_args.tH1[sd] = tp.b[i].H1[sd]; ea_args.tO[sd] = tp.b[i].O[sd]; }
       }
-      // split float16 matrix path: the same launch on mdx_edge2s.hip (the section combinations the product path uses)
-      if (split_a && use_agg() && (!tape || (ea_args.flags & EA_TAPE_FFN))) ea_args.flags |= EA_SPLIT;
+      ea_args.flags |= split_a;  // split float16 matrix path: the same launch on mdx_edge2s.hip
       { ProfScope ps(PK_EDGE_A, s); LCHK(run_ea(g, ea_args, s)); }
     }
     if (fused_tape) {
@@ -1538,20 +1417,13 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
       LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE | split_b, wi.NT), s));
       continue;
     }
-    if (use_agg())
-      launch_seg_reduce_block2(wi.P, wi.PR, wi.FL, g->pbase, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
-    else
-      launch_seg_reduce_block(wi.M, wi.FL, wi.FR, g->row_ptr, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
-    if (tape) {
-      launch_node(make_nd(m, g, wi, i, -1, ND_MID, wi.NT, nullptr), s);
-    } else {  // no tape: fuse the next block's PRE into this node launch (tables double-buffered like run_blocks)
-      float* NTn = (wr.NT == w.NT) ? w.NT2 : w.NT;
-      launch_node(make_nd(m, g, wi, i, i + 1 < nb ? i + 1 : -1, ND_MID | (i + 1 < nb ? ND_PRE : 0), wi.NT, NTn), s);
-      LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE | split_b, wi.NT), s));
-      wr.NT = NTn;
-      continue;
-    }
+    // no tape: the reduction left after the in-kernel sums as a launch of its own, then MID of this block fused with the next
+    // block's PRE (tables double-buffered like run_blocks)
+    launch_seg_reduce_block2(wi.P, wi.PR, wi.FL, g->pbase, g->col_ptr, g->col_eids, wi.aggr, wi.SL, wi.SR, (int)g->N, s);
+    float* NTn = (wr.NT == w.NT) ? w.NT2 : w.NT;
+    launch_node(make_nd(m, g, wi, i, i + 1 < nb ? i + 1 : -1, ND_MID | (i + 1 < nb ? ND_PRE : 0), wi.NT, NTn), s);
     LCHK(run_eb(g, make_eb(m, g, wi, i, pos, Hep, wr.HeA, EB_EDGE | split_b, wi.NT), s));
+    wr.NT = NTn;
   }
   if (tape) {
     HIPCHK(hipMemcpyAsync(tp.HnF, wr.Hn, nHn, hipMemcpyDeviceToDevice, s));
@@ -1600,17 +1472,16 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
     et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT; et.wq = wq_for(g, s);
     et.ssWselfT = m->ebw[i].ss.WselfT; et.ssWoutT = m->ebw[i].ss.WoutT;
-    const bool split_bwd = m->matrix_path == MDX_MATRIX_SPLIT_F16 && mdx_use_rowowner() && ffn_tape();
+    const bool split_bwd = m->matrix_path == MDX_MATRIX_SPLIT_F16;
     et.split = split_bwd ? 1 : 0;
     if (split_bwd) launch_edge_tail_bwd2s(et, s);
-    else if (mdx_use_rowowner()) launch_edge_tail_bwd2(et, s); else launch_edge_tail_bwd(et, s);
+    else launch_edge_tail_bwd2(et, s);
     launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
     eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
-    if (ffn_tape())
-      for (int sd = 0; sd < 2; ++sd) { eb.BL[sd] = k.BL[sd]; eb.H1[sd] = k.H1[sd]; eb.O[sd] = k.O[sd]; }
+    for (int sd = 0; sd < 2; ++sd) { eb.BL[sd] = k.BL[sd]; eb.H1[sd] = k.H1[sd]; eb.O[sd] = k.O[sd]; }
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = et.wq;
     eb.split = split_bwd ? 1 : 0;
@@ -1618,8 +1489,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
       ProfScope ps(PK_EDGE_BWD, s);
       if (split_bwd) {
         if (launch_edge_bwd2s(eb, s) != 0) return fail(MDX_ERR_STATE, "split float16 backward: the forward tape holds no BondFFN intermediates");
-      } else if (mdx_use_rowowner()) launch_edge_bwd2(eb, s);
-      else launch_edge_bwd(eb, s);
+      } else launch_edge_bwd2(eb, s);
     }
     {
       SegBwdArgs sr{};

@@ -23,378 +23,6 @@ constexpr int LD32 = mdx_ld(32);
 constexpr int LD16 = mdx_ld(16);
 
 // =================================================================================================
-// B1: EdgeBlock tail backward.   He_{i+1} = He' + Wout relu(LN(u)) + b,
-//      u = SL[l] + SR[r] + nfl[l] + nfr[r] + Wself He' + b
-//   in : gHe = dL/dHe_{i+1};  out: GU = dL/du,  GHEP = gHe + Wself^T GU   (partial dL/dHe')
-// =================================================================================================
-constexpr int TET = MDX_ET;
-constexpr int TTE = 16 * TET;
-constexpr int T_HEP = 0;
-constexpr int T_G = T_HEP + TTE * LD64;
-constexpr int T_X = T_G + TTE * LD64;
-constexpr int T_RED = T_X + TTE * LD64;
-constexpr int T_TOTAL = T_RED + 16 * TTE;
-
-__device__ __forceinline__ void load_rows64_t(const float* __restrict__ src, int e0, int E, float* dst, int ld, int tid,
-                                              int TE) {
-  for (int i = tid; i < TE * 16; i += MDX_WG) {
-    const int row = i >> 4, c4 = i & 15;
-    const int e = e0 + row;
-    sts4(dst + row * ld + 4 * c4, (e < E) ? ldg4(src + (size_t)e * 64 + 4 * c4) : splat4(0.f));
-  }
-}
-
-__global__ __launch_bounds__(MDX_WG, 2) void edge_tail_bwd_kernel(const EdgeTailBwdArgs a, const int ntiles) {
-  __shared__ __attribute__((aligned(16))) float smem[T_TOTAL];
-  float* Hep = smem + T_HEP;
-  float* G = smem + T_G;
-  float* X = smem + T_X;
-  float* red = smem + T_RED;
-  float *red2 = red + 4 * TTE, *red3 = red + 8 * TTE, *red4 = red + 12 * TTE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, q = lane >> 4;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int e0 = tile * TTE, E = a.E;
-  const int f = 16 * wave + 4 * q;
-  int li[TET], ri[TET];
-  bool valid[TET];
-#pragma unroll
-  for (int et = 0; et < TET; ++et) {
-    const int e = e0 + 16 * et + c;
-    valid[et] = e < E;
-    li[et] = valid[et] ? a.l[e] : 0;
-    ri[et] = valid[et] ? a.r[e] : 0;
-  }
-  load_rows64_t(a.Hep, e0, E, Hep, LD64, tid, TTE);
-  load_rows64_t(a.gHe, e0, E, G, LD64, tid, TTE);
-  __syncthreads();
-  // recompute u -> x_hat
-  f32x4 u[1][TET];
-  const f32x4 bs = ldg4(a.w.bself + f);
-#pragma unroll
-  for (int et = 0; et < TET; ++et) {
-    f32x4 v = ldg4(a.SL + (size_t)li[et] * 64 + f) + ldg4(a.SR + (size_t)ri[et] * 64 + f);
-    v = v + ldg4(a.NT + (size_t)li[et] * MDX_NTW + MDX_NT_NFL + f);
-    v = v + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_NFR + f);
-    u[0][et] = v + bs;
-  }
-  gemm_tile<1, TET, 64>(u, a.w.Wself, 4, wave, Hep, LD64, lane);
-  float rstd[TET];
-  ln_xhat<1, TET, 4>(u, rstd, red, red2, wave, lane, true);
-  // gy = Wout^T gHe
-  f32x4 g[1][TET];
-  acc_zero<1, TET>(g);
-  gemm_tile<1, TET, 64>(g, a.WoutT, 4, wave, G, LD64, lane);
-  ln_relu_bwd<1, TET, 4>(g, u, rstd, a.w.lng, a.w.lnb, wave, red3, red4, wave, lane, true);
-#pragma unroll
-  for (int et = 0; et < TET; ++et)
-    if (valid[et]) stg4(a.GU + (size_t)(e0 + 16 * et + c) * 64 + f, g[0][et]);
-  acc_to_lds<1, TET>(g, X, LD64, 0, wave, lane);
-  __syncthreads();
-  f32x4 o[1][TET];
-#pragma unroll
-  for (int et = 0; et < TET; ++et) o[0][et] = lds4(G + (16 * et + c) * LD64 + f);
-  gemm_tile<1, TET, 64>(o, a.WselfT, 4, wave, X, LD64, lane);
-#pragma unroll
-  for (int et = 0; et < TET; ++et)
-    if (valid[et]) stg4(a.GHEP + (size_t)(e0 + 16 * et + c) * 64 + f, o[0][et]);
-}
-
-// =================================================================================================
-// B2: backward of edge kernel A for one tile of 32 edges (recompute + dgrad).
-// =================================================================================================
-constexpr int BET = 2;
-constexpr int BTE = 16 * BET;
-constexpr int B_HEP = 0;                      // [BTE][72]  He'
-constexpr int B_X = B_HEP + BTE * LD64;       // [BTE][264]
-constexpr int B_Y = B_X + BTE * LD256;        // [BTE][264]
-// S, S2, GG are only live in the BondFFN / edge_embs sections, Y only in the message-path section: they share
-// storage, which brings the workgroup to 78.8 KB of LDS = two workgroups per CU.
-constexpr int B_S = B_Y;                      // [BTE][72]
-constexpr int B_S2 = B_S + BTE * LD64;        // [BTE][72]
-constexpr int B_GG = B_S2 + BTE * LD64;       // [BTE][40]
-static_assert(B_GG + BTE * LD32 <= B_Y + BTE * LD256, "aliased buffers must fit inside Y");
-constexpr int B_RED = B_Y + BTE * LD256;      // 4 x (4*BTE)
-constexpr int B_TOTAL = B_RED + 16 * BTE;
-
-__global__ __launch_bounds__(MDX_WG, 2) void edge_bwd_kernel(const EdgeBwdArgs a, const int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Hep = smem + B_HEP;
-  float* X = smem + B_X;
-  float* Y = smem + B_Y;
-  float* S = smem + B_S;
-  float* S2 = smem + B_S2;
-  float* GG = smem + B_GG;
-  float* red = smem + B_RED;
-  float *red2 = red + 4 * BTE, *red3 = red + 8 * BTE, *red4 = red + 12 * BTE;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, q = lane >> 4;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int e0 = tile * BTE, E = a.E;
-  int li[BET], ri[BET];
-  float tt[BET];
-  bool valid[BET];
-#pragma unroll
-  for (int et = 0; et < BET; ++et) {
-    const int e = e0 + 16 * et + c;
-    valid[et] = e < E;
-    li[et] = valid[et] ? a.l[e] : 0;
-    ri[et] = valid[et] ? a.r[e] : 0;
-    tt[et] = valid[et] ? a.te[e] : 0.f;
-  }
-  load_rows64_t(a.Hep, e0, E, Hep, LD64, tid, BTE);
-  __syncthreads();
-
-  // running dL/dHe' for this wave's 16-feature slice (starts from the tail's partial gradient)
-  const int f1 = 16 * wave + 4 * q;
-  f32x4 ghe[1][BET];
-#pragma unroll
-  for (int et = 0; et < BET; ++et)
-    ghe[0][et] = valid[et] ? ldg4(a.GHEP + (size_t)(e0 + 16 * et + c) * 64 + f1) : splat4(0.f);
-
-  const int ft0 = 4 * wave;
-  // ---------------- NodeBlock message path ------------------------------------------------------
-  {
-    // forward values of this section come from the tape the forward kernel wrote (sigmoid(gate), edge_net output, gated
-    // message): three (E,256) reads replace ~390 kFLOP/edge of recomputation (gate and edge_net second layers, msg_net)
-    // backward: gm = dL/d(aggr)[l];  M = m0 * sg
-    f32x4 gg2[4][BET];
-    {
-      f32x4 gm0[4][BET];
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et) {
-          const size_t o = (size_t)(e0 + 16 * et + c) * MDX_ND + 16 * (ft0 + ft) + 4 * q;
-          const f32x4 sg = valid[et] ? ldg4(a.SG + o) : splat4(0.f);
-          const f32x4 mg = valid[et] ? ldg4(a.M + o) : splat4(0.f);
-          const f32x4 gm = ldg4(a.GNT + (size_t)li[et] * MDX_NTW + MDX_NT_C + 16 * (ft0 + ft) + 4 * q);
-          gm0[ft][et] = gm * sg;
-          gg2[ft][et] = gm * mg * (splat4(1.f) - sg);  // m0 * sg = M
-        }
-      acc_to_lds<4, BET>(gm0, Y, LD256, 0, ft0, lane);
-    }
-    __syncthreads();
-    {
-      f32x4 gp[4][BET];
-      acc_zero<4, BET>(gp);
-      gemm_tile<4, BET, 256>(gp, a.wt.WmT, 16, ft0, Y, LD256, lane);
-      // p = he * h[r]:  d he = gp * h[r] ; d h[r] = gp * he
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et) {
-          const int f = 16 * (ft0 + ft) + 4 * q;
-          if (valid[et]) {
-            const size_t o = (size_t)(e0 + 16 * et + c) * MDX_ND + f;
-            stg4(a.GH + o, gp[ft][et] * ldg4(a.HE + o));
-          }
-          gp[ft][et] = gp[ft][et] * ldg4(a.H + (size_t)ri[et] * MDX_ND + f);
-        }
-      __syncthreads();  // all waves done reading Y (gm0)
-      acc_to_lds<4, BET>(gp, Y, LD256, 0, ft0, lane);
-    }
-    __syncthreads();
-    {  // through edge_net: he = W2 relu(LN(q)) + b2, q = W1 He' + b1
-      f32x4 gt[4][BET], xh[4][BET];
-      acc_zero<4, BET>(gt);
-      gemm_tile<4, BET, 256>(gt, a.wt.W2T, 16, ft0, Y, LD256, lane);
-      acc_bias<4, BET>(xh, a.w.en.b1, ft0, lane);
-      gemm_tile<4, BET, 64>(xh, a.w.en.W1, 16, ft0, Hep, LD64, lane);
-      float rstd[BET];
-      ln_xhat<4, BET, 4>(xh, rstd, red, red2, wave, lane, true);
-      ln_relu_bwd<4, BET, 4>(gt, xh, rstd, a.w.en.g, a.w.en.be, ft0, red3, red4, wave, lane, true);
-      acc_to_lds<4, BET>(gt, X, LD256, 0, ft0, lane);
-    }
-    __syncthreads();
-    gemm_tile<1, BET, 256>(ghe, a.wt.W1T, 4, wave, X, LD256, lane);
-    __syncthreads();  // X, Y free
-    {  // gate backward: g = Wg2 relu(LN(qg)) + b, qg = Wg1e He' + gx[r] + t wt + b
-      acc_to_lds<4, BET>(gg2, Y, LD256, 0, ft0, lane);
-      __syncthreads();
-      f32x4 gt[4][BET], xh[4][BET];
-      acc_zero<4, BET>(gt);
-      gemm_tile<4, BET, 256>(gt, a.wt.Wg2T, 16, ft0, Y, LD256, lane);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft) {
-        const int f = 16 * (ft0 + ft) + 4 * q;
-        const f32x4 b = ldg4(a.w.bg1 + f), wt = ldg4(a.w.wtg1 + f);
-#pragma unroll
-        for (int et = 0; et < BET; ++et)
-          xh[ft][et] = b + ldg4(a.NT + (size_t)ri[et] * MDX_NTW + MDX_NT_GX + f) + splat4(tt[et]) * wt;
-      }
-      gemm_tile<4, BET, 64>(xh, a.w.Wg1e, 16, ft0, Hep, LD64, lane);
-      float rstd[BET];
-      ln_xhat<4, BET, 4>(xh, rstd, red, red2, wave, lane, true);
-      ln_relu_bwd<4, BET, 4>(gt, xh, rstd, a.w.gg, a.w.gb, ft0, red3, red4, wave, lane, true);
-#pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et)
-          if (valid[et]) stg4(a.GGX + (size_t)(e0 + 16 * et + c) * MDX_ND + 16 * (ft0 + ft) + 4 * q, gt[ft][et]);
-      acc_to_lds<4, BET>(gt, X, LD256, 0, ft0, lane);
-    }
-    __syncthreads();
-    gemm_tile<1, BET, 256>(ghe, a.wt.Wg1eT, 4, wave, X, LD256, lane);
-    __syncthreads();
-  }
-
-  // ---------------- the two BondFFNs -----------------------------------------------------------------
-#pragma unroll 1
-  for (int s = 0; s < 2; ++s) {
-    const FfnW& w = a.w.ffn[s];
-    const FfnWT& wt = a.wt.ffn[s];
-    const int nlcol = s ? MDX_NT_NLR : MDX_NT_NLL;
-    const int gxcol = s ? MDX_NT_GXR : MDX_NT_GXL;
-    const int gfcol = s ? MDX_NT_NFR : MDX_NT_NFL;  // A_r (for right) / A_l (for left) live in these columns of GNT
-    int idx[BET], oidx[BET];
-#pragma unroll
-    for (int et = 0; et < BET; ++et) {
-      idx[et] = s ? ri[et] : li[et];    // node whose features enter the FFN
-      oidx[et] = s ? li[et] : ri[et];   // node the FFN output is summed into
-    }
-    const int fa = 2 * wave;
-    f32x4 bl[2][BET], nlv[2][BET], xh1[2][BET], o[1][BET], sgt[1][BET], xhg[1][BET];
-    float rstd1[BET], rstdg[BET];
-    const bool act = wave < 2;
-    {  // forward recompute
-      acc_zero<2, BET>(bl);
-      gemm_tile<2, BET, 64>(bl, w.Wbl, 8, fa, Hep, LD64, lane);
-      f32x4 inter[2][BET];
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et) {
-          nlv[ft][et] = ldg4(a.NT + (size_t)idx[et] * MDX_NTW + nlcol + 16 * (fa + ft) + 4 * q);
-          inter[ft][et] = bl[ft][et] * nlv[ft][et];
-        }
-      acc_to_lds<2, BET>(inter, X, LD256, 0, fa, lane);
-      __syncthreads();
-      acc_bias<2, BET>(xh1, w.inter.b1, fa, lane);
-      gemm_tile<2, BET, 128>(xh1, w.inter.W1, 8, fa, X, LD256, lane);
-      ln_xhat<2, BET, 4>(xh1, rstd1, red, red2, wave, lane, true);
-      f32x4 i1[2][BET];
-      ln_apply_relu<2, BET>(i1, xh1, w.inter.g, w.inter.be, fa, lane);
-      acc_to_lds<2, BET>(i1, X, LD256, 128, fa, lane);
-      __syncthreads();
-      acc_bias<1, BET>(o, w.inter.b2, wave, lane);
-      gemm_tile<1, BET, 128>(o, w.inter.W2, 4, wave, X + 128, LD256, lane);
-      // gate
-      if (act) {
-        const int f = 16 * wave + 4 * q;
-        const f32x4 b = ldg4(w.bg1 + f), wtv = ldg4(w.wtg1 + f);
-#pragma unroll
-        for (int et = 0; et < BET; ++et)
-          xhg[0][et] = b + ldg4(a.NT + (size_t)idx[et] * MDX_NTW + gxcol + f) + splat4(tt[et]) * wtv;
-        gemm_tile<1, BET, 64>(xhg, w.Wg1e, 2, wave, Hep, LD64, lane);
-      } else {
-        acc_zero<1, BET>(xhg);
-      }
-      ln_xhat<1, BET, 2>(xhg, rstdg, red, red2, wave, lane, act);
-      if (act) {
-        f32x4 g1[1][BET];
-        ln_apply_relu<1, BET>(g1, xhg, w.gg, w.gb, wave, lane);
-        acc_to_lds<1, BET>(g1, GG, LD32, 0, wave, lane);
-      }
-      __syncthreads();
-      acc_bias<1, BET>(sgt, w.bg2, wave, lane);
-      gemm_tile<1, BET, 32>(sgt, w.Wg2, 4, wave, GG, LD32, lane);
-#pragma unroll
-      for (int et = 0; et < BET; ++et) sgt[0][et] = sigmoid4(sgt[0][et]);
-    }
-    // backward: f = o * sigmoid(gate);  gf = A[oidx]
-    {
-      f32x4 go[1][BET], ggt[1][BET];
-#pragma unroll
-      for (int et = 0; et < BET; ++et) {
-        const f32x4 gf = ldg4(a.GNT + (size_t)oidx[et] * MDX_NTW + gfcol + f1);
-        go[0][et] = gf * sgt[0][et];
-        ggt[0][et] = gf * o[0][et] * sgt[0][et] * (splat4(1.f) - sgt[0][et]);
-      }
-      acc_to_lds<1, BET>(go, S, LD64, 0, wave, lane);
-      acc_to_lds<1, BET>(ggt, S2, LD64, 0, wave, lane);
-    }
-    __syncthreads();
-    {
-      f32x4 gi1[2][BET];
-      acc_zero<2, BET>(gi1);
-      gemm_tile<2, BET, 64>(gi1, wt.Wi2T, 8, fa, S, LD64, lane);
-      ln_relu_bwd<2, BET, 4>(gi1, xh1, rstd1, w.inter.g, w.inter.be, fa, red3, red4, wave, lane, true);
-      acc_to_lds<2, BET>(gi1, X, LD256, 0, fa, lane);  // X[:, :128] (inter) no longer needed
-      __syncthreads();
-      f32x4 gin[2][BET];
-      acc_zero<2, BET>(gin);
-      gemm_tile<2, BET, 128>(gin, wt.Wi1T, 8, fa, X, LD256, lane);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int et = 0; et < BET; ++et) {
-          if (valid[et]) stg4(a.GNL[s] + (size_t)(e0 + 16 * et + c) * 128 + 16 * (fa + ft) + 4 * q, gin[ft][et] * bl[ft][et]);
-          gin[ft][et] = gin[ft][et] * nlv[ft][et];
-        }
-      acc_to_lds<2, BET>(gin, X, LD256, 128, fa, lane);  // X[:, 128:] (i1) no longer needed
-      __syncthreads();
-      gemm_tile<1, BET, 128>(ghe, wt.WblT, 4, wave, X + 128, LD256, lane);
-    }
-    {  // gate backward
-      f32x4 ggg[1][BET];
-      acc_zero<1, BET>(ggg);
-      if (act) gemm_tile<1, BET, 64>(ggg, wt.Wg2T, 2, wave, S2, LD64, lane);
-      ln_relu_bwd<1, BET, 2>(ggg, xhg, rstdg, w.gg, w.gb, wave, red3, red4, wave, lane, act);
-      if (act) {
-#pragma unroll
-        for (int et = 0; et < BET; ++et)
-          if (valid[et]) stg4(a.GGXS[s] + (size_t)(e0 + 16 * et + c) * 32 + 16 * wave + 4 * q, ggg[0][et]);
-        acc_to_lds<1, BET>(ggg, GG, LD32, 0, wave, lane);
-      }
-      __syncthreads();
-      gemm_tile<1, BET, 32>(ghe, wt.Wg1eT, 4, wave, GG, LD32, lane);
-    }
-    __syncthreads();
-  }
-
-  // ---------------- edge_embs backward: He' = Wemb [He_i | D] + b -----------------------------------------
-  acc_to_lds<1, BET>(ghe, S, LD64, 0, wave, lane);
-  __syncthreads();
-  {
-    f32x4 gi[1][BET];
-    acc_zero<1, BET>(gi);
-    gemm_tile<1, BET, 64>(gi, a.wt.WembHT, 4, wave, S, LD64, lane);
-#pragma unroll
-    for (int et = 0; et < BET; ++et)
-      if (valid[et]) stg4(a.gHe_out + (size_t)(e0 + 16 * et + c) * 64 + f1, gi[0][et]);
-  }
-  if (wave == 0) {
-    f32x4 gd[1][BET];
-    acc_zero<1, BET>(gd);
-    gemm_tile<1, BET, 64>(gd, a.wt.WembDT, 1, 0, S, LD64, lane);
-#pragma unroll
-    for (int et = 0; et < BET; ++et) {
-      // dD_k/dd = D_k * 2 c_k (dc - o_k) for 0 <= d <= cutoff (clamp passes the gradient inclusively)
-      const float dx = a.pos[3 * li[et] + 0] - a.pos[3 * ri[et] + 0];
-      const float dy = a.pos[3 * li[et] + 1] - a.pos[3 * ri[et] + 1];
-      const float dz = a.pos[3 * li[et] + 2] - a.pos[3 * ri[et] + 2];
-      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-      const float dc = fminf(fmaxf(d, 0.f), a.cutoff);
-      float sacc = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 4 * q + r;
-        const float uu = dc - a.soff[k];
-        const float Dk = expf(a.scoef[k] * (uu * uu));
-        sacc += gd[0][et][r] * Dk * 2.0f * a.scoef[k] * uu;
-      }
-      sacc = red_q(sacc);
-      if (q == 0 && valid[et]) {
-        const int e = e0 + 16 * et + c;
-        a.gdist[e] += (d <= a.cutoff) ? sacc : 0.f;
-      }
-    }
-  }
-}
-
-// =================================================================================================
 // Node backward.
 //   TAIL (block i):  Hn_{i+1} = Hn_i + Wout relu(LN(z)) + b,  z = centroid(Hn_i) + aggr   -> GZ = dL/dz
 //                    (written into the centroid columns of the gradient table GNT)
@@ -728,23 +356,6 @@ __global__ void pos_grad_kernel(const float* __restrict__ w, const int* __restri
 }
 
 }  // namespace
-
-void launch_edge_tail_bwd(const EdgeTailBwdArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
-  const int ntiles = (a.E + TTE - 1) / TTE;
-  hipLaunchKernelGGL(edge_tail_bwd_kernel, dim3(ntiles), dim3(MDX_WG), 0, s, a, ntiles);
-}
-
-void launch_edge_bwd(const EdgeBwdArgs& a, hipStream_t s) {
-  if (a.E <= 0) return;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)edge_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B_TOTAL * 4);
-    attr = true;
-  }
-  const int ntiles = (a.E + BTE - 1) / BTE;
-  hipLaunchKernelGGL(edge_bwd_kernel, dim3(ntiles), dim3(MDX_WG), B_TOTAL * 4, s, a, ntiles);
-}
 
 void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s) {
   if (a.N <= 0) return;

@@ -453,15 +453,13 @@ void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s) {
   static bool attr = false;
   constexpr int lds = (4 * PARK_FLOATS + BW_CONST_FLOATS) * 4;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)edge_bwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)edge_bwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   const int nunits = (a.E + ROWS - 1) / ROWS;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
   const WorkQ wq = make_workq(a.wq, nunits, grid, mdx_num_cus());
-  if (a.BL[0] && a.BL[1] && a.H1[0] && a.H1[1] && a.O[0] && a.O[1])
-    hipLaunchKernelGGL(edge_bwd2_kernel<true>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
-  else
-    hipLaunchKernelGGL(edge_bwd2_kernel<false>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
+  // (the forward always writes the BondFFN tape; the recompute form of round 2, TAPE = false, is kept in the source as the
+  // reference for what the tape replaces but is no longer instantiated)
+  hipLaunchKernelGGL(edge_bwd2_kernel<true>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
 }

@@ -239,3 +239,8 @@ int launch_edge_b2(const EdgeBArgs& a, hipStream_t s) {
     default: return mdx_set_error(MDX_ERR_UNSUPPORTED, "edge kernel B: unsupported section flags");
   }
 }
+
+int launch_edge_b(const EdgeBArgs& a, hipStream_t s) {
+  if (a.E <= 0) return MDX_OK;
+  return (a.flags & EB_SPLIT) ? launch_edge_b2s(a, s) : launch_edge_b2(a, s);
+}

@@ -359,7 +359,6 @@ int launch_edge_a2s(const EdgeAArgs& a, hipStream_t s) {
     case EA_EMB | EA_NODE | EA_FFN | EA_AGG: launch_a2s<EA_EMB | EA_NODE | EA_FFN | EA_AGG>(a, s); return MDX_OK;
     case EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE | EA_TAPE_FFN:
       launch_a2s<EA_EMB | EA_NODE | EA_FFN | EA_AGG | EA_TAPE | EA_TAPE_FFN>(a, s); return MDX_OK;
-    case EA_EMB | EA_NODE | EA_FFN: launch_a2s<EA_EMB | EA_NODE | EA_FFN>(a, s); return MDX_OK;
     default: return mdx_set_error(MDX_ERR_UNSUPPORTED, "split-precision edge kernel A: unsupported section flags");
   }
 }

@@ -62,9 +62,6 @@ struct EdgeAW {  // weights of edge kernel A for one block
   MlpW en;                                         // edge_net 64 -> 256 -> 256
   const float *Wm, *bm;                            // msg_net 256 x 256
   FfnW ffn[2];                                     // left, right
-  // first layers of both BondFFNs that read He', fused into one (320 x 64) pack: the 80 rows of wave w are
-  // [bond_linear_s rows 64h..64h+63 | gate layer-1 edge part rows 16h..16h+15], s = w/2, h = w%2
-  const float* Wffa;
   EdgeAS s;
   EdgeAS ss;  // the same streams split into float16 hi / lo halves (mdx_split.h; EA_SPLIT launches)
 };
@@ -73,9 +70,6 @@ struct EdgeBW {  // weights of edge kernel B for one block
   const float *Wself, *bself, *lng, *lnb, *Wout, *bout;  // EdgeBlock tail
   // PosUpdate.edge_lin (BondFFN bond 64, node 64, inter 256, out 1)
   const float *Wbl, *Wnl;          // 256 x 64 each, no bias
-  // the same two with the gate's first layer riding along: (320 x 64) packs whose 80 rows for wave w are
-  // [rows 64w..64w+63 of Wbl (Wnl) | rows 16w..16w+15 of the gate's He (a) part for w < 2, zeros for w >= 2]
-  const float *WblG, *WnlG;
   const float *Wi1, *bi1, *ig, *ib;  // inter_module first layer 256x256 + LN
   const float *wi2;                // (256) second layer row
   float bi2;
@@ -270,9 +264,7 @@ struct BondDecArgs {
   BondDecW w;
 };
 
-void launch_edge_tail_bwd(const EdgeTailBwdArgs& a, hipStream_t s);
-void launch_edge_bwd(const EdgeBwdArgs& a, hipStream_t s);
-void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s);  // row-owner version (mdx_bwd2.hip)
+void launch_edge_bwd2(const EdgeBwdArgs& a, hipStream_t s);  // row-owner guidance backward (mdx_bwd2.hip)
 void launch_edge_tail_bwd2(const EdgeTailBwdArgs& a, hipStream_t s);
 int launch_edge_bwd2s(const EdgeBwdArgs& a, hipStream_t s);       // split float16 builds (mdx_bwd2s.hip); nonzero = tape missing
 void launch_edge_tail_bwd2s(const EdgeTailBwdArgs& a, hipStream_t s);
@@ -298,13 +290,12 @@ void launch_dist_to_pos(const float* gdist, const float* pos, const int* l, cons
 // all four return MDX_OK or an error code with mdx_last_error set (a section-flag combination that is not built)
 int launch_edge_a(const EdgeAArgs& a, hipStream_t s);
 int launch_edge_b(const EdgeBArgs& a, hipStream_t s);
-// row-owner versions (mdx_edge2.hip); launch_edge_a/b dispatch to them unless MDX_TILE_KERNELS=1 is set in the environment
+// the exact fp32 builds (mdx_edge2.hip, mdx_edge2b.hip); launch_edge_a/b dispatch to them, or to the split builds below
 int launch_edge_a2(const EdgeAArgs& a, hipStream_t s);
 int launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
 // split-precision builds of the two (mdx_edge2s.hip, mdx_edge2bs.hip): taken when the flags carry EA_SPLIT / EB_SPLIT
 int launch_edge_a2s(const EdgeAArgs& a, hipStream_t s);
 int launch_edge_b2s(const EdgeBArgs& a, hipStream_t s);
-bool mdx_use_rowowner();
 int mdx_num_cus();
 void launch_node(const NodeArgs& a, hipStream_t s);
 
@@ -318,8 +309,6 @@ struct StepTransArgs {  // mdx_transition.hip: the transitions of one sampling s
   uint8_t *node_cls, *half_cls;
 };
 void launch_step_transition(const StepTransArgs& a, hipStream_t s);
-void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, const int* row_ptr, const int* col_ptr,
-                             const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s);
 // the same three sums after an EA_AGG edge kernel A: aggr / SR combine each node's partial rows pbase[v] .. pbase[v+1] of P / PR
 // in order, SL is still the indexed sum over FL
 void launch_seg_reduce_block2(const float* P, const float* PR, const float* FL, const int* pbase, const int* col_ptr,

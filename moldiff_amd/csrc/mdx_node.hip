@@ -198,29 +198,6 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce_kernel(const float* __restr
   stg4(out + (size_t)v * C + 4 * c4, s0);
 }
 
-// The three reductions that follow edge kernel A in one launch: aggr = sum_{left = v} M (E,256), SR = sum_{left = v} FR (E,64),
-// SL = sum_{right = v} FL (E,64, through the by-right index list).  A workgroup of six waves serves four nodes: waves 0-3 one
-// node's M run each, wave 4 the four FR runs (16 lanes each), wave 5 the four FL runs.  The 64-wide sums are latency-bound on their
-// own (3.2 TB/s); side by side with the 256-wide one they disappear under it.  Same per-lane loop as seg_reduce_kernel: same bits.
-__global__ __launch_bounds__(384) void seg_reduce_block_kernel(const float* __restrict__ M, const float* __restrict__ FL,
-                                                               const float* __restrict__ FR, const int* __restrict__ row_ptr,
-                                                               const int* __restrict__ col_ptr, const int* __restrict__ col_eids,
-                                                               float* __restrict__ aggr, float* __restrict__ SL,
-                                                               float* __restrict__ SR, int N) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int v0 = blockIdx.x * 4;
-  if (wave < 4) {
-    const int v = v0 + wave;
-    if (v < N) stg4(aggr + (size_t)v * 256 + 4 * lane, seg_sum<256>(M, row_ptr, nullptr, v, lane));
-  } else {
-    const int v = v0 + (lane >> 4), c4 = lane & 15;
-    if (v >= N) return;
-    if (wave == 4)
-      stg4(SR + (size_t)v * 64 + 4 * c4, seg_sum<64>(FR, row_ptr, nullptr, v, c4));
-    else
-      stg4(SL + (size_t)v * 64 + 4 * c4, seg_sum<64>(FL, col_ptr, col_eids, v, c4));
-  }
-}
 
 // The same three sums after an EA_AGG edge kernel A (round 3): the kernel has already summed every node's run inside each 16-row
 // unit, so aggr[v] / SR[v] are the in-order sums of v's partial rows pbase[v] .. pbase[v+1] of P (256 wide) / PR (64 wide) -- at most
@@ -492,13 +469,6 @@ void launch_seg_reduce(const float* src, const int* ptr, const int* eids, float*
   else
     hipLaunchKernelGGL(seg_reduce3_kernel, dim3((3 * N + MDX_WG - 1) / MDX_WG), dim3(MDX_WG), 0, s, src, ptr, eids, out,
                        addend, N);
-}
-
-void launch_seg_reduce_block(const float* M, const float* FL, const float* FR, const int* row_ptr, const int* col_ptr,
-                             const int* col_eids, float* aggr, float* SL, float* SR, int N, hipStream_t s) {
-  if (N <= 0) return;
-  hipLaunchKernelGGL(seg_reduce_block_kernel, dim3((N + 3) / 4), dim3(384), 0, s, M, FL, FR, row_ptr, col_ptr, col_eids, aggr, SL, SR,
-                     N);
 }
 
 void launch_seg_reduce_block2(const float* P, const float* PR, const float* FL, const int* pbase, const int* col_ptr,

@@ -447,11 +447,7 @@ constexpr int MDX_WQ_PAIRS = 512;  // lines per counter set (>= #CUs)
 
 inline WorkQ make_workq(int* ctr, int nunits, int grid, int ncus) {
   WorkQ w{};
-  static const int cap = [] {  // MDX_WQ_NPAIRS: fewer, larger sharing groups (A/B experiments)
-    const char* e = getenv("MDX_WQ_NPAIRS");
-    return e ? atoi(e) : MDX_WQ_PAIRS;
-  }();
-  w.npairs = std::max(1, std::min(std::min(grid, ncus), std::min(cap, MDX_WQ_PAIRS)));
+  w.npairs = std::max(1, std::min(std::min(grid, ncus), MDX_WQ_PAIRS));
   w.ctr = ctr;
   w.nunits = nunits;
   return w;

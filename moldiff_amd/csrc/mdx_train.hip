@@ -1926,7 +1926,7 @@ extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, in
   if (half_kind != 1 && half_kind != 2) return bad("xgemm_nt: half_kind must be 1 (bfloat16) or 2 (float16)");
   hipStream_t s = (hipStream_t)stream;
   // float16 rows, widths the row-owner kernel is instantiated for: whole weight resident in LDS, no K loop over barriers
-  static const bool no_rows = [] { const char* e = getenv("MDX_HGEMM_ROWS"); return e && e[0] == '0'; }();
+  constexpr bool no_rows = false;   // (round 3 A/B knob MDX_HGEMM_ROWS removed: the row-owner kernel is 84 -> 47 us on 256 -> 256)
   const int kt = (int)(K / 32), ftn = (int)(N / 16);
   if (!no_rows && half_kind == 2 && A.h && M >= 1024 && K % 32 == 0 && N % 16 == 0 && (kt == 1 || kt == 2 || kt == 4 || kt == 8) &&
       (ftn == 2 || ftn == 4 || ftn == 8 || ftn == 16) && (lda & 7) == 0 && (reinterpret_cast<uintptr_t>(Av) & 15) == 0) {
@@ -1953,7 +1953,7 @@ extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, in
   }
   // measured on the training step (ms per step, fp16 mode): TN <= 64: 52.0, <= 128: 51.5, <= 256: 54.7 (one workgroup per CU) -- the
   // re-reads of A were L2 hits all along; the kernel is bound by its short K loop (one 64-wide chunk in flight per workgroup)
-  static const int tn_max = [] { const char* e = getenv("MDX_HGEMM_TN_MAX"); return e ? atoi(e) : 128; }();
+  constexpr int tn_max = 128;
   const int tn = std::min(tn_max, N <= 64 ? 64 : N <= 128 ? 128 : 256);
   dim3 grid((unsigned)((N + tn - 1) / tn), (unsigned)((M + G_TM - 1) / G_TM), 1);
 #define MDX_XNT3(HT, R, TNv)                                                                                                              \
@@ -1997,14 +1997,14 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
   int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
   mper = (mper + HW_MC - 1) / HW_MC * HW_MC;
   const int S = (int)((std::max<int64_t>(M, 1) + mper - 1) / mper);
-  static const int wide = [] { const char* e = getenv("MDX_WGRAD_TILE"); return e ? atoi(e) : 64; }();   // 128: wide tiles (A/B)
+  constexpr int wide = 64;   // (128-wide tiles for this conversion kernel measured slower: 47.9 vs 44.0 ms per step, occupancy 4 -> 2)
   const int tnw = (wide >= 128 && N >= 128) ? 128 : 64, tkw = (wide >= 128 && K >= 128) ? 128 : 64;
   dim3 grid((unsigned)((K + tkw - 1) / tkw), (unsigned)((N + tnw - 1) / tnw), (unsigned)S);
   const size_t nc = (size_t)(S + RED_CHUNK - 1) / RED_CHUNK;
   float* scratch = partial + (size_t)S * N * K;
   float* pb = db ? scratch + nc * N * K : nullptr;
   // float16 containers on both sides, tile-aligned widths: the transpose-read kernel (no conversion, no register transposes)
-  static const bool no_tr = [] { const char* e = getenv("MDX_WGRAD_TR"); return e && e[0] == '0'; }();
+  constexpr bool no_tr = false;
   if (!no_tr && half_kind == 2 && G.h && X.h && N % 64 == 0 && K % 64 == 0 && ldg % 8 == 0 && ldx % 8 == 0 &&
       (reinterpret_cast<uintptr_t>(Gv) & 15) == 0 && (reinterpret_cast<uintptr_t>(Xv) & 15) == 0) {
     const int tn = N % 128 == 0 ? 128 : 64, tk = K % 128 == 0 ? 128 : 64;

@@ -347,12 +347,11 @@ _ENV = None
 
 
 def _env():
-    """the A/B knobs of the weight-gradient split, read once (this runs for every weight gradient of every step)"""
+    """constants of the weight-gradient split (round 3's A/B environment knobs are gone: transpose-read kernel on, 512 workgroups
+    targeted, 64-wide tiles for the conversion kernel)"""
     global _ENV
     if _ENV is None:
-        import os
-        _ENV = (os.environ.get('MDX_WGRAD_TR') != '0', int(os.environ.get('MDX_WGRAD_TR_WGS', 512)),
-                os.environ.get('MDX_WGRAD_TILE') == '128' and os.environ.get('MDX_WGRAD_SPLITS') != 'old')
+        _ENV = (True, 512, False)
     return _ENV
 
 
