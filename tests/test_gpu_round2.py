@@ -145,8 +145,12 @@ def test_standalone_bond_ffn_vs_reference_golden(i):
     ref = O.bond_ffn(P, f'denoiser.edge_blocks.{i}.bond_ffn_right', ea, x[ei[1]], et)
     out_r = m.denoiser.edge_blocks[i].bond_ffn_right(ea.to(DEV), x[ei[1]].to(DEV), et.to(DEV))
     assert U.maxdiff(out_r, ref) < 2e-5
-    with pytest.raises(NotImplementedError):
-        m.denoiser.pos_blocks[i].edge_lin(ea.to(DEV), ea.to(DEV), et.to(DEV))
+    # PosUpdate.edge_lin (out_dim = 1) called on its own runs the layer operators since round 4: against the oracle here, against
+    # the reference's golden in tests/test_gpu_round4.py
+    with torch.no_grad():
+        out_l = m.denoiser.pos_blocks[i].edge_lin(ea.to(DEV), ea.to(DEV), et.to(DEV))
+        ref_l = O.bond_ffn(P, f'denoiser.pos_blocks.{i}.edge_lin', ea, ea, et)
+    assert out_l.shape == (ea.shape[0], 1) and U.maxdiff(out_l, ref_l) < 2e-5
 
 
 def test_config4_split_every_shard_equals_the_unsharded_batch():

@@ -110,6 +110,41 @@ def test_split_bond_predictor_logits_and_gradient_vs_golden(split_path):
     TB.test_guidance_gradient_with_distances_straddling_the_cutoff_vs_oracle_autograd()
 
 
+@pytest.mark.parametrize('sizes', [[1, 7, 2, 1, 0, 5], [2, 2], [3]])
+def test_split_forward_with_degenerate_molecules_matches_oracle(split_path, sizes):
+    """single atoms (no edges), empty molecules, odd numbers of 16-row units per 32-row work item"""
+    from tests.test_gpu_edgecases import test_forward_with_degenerate_molecules_matches_oracle
+    test_forward_with_degenerate_molecules_matches_oracle(sizes)
+
+
+def test_split_edge_cases(split_path):
+    """a molecule whose node runs span several units, the empty / single-atom batches, a general (non-molecule) graph in shuffled edge
+    order, and NaN propagation from coincident atoms -- the exact path's edge-case tests on the split kernels"""
+    from tests import test_gpu_edgecases as TE
+    TE.test_molecule_larger_than_a_tile_matches_oracle()
+    TE.test_empty_batch_and_single_atom_batch_do_not_crash()
+    TE.test_general_graph_not_molecule_layout()
+    TE.test_coincident_atoms_propagate_nan_like_the_reference()
+    TE.test_distance_smearing_clamps_at_the_cutoff_like_the_reference()
+
+
+def test_split_path_refuses_weights_outside_float16_range():
+    """mdx_model_set_matrix_path(split) on a model holding a weight of magnitude >= 65504: MDX_ERR_UNSUPPORTED, the exact path keeps working"""
+    import moldiff_amd as M
+    from moldiff_amd.harness import default_config
+    m = M.MolDiff(default_config('MolDiff_simple'), 8, 6).eval()
+    sd = M.recipe_state_dict(m, U.KEYS['seeds']['MolDiff'])
+    sd['denoiser.edge_blocks.0.self_ffn.weight'] = sd['denoiser.edge_blocks.0.self_ffn.weight'].clone()
+    sd['denoiser.edge_blocks.0.self_ffn.weight'][0, 0] = 7.0e4
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    m.matrix_path = 'split_f16'
+    with pytest.raises(RuntimeError, match="float16's range"):
+        m._engine()
+    m.matrix_path = 'exact_f32'
+    assert m._engine()._path == 'exact_f32'
+
+
 def test_split_molecule_result_does_not_depend_on_its_batch(split_path):
     """The in-kernel segment sums are cut per graph in the split kernels too: a molecule alone == the molecule inside a batch."""
     m = U.moldiff('MolDiff_simple', DEV)

@@ -488,21 +488,21 @@ int main(int argc, char** argv) {
   run<3, 1, 2, 2, true>("split f16 x3 (W * 2^sw)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
   run<3, 2, 2, 1, true>("split f16 x3 (W * 2^sw)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
   run<3, 2, 4, 1, true>("split f16 x3 (W * 2^sw)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
-  run<4, 1, 4, 2, true>("split, lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
-  run<4, 2, 4, 1, true>("split, lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
-  run<5, 1, 4, 2, true>("SHIPPED: + Wlo Xlo (4 terms)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
-  run<5, 2, 4, 1, true>("SHIPPED: + Wlo Xlo (4 terms)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<4, 1, 4, 2, true>("SHIPPED: lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<4, 2, 4, 1, true>("SHIPPED: lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<5, 1, 4, 2, true>("variant: + Wlo Xlo (4 terms)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<5, 2, 4, 1, true>("variant: + Wlo Xlo (4 terms)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<1, 1, 4, 2, true>("plain f16 x1 (speed ref)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
   run<1, 2, 4, 1, true>("plain f16 x1 (speed ref)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
   // without LayerNorm: two layers (the error of the bare products; no scale absorption -> unscaled pack)
   run<0, 1, 4, 2, false>("exact fp32, no LN, 2 layers", d, d.Wf32, P, eps, hX, refNo, 2, nref);
   run<3, 1, 4, 2, false>("split f16 x3 unscaled, no LN", d, d.Wsplit0, P, eps, hX, refNo, 2, nref);
-  run<4, 1, 4, 2, false>("split 3 terms, no LN", d, d.Wsplit2, P, eps, hX, refNo, 2, nref);
-  run<5, 1, 4, 2, false>("SHIPPED split 4 terms, no LN", d, d.Wsplit2, P, eps, hX, refNo, 2, nref);
+  run<4, 1, 4, 2, false>("SHIPPED split 3 terms, no LN", d, d.Wsplit2, P, eps, hX, refNo, 2, nref);
+  run<5, 1, 4, 2, false>("variant 4 terms, no LN", d, d.Wsplit2, P, eps, hX, refNo, 2, nref);
   printf("-- inputs scaled by 2^-7 (|x| ~ 0.01), two layers without LayerNorm: errors relative to max |y|\n");
   run<0, 1, 4, 2, false>("exact fp32, small x", d, d.Wf32, P, eps, hX, refSm, 2, nref, d.Xsmall);
   run<3, 1, 4, 2, false>("split unscaled lo, small x", d, d.Wsplit0, P, eps, hX, refSm, 2, nref, d.Xsmall);
-  run<4, 1, 4, 2, false>("split 3 terms, small x", d, d.Wsplit2, P, eps, hX, refSm, 2, nref, d.Xsmall);
-  run<5, 1, 4, 2, false>("SHIPPED split 4 terms, small x", d, d.Wsplit2, P, eps, hX, refSm, 2, nref, d.Xsmall);
+  run<4, 1, 4, 2, false>("SHIPPED split 3 terms, small x", d, d.Wsplit2, P, eps, hX, refSm, 2, nref, d.Xsmall);
+  run<5, 1, 4, 2, false>("variant 4 terms, small x", d, d.Wsplit2, P, eps, hX, refSm, 2, nref, d.Xsmall);
   return 0;
 }
