@@ -52,6 +52,7 @@ struct BlockW {
   EdgeAW ea;
   EdgeBW eb;
   NodeW nd;  // mid fields = tail of this block, pre fields = pre-stage of this block
+  NodeWS nds;  // the same matrices as split float16 packs
 };
 
 struct mdx_model_s {
@@ -176,6 +177,37 @@ struct PackCtx {
             }
     std::memcpy(pk.host.data() + off, hbuf.data(), hbuf.size() * 2);
     pk.bind(slot, off);
+  }
+  // dense split pack of the tile kernels (mdx_node_s.hip gemm_tile_s): 1-KiB fragment index (g*FT + ft)*2 + h, g = k/32, h = 0 hi /
+  // 1 lo (x 2^11); lane (q, c) half t <- W[16 ft + c][col0 + 32 g + 16 (t / 4) + 4 q + t % 4]
+  void pack_dense_split(const float** slot, const std::vector<float>& W, int F, int ldw, int col0, int K) {
+    const int FT = (F + 15) / 16, G = (K + 31) / 32;
+    size_t off = pk.reserve((size_t)G * FT * 512);
+    std::vector<uint16_t> hbuf((size_t)G * FT * 1024, 0);
+    for (int g = 0; g < G; ++g)
+      for (int ft = 0; ft < FT; ++ft)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int t = 0; t < 8; ++t) {
+            const int f = 16 * ft + (lane & 15), k = 32 * g + 16 * (t / 4) + 4 * (lane >> 4) + t % 4;
+            const float w = (f < F && k < K) ? W[(size_t)f * ldw + col0 + k] : 0.f;
+            if (!(std::fabs(w) < 65504.0f)) m->split_ok = false;
+            m->split_wmax = std::max(m->split_wmax, std::fabs(w));
+            const _Float16 hi = (_Float16)w;
+            const _Float16 lo = (_Float16)((w - (float)hi) * 2048.0f);
+            uint16_t uh, ul;
+            std::memcpy(&uh, &hi, 2);
+            std::memcpy(&ul, &lo, 2);
+            const size_t fr = ((size_t)g * FT + ft) * 2;
+            hbuf[(fr * 64 + lane) * 8 + t] = uh;
+            hbuf[((fr + 1) * 64 + lane) * 8 + t] = ul;
+          }
+    std::memcpy(pk.host.data() + off, hbuf.data(), hbuf.size() * 2);
+    pk.bind(slot, off);
+  }
+  void packDS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    pack_dense_split(slot, t->data, F, ldw, col0, K);
   }
   void packSS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
     const HostTensor* t = get(key, {F, ldw});
@@ -324,6 +356,9 @@ int pack_model(mdx_model_s* m) {
     c.packA(&b.nd.Wout, nb + ".out_transform.weight", ND, ND, 0, ND);
     c.vec(&b.nd.bout, nb + ".out_transform.bias", ND);
     c.mlp(&b.nd.nn, nb + ".node_net", ND, ND, ND);
+    c.packDS(&b.nds.Wout, nb + ".out_transform.weight", ND, ND, 0, ND);
+    c.packDS(&b.nds.nnW1, nb + ".node_net.net.0.weight", ND, ND, 0, ND);
+    c.packDS(&b.nds.nnW2, nb + ".node_net.net.3.weight", ND, ND, 0, ND);
     {  // concatenated per-node table weights (960 x 256) + bias
       std::vector<float> W((size_t)MDX_NTW * ND, 0.f), bias(MDX_NTW, 0.f);
       auto put = [&](const std::string& key, int rows, int ldw, int col0, int dst_row, const std::string& bkey) {
@@ -345,12 +380,17 @@ int pack_model(mdx_model_s* m) {
       put(eb + ".bond_ffn_left.gate.net.0.weight", 32, GIN, ED, MDX_NT_GXL, "");
       put(eb + ".bond_ffn_right.gate.net.0.weight", 32, GIN, ED, MDX_NT_GXR, "");
       c.pack_dense(&b.nd.Wcat, W, MDX_NTW, ND, 0, ND);
+      c.pack_dense_split(&b.nds.Wcat, W, MDX_NTW, ND, 0, ND);
       c.wcat_dense[i] = W;
       c.raw(&b.nd.bcat, bias);
     }
     if (cf.update_pos) {
       c.mlp(&b.nd.left, pb + ".left_lin_edge", ND, ED, ED);
       c.mlp(&b.nd.right, pb + ".right_lin_edge", ND, ED, ED);
+      c.packDS(&b.nds.leftW1, pb + ".left_lin_edge.net.0.weight", ED, ND, 0, ND);
+      c.packDS(&b.nds.leftW2, pb + ".left_lin_edge.net.3.weight", ED, ED, 0, ED);
+      c.packDS(&b.nds.rightW1, pb + ".right_lin_edge.net.0.weight", ED, ND, 0, ND);
+      c.packDS(&b.nds.rightW2, pb + ".right_lin_edge.net.3.weight", ED, ED, 0, ED);
       const std::string el = pb + ".edge_lin";
       c.packA(&b.eb.Wbl, el + ".bond_linear.weight", ND, ED, 0, ED);
       c.packA(&b.eb.Wnl, el + ".node_linear.weight", ND, ED, 0, ED);
@@ -972,8 +1012,9 @@ NodeArgs make_nd(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int im
   NodeArgs a{};
   a.N = (int)g->N; a.flags = flags; a.Hn = w.Hn; a.aggr = w.aggr; a.NTin = NTin ? NTin : w.NT; a.dHn = nullptr; a.Lf = w.Lf;
   a.Rf = w.Rf; a.H = w.H; a.NT = NTout ? NTout : w.NT;
-  if (imid >= 0) a.wmid = m->blocks[imid].nd;
-  if (ipre >= 0) a.wpre = m->blocks[ipre].nd;
+  if (imid >= 0) { a.wmid = m->blocks[imid].nd; a.smid = m->blocks[imid].nds; }
+  if (ipre >= 0) { a.wpre = m->blocks[ipre].nd; a.spre = m->blocks[ipre].nds; }
+  if (m->matrix_path == MDX_MATRIX_SPLIT_F16) a.flags |= ND_SPLIT;
   return a;
 }
 

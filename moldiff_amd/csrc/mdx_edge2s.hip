@@ -362,11 +362,3 @@ int launch_edge_a2s(const EdgeAArgs& a, hipStream_t s) {
     default: return mdx_set_error(MDX_ERR_UNSUPPORTED, "split-precision edge kernel A: unsupported section flags");
   }
 }
-#ifdef MDX_SPLIT_PROBE  // register-pressure probes (development only)
-void mdx_split_probe(const EdgeAArgs& a, hipStream_t s) {
-  launch_a2s<EA_EMB | EA_NODE>(a, s);
-  launch_a2s<EA_EMB | EA_FFN>(a, s);
-  launch_a2s<EA_NODE>(a, s);
-  launch_a2s<EA_FFN>(a, s);
-}
-#endif

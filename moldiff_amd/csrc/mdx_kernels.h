@@ -89,6 +89,11 @@ struct NodeW {  // weights of the node kernel
   const float *Wcat, *bcat;    // concatenated (960 x 256) + bias (960, zeros where the reference has none)
 };
 
+struct NodeWS {  // the node kernel's matrices as dense split float16 packs (mdx_node_s.hip, PackCtx::pack_dense_split)
+  const float *Wout, *leftW1, *leftW2, *rightW1, *rightW2;  // MID stage
+  const float *nnW1, *nnW2, *Wcat;                          // PRE stage
+};
+
 struct EdgeAArgs {
   int E, flags;
   const int *l, *r;       // internal order
@@ -167,11 +172,13 @@ struct NodeArgs {
   float *SL, *SR;
   float* aggr_out;       // optional (N,256), fused reduction only: the summed messages, kept for the guidance tape
   NodeW wmid, wpre;
+  NodeWS smid, spre;     // split float16 packs of the same matrices (ND_SPLIT launches)
 };
 #define ND_MID 1
 #define ND_PRE 2
 #define ND_DELTA 4
 #define ND_POSMLP 8
+#define ND_SPLIT 16   // matrix products on the split float16 path (mdx_node_s.hip)
 
 // ---- backward (bond-predictor guidance gradient; dgrad only, no weight gradients) ---------------------
 struct FfnWT {
@@ -297,7 +304,8 @@ int launch_edge_b2(const EdgeBArgs& a, hipStream_t s);
 int launch_edge_a2s(const EdgeAArgs& a, hipStream_t s);
 int launch_edge_b2s(const EdgeBArgs& a, hipStream_t s);
 int mdx_num_cus();
-void launch_node(const NodeArgs& a, hipStream_t s);
+void launch_node(const NodeArgs& a, hipStream_t s);    // dispatches to launch_node_s when the flags carry ND_SPLIT
+void launch_node_s(const NodeArgs& a, hipStream_t s);
 
 // out[v][0..C) (+)= sum_{j in ptr[v]..ptr[v+1]} src[(eids ? eids[j] : j)][0..C)
 struct StepTransArgs {  // mdx_transition.hip: the transitions of one sampling step in one launch (Kn = 8, Ke = 6)

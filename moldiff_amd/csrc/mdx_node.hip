@@ -13,41 +13,9 @@
                          // loop; cutting the per-tile chain over three workgroups or 32-node tiles on top of it: no further gain)
 #endif
 #include "mdx_tile.h"
+#include "mdx_node_common.h"
 
 namespace {
-
-constexpr int NT_ = MDX_NT;
-constexpr int TN = 16 * NT_;
-constexpr int LD64 = mdx_ld(64);
-constexpr int LD256 = mdx_ld(256);
-constexpr int OFF_HN = 0;
-constexpr int OFF_X = OFF_HN + TN * LD256;
-constexpr int OFF_S = OFF_X + TN * LD256;
-constexpr int OFF_RED = OFF_S + TN * LD64;
-constexpr int OFF_RED2 = OFF_RED + 4 * TN;
-constexpr int NODE_LDS_FLOATS = OFF_RED2 + 4 * TN;
-
-// sum over the run ptr[v] .. ptr[v+1] of row i (or eids[i]) of src, this lane's four features: 4 independent loads in flight,
-// summed in CSR order
-template <int C>
-__device__ __forceinline__ f32x4 seg_sum(const float* __restrict__ src, const int* __restrict__ ptr, const int* __restrict__ eids,
-                                         int v, int c4) {
-  const int j0 = ptr[v], j1 = ptr[v + 1];
-  f32x4 s0 = splat4(0.f);
-  int j = j0;
-  for (; j + 4 <= j1; j += 4) {
-    const int i0 = eids ? eids[j] : j, i1 = eids ? eids[j + 1] : j + 1, i2 = eids ? eids[j + 2] : j + 2,
-              i3 = eids ? eids[j + 3] : j + 3;
-    const f32x4 a0 = ldg4(src + (size_t)i0 * C + 4 * c4), a1 = ldg4(src + (size_t)i1 * C + 4 * c4),
-                a2 = ldg4(src + (size_t)i2 * C + 4 * c4), a3 = ldg4(src + (size_t)i3 * C + 4 * c4);
-    s0 = (((s0 + a0) + a1) + a2) + a3;
-  }
-  for (; j < j1; ++j) {
-    const int i0 = eids ? eids[j] : j;
-    s0 = s0 + ldg4(src + (size_t)i0 * C + 4 * c4);
-  }
-  return s0;
-}
 
 __device__ __forceinline__ void mlp_small(const MlpW& w, const float* Hn, float* S, float* red, float* red2, float* out,
                                           int v0, int N, int wave, int lane) {
@@ -448,6 +416,7 @@ __global__ __launch_bounds__(MDX_WG, 2) void decode_kernel(const DecodeArgs a, c
 
 void launch_node(const NodeArgs& a, hipStream_t s) {
   if (a.N <= 0) return;
+  if (a.flags & ND_SPLIT) return launch_node_s(a, s);
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute((const void*)node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NODE_LDS_FLOATS * 4);

@@ -56,6 +56,11 @@ __device__ __forceinline__ void to_xs(XS<(FT + 1) / 2>& o, const f32x4 (&y)[FT][
       for (int t = 0; t < 8; ++t) {
         const int ft = 2 * g + t / 4;
         const float v = ft < FT ? y[ft][rt][t % 4] : 0.f;
+        if (MDX_ABL & 8) {  // timing-only ablation: no conversion arithmetic (wrong results)
+          o.hi[g][rt][t] = __builtin_bit_cast(_Float16, (unsigned short)(__float_as_uint(v) >> 16));
+          o.lo[g][rt][t] = __builtin_bit_cast(_Float16, (unsigned short)(__float_as_uint(v)));
+          continue;
+        }
         const _Float16 h = (_Float16)v;
         o.hi[g][rt][t] = h;
         o.lo[g][rt][t] = (_Float16)((v - (float)h) * MDX_LO_UP);
@@ -69,7 +74,10 @@ template <int KG, int FT>
 __device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, const WS& w, WRing& ring, const WS& wnext) {
   static_assert(FT % 2 == 0, "feature tiles come in pairs");
   constexpr int NP = (FT / 2) * KG * 2;
-  constexpr int PRIME_AT = NP > 3 ? NP - 3 : 0;
+#ifndef MDX_SPLIT_PRIME_AHEAD
+#define MDX_SPLIT_PRIME_AHEAD 3   // half-steps before the end of a GEMM at which the next stream's first fragments are requested
+#endif
+  constexpr int PRIME_AT = NP > MDX_SPLIT_PRIME_AHEAD ? NP - MDX_SPLIT_PRIME_AHEAD : 0;
   WRing nx;
   f32x4 t0[RR], t1[RR], u0[RR], u1[RR];
   __builtin_amdgcn_s_setprio(0);
@@ -78,8 +86,8 @@ __device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, con
     constexpr int ftp = p / (2 * KG), g = (p / 2) % KG, h = p % 2;
     const h8 a0 = __builtin_bit_cast(h8, ring.a[p % MDX_RING][0]), a1 = __builtin_bit_cast(h8, ring.a[p % MDX_RING][1]);
     if constexpr (p + MDX_RING < NP) {
-      ring.a[p % MDX_RING][0] = ws_frag(w, 2 * (p + MDX_RING));
-      ring.a[p % MDX_RING][1] = ws_frag(w, 2 * (p + MDX_RING) + 1);
+      ring.a[p % MDX_RING][0] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING));
+      ring.a[p % MDX_RING][1] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING) + 1);
     }
     if constexpr (p == PRIME_AT) ring_prime(nx, wnext);
     if constexpr (g == 0 && h == 0) {
@@ -87,6 +95,7 @@ __device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, con
       for (int rt = 0; rt < RR; ++rt) t0[rt] = t1[rt] = u0[rt] = u1[rt] = splat4(0.f);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((MDX_ABL & 16) != 0 && (p % 8) != 0) return;  // timing-only ablation: 1/8 of the MFMAs
     // MFMAs on the same accumulator are kept two instructions apart
     if constexpr (h == 0) {
 #pragma unroll

@@ -117,6 +117,10 @@ __device__ __forceinline__ void gemm_tile_impl(f32x4 (&acc)[FTW][ET], f32x4 (&a0
     if constexpr (g + D - 1 < G) load_a(a[(g + D - 1) % D], g + D - 1);
     if constexpr (g + 1 < G) load_b(b[(g + 1) & 1], g + 1);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef MDX_TILE_ABL_MFMA  // timing-only ablation (wrong results): one MFMA in eight
+    if constexpr (g % 2 == 0)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][0][0], b[g & 1][0][0], acc[0][0], 0, 0, 0);
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -124,6 +128,7 @@ __device__ __forceinline__ void gemm_tile_impl(f32x4 (&acc)[FTW][ET], f32x4 (&a0
 #pragma unroll
         for (int et = 0; et < ET; ++et)
           acc[ft][et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % D][ft][s], b[g & 1][et][s], acc[ft][et], 0, 0, 0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   });
 }
