@@ -70,6 +70,7 @@ struct mdx_model_s {
   BondDecW dec{};
   std::vector<EdgeBwdW> ebw;
   std::vector<NodeBwdW> nbw;
+  std::vector<NodeBwdWS> nbws;
   // matrix path of the row-owner edge kernels: 0 = exact fp32 MFMA (default), 1 = split float16 (mdx_split.h).  Both weight
   // packs are always built; split_ok is false when a weight would overflow the scaled float16 range (the path is then refused).
   int matrix_path = 0;
@@ -233,6 +234,16 @@ struct PackCtx {
     for (int k = 0; k < K; ++k)
       for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
     pack_stream(slot, Wt, K, Fp, 0, Fp);
+  }
+  // transposed dense split pack (node_bwd_s_kernel)
+  void packTDS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
+    const HostTensor* t = get(key, {F, ldw});
+    if (!t) return;
+    const int Fp = (F + 15) / 16 * 16;
+    std::vector<float> Wt((size_t)K * Fp, 0.f);
+    for (int k = 0; k < K; ++k)
+      for (int f = 0; f < F; ++f) Wt[(size_t)k * Fp + f] = t->data[(size_t)f * ldw + col0 + k];
+    pack_dense_split(slot, Wt, K, Fp, 0, Fp);
   }
   // transposed split stream pack (mdx_bwd2s.hip)
   void packTSS(const float** slot, const std::string& key, int F, int ldw, int col0, int K) {
@@ -454,6 +465,7 @@ int pack_model(mdx_model_s* m) {
     // transposed packs for the data-gradient backward (guidance)
     m->ebw.assign(cf.num_blocks, EdgeBwdW{});
     m->nbw.assign(cf.num_blocks, NodeBwdW{});
+    m->nbws.assign(cf.num_blocks, NodeBwdWS{});
     for (int i = 0; i < cf.num_blocks; ++i) {
       const std::string si = std::to_string(i);
       const std::string nb = net + "node_blocks_with_edge." + si, eb = net + "edge_blocks." + si;
@@ -526,7 +538,11 @@ int pack_model(mdx_model_s* m) {
           for (int f = 0; f < ND; ++f)
             for (int k = 0; k < kc; ++k) Mt[(size_t)f * kc + k] = Wcat[(size_t)(256 * ch + k) * ND + f];
           c.pack_dense(&n.WcatT[ch], Mt, ND, kc, 0, kc);
+          c.pack_dense_split(&m->nbws[i].WcatT[ch], Mt, ND, kc, 0, kc);
         }
+      c.packTDS(&m->nbws[i].WoutT, nb + ".out_transform.weight", ND, ND, 0, ND);
+      c.packTDS(&m->nbws[i].W1T, nb + ".node_net.net.0.weight", ND, ND, 0, ND);
+      c.packTDS(&m->nbws[i].W2T, nb + ".node_net.net.3.weight", ND, ND, 0, ND);
     }
   }
   if (!c.missing.empty()) return fail(MDX_ERR_STATE, "missing or mis-shaped parameter: %s", c.missing.c_str());
@@ -1506,7 +1522,9 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     const TapeBlock& k = tp.b[i];
     NodeBwdArgs nt{};
     nt.N = N; nt.flags = NB_TAIL; nt.gHn = gHn; nt.Hn = k.Hn; nt.NTin = k.NT; nt.aggr = k.aggr; nt.GNT = GNT; nt.gH = gH;
-    nt.w = m->blocks[i].nd; nt.wt = m->nbw[i];
+    nt.w = m->blocks[i].nd; nt.wt = m->nbw[i]; nt.ws = m->blocks[i].nds; nt.wts = m->nbws[i];
+    const int nb_split = m->matrix_path == MDX_MATRIX_SPLIT_F16 ? NB_SPLIT : 0;
+    nt.flags |= nb_split;
     launch_node_bwd(nt, s);
     EdgeTailBwdArgs et{};
     et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
@@ -1538,7 +1556,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
       sr.GNL0 = tp.GNL0; sr.GNL1 = tp.GNL1; sr.GGXS0 = tp.GGXS0; sr.GGXS1 = tp.GGXS1; sr.gH = gH; sr.GNT = GNT;
       launch_seg_reduce_bwd_block(sr, s);
     }
-    nt.flags = NB_PRE;
+    nt.flags = NB_PRE | nb_split;
     launch_node_bwd(nt, s);
     std::swap(gHe, gHe2);
   }

@@ -14,6 +14,7 @@
 #define MDX_TILE_RING 4  // weight groups in flight per wave (node_bwd 0.79 -> 0.73, edge_tail_bwd 0.69 -> 0.68 ms per guided step)
 #endif
 #include "mdx_tile.h"
+#include "mdx_tile_split.h"
 
 namespace {
 
@@ -119,6 +120,89 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_bwd_kernel(const NodeBwdArgs a
     acc_to_lds<4, NBT>(gt, A, LD256, 0, ft0, lane);
     __syncthreads();
     gemm_tile<4, NBT, 256>(acc, a.wt.W1T, 16, ft0, A, LD256, lane);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int et = 0; et < NBT; ++et)
+        if (valid[et]) stg4(a.gHn + (size_t)vi[et] * MDX_ND + 16 * (ft0 + ft) + 4 * q, acc[ft][et]);
+  }
+}
+
+// the same kernel on the split float16 matrix path (gemm_tile_s, split packs of the transposed weights): NB_SPLIT launches
+__global__ __launch_bounds__(MDX_WG, 2) void node_bwd_s_kernel(const NodeBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* A = smem + N_A;
+  float* B = smem + N_B;
+  float* red = smem + N_RED;
+  float *red2 = red + 4 * NTN, *red3 = red + 8 * NTN, *red4 = red + 12 * NTN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int v0 = blockIdx.x * NTN, N = a.N, ft0 = 4 * wave;
+  bool valid[NBT];
+  int vi[NBT];
+#pragma unroll
+  for (int et = 0; et < NBT; ++et) {
+    vi[et] = v0 + 16 * et + c;
+    valid[et] = vi[et] < N;
+    if (!valid[et]) vi[et] = N - 1;
+  }
+  if (a.flags & NB_TAIL) {
+    load_rows_ld(a.gHn, MDX_ND, MDX_ND, v0, N, A, LD256, tid);
+    f32x4 z[4][NBT];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int et = 0; et < NBT; ++et) {
+        const int f = 16 * (ft0 + ft) + 4 * q;
+        z[ft][et] = ldg4(a.NTin + (size_t)vi[et] * MDX_NTW + MDX_NT_C + f) + ldg4(a.aggr + (size_t)vi[et] * MDX_ND + f);
+      }
+    float rstd[NBT];
+    ln_xhat<4, NBT, 4>(z, rstd, red, red2, wave, lane, true);  // (barriers also cover the load of A)
+    f32x4 g[4][NBT];
+    acc_zero<4, NBT>(g);
+    gemm_tile_s<4, NBT, 256>(g, a.wts.WoutT, 16, ft0, A, LD256, lane);
+    ln_relu_bwd<4, NBT, 4>(g, z, rstd, a.w.lng, a.w.lnb, ft0, red3, red4, wave, lane, true);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int et = 0; et < NBT; ++et)
+        if (valid[et]) stg4(a.GNT + (size_t)vi[et] * MDX_NTW + MDX_NT_C + 16 * (ft0 + ft) + 4 * q, g[ft][et]);
+  }
+  if (a.flags & NB_PRE) {
+    f32x4 acc[4][NBT];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+      for (int et = 0; et < NBT; ++et) acc[ft][et] = ldg4(a.gHn + (size_t)vi[et] * MDX_ND + 16 * (ft0 + ft) + 4 * q);
+    // Wcat^T GNT in 4 K-chunks
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {
+      const int kc = ch < 3 ? 256 : 192;
+      __syncthreads();
+      load_rows_ld(a.GNT + 256 * ch, MDX_NTW, kc, v0, N, A, LD256, tid);
+      __syncthreads();
+      if (ch < 3)
+        gemm_tile_s<4, NBT, 256>(acc, a.wts.WcatT[ch], 16, ft0, A, LD256, lane);
+      else
+        gemm_tile_s<4, NBT, 192>(acc, a.wts.WcatT[ch], 16, ft0, A, LD256, lane);
+    }
+    __syncthreads();
+    // node_net backward: H = W2 relu(LN(q)) + b2, q = W1 Hn + b1
+    load_rows_ld(a.gH, MDX_ND, MDX_ND, v0, N, A, LD256, tid);
+    load_rows_ld(a.Hn, MDX_ND, MDX_ND, v0, N, B, LD256, tid);
+    __syncthreads();
+    f32x4 gt[4][NBT], xh[4][NBT];
+    acc_zero<4, NBT>(gt);
+    gemm_tile_s<4, NBT, 256>(gt, a.wts.W2T, 16, ft0, A, LD256, lane);
+    acc_bias<4, NBT>(xh, a.w.nn.b1, ft0, lane);
+    gemm_tile_s<4, NBT, 256>(xh, a.ws.nnW1, 16, ft0, B, LD256, lane);
+    float rstd[NBT];
+    ln_xhat<4, NBT, 4>(xh, rstd, red, red2, wave, lane, true);
+    ln_relu_bwd<4, NBT, 4>(gt, xh, rstd, a.w.nn.g, a.w.nn.be, ft0, red3, red4, wave, lane, true);
+    __syncthreads();
+    acc_to_lds<4, NBT>(gt, A, LD256, 0, ft0, lane);
+    __syncthreads();
+    gemm_tile_s<4, NBT, 256>(acc, a.wts.W1T, 16, ft0, A, LD256, lane);
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
@@ -362,9 +446,13 @@ void launch_node_bwd(const NodeBwdArgs& a, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)node_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, N_TOTAL * 4);
+    (void)hipFuncSetAttribute((const void*)node_bwd_s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, N_TOTAL * 4);
     attr = true;
   }
-  hipLaunchKernelGGL(node_bwd_kernel, dim3((a.N + NTN - 1) / NTN), dim3(MDX_WG), N_TOTAL * 4, s, a);
+  if (a.flags & NB_SPLIT)
+    hipLaunchKernelGGL(node_bwd_s_kernel, dim3((a.N + NTN - 1) / NTN), dim3(MDX_WG), N_TOTAL * 4, s, a);
+  else
+    hipLaunchKernelGGL(node_bwd_kernel, dim3((a.N + NTN - 1) / NTN), dim3(MDX_WG), N_TOTAL * 4, s, a);
 }
 
 void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s) {

@@ -244,6 +244,10 @@ struct EdgeBwdArgs {
   EdgeBwdW wt;
 };
 
+struct NodeBwdWS {  // split float16 dense packs of NodeBwdW (mdx_bondpred.hip node_bwd_s_kernel)
+  const float *WoutT, *W1T, *W2T, *WcatT[4];
+};
+
 struct NodeBwdArgs {
   int N, flags;
   float* gHn;                  // (N,256) in/out
@@ -253,9 +257,12 @@ struct NodeBwdArgs {
   const float* gH;             // (N,256) dL/d node_net(x)
   NodeW w;
   NodeBwdW wt;
+  NodeWS ws;       // split packs (NB_SPLIT): node_net's first layer for the recompute ...
+  NodeBwdWS wts;   // ... and the transposed matrices
 };
 #define NB_TAIL 1
 #define NB_PRE 2
+#define NB_SPLIT 4  // matrix products on the split float16 path
 
 struct BondDecW {
   const float *W1e, *W1n, *b1, *g1, *be1, *W2, *b2, *g2, *be2, *W3, *b3;
