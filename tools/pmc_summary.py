@@ -24,7 +24,7 @@ import re
 def kernel_key(name):
     """'void (anonymous namespace)::edge_a2_kernel<15>(EdgeAArgs, ...)' -> 'edge_a2_kernel<15>' for the library's own block kernels
     (the keys bench.py looks up through mdx_profile_kernel_name); None for everything else."""
-    m = re.search(r'((?:edge_a2s|edge_b2s|edge_bwd2s|edge_tail_bwd2s|edge_a2|edge_b2|edge_a|edge_b|node|node_bwd|seg_reduce_block2|seg_reduce_block|edge_bwd2|edge_bwd|edge_tail_bwd2|'
+    m = re.search(r'((?:edge_a2s|edge_b2s|edge_bwd2s|edge_tail_bwd2s|node_bwd_s|node_s|edge_a2|edge_b2|edge_a|edge_b|node|node_bwd|seg_reduce_block2|seg_reduce_block|edge_bwd2|edge_bwd|edge_tail_bwd2|'
                   r'seg_reduce_bwd_block|seg_reduce)_kernel(?:<[0-9a-z, ]+>)?)\(', name)
     return m.group(1) if m else None
 
