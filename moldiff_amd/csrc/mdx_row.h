@@ -20,7 +20,8 @@
 #include "mdx_tile.h"
 
 #ifndef MDX_ABL
-#define MDX_ABL 0  // timing-only ablations (wrong results): 1 no stores, 2 no row gathers, 4 weight stream served from L1
+#define MDX_ABL 0  // timing-only ablations (wrong results): 1 no stores, 2 no row gathers, 4 weight stream served from L1, 8 / 16 / 32 (split
+                   // kernels, mdx_split.h): no operand conversion arithmetic / one MFMA in eight / no weight loads at all
 #endif
 #ifndef MDX_RING
 #define MDX_RING 2  // steps (2 KiB each) of the weight stream in flight per wave
@@ -49,6 +50,7 @@ __device__ __forceinline__ f32x4 ws_frag(const WS& w, int frag) {
 // first MDX_RING steps of a stream (every stream pack ends in MDX_RING_PAD zero steps, so priming a stream shorter than the
 // ring stays in bounds)
 __device__ __forceinline__ void ring_prime(WRing& r, const WS& w) {
+  if (MDX_ABL & 32) return;  // timing-only ablation: no weight loads at all (the ring keeps whatever it held)
 #pragma unroll
   for (int p = 0; p < MDX_RING; ++p) {
     r.a[p][0] = ws_frag(w, 2 * p);

@@ -85,7 +85,7 @@ __device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, con
     constexpr int p = decltype(pc)::value;
     constexpr int ftp = p / (2 * KG), g = (p / 2) % KG, h = p % 2;
     const h8 a0 = __builtin_bit_cast(h8, ring.a[p % MDX_RING][0]), a1 = __builtin_bit_cast(h8, ring.a[p % MDX_RING][1]);
-    if constexpr (p + MDX_RING < NP) {
+    if constexpr (p + MDX_RING < NP && !(MDX_ABL & 32)) {
       ring.a[p % MDX_RING][0] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING));
       ring.a[p % MDX_RING][1] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING) + 1);
     }
