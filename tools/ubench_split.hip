@@ -229,6 +229,15 @@ __device__ __forceinline__ void gemm_split(f32x4 (&y)[16][R], const h8 (&xh)[8][
   });
 }
 
+// phase stamps of one wave (block 0, wave 0) in its second pass over the chain: [layer][0 start, 1 operand split, 2 GEMM, 3 LayerNorm]
+__device__ unsigned long long g_stamp[64];
+#define STAMP(i)                                                                             \
+  do {                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    if (blockIdx.x == 0 && tid == 0 && r == 1 && l < 8) g_stamp[l * 4 + (i)] = clock64();    \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+
 // KIND 0: exact fp32;  3: split float16, lo halves unscaled, one accumulator (first cut);  4: split float16 as shipped
 // (mdx_split.h: lo halves scaled by 2^11, cross terms in accumulators of their own);  1: plain float16 (one product)
 template <int KIND, int R, int DEPTH, int WPS, bool LN>
@@ -254,22 +263,38 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict
 #pragma unroll
         for (int rt = 0; rt < R; ++rt) y[ft][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int mbase = __builtin_amdgcn_readfirstlane(m) * 262144;
+      STAMP(0);
       if constexpr (KIND == 0) {
         gemm_f32<R, DEPTH>(y, x, ws, mbase);
       } else if constexpr (KIND == 4 || KIND == 5) {
         h8 xh[8][R], xl[8][R];
         split_x<R>(x, xh, xl, 2048.0f);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+          for (int rt = 0; rt < R; ++rt) asm volatile("" : "+v"(xh[g][rt]), "+v"(xl[g][rt]));
+        STAMP(1);
         gemm_split2<R, DEPTH, KIND == 5 ? 4 : 3>(y, xh, xl, ws, mbase);
       } else {
         h8 xh[8][R], xl[8][R];
         split_x<R>(x, xh, xl);
         gemm_split<R, DEPTH, KIND>(y, xh, xl, ws, mbase);
       }
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) asm volatile("" : "+v"(y[g][rt]));
+      STAMP(2);
       if (LN) {
         const float* gbp = gb + (size_t)m * 512;
         asm volatile("" : "+s"(gbp));
         ln_relu<R>(y, gbp, gbp + 256, q, eps);
       }
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+#pragma unroll
+        for (int rt = 0; rt < R; ++rt) asm volatile("" : "+v"(y[g][rt]));
+      STAMP(3);
 #pragma unroll
       for (int g = 0; g < 16; ++g)
 #pragma unroll
@@ -420,6 +445,15 @@ static void run(const char* name, const Dev& d, const void* W, const Problem& P,
     float ms;
     hipEventElapsedTime(&ms, a, b);
     best = ms < best ? ms : best;
+  }
+  if (getenv("UB_STAMPS")) {
+    unsigned long long st[64];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof(st));
+    printf("    phase cycles (layers 1..4 of the second pass): ");
+    for (int l = 1; l < 5; ++l)
+      printf("[split %llu gemm %llu ln %llu next %llu] ", st[l * 4 + 1] - st[l * 4], st[l * 4 + 2] - st[l * 4 + 1], st[l * 4 + 3] - st[l * 4 + 2],
+             st[(l + 1) * 4] - st[l * 4 + 3]);
+    printf("\n");
   }
   const double flop = (double)grid * 4 * reps * nl * 2.0 * 256 * 256 * 16 * R;
   printf("%-34s R=%d depth=%d wps=%d LN=%d vgpr=%3d scratch=%d : %7.3f ms %7.1f eq.TFLOP/s (%.2fx of 157.3) | %d layers: max err %.3e rms %.3e (max |y| %.2f)\n",
