@@ -28,6 +28,20 @@
 #include <algorithm>
 int mdx_set_error(int code, const char* msg);
 
+// phase trace of the split kernel (tools/trace_edge2s.py); compiled out of the library
+#ifdef MDX_TRACE2S
+__device__ unsigned long long* mdx_trace2s_buf = nullptr;
+extern "C" int mdx_debug_set_trace2s(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(mdx_trace2s_buf), &p, sizeof(p)); }
+#define STAMPS(i)                                                                                  \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (lane == 0 && mdx_trace2s_buf) mdx_trace2s_buf[(size_t)unit * 32 + (i)] = clock64();        \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define STAMPS(i) ((void)0)
+#endif
+
 namespace {
 
 template <int FLAGS>
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
     const bool inode = do_node && (mode & 1), iffn = do_ffn && (mode & 10);
     const int sfirst = (mode & 2) ? 0 : 1, slast = (mode & 8) ? 1 : 0;
     // ---- He' = edge_embs([He | smear(d)]) ; hx = its split operand (the fp32 rows are only needed for the store) ------------
+    STAMPS(0);
     XS<2> hx;
     {
       f32x4 hep[4][RR];
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
         to_xs<5>(xs, x);
         row_bias<4, RR>(hep, c_bemb, q);
         rgemm_s<3, 4>(hep, xs, W(S.Wemb), ring, W(inode ? S.Wg1e : iffn ? S.ffn[sfirst].Wbl : wfirst));
+        STAMPS(1);
         if (mode & 4) row_store<4, RR>(hep, a.He_out, t.row, t.valid, 64, q);
       } else {
 #pragma unroll
@@ -193,13 +209,17 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
           for (int rt = 0; rt < RR; ++rt) y[ft][rt] = (b + y[ft][rt]) + splat4(tg[rt]) * wt;
         }
       }
+      STAMPS(2);
       rgemm_s<2, 16>(y, hx, W(S.Wg1e), ring, W(S.Wg2));
+      STAMPS(3);
       row_layernorm<16, RR>(y, c_gg, c_gb, q);
       {
         XS<8> ys;
         to_xs<16>(ys, y);
         row_bias<16, RR>(z, c_bg2, q);
+        STAMPS(4);
         rgemm_s<8, 16>(z, ys, W(S.Wg2), ring, W(S.W1));
+        STAMPS(5);
       }
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft)
@@ -211,13 +231,17 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
         }
       // edge_net
       row_bias<16, RR>(y, c_eb1, q);
+      STAMPS(6);
       rgemm_s<2, 16>(y, hx, W(S.W1), ring, W(S.W2));
+      STAMPS(7);
       row_layernorm<16, RR>(y, c_eg, c_ebe, q);
       {
         XS<8> ys;
         to_xs<16>(ys, y);
         row_bias<16, RR>(z, c_eb2, q);
+        STAMPS(8);
         rgemm_s<8, 16>(z, ys, W(S.W2), ring, W(S.Wm));
+        STAMPS(9);
       }
       if (a.tHE) row_store<16, RR, TAPE_NT>(z, a.tHE, t.row, t.valid, MDX_ND, q);
       row_gather<16, RR>(y, a.H, t.ri, MDX_ND, q);
@@ -227,7 +251,9 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
         XS<8> zs;
         to_xs<16>(zs, z);
         row_bias<16, RR>(y, c_bm, q);
+        STAMPS(10);
         rgemm_s<8, 16>(y, zs, W(S.Wm), ring, W(iffn ? S.ffn[sfirst].Wbl : wfirst));
+        STAMPS(11);
       }
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft)
