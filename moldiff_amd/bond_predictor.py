@@ -70,8 +70,6 @@ class BondPredictor(Module):
 
     def __init__(self, config, num_node_types, num_edge_types, **kwargs):
         # variants the kernels are not built for are rejected BEFORE any sub-module exists (INTEGRATION.md "unsupported variants")
-        if config.diff.num_timesteps == 0:
-            raise NotImplementedError('num_timesteps == 0 (time-free predictor, models/bond_predictor.py:27-31) is not built')
         if config.encoder.get('update_pos', True) if hasattr(config.encoder, 'get') else getattr(config.encoder, 'update_pos', True):
             raise NotImplementedError('the bond predictor kernels assume encoder.update_pos=False (the shipped config)')
         super().__init__()
@@ -80,10 +78,14 @@ class BondPredictor(Module):
         self.num_edge_types = num_edge_types
         self.define_betas_alphas(config.diff)
         node_dim, edge_dim = config.node_dim, config.edge_dim
-        time_dim = config.diff.time_dim
+        # num_timesteps == 0: the time-free predictor (models/bond_predictor.py:27-31) -- full-width embedders, no time embedding,
+        # clean inputs in get_loss and t = 0 for the encoder's time columns (:97-102, :141-144)
+        time_dim = config.diff.time_dim if self.num_timesteps > 0 else 0
+        self.time_dim = time_dim
         self.node_embedder = nn.Linear(num_node_types, node_dim - time_dim, bias=False)
         self.edge_embedder = nn.Linear(num_node_types * 2, edge_dim - time_dim, bias=False)
-        self.time_emb = GaussianSmearing(stop=self.num_timesteps, num_gaussians=time_dim, type_='linear')
+        if self.num_timesteps != 0:
+            self.time_emb = GaussianSmearing(stop=self.num_timesteps, num_gaussians=time_dim, type_='linear')
         self.encoder = NodeEdgeNet(node_dim, edge_dim, **config.encoder)
         self.edge_decoder = MLP(edge_dim + node_dim, num_edge_types, edge_dim, num_layer=3)
         self.edge_weight = torch.tensor([0.1] + [1.] * (self.num_edge_types - 1), dtype=torch.float32)
@@ -112,7 +114,7 @@ class BondPredictor(Module):
         if self._eng is None or sig != self._eng_sig:
             e = self.encoder
             eng = _lib.Model(_lib.MDX_KIND_BONDPRED, num_blocks=e.num_blocks, cutoff=e.cutoff, update_pos=False,
-                             time_dim=self.config.diff.time_dim, num_timesteps=self.num_timesteps,
+                             time_dim=self.time_dim, num_timesteps=self.num_timesteps,
                              num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
                              node_dim=e.node_dim, edge_dim=e.edge_dim, num_gaussians=e.distance_expansion.offset.numel())
             eng.upload(self.state_dict())
@@ -134,9 +136,14 @@ class BondPredictor(Module):
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         noise = noise or {}
         with torch.no_grad():
-            t = self.sample_time(num_mol, node_pos.device)[0] if time_step is None else time_step
-            pos = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
-            h_node = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))[0]
+            if self.num_timesteps != 0:
+                t = self.sample_time(num_mol, node_pos.device)[0] if time_step is None else time_step
+                pos = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
+                h_node = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))[0]
+            else:  # time-free: clean one-hot types and positions (models/bond_predictor.py:100-102)
+                t = torch.zeros(num_mol, dtype=torch.long, device=node_pos.device)
+                pos = node_pos
+                h_node = torch.nn.functional.one_hot(node_type, self.num_node_types).float()
             edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
             batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
         with torch.enable_grad() if train else torch.no_grad():
@@ -151,6 +158,8 @@ class BondPredictor(Module):
 
     def forward(self, h_node, pos_node, batch_node, edge_index, batch_edge, t, _graph=None):
         """Predict the bond type of every half-edge (first half of `edge_index`) -> (Eh, num_edge_types)."""
+        if self.num_timesteps == 0:  # the reference ignores `t` here and feeds zeros to the encoder (:143)
+            t = torch.zeros(int(batch_node.max()) + 1 if t is None else int(t.numel()), dtype=torch.long, device=pos_node.device)
         _lib._need_gpu(h_node, pos_node, batch_node, edge_index, t)
         eng = self._engine()
         g = _graph if _graph is not None else _lib.graph_for(edge_index, batch_node, int(t.numel()))

@@ -437,8 +437,10 @@ int pack_model(mdx_model_s* m) {
     if (const HostTensor* t = c.get("node_embedder.weight", {nd_emb, cf.num_node_types})) c.raw(&m->Wn, t->data);
     if (const HostTensor* t = c.get("edge_embedder.weight", {ed_emb, ein})) c.raw(&m->We, t->data);
     const std::string te = cf.kind == MDX_KIND_MOLDIFF ? "time_emb.0." : "time_emb.";
-    c.vec(&m->toff, te + "offset", cf.time_dim);
-    c.vec(&m->tcoef, te + "coeff", cf.time_dim);
+    if (cf.time_dim > 0) {  // 0: the time-free bond predictor (models/bond_predictor.py:27-31) has no time embedding
+      c.vec(&m->toff, te + "offset", cf.time_dim);
+      c.vec(&m->tcoef, te + "coeff", cf.time_dim);
+    }
   }
   if (cf.kind == MDX_KIND_MOLDIFF) {
     c.mlp(&m->nodedec, "node_decoder", ND, ND, cf.num_node_types, 16);
@@ -1229,7 +1231,7 @@ extern "C" int mdx_moldiff_forward(mdx_model_t m, mdx_graph_t g, const float* h_
   const mdx_config& cf = m->cfg;
   EmbedArgs ea{};
   ea.N = (int)g->N; ea.E = (int)g->E; ea.Kn = cf.num_node_types; ea.Ke = cf.num_edge_types; ea.time_dim = cf.time_dim;
-  ea.T = cf.num_timesteps; ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node_pert;
+  ea.T = std::max(cf.num_timesteps, 1); ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node_pert;
   ea.int2ref = g->int2ref; ea.l = g->left; ea.r = g->right; ea.node_graph = g->node_graph; ea.t = t; ea.Wn = m->Wn;
   ea.We = m->We; ea.toff = m->toff; ea.tcoef = m->tcoef; ea.Hn = w.Hn; ea.He = w.HeA; ea.tn = w.tn; ea.te = w.te;
   if (h_edge_pert) {
@@ -1429,7 +1431,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
   const mdx_config& cf = m->cfg;
   EmbedArgs ea{};
   ea.N = (int)g->N; ea.E = (int)g->E; ea.Kn = cf.num_node_types; ea.Ke = cf.num_edge_types; ea.time_dim = cf.time_dim;
-  ea.T = cf.num_timesteps; ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node; ea.xe = nullptr;
+  ea.T = std::max(cf.num_timesteps, 1); ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node; ea.xe = nullptr;
   ea.int2ref = g->int2ref; ea.l = g->left; ea.r = g->right; ea.node_graph = g->node_graph; ea.t = t; ea.Wn = m->Wn;
   ea.We = m->We; ea.toff = m->toff; ea.tcoef = m->tcoef; ea.Hn = w.Hn; ea.He = w.HeA; ea.tn = w.tn;
   ea.te = tape ? tp.te : w.te;

@@ -181,9 +181,13 @@ def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge
     g = TrainGraph(edge_index, h_node.shape[0])
     tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
     h_edge = cat(h_node[edge_index[0]], h_node[edge_index[1]])            # one-hot pairs: pure indexing
-    h_node = cat32(T.linear(h_node, model.node_embedder.weight), time_embedding(model.time_emb, tn))
-    h_edge = cat(T.linear(h_edge, model.edge_embedder.weight), time_embedding(model.time_emb, te))
-    T_ = float(model.num_timesteps)
+    if model.num_timesteps != 0:
+        h_node = cat32(T.linear(h_node, model.node_embedder.weight), time_embedding(model.time_emb, tn))
+        h_edge = cat(T.linear(h_edge, model.edge_embedder.weight), time_embedding(model.time_emb, te))
+    else:  # time-free predictor: full-width embedders, t = 0 (models/bond_predictor.py:141-144)
+        h_node = T.linear(h_node, model.node_embedder.weight)
+        h_edge = T.linear(h_edge, model.edge_embedder.weight)
+    T_ = float(max(model.num_timesteps, 1))
     h_node, _, h_edge = node_edge_net(model.encoder, h_node, pos_node, h_edge, g,
                                       (tn.unsqueeze(-1) / T_).float(), (te.unsqueeze(-1) / T_).float())
     n_half = h_edge.shape[0] // 2

@@ -247,14 +247,21 @@ def moldiff_forward(P, cfg, h_node_pert, pos_pert, batch_node, h_edge_pert, edge
 
 
 def bondpred_forward(P, cfg, h_node, pos, batch_node, edge_index, batch_edge, t):
-    """bond_predictor.py:128-162 (num_timesteps != 0 branch)."""
+    """bond_predictor.py:128-162; num_timesteps == 0 is the time-free predictor (:141-144: full-width embedders, t = 0)."""
     T = cfg['num_timesteps']
-    toff, tco = P['time_emb.offset'], P['time_emb.coeff']
     he = torch.cat([h_node[edge_index[0]], h_node[edge_index[1]]], -1)
-    tn = t.index_select(0, batch_node).to(toff.dtype)
-    te = t.index_select(0, batch_edge).to(toff.dtype)
-    hn = torch.cat([F.linear(h_node, P['node_embedder.weight']), smear(tn, toff, tco, 0.0, T)], -1)
-    he = torch.cat([F.linear(he, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
+    if T != 0:
+        toff, tco = P['time_emb.offset'], P['time_emb.coeff']
+        tn = t.index_select(0, batch_node).to(toff.dtype)
+        te = t.index_select(0, batch_edge).to(toff.dtype)
+        hn = torch.cat([F.linear(h_node, P['node_embedder.weight']), smear(tn, toff, tco, 0.0, T)], -1)
+        he = torch.cat([F.linear(he, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
+    else:
+        hn = F.linear(h_node, P['node_embedder.weight'])
+        he = F.linear(he, P['edge_embedder.weight'])
+        tn = torch.zeros(h_node.shape[0], dtype=pos.dtype)
+        te = torch.zeros(edge_index.shape[1], dtype=pos.dtype)
+        T = 1
     hn, _, he = node_edge_net(P, 'encoder', hn, pos, he, edge_index, tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
                               num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], update_pos=False)
     nh = he.shape[0] // 2
@@ -441,9 +448,13 @@ def bondpred_loss(Pb, cfgb, tabs, node_type, node_pos, batch_node, halfedge_type
     """BondPredictor.get_loss (models/bond_predictor.py:84-124) with the draws passed in: noise = dict(eps_pos, u_node).
     `tabs` = {'pos': {'alphas_bar'}, 'node': {'q_mats'}} of the predictor's own schedules."""
     t = time_step
-    a_bar = tabs['pos']['alphas_bar'][t][batch_node].unsqueeze(-1)
-    pos = a_bar.sqrt() * node_pos + (1 - a_bar).sqrt() * noise['eps_pos']
-    hn = cat_add_noise(tabs['node'], node_type, t, batch_node, noise['u_node'])[0]
+    if cfgb['num_timesteps'] != 0:
+        a_bar = tabs['pos']['alphas_bar'][t][batch_node].unsqueeze(-1)
+        pos = a_bar.sqrt() * node_pos + (1 - a_bar).sqrt() * noise['eps_pos']
+        hn = cat_add_noise(tabs['node'], node_type, t, batch_node, noise['u_node'])[0]
+    else:  # time-free predictor: clean inputs (:100-102)
+        pos = node_pos
+        hn = F.one_hot(node_type, Pb['node_embedder.weight'].shape[1]).to(node_pos.dtype)
     edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], 1)
     batch_edge = torch.cat([batch_halfedge, batch_halfedge], 0)
     logits = bondpred_forward(Pb, cfgb, hn, pos, batch_node, edge_index, batch_edge, t)
