@@ -77,6 +77,9 @@ int mdx_model_finalize(mdx_model_t m);
 #define MDX_MATRIX_SPLIT_F16 1
 int mdx_model_set_matrix_path(mdx_model_t m, int32_t path);
 int mdx_model_get_matrix_path(mdx_model_t m, int32_t* path);
+/* Lower clamp of the distance smearing, GaussianSmearing(start, stop = cutoff) of models/graph.py:330-333 / common.py:233-235.
+ * 0 (the default) in every shipped config; the offset / coeff tables always come from the state_dict.  Any time before a forward. */
+int mdx_model_set_smear_start(mdx_model_t m, float start);
 
 /* ---- graph handle: CSR plan of one packed batch (utils/transforms.py:125-156 produces the inputs) */
 /* h_edge_index: (2,E) int64 row-major, row 0 = left/row, row 1 = right/col; h_batch_node: (N) int64,

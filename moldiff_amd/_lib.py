@@ -17,7 +17,7 @@ MDX_KIND_MOLDIFF, MDX_KIND_BONDPRED, MDX_KIND_NET = 0, 1, 2
 EXPORTS = [
     'mdx_last_error', 'mdx_version', 'mdx_device_count',
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
-    'mdx_model_set_matrix_path', 'mdx_model_get_matrix_path',
+    'mdx_model_set_matrix_path', 'mdx_model_get_matrix_path', 'mdx_model_set_smear_start',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_bond_ffn', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
@@ -77,6 +77,7 @@ def lib():
         L.mdx_model_set_param.argtypes = [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int32]
         L.mdx_model_finalize.argtypes = [c_void_p]
         L.mdx_model_set_matrix_path.argtypes = [c_void_p, c_int32]
+        L.mdx_model_set_smear_start.argtypes = [c_void_p, c_float]
         L.mdx_model_get_matrix_path.argtypes = [c_void_p, POINTER(c_int32)]
         L.mdx_graph_create.argtypes = [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, POINTER(c_void_p)]
         L.mdx_graph_destroy.argtypes = [c_void_p]
@@ -346,13 +347,15 @@ class Model:
         return self
 
     def __init__(self, kind, *, num_blocks, cutoff, update_pos, time_dim=0, num_timesteps=1, num_node_types=1,
-                 num_edge_types=1, node_dim=256, edge_dim=64, num_gaussians=16):
+                 num_edge_types=1, node_dim=256, edge_dim=64, num_gaussians=16, smear_start=0.0):
         cfg = MdxConfig(kind, node_dim, edge_dim, num_blocks, float(cutoff), num_gaussians, int(bool(update_pos)),
                         time_dim, num_timesteps, num_node_types, num_edge_types)
         h = c_void_p()
         check(lib().mdx_model_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
         self.cfg = cfg
+        if float(smear_start) != 0.0:   # GaussianSmearing(start != 0): models/graph.py:330-333
+            check(lib().mdx_model_set_smear_start(h, float(smear_start)))
 
     def upload(self, state_dict, prefix=''):
         for k, v in state_dict.items():

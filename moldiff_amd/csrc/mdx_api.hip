@@ -59,6 +59,7 @@ struct mdx_model_s {
   mdx_config cfg;
   std::map<std::string, HostTensor> params;
   bool finalized = false;
+  float smear_start = 0.f;  // lower clamp of the distance smearing (mdx_model_set_smear_start)
   float* arena = nullptr;  // device
   size_t arena_floats = 0;
   std::vector<BlockW> blocks;
@@ -621,6 +622,12 @@ extern "C" int mdx_model_set_matrix_path(mdx_model_t m, int32_t path) {
   m->matrix_path = path;
   return MDX_OK;
 }
+extern "C" int mdx_model_set_smear_start(mdx_model_t m, float start) {
+  if (!m) return fail(MDX_ERR_ARG, "null model");
+  if (!(start >= 0.f) || !(start < m->cfg.cutoff)) return fail(MDX_ERR_ARG, "smearing start %g outside [0, cutoff)", (double)start);
+  m->smear_start = start;
+  return MDX_OK;
+}
 extern "C" int mdx_model_get_matrix_path(mdx_model_t m, int32_t* path) {
   if (!m || !path) return fail(MDX_ERR_ARG, "null argument");
   *path = m->matrix_path;
@@ -975,7 +982,7 @@ EdgeAArgs make_ea(const mdx_model_s* m, const mdx_graph_s* g, const Ws& w, int i
   EdgeAArgs a{};
   a.E = (int)g->E; a.flags = flags; a.l = g->left; a.r = g->right; a.te = w.te; a.tn_r = w.tnr_set ? w.tnr : nullptr;
   a.pos = pos; a.dist_in = nullptr;
-  a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = NT ? NT : w.NT;
+  a.soff = m->soff; a.scoef = m->scoef; a.cutoff = m->cfg.cutoff; a.smear_start = m->smear_start; a.He_in = He_in; a.He_out = He_out; a.H = w.H; a.NT = NT ? NT : w.NT;
   a.M = w.M; a.F[0] = w.FL; a.F[1] = w.FR; a.w = m->blocks[i].ea;
   if (flags & EA_AGG) {  // segment sums inside the kernel: M and the BondFFN-right rows stay out of HBM
     a.M = nullptr; a.F[1] = nullptr;
@@ -1540,7 +1547,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
-    eb.cutoff = cf.cutoff; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
+    eb.cutoff = cf.cutoff; eb.smear_start = m->smear_start; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
     for (int sd = 0; sd < 2; ++sd) { eb.BL[sd] = k.BL[sd]; eb.H1[sd] = k.H1[sd]; eb.O[sd] = k.O[sd]; }
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;

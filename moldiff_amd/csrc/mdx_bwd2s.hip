@@ -337,7 +337,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2s_kernel(const EdgeB
         const float dy = a.pos[3 * t.li[rt] + 1] - a.pos[3 * t.ri[rt] + 1];
         const float dz = a.pos[3 * t.li[rt] + 2] - a.pos[3 * t.ri[rt] + 2];
         const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float dc = fminf(fmaxf(d, 0.f), a.cutoff);
+        const float dc = fminf(fmaxf(d, a.smear_start), a.cutoff);
         float sacc = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_bwd2s_kernel(const EdgeB
           sacc += gd[0][rt][r] * Dk * 2.0f * coef[r] * uu;
         }
         sacc = red_q(sacc);
-        if (q == 0 && t.valid[rt]) a.gdist[t.row[rt]] += (d <= a.cutoff) ? sacc : 0.f;
+        if (q == 0 && t.valid[rt]) a.gdist[t.row[rt]] += (d >= a.smear_start && d <= a.cutoff) ? sacc : 0.f;  // clamp passes the gradient inside [start, stop]
       }
     }
     STAMPW(40);

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void edge_a2s_kernel(const EdgeAAr
         for (int rt = 0; rt < RR; ++rt) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) x[g][rt] = pr.x[g][rt];
-          const float u0 = fminf(fmaxf(pr.d[rt], 0.f), a.cutoff);
+          const float u0 = fminf(fmaxf(pr.d[rt], a.smear_start), a.cutoff);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float u = u0 - off[s];

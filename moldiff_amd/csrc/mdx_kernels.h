@@ -102,7 +102,7 @@ struct EdgeAArgs {
   const float* pos;       // (N,3)
   const float* dist_in;   // optional (E) internal order: use instead of |pos[l]-pos[r]| (unused in product path)
   const float *soff, *scoef;  // distance smearing tables (16)
-  float cutoff;
+  float cutoff, smear_start;  // GaussianSmearing clamp [smear_start, cutoff] (common.py:233-235)
   const float* He_in;     // (E,64)
   float* He_out;          // (E,64) = edge_embs([He|D])   (== He_in when !EA_EMB)
   const float* H;         // (N,256) node_net(x)
@@ -227,7 +227,7 @@ struct EdgeBwdArgs {
   const float* te;
   const float* pos;
   const float *soff, *scoef;
-  float cutoff;
+  float cutoff, smear_start;  // GaussianSmearing clamp [smear_start, cutoff] (common.py:233-235)
   const float *Hep, *GHEP;     // (E,64)
   const float *H, *NT;         // tape node tables of this block
   const float *SG, *HE, *M;    // tape (E,256): sigmoid(gate), edge_net output, gated message (M = msg_net(he*h[r]) * SG)

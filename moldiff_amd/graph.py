@@ -170,8 +170,6 @@ class NodeEdgeNet(Module):
         self.update_pos = not ('update_pos' in kwargs and not kwargs['update_pos'])
         if not self.update_edge:
             raise NotImplementedError('update_edge=False is not built (no shipped config uses it)')
-        if start != 0:
-            raise NotImplementedError('distance smearing start != 0 is not built')
         input_edge_dim = edge_dim + num_gaussians
         self.node_blocks_with_edge = ModuleList()
         self.edge_embs = ModuleList()
@@ -204,7 +202,7 @@ class NodeEdgeNet(Module):
         if self._eng is None or sig != self._eng_sig:
             eng = _lib.Model(_lib.MDX_KIND_NET, num_blocks=self.num_blocks, cutoff=self.cutoff, update_pos=self.update_pos,
                              node_dim=self.node_dim, edge_dim=self.edge_dim,
-                             num_gaussians=self.distance_expansion.offset.numel())
+                             num_gaussians=self.distance_expansion.offset.numel(), smear_start=self.distance_expansion.start)
             eng.upload(self.state_dict())
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)

@@ -6,7 +6,11 @@ REAL reference on CPU.  BUILD-CONTAINER ONLY (needs /root/reference, read-only).
   * time-free bond predictor: `BondPredictor` with `diff.num_timesteps = 0` (models/bond_predictor.py:27-31 full-width embedders and
     no time embedding, :97-102 clean inputs in get_loss, :141-144 t = 0 for the encoder): forward logits on a 5-molecule batch, the
     loss and the norm (and, for small tensors, the values) of every parameter gradient.
-Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seed 20230811).
+  * distance smearing with `start != 0` (models/graph.py:330-333, common.py:233-235): MolDiff.forward (simple config) with
+    `denoiser.start = 0.7` on a compact batch (about half of the pairs closer than 0.7, where the clamp acts), and the bond predictor
+    with `encoder.start = 0.7`: logits and the reference's own autograd gradient of the `uncertainty` guidance objective w.r.t. the
+    positions (the clamp passes no gradient below `start`).
+Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 / 20230812 / 20230813).
 """
 import json
 import os
@@ -86,6 +90,56 @@ def main():
         if g.numel() <= 256:
             out[f'tf_grad_full/{k}'] = g.numpy()
     out['tf_keys'] = np.array(sorted(sd))
+
+    # ---- distance smearing start != 0 ---------------------------------------------------------------------------------------
+    START = 0.7
+    sizes = [5, 7, 4]
+    bn, hei, bh, node_type, node_pos, half_type = batch(sizes, 89)
+    node_pos = node_pos * 0.15   # compact: about half of the pairs are closer than START
+    ei, be = torch.cat([hei, hei.flip(0)], 1), torch.cat([bh, bh])
+    dist = (node_pos[ei[0]] - node_pos[ei[1]]).norm(dim=-1)
+    print('smearing start: pairs below start', float((dist < START).float().mean()))
+    g = np.random.Generator(np.random.PCG64(97))
+    t = torch.tensor([500, 17, 903])
+    cfg = ref_shim.load_yaml_cfg('configs/train/train_MolDiff_simple.yml')
+    cfg.model.denoiser.start = START
+    md = MolDiff(cfg.model, 8, 6).eval()
+    sd = md.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+    sd.update(O.recipe_state_dict(shapes, 20230812))
+    md.load_state_dict(sd, strict=True)
+    Pm = {k: v.detach().clone() for k, v in md.state_dict().items()}
+    h_node = torch.from_numpy(g.random((len(bn), 8)).astype(np.float32))
+    h_half = torch.from_numpy(g.random((len(bh), 6)).astype(np.float32))
+    h_edge = torch.cat([h_half, h_half])
+    with torch.no_grad():
+        ref = md(h_node, node_pos, bn, h_edge, ei, be, t)
+        orc = O.moldiff_forward(Pm, dict(num_timesteps=1000, num_blocks=6, cutoff=15, start=START), h_node, node_pos, bn, h_edge, ei, be, t)
+    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+        pins[f'variant_start_{k}'] = float((ref[k] - orc[k]).abs().max())
+        out[f'st_{k}'] = ref[k].numpy()
+    out.update({'st_sizes': np.array(sizes), 'st_pos': node_pos.numpy(), 'st_h_node': h_node.numpy(), 'st_h_half': h_half.numpy(),
+                'st_t': t.numpy(), 'st_start': np.float32(START), 'st_offset0': Pm['denoiser.distance_expansion.offset'].numpy()})
+    cfgp = ref_shim.load_yaml_cfg('configs/train/train_bondpred.yml')
+    cfgp.model.encoder.start = START
+    mb = BondPredictor(cfgp.model, 8, 5).eval()
+    sd = mb.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+    sd.update(O.recipe_state_dict(shapes, 20230813))
+    mb.load_state_dict(sd, strict=True)
+    Pp = {k: v.detach().clone() for k, v in mb.state_dict().items()}
+    hn1 = torch.nn.functional.one_hot(node_type, 8).float()
+    pos = node_pos.clone().requires_grad_(True)
+    lg = mb(hn1, pos, bn, ei, be, t)
+    (gpos,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lg, -1)).log().sum(), pos)
+    cfgb = dict(num_timesteps=1000, num_blocks=cfgp.model.encoder.num_blocks, cutoff=cfgp.model.encoder.cutoff, start=START)
+    po = node_pos.clone().requires_grad_(True)
+    lo = O.bondpred_forward(Pp, cfgb, hn1, po, bn, ei, be, t)
+    (go,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lo, -1)).log().sum(), po)
+    pins['variant_start_bond_logits'] = float((lg - lo).abs().max())
+    pins['variant_start_bond_gpos'] = float((gpos - go).abs().max())
+    out.update({'st_node_type': node_type.numpy(), 'st_bond_logits': lg.detach().numpy(), 'st_bond_gpos': gpos.numpy()})
+    print('smearing start: oracle vs reference', {k: v for k, v in pins.items() if 'start' in k})
 
     np.savez_compressed(os.path.join(OUT, 'variants.npz'), **out)
     pf = os.path.join(OUT, 'PINNING.json')

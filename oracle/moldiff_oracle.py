@@ -210,14 +210,14 @@ def pos_update(P, pre, h_node, h_edge, edge_index, rel, dist, edge_time):
 
 
 def node_edge_net(P, pre, h_node, pos, h_edge, edge_index, node_time, edge_time, *,
-                  num_blocks, cutoff, update_pos=True, num_gaussians=16):
-    """graph.py:348-374 (update_edge=True only, the two shipped configs)."""
+                  num_blocks, cutoff, update_pos=True, num_gaussians=16, start=0.0):
+    """graph.py:348-374 (update_edge=True only, the two shipped configs).  `start`: GaussianSmearing's lower clamp (:330-333)."""
     off, coeff = P[pre + '.distance_expansion.offset'], P[pre + '.distance_expansion.coeff']
     for i in range(num_blocks):
         if update_pos or i == 0:
             rel = pos[edge_index[0]] - pos[edge_index[1]]
             dist = torch.norm(rel, dim=-1, p=2)
-            dfeat = smear(dist, off, coeff, 0.0, cutoff)
+            dfeat = smear(dist, off, coeff, start, cutoff)
         h_edge = lin(P, f'{pre}.edge_embs.{i}', torch.cat([h_edge, dfeat], -1))
         dn = node_block(P, f'{pre}.node_blocks_with_edge.{i}', h_node, edge_index, h_edge, node_time)
         h_edge = h_edge + edge_block(P, f'{pre}.edge_blocks.{i}', h_edge, edge_index, h_node, edge_time)
@@ -239,7 +239,7 @@ def moldiff_forward(P, cfg, h_node_pert, pos_pert, batch_node, h_edge_pert, edge
     he = torch.cat([F.linear(h_edge_pert, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
     hn, pos, he = node_edge_net(P, 'denoiser', hn, pos_pert, he, edge_index,
                                 tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
-                                num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'])
+                                num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], start=cfg.get('start', 0.0))
     nh = he.shape[0] // 2
     return {'pred_node': mlp(P, 'node_decoder', hn),
             'pred_pos': pos,
@@ -263,7 +263,7 @@ def bondpred_forward(P, cfg, h_node, pos, batch_node, edge_index, batch_edge, t)
         te = torch.zeros(edge_index.shape[1], dtype=pos.dtype)
         T = 1
     hn, _, he = node_edge_net(P, 'encoder', hn, pos, he, edge_index, tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
-                              num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], update_pos=False)
+                              num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], update_pos=False, start=cfg.get('start', 0.0))
     nh = he.shape[0] // 2
     ext = torch.cat([he[:nh] + he[nh:], hn[edge_index[0, :nh]] + hn[edge_index[1, :nh]]], -1)
     return mlp(P, 'edge_decoder', ext, layers=3)

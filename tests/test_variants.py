@@ -2,6 +2,8 @@
 reference (oracle/make_goldens_variants.py -> tests/golden/variants.npz).
 
   * time-free bond predictor: diff.num_timesteps = 0 (models/bond_predictor.py:27-31, :97-102, :141-144)
+  * distance smearing with start != 0 (models/graph.py:330-333, common.py:233-235): forward of the denoiser, and the predictor's
+    position gradient where the clamp cuts it
 """
 import copy
 
@@ -118,3 +120,94 @@ def test_gpu_timefree_predictor_guidance_gradient_matches_oracle_autograd():
     lo = O.bondpred_forward(Pb, cfgb, h.cpu(), pc, args[2].cpu(), ei.cpu(), be.cpu(), None)
     (go,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lo, -1)).log().sum(), pc)
     assert U.maxdiff(g, go) <= 1e-4 * max(1.0, float(go.abs().max()))
+
+
+# ---- distance smearing with start != 0 -----------------------------------------------------------------------------------------
+def _start_models(device):
+    key = 'start' + str(device)
+    if key not in _models:
+        z = U.gold('variants.npz')
+        start = float(z['st_start'])
+        cfg = copy.deepcopy(default_config('MolDiff_simple'))
+        cfg.denoiser.start = start
+        md = M.MolDiff(cfg, 8, 6).eval()
+        md.load_state_dict(M.recipe_state_dict(md, 20230812), strict=True)
+        cfgp = copy.deepcopy(default_config('bondpred'))
+        cfgp.encoder.start = start
+        mb = M.BondPredictor(cfgp, 8, 5).eval()
+        mb.load_state_dict(M.recipe_state_dict(mb, 20230813), strict=True)
+        _models[key] = (md.to(device), mb.to(device))
+    return _models[key]
+
+
+def _start_case(device='cpu'):
+    z = U.gold('variants.npz')
+    bn, hei, bh, ei, be = U.graph_from_sizes([int(s) for s in z['st_sizes']], device)
+    f = lambda k: torch.from_numpy(z[k]).to(device)
+    hh = f('st_h_half')
+    return z, (f('st_h_node'), f('st_pos'), bn, torch.cat([hh, hh]), ei, be, f('st_t')), f('st_node_type')
+
+
+def test_smearing_start_reaches_the_tables_and_the_oracle():
+    z, args, node_type = _start_case()
+    md, mb = _start_models('cpu')
+    assert md.denoiser.distance_expansion.start == pytest.approx(0.7) and mb.encoder.distance_expansion.start == pytest.approx(0.7)
+    assert U.maxdiff(md.denoiser.distance_expansion.offset, z['st_offset0']) == 0.0
+    with torch.no_grad():
+        got = O.moldiff_forward(U.params(md), dict(num_timesteps=1000, num_blocks=6, cutoff=15, start=0.7), *args)
+    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+        assert U.maxdiff(got[k], z[f'st_{k}']) <= 1e-6, k
+    # ... and the clamp matters on this batch: the start = 0 evaluation differs
+    with torch.no_grad():
+        other = O.moldiff_forward(U.params(md), dict(num_timesteps=1000, num_blocks=6, cutoff=15), *args)
+    assert U.maxdiff(other['pred_pos'], z['st_pred_pos']) > 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_forward_with_smearing_start_matches_reference_golden():
+    z, args, _ = _start_case('cuda')
+    md, _ = _start_models('cuda')
+    with torch.no_grad():
+        got = md(*args)
+    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+        assert U.maxdiff(got[k], z[f'st_{k}']) <= 1e-4, (k, U.maxdiff(got[k], z[f'st_{k}']))
+
+
+@pytest.mark.gpu
+def test_gpu_predictor_position_gradient_with_smearing_start_matches_reference_autograd():
+    """d uncertainty / d pos from the hand-written backward vs the REFERENCE's autograd: below `start` the clamp passes nothing."""
+    z, args, node_type = _start_case('cuda')
+    _, mb = _start_models('cuda')
+    h = torch.nn.functional.one_hot(node_type, 8).float()
+    pos = args[1].clone().requires_grad_(True)
+    logits = mb(h, pos, args[2], args[4], args[5], args[6])
+    assert U.maxdiff(logits, z['st_bond_logits']) <= 2e-5 * max(1.0, float(np.abs(z['st_bond_logits']).max()))
+    (g,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), pos)
+    want = z['st_bond_gpos']
+    assert U.maxdiff(g, want) <= 1e-4 * max(1.0, float(np.abs(want).max())), U.maxdiff(g, want)
+
+
+@pytest.mark.gpu
+def test_gpu_training_with_smearing_start_matches_oracle_autograd():
+    """get_loss through the layer operators (train_ops.smear takes the clamp bounds) vs autograd through the pinned oracle."""
+    z, args, node_type = _start_case('cuda')
+    md, _ = _start_models('cuda')
+    hn, pos, bn, he, ei, be, t = args
+    n_half = he.shape[0] // 2
+    from moldiff_amd import train_graph
+    md.zero_grad(set_to_none=True)
+    out = train_graph.moldiff_forward(md, hn, pos, bn, he, ei, be, t)
+    loss = (out['pred_pos'] ** 2).sum() + out['pred_node'].sum() + out['pred_halfedge'][:n_half].square().sum()
+    loss.backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and not O.is_frozen_key(k)) for k, v in md.state_dict().items()}
+    oo = O.moldiff_forward(P, dict(num_timesteps=1000, num_blocks=6, cutoff=15, start=0.7), *[a.cpu() for a in args])
+    lo = (oo['pred_pos'] ** 2).sum() + oo['pred_node'].sum() + oo['pred_halfedge'][:n_half].square().sum()
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) <= 2e-5 * max(1.0, abs(float(lo.detach())))
+    gmax = max(float(v.grad.norm()) for v in P.values() if v.grad is not None)
+    for k, p in md.named_parameters():
+        if P[k].grad is None:
+            continue
+        scale = max(float(P[k].grad.norm()), 1e-3 * gmax)
+        assert float((p.grad.cpu() - P[k].grad).norm()) / scale <= 1e-4, k
+    md.zero_grad(set_to_none=True)
