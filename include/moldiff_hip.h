@@ -145,6 +145,11 @@ int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* pos, const 
 int mdx_pos_posterior(const float* coef_x0, const float* coef_xt, const float* std, const float* x_t,
                       const float* x_recon, const float* eps, const int64_t* t, const int64_t* batch, int64_t n,
                       float* out, void* stream);
+/* The same for rows of any width C: x (n,C).  categorical_space = 'continuous' runs the atom (C = num_node_types) and bond
+ * (C = num_edge_types) features through it with their own schedules, models/model.py:301-304. */
+int mdx_gauss_posterior(const float* coef_x0, const float* coef_xt, const float* std, const float* x_t,
+                        const float* x_recon, const float* eps, const int64_t* t, const int64_t* batch, int64_t n, int32_t C,
+                        float* out, void* stream);
 /* GeneralCategoricalTransition.q_v_posterior(v0_prob=True), transition.py:285-315.  in0 = log_v0, or raw
  * logits when is_logits != 0 (fuses F.log_softmax of model.py:291,297).  (n,K), K <= 8. */
 int mdx_cat_posterior(const float* q_mats, const float* qT_onestep, int32_t K, int32_t T, const float* in0,

@@ -17,7 +17,7 @@ MDX_KIND_MOLDIFF, MDX_KIND_BONDPRED, MDX_KIND_NET = 0, 1, 2
 EXPORTS = [
     'mdx_last_error', 'mdx_version', 'mdx_device_count',
     'mdx_model_create', 'mdx_model_destroy', 'mdx_model_set_param', 'mdx_model_finalize',
-    'mdx_model_set_matrix_path', 'mdx_model_get_matrix_path', 'mdx_model_set_smear_start',
+    'mdx_model_set_matrix_path', 'mdx_model_get_matrix_path', 'mdx_model_set_smear_start', 'mdx_gauss_posterior',
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_bond_ffn', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
@@ -100,6 +100,7 @@ def lib():
         L.mdx_bondpred_tape_bytes.restype = c_size_t
         L.mdx_bondpred_tape_bytes.argtypes = [c_int64, c_int64, c_int32]
         L.mdx_pos_posterior.argtypes = [c_void_p] * 8 + [c_int64, c_void_p, c_void_p]
+        L.mdx_gauss_posterior.argtypes = [c_void_p] * 8 + [c_int64, c_int32, c_void_p, c_void_p]
         L.mdx_cat_posterior.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
@@ -382,8 +383,12 @@ def pos_posterior(c0, ct, sd, x_t, x_recon, eps, t, batch):
     # caching allocator at once and the next conversion in the same argument list may reuse its block
     x_t, x_recon, eps, t, batch = f32c(x_t), f32c(x_recon), f32c(eps), i64c(t), i64c(batch)
     out = torch.empty_like(x_t)
-    check(lib().mdx_pos_posterior(ptr(c0), ptr(ct), ptr(sd), ptr(x_t), ptr(x_recon), ptr(eps), ptr(t),
-                                  ptr(batch), x_t.shape[0], ptr(out), stream()))
+    if x_t.shape[-1] == 3:
+        check(lib().mdx_pos_posterior(ptr(c0), ptr(ct), ptr(sd), ptr(x_t), ptr(x_recon), ptr(eps), ptr(t),
+                                      ptr(batch), x_t.shape[0], ptr(out), stream()))
+    else:   # class features of the continuous categorical space
+        check(lib().mdx_gauss_posterior(ptr(c0), ptr(ct), ptr(sd), ptr(x_t), ptr(x_recon), ptr(eps), ptr(t),
+                                        ptr(batch), x_t.shape[0], x_t.shape[-1], ptr(out), stream()))
     return out
 
 

@@ -98,13 +98,16 @@ class BondPredictor(Module):
         if T == 0:
             return
         self.categorical_space = getattr(config, 'categorical_space', 'discrete')
-        if self.categorical_space != 'discrete':
-            raise NotImplementedError("categorical_space='continuous' is not built")
-        self.scaling = [1., 1., 1.]
+        if self.categorical_space not in ('discrete', 'continuous'):
+            raise ValueError(self.categorical_space)
+        self.scaling = list(getattr(config, 'scaling', [1., 1., 1.])) if self.categorical_space == 'continuous' else [1., 1., 1.]
+        assert self.scaling[0] == 1, 'scaling for pos should be 1'
         self.pos_transition = ContigousTransition(get_beta_schedule(num_timesteps=T, **config.diff_pos))
-        self.node_transition = GeneralCategoricalTransition(
-            get_beta_schedule(num_timesteps=T, **config.diff_atom), self.num_node_types,
-            init_prob=config.diff_atom.init_prob)
+        node_betas = get_beta_schedule(num_timesteps=T, **config.diff_atom)
+        if self.categorical_space == 'discrete':
+            self.node_transition = GeneralCategoricalTransition(node_betas, self.num_node_types, init_prob=config.diff_atom.init_prob)
+        else:  # models/bond_predictor.py:69-71: noisy real-valued atom features
+            self.node_transition = ContigousTransition(node_betas, self.num_node_types, self.scaling[1])
 
     # None = follow _lib.default_matrix_path (exact fp32 unless MOLDIFF_MATRIX_PATH says otherwise); or 'exact_f32' / 'split_f16'
     matrix_path = None
@@ -139,7 +142,8 @@ class BondPredictor(Module):
             if self.num_timesteps != 0:
                 t = self.sample_time(num_mol, node_pos.device)[0] if time_step is None else time_step
                 pos = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
-                h_node = self.node_transition.add_noise(node_type, t, batch_node, noise.get('u_node'))[0]
+                h_node = self.node_transition.add_noise(
+                    node_type, t, batch_node, noise.get('u_node' if self.categorical_space == 'discrete' else 'eps_node'))[0]
             else:  # time-free: clean one-hot types and positions (models/bond_predictor.py:100-102)
                 t = torch.zeros(num_mol, dtype=torch.long, device=node_pos.device)
                 pos = node_pos

@@ -1588,6 +1588,16 @@ extern "C" int mdx_pos_posterior(const float* c0, const float* ct, const float* 
   return MDX_OK;
 }
 
+extern "C" int mdx_gauss_posterior(const float* c0, const float* ct, const float* sd, const float* x_t, const float* x_recon,
+                                   const float* eps, const int64_t* t, const int64_t* batch, int64_t n, int32_t C, float* out,
+                                   void* stream) {
+  if (n < 0 || C < 1 || (n > 0 && (!c0 || !ct || !sd || !x_t || !x_recon || !eps || !t || !batch || !out)))
+    return fail(MDX_ERR_ARG, "bad argument");
+  launch_gauss_posterior(c0, ct, sd, x_t, x_recon, eps, t, batch, (int)n, (int)C, out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
 extern "C" int mdx_cat_posterior(const float* q_mats, const float* qT, int32_t K, int32_t T, const float* in0,
                                  int32_t is_logits, const float* log_vt, const int64_t* t, const int64_t* batch, int64_t n,
                                  float* out, void* stream) {

@@ -357,6 +357,8 @@ struct DecodeArgs {
 void launch_decode(const DecodeArgs& a, hipStream_t s);
 
 // transitions / noise (mdx_transition.hip)
+void launch_gauss_posterior(const float* c0, const float* ct, const float* sd, const float* xt, const float* x0, const float* eps,
+                            const int64_t* t, const int64_t* batch, int n, int C, float* out, hipStream_t s);
 void launch_pos_posterior(const float* c0, const float* ct, const float* sd, const float* xt, const float* x0,
                           const float* eps, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
 void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, const float* logits_or_log_v0, int is_logits,

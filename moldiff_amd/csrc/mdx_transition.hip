@@ -34,6 +34,19 @@ __global__ void pos_posterior_kernel(const float* __restrict__ c0, const float* 
   pos_posterior_elem(c0, ct, sd, xt, x0, eps, t, batch, n, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// the same posterior for rows of any width C (continuous categorical space: atom / bond features are real vectors, model.py:301-304)
+__global__ void gauss_posterior_kernel(const float* __restrict__ c0, const float* __restrict__ ct, const float* __restrict__ sd,
+                                       const float* __restrict__ xt, const float* __restrict__ x0, const float* __restrict__ eps,
+                                       const int64_t* __restrict__ t, const int64_t* __restrict__ batch, int n, int C,
+                                       float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * C) return;
+  const int64_t tv = t[batch[i / C]];
+  const float mu = c0[tv] * x0[i] + ct[tv] * xt[i];
+  const float x = mu + sd[tv] * eps[i];
+  out[i] = (tv == 0) ? mu : x;
+}
+
 template <int K>
 __device__ __forceinline__ void cat_posterior_row(const float* __restrict__ qmats, const float* __restrict__ qT1, int T,
                                                   const float* __restrict__ in0, int is_logits, const float* __restrict__ log_vt,
@@ -215,6 +228,13 @@ __global__ void philox_noise_kernel(uint64_t seed, int draw, const int* __restri
 }
 
 }  // namespace
+
+void launch_gauss_posterior(const float* c0, const float* ct, const float* sd, const float* xt, const float* x0, const float* eps,
+                            const int64_t* t, const int64_t* batch, int n, int C, float* out, hipStream_t s) {
+  if (n <= 0 || C <= 0) return;
+  hipLaunchKernelGGL(gauss_posterior_kernel, dim3(((size_t)n * C + 255) / 256), dim3(256), 0, s, c0, ct, sd, xt, x0, eps, t, batch, n,
+                     C, out);
+}
 
 void launch_pos_posterior(const float* c0, const float* ct, const float* sd, const float* xt, const float* x0,
                           const float* eps, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s) {

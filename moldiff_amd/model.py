@@ -62,17 +62,21 @@ class MolDiff(Module):
     def define_betas_alphas(self, config):
         self.num_timesteps = config.num_timesteps
         self.categorical_space = getattr(config, 'categorical_space', 'discrete')
-        if self.categorical_space != 'discrete':
-            raise NotImplementedError("categorical_space='continuous' is not built (no shipped config uses it)")
-        self.scaling = [1., 1., 1.]
+        if self.categorical_space not in ('discrete', 'continuous'):
+            raise ValueError(self.categorical_space)
+        # continuous: classes are real vectors (one-hot / scaling) under Gaussian diffusion, models/model.py:54-56,76-78,91-93
+        self.scaling = list(getattr(config, 'scaling', [1., 1., 1.])) if self.categorical_space == 'continuous' else [1., 1., 1.]
+        assert self.scaling[0] == 1, 'scaling for pos should be 1'
         T = self.num_timesteps
         self.pos_transition = ContigousTransition(get_beta_schedule(num_timesteps=T, **config.diff_pos))
-        self.node_transition = GeneralCategoricalTransition(
-            get_beta_schedule(num_timesteps=T, **config.diff_atom), self.num_node_types,
-            init_prob=config.diff_atom.init_prob)
-        self.edge_transition = GeneralCategoricalTransition(
-            get_beta_schedule(num_timesteps=T, **config.diff_bond), self.num_edge_types,
-            init_prob=config.diff_bond.init_prob)
+        node_betas = get_beta_schedule(num_timesteps=T, **config.diff_atom)
+        edge_betas = get_beta_schedule(num_timesteps=T, **config.diff_bond)
+        if self.categorical_space == 'discrete':
+            self.node_transition = GeneralCategoricalTransition(node_betas, self.num_node_types, init_prob=config.diff_atom.init_prob)
+            self.edge_transition = GeneralCategoricalTransition(edge_betas, self.num_edge_types, init_prob=config.diff_bond.init_prob)
+        else:
+            self.node_transition = ContigousTransition(node_betas, self.num_node_types, self.scaling[1])
+            self.edge_transition = ContigousTransition(edge_betas, self.num_edge_types, self.scaling[2])
 
     # ---- engine ---------------------------------------------------------------------------------
     # None = follow _lib.default_matrix_path (exact fp32 unless MOLDIFF_MATRIX_PATH says otherwise); or 'exact_f32' / 'split_f16'
@@ -129,10 +133,40 @@ class MolDiff(Module):
             return self._get_loss(train, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge,
                                   num_mol, time_step, noise)
 
+    def _get_loss_continuous(self, train, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol,
+                             time_step, noise):
+        """models/model.py:144-148,185-187: Gaussian perturbation of the scaled one-hot classes, 30 x MSE on the decoders' outputs.
+        noise = dict(eps_pos, eps_node, eps_halfedge) may be injected."""
+        noise = noise or {}
+        with torch.no_grad():
+            t = self.sample_time(num_mol, node_pos.device)[0] if time_step is None else time_step
+            pos_pert = self.pos_transition.add_noise(node_pos, t, batch_node, noise.get('eps_pos'))
+            h_node, h_node_0 = self.node_transition.add_noise(node_type, t, batch_node, noise.get('eps_node'))
+            h_half, h_half_0 = self.edge_transition.add_noise(halfedge_type, t, batch_halfedge, noise.get('eps_halfedge'))
+            edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
+            batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
+            h_edge = torch.cat([h_half, h_half], dim=0)
+        if train:
+            from . import train_graph
+            preds = train_graph.moldiff_forward(self, h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t)
+        else:
+            preds = self.forward(h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t,
+                                 _graph=_lib.graph_for_halfedges(halfedge_index, batch_node, int(t.numel())))
+        loss_pos = F.mse_loss(preds['pred_pos'], node_pos)
+        out = {'loss_node': F.mse_loss(preds['pred_node'], h_node_0) * 30, 'loss_edge': F.mse_loss(preds['pred_halfedge'], h_half_0) * 30}
+        if self.bond_len_loss:
+            bond_index = halfedge_index[:, halfedge_type > 0]
+            true_len = torch.norm(node_pos[bond_index[0]] - node_pos[bond_index[1]], dim=-1)
+            pred_len = torch.norm(preds['pred_pos'][bond_index[0]] - preds['pred_pos'][bond_index[1]], dim=-1)
+            out['loss_len'] = F.mse_loss(pred_len, true_len)
+        total = loss_pos + out['loss_node'] + out['loss_edge'] + out.get('loss_len', 0)
+        return {'loss': total, 'loss_pos': loss_pos, **out}
+
     def _get_loss(self, train, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol,
                   time_step, noise):
-        if self.categorical_space != 'discrete':
-            raise NotImplementedError(self.categorical_space)
+        if self.categorical_space == 'continuous':
+            return self._get_loss_continuous(train, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge,
+                                             num_mol, time_step, noise)
         dev = node_pos.device
         noise = noise or {}
         with torch.no_grad():
@@ -198,6 +232,11 @@ class MolDiff(Module):
         overlap_guidance=True runs the guidance chain on a side stream concurrently with the denoiser forward of the same step
         (same results).  It paid in round 1 (0.7 ms per step, the kernels left tails for each other); with the round-2 kernels
         filling every CU by themselves it costs 0.5 ms (27.6 vs 28.1 ms per step), so in line is the default."""
+        if self.categorical_space == 'continuous':
+            if guidance is not None and guidance[1] > 0:
+                raise NotImplementedError('guidance in the continuous categorical space: the reference objectives that read the sampled '
+                                          'bond classes do not exist there (models/model.py:340-359); not built')
+            return _ContinuousSampler(self, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj)
         return _Sampler(self, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj,
                         bond_predictor, guidance, overlap_guidance)
 
@@ -404,3 +443,86 @@ class _Sampler:
             node_ids, pos, half_ids = self.node_ids[p:p + 1], self.pos_traj[p:p + 1], self.half_ids[p:p + 1]
         traj = [LazyOneHot(node_ids, self.Kn), pos, LazyOneHot(half_ids, self.Ke)]
         return {'pred': [self.preds[0], self.preds[1], self.preds[2]], 'traj': traj}
+
+
+class _ContinuousSampler:
+    """The reverse chain for categorical_space == 'continuous' (models/model.py:244-308 with the else-branches :249-251, :301-304):
+    atom and bond features are real vectors that start from N(0, I) and follow the same Gaussian posterior as the positions, each
+    with its own schedule.  Same interface as ``_Sampler``.  A step is the fused denoiser forward plus three posterior launches
+    (``mdx_gauss_posterior``); the noise comes from the library's per-molecule Philox streams like in the discrete chain -- the
+    normals of the class features by the inverse normal CDF of its uniforms -- so results do not depend on sharding.
+    No shipped config uses this space: it is built for parity, not tuned."""
+
+    def __init__(self, model, n_graphs, batch_node, halfedge_index, batch_halfedge, seed, mol_ids, noise, return_traj):
+        _lib._need_gpu(batch_node, halfedge_index, batch_halfedge)
+        self.m = m = model
+        self.dev = dev = batch_node.device
+        self.T, self.Kn, self.Ke = m.num_timesteps, m.num_node_types, m.num_edge_types
+        self.N, self.Eh = int(batch_node.numel()), int(batch_halfedge.numel())
+        self.n_graphs = n_graphs
+        self.eng = m._engine()
+        self.edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
+        self.batch_edge = torch.cat([batch_halfedge, batch_halfedge], dim=0)
+        self.g = _lib.Graph(self.edge_index, batch_node, n_graphs, mol_ids)
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        self.noise = noise
+        self.return_traj = return_traj
+        f32 = dict(dtype=torch.float32, device=dev)
+        nT = self.T + 1 if return_traj else 2
+        self.node_traj = torch.zeros(nT, self.N, self.Kn, **f32)
+        self.pos_traj = torch.zeros(nT, self.N, 3, **f32)
+        self.half_traj = torch.zeros(nT, self.Eh, self.Ke, **f32)
+        self.bn, self.bh = _lib.i64c(batch_node), _lib.i64c(batch_halfedge)
+        self.t = torch.empty(max(n_graphs, 1), dtype=torch.int64, device=dev)
+        self.eps, self.u_n, self.u_h = torch.empty(self.N, 3, **f32), torch.empty(self.N, self.Kn, **f32), torch.empty(self.Eh, self.Ke, **f32)
+        self.preds = None
+        self.cur = 0
+
+    def _frame(self, j):
+        return j if self.return_traj else j % 2
+
+    def _draw(self, draw):
+        """(eps_pos, eps_node, eps_halfedge) ~ N(0, 1) of draw index `draw` (0 = prior, i + 1 = iteration i)."""
+        if self.noise is not None:
+            return tuple(x.to(self.dev, torch.float32) for x in self.noise(draw))
+        _lib.check(_lib.lib().mdx_noise(self.g.h, ctypes.c_uint64(self.seed), draw, self.Kn, self.Ke, _lib.ptr(self.eps),
+                                        _lib.ptr(self.u_n), _lib.ptr(self.u_h), _lib.stream()))
+        lo, hi = 2.0 ** -24, 1.0 - 2.0 ** -24
+        z = lambda u: torch.special.ndtri(u.clamp(lo, hi).double()).float()
+        return self.eps.clone(), z(self.u_n), z(self.u_h)
+
+    @torch.no_grad()
+    def init(self):
+        e, a, b = self._draw(0)
+        self.node_traj[0].copy_(a); self.pos_traj[0].copy_(e); self.half_traj[0].copy_(b)
+        self.cur = 0
+
+    @torch.no_grad()
+    def step(self, i):
+        m, c, n = self.m, self.cur, self._frame(i + 1)
+        self.t.fill_(self.T - 1 - i)
+        t = self.t[:self.n_graphs]
+        e, a, b = self._draw(i + 1)
+        h_node, pos, h_half = self.node_traj[c], self.pos_traj[c], self.half_traj[c]
+        preds = m.forward(h_node, pos, self.bn, torch.cat([h_half, h_half], dim=0), self.edge_index, self.batch_edge, t, _graph=self.g)
+        self.pos_traj[n].copy_(m.pos_transition.get_prev_from_recon(pos, preds['pred_pos'], t, self.bn, eps=e))
+        self.node_traj[n].copy_(m.node_transition.get_prev_from_recon(h_node, preds['pred_node'], t, self.bn, eps=a))
+        self.half_traj[n].copy_(m.edge_transition.get_prev_from_recon(h_half, preds['pred_halfedge'], t, self.bh, eps=b))
+        self.preds = (preds['pred_node'], preds['pred_pos'], preds['pred_halfedge'])
+        self.cur = n
+
+    def state(self):
+        return {'h_node': self.node_traj[self.cur], 'pos': self.pos_traj[self.cur], 'h_halfedge': self.half_traj[self.cur]}
+
+    def set_state(self, h_node, pos, h_halfedge, frame=0):
+        f = self._frame(frame)
+        self.node_traj[f].copy_(h_node); self.pos_traj[f].copy_(pos); self.half_traj[f].copy_(h_halfedge)
+        self.cur = f
+
+    def result(self):
+        if self.return_traj:
+            traj = [self.node_traj, self.pos_traj, self.half_traj]
+        else:
+            p = self.cur
+            traj = [self.node_traj[p:p + 1], self.pos_traj[p:p + 1], self.half_traj[p:p + 1]]
+        return {'pred': list(self.preds), 'traj': traj}

@@ -10,8 +10,13 @@ REAL reference on CPU.  BUILD-CONTAINER ONLY (needs /root/reference, read-only).
     `denoiser.start = 0.7` on a compact batch (about half of the pairs closer than 0.7, where the clamp acts), and the bond predictor
     with `encoder.start = 0.7`: logits and the reference's own autograd gradient of the `uncertainty` guidance objective w.r.t. the
     positions (the clamp passes no gradient below `start`).
-Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 / 20230812 / 20230813).
+  * `categorical_space: continuous` (models/model.py:54-56,76-78,91-93): atom / bond classes as real vectors under Gaussian
+    diffusion with `scaling = [1, 4, 8]`.  MolDiff.get_loss with every draw pinned (loss terms + parameter-gradient norms), and the
+    first three iterations of MolDiff.sample() (the prior draw, each iteration's noise, the states and the last predictions), obtained
+    like guidance_types.npz: `tqdm` in models.model replaced by an islice, the RNG entry points by a seeded generator.
+Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 .. 20230814).
 """
+import itertools
 import json
 import os
 import sys
@@ -140,6 +145,103 @@ def main():
     pins['variant_start_bond_gpos'] = float((gpos - go).abs().max())
     out.update({'st_node_type': node_type.numpy(), 'st_bond_logits': lg.detach().numpy(), 'st_bond_gpos': gpos.numpy()})
     print('smearing start: oracle vs reference', {k: v for k, v in pins.items() if 'start' in k})
+
+    # ---- categorical_space = continuous ---------------------------------------------------------------------------------------
+    import models.model as mm
+    from oracle.make_goldens_guidance import Draws
+    SC = [1., 4., 8.]
+    cfg = ref_shim.load_yaml_cfg('configs/train/train_MolDiff_simple.yml')
+    cfg.model.diff.categorical_space = 'continuous'
+    cfg.model.diff.scaling = SC
+    mc = MolDiff(cfg.model, 8, 6).eval()
+    sd = mc.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+    sd.update(O.recipe_state_dict(shapes, 20230814))
+    mc.load_state_dict(sd, strict=True)
+    Pc = {k: v.detach().clone() for k, v in mc.state_dict().items()}
+    out['ct_keys'] = np.array(sorted(sd))
+    tabs = {n: {k: Pc[f'{n}_transition.{k}'] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')} for n in ('pos', 'node', 'edge')}
+    CFG = dict(num_timesteps=1000, num_blocks=6, cutoff=15)
+    # (a) get_loss: draws = randint (time), normal_ x3 (pos, node, halfedge)
+    sizes = [7, 5, 12, 9, 3]
+    bn, hei, bh, node_type, node_pos, half_type = batch(sizes, 101)
+    B = len(sizes)
+    g = np.random.Generator(np.random.PCG64(103))
+    t_half = torch.tensor([0, 437, 850])
+    eps = [torch.from_numpy(g.standard_normal(shp).astype(np.float32)) for shp in ((len(bn), 3), (len(bn), 8), (len(bh), 6))]
+    queue = [e.clone() for e in eps]
+    saved = (torch.randint, torch.Tensor.normal_)
+
+    def randint(lo, hi, size, device=None, **kw):
+        assert tuple(size) == tuple(t_half.shape)
+        return t_half.clone()
+
+    def normal_(self_, *a, **kw):
+        e = queue.pop(0)
+        assert e.shape == self_.shape, (e.shape, self_.shape)
+        return self_.copy_(e)
+
+    torch.randint, torch.Tensor.normal_ = randint, normal_
+    try:
+        ref = mc.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
+    finally:
+        torch.randint, torch.Tensor.normal_ = saved
+    assert not queue
+    mc.zero_grad()
+    ref['loss'].backward()
+    ref_grads = {k: v.grad.detach().clone() for k, v in mc.named_parameters() if v.grad is not None}
+    t = torch.cat([t_half, 1000 - t_half - 1])[:B]
+    Pg = {k: (v.clone().requires_grad_(True) if k in ref_grads else v) for k, v in Pc.items()}
+    orc = O.moldiff_loss_continuous(Pg, CFG, tabs, SC, node_type, node_pos, bn, half_type, hei, bh, B, t,
+                                    dict(eps_pos=eps[0], eps_node=eps[1], eps_halfedge=eps[2]))
+    orc['loss'].backward()
+    pins['variant_continuous_param_grads'] = max(float((Pg[k].grad - gg).abs().max()) for k, gg in ref_grads.items())
+    for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+        pins[f'variant_continuous_{k}'] = abs(float(ref[k].detach()) - float(orc[k].detach()))
+        out[f'ct_{k}'] = np.float32(float(ref[k].detach()))
+    for k, gg in ref_grads.items():
+        out[f'ct_grad_norm/{k}'] = np.float64(gg.double().norm())
+        if gg.numel() <= 256:
+            out[f'ct_grad_full/{k}'] = gg.numpy()
+    out.update({'ct_sizes': np.array(sizes), 'ct_node_type': node_type.numpy(), 'ct_node_pos': node_pos.numpy(),
+                'ct_halfedge_type': half_type.numpy(), 'ct_t': t.numpy(), 'ct_eps_pos': eps[0].numpy(), 'ct_eps_node': eps[1].numpy(),
+                'ct_eps_halfedge': eps[2].numpy(), 'ct_scaling': np.array(SC, dtype=np.float32)})
+    # (b) sample(): the prior and the first NS iterations
+    NS = 3
+    ssz = [5, 7, 4]
+    sbn, shei, sbh = batch(ssz, 107)[:3]
+    d = Draws(4243)
+    saved = (torch.randn, torch.randn_like, mm.tqdm)
+    torch.randn, torch.randn_like = d.randn, d.randn_like
+    mm.tqdm = lambda it, total=None: itertools.islice(it, 0, NS)
+    try:
+        res = mc.sample(n_graphs=len(ssz), batch_node=sbn, halfedge_index=shei, batch_halfedge=sbh)
+    finally:
+        torch.randn, torch.randn_like, mm.tqdm = saved
+    kinds = [k for k, _ in d.log]
+    assert kinds == ['randn'] * 3 + ['randn_like'] * (3 * NS), kinds
+    traj = res['traj']
+    out.update({'cs_sizes': np.array(ssz), 'cs_nsteps': np.int64(NS), 'cs_init_node': traj[0][0].numpy(), 'cs_init_pos': traj[1][0].numpy(),
+                'cs_init_halfedge': traj[2][0].numpy()})
+    assert torch.equal(traj[0][0], d.log[0][1]) and torch.equal(traj[1][0], d.log[1][1]) and torch.equal(traj[2][0], d.log[2][1])
+    state = {'h_node': traj[0][0], 'pos': traj[1][0], 'h_halfedge': traj[2][0]}
+    gd = {'batch_node': sbn, 'halfedge_index': shei, 'batch_halfedge': sbh, 'n_graphs': len(ssz)}
+    worst = 0.0
+    for j in range(NS):
+        noise = {'eps_pos': d.log[3 + 3 * j][1], 'eps_node': d.log[4 + 3 * j][1], 'eps_halfedge': d.log[5 + 3 * j][1]}
+        for k, v in noise.items():
+            out[f'cs_{j}_{k}'] = v.numpy()
+        with torch.no_grad():
+            state, preds = O.sample_step_continuous(Pc, CFG, tabs, state, gd, 999 - j, noise)
+        for k, ti in (('h_node', 0), ('pos', 1), ('h_halfedge', 2)):
+            worst = max(worst, float((state[k] - traj[ti][j + 1]).abs().max()))
+            out[f'cs_{j}_{k}'] = traj[ti][j + 1].numpy()
+            state[k] = traj[ti][j + 1]      # teacher-forced on the reference's own trajectory
+    for k, v in zip(('pred_node', 'pred_pos', 'pred_halfedge'), res['pred']):
+        worst = max(worst, float((preds[k] - v).abs().max()))
+        out[f'cs_{k}'] = v.numpy()
+    pins['variant_continuous_sample_steps'] = worst
+    print('continuous space: oracle vs reference', {k: v for k, v in pins.items() if 'continuous' in k})
 
     np.savez_compressed(os.path.join(OUT, 'variants.npz'), **out)
     pf = os.path.join(OUT, 'PINNING.json')

@@ -377,6 +377,50 @@ def sample_step(P, cfg, tabs, state, graph, step, noise, Pb=None, cfgb=None, gui
     return new, preds
 
 
+def sample_step_continuous(P, cfg, tabs, state, graph, step, noise):
+    """One iteration of model.py:272-308 for categorical_space == 'continuous': atom and bond features are real vectors that follow
+    the same Gaussian posterior as the positions (transition.py:44-63), each with its own schedule.
+    state: dict(h_node (N,Kn), pos, h_halfedge (Eh,Ke)); noise: dict(eps_pos, eps_node, eps_halfedge) ~ N(0,1);
+    tabs: {'pos' | 'node' | 'edge': {coef_x0, coef_xt, std}}.  Returns (new_state, preds)."""
+    bn, hei, bh = graph['batch_node'], graph['halfedge_index'], graph['batch_halfedge']
+    B = graph.get('n_graphs', int(bn.max()) + 1 if bn.numel() else 0)
+    edge_index = torch.cat([hei, hei.flip(0)], 1)
+    batch_edge = torch.cat([bh, bh], 0)
+    t = torch.full((B,), step, dtype=torch.long)
+    preds = moldiff_forward(P, cfg, state['h_node'], state['pos'], bn,
+                            torch.cat([state['h_halfedge']] * 2, 0), edge_index, batch_edge, t)
+    new = {'pos': pos_posterior(tabs['pos'], state['pos'], preds['pred_pos'], t, bn, noise['eps_pos']),
+           'h_node': pos_posterior(tabs['node'], state['h_node'], preds['pred_node'], t, bn, noise['eps_node']),
+           'h_halfedge': pos_posterior(tabs['edge'], state['h_halfedge'], preds['pred_halfedge'], t, bh, noise['eps_halfedge'])}
+    return new, preds
+
+
+def moldiff_loss_continuous(P, cfg, tabs, scaling, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge,
+                            num_mol, time_step, noise):
+    """MolDiff.get_loss for categorical_space == 'continuous' (models/model.py:128-201 with :144-148 and :185-187): one-hot classes
+    divided by `scaling` (= config.diff.scaling, [pos, node, edge]) are perturbed like positions (transition.py:27-42) and scored
+    with 30 x MSE.  noise = dict(eps_pos, eps_node, eps_halfedge); tabs[...]['alphas_bar']."""
+    t = time_step
+    Kn, Ke = P['node_embedder.weight'].shape[1], P['edge_embedder.weight'].shape[1]
+
+    def pert(tab, x, batch, eps):
+        a_bar = tab['alphas_bar'][t][batch].unsqueeze(-1)
+        return a_bar.sqrt() * x + (1 - a_bar).sqrt() * eps
+
+    pos_pert = pert(tabs['pos'], node_pos, batch_node, noise['eps_pos'])
+    hn0 = F.one_hot(node_type, Kn).to(node_pos.dtype) / scaling[1]   # (the dtype of the inputs: float64 when a test arbitrates)
+    hh0 = F.one_hot(halfedge_type, Ke).to(node_pos.dtype) / scaling[2]
+    hn = pert(tabs['node'], hn0, batch_node, noise['eps_node'])
+    hh = pert(tabs['edge'], hh0, batch_halfedge, noise['eps_halfedge'])
+    edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], 1)
+    batch_edge = torch.cat([batch_halfedge, batch_halfedge], 0)
+    preds = moldiff_forward(P, cfg, hn, pos_pert, batch_node, torch.cat([hh, hh], 0), edge_index, batch_edge, t)
+    loss_pos = F.mse_loss(preds['pred_pos'], node_pos)
+    loss_node = F.mse_loss(preds['pred_node'], hn0) * 30
+    loss_edge = F.mse_loss(preds['pred_halfedge'], hh0) * 30
+    return {'loss': loss_pos + loss_node + loss_edge, 'loss_pos': loss_pos, 'loss_node': loss_node, 'loss_edge': loss_edge}
+
+
 # --------------------------------------------------------------------------------------
 # harness pieces
 # --------------------------------------------------------------------------------------

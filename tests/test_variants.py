@@ -4,6 +4,8 @@ reference (oracle/make_goldens_variants.py -> tests/golden/variants.npz).
   * time-free bond predictor: diff.num_timesteps = 0 (models/bond_predictor.py:27-31, :97-102, :141-144)
   * distance smearing with start != 0 (models/graph.py:330-333, common.py:233-235): forward of the denoiser, and the predictor's
     position gradient where the clamp cuts it
+  * categorical_space = 'continuous' (models/model.py:54-56,76-78,91-93,144-148,185-187,249-251,301-304): get_loss with pinned
+    draws, and the first iterations of sample() with the reference's own draws
 """
 import copy
 
@@ -211,3 +213,160 @@ def test_gpu_training_with_smearing_start_matches_oracle_autograd():
         scale = max(float(P[k].grad.norm()), 1e-3 * gmax)
         assert float((p.grad.cpu() - P[k].grad).norm()) / scale <= 1e-4, k
     md.zero_grad(set_to_none=True)
+
+
+# ---- categorical_space = 'continuous' ---------------------------------------------------------------------------------------------
+CFG_C = dict(num_timesteps=1000, num_blocks=6, cutoff=15)
+
+
+def continuous(device='cpu'):
+    key = 'cont' + str(device)
+    if key not in _models:
+        cfg = copy.deepcopy(default_config('MolDiff_simple'))
+        cfg.diff.categorical_space = 'continuous'
+        cfg.diff.scaling = [1., 4., 8.]
+        m = M.MolDiff(cfg, 8, 6).eval()
+        m.load_state_dict(M.recipe_state_dict(m, 20230814), strict=True)
+        _models[key] = m.to(device)
+    return _models[key]
+
+
+def _tabs(P):
+    return {n: {k: P[f'{n}_transition.{k}'] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')} for n in ('pos', 'node', 'edge')}
+
+
+def _ct_case(device='cpu'):
+    z = U.gold('variants.npz')
+    bn, hei, bh, _, _ = U.graph_from_sizes([int(s) for s in z['ct_sizes']], device)
+    f = lambda k: torch.from_numpy(z[k]).to(device)
+    args = (f('ct_node_type'), f('ct_node_pos'), bn, f('ct_halfedge_type'), hei, bh, len(z['ct_sizes']))
+    noise = {k: f('ct_' + k) for k in ('eps_pos', 'eps_node', 'eps_halfedge')}
+    return z, args, f('ct_t'), noise
+
+
+def test_continuous_space_has_the_reference_state_dict_and_the_oracle_matches_the_golden():
+    z, args, t, noise = _ct_case()
+    m = continuous()
+    assert sorted(m.state_dict()) == [str(k) for k in z['ct_keys']]
+    P = U.params(m)
+    with torch.no_grad():
+        got = O.moldiff_loss_continuous(P, CFG_C, _tabs(P), [1., 4., 8.], *args, t, noise)
+    for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+        assert abs(float(got[k]) - float(z['ct_' + k])) <= 1e-6 * max(1.0, float(z['ct_' + k])), k
+
+
+def _cs_graph(z, device='cpu'):
+    bn, hei, bh, _, _ = U.graph_from_sizes([int(s) for s in z['cs_sizes']], device)
+    return bn, hei, bh
+
+
+def test_oracle_continuous_sample_steps_match_reference_golden():
+    z = U.gold('variants.npz')
+    bn, hei, bh = _cs_graph(z)
+    P = U.params(continuous())
+    gd = {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': len(z['cs_sizes'])}
+    state = {'h_node': torch.from_numpy(z['cs_init_node']), 'pos': torch.from_numpy(z['cs_init_pos']),
+             'h_halfedge': torch.from_numpy(z['cs_init_halfedge'])}
+    for j in range(int(z['cs_nsteps'])):
+        noise = {k: torch.from_numpy(z[f'cs_{j}_{k}']) for k in ('eps_pos', 'eps_node', 'eps_halfedge')}
+        with torch.no_grad():
+            new, preds = O.sample_step_continuous(P, CFG_C, _tabs(P), state, gd, 999 - j, noise)
+        for k in ('h_node', 'pos', 'h_halfedge'):
+            assert U.maxdiff(new[k], z[f'cs_{j}_{k}']) <= 1e-6, (j, k)
+            state[k] = torch.from_numpy(z[f'cs_{j}_{k}'])
+    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+        assert U.maxdiff(preds[k], z['cs_' + k]) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_continuous_space_loss_and_gradients_match_reference():
+    z, args, t, noise = _ct_case('cuda')
+    m = continuous('cuda')
+    with torch.no_grad():
+        ev = m.get_loss(*args, time_step=t, noise=noise)       # fused evaluation path
+    m.zero_grad(set_to_none=True)
+    got = m.get_loss(*args, time_step=t, noise=noise)           # layer operators + autograd
+    for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+        want = float(z['ct_' + k])
+        assert abs(float(ev[k]) - want) <= RTOL * max(1.0, abs(want)), ('eval', k, float(ev[k]), want)
+        assert abs(float(got[k].detach()) - want) <= RTOL * max(1.0, abs(want)), ('train', k, float(got[k].detach()), want)
+    got['loss'].backward()
+    # Gradients.  On this batch (30 x MSE on real-valued class features) the reference's OWN fp32 gradients sit up to 9e-4 from the
+    # float64 evaluation of the same function in the relative measure of tests/test_loss.py, so the golden alone cannot carry a 1e-4
+    # contract: the rule of tests/test_gpu_fullsize.py applies -- against float64, max(contract, 1.5 x |reference fp32 - float64|).
+    Pc = U.params(continuous())
+    P64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in Pc.items()}
+    P64 = {k: (v.requires_grad_(True) if (v.dtype.is_floating_point and not O.is_frozen_key(k)) else v) for k, v in P64.items()}
+    a64 = [x.cpu().double() if (torch.is_tensor(x) and x.dtype.is_floating_point) else (x.cpu() if torch.is_tensor(x) else x) for x in args]
+    O.moldiff_loss_continuous(P64, CFG_C, _tabs(P64), [1., 4., 8.], *a64, t.cpu(), {k: v.cpu().double() for k, v in noise.items()})['loss'].backward()
+    names = [k[len('ct_grad_norm/'):] for k in z.files if k.startswith('ct_grad_norm/')]
+    P = dict(m.named_parameters())
+    assert set(names) == {k for k, v in P.items() if v.requires_grad}
+    gmax = max(float(z[f'ct_grad_norm/{k}']) for k in names)
+    for k in names:
+        g, g64 = P[k].grad, P64[k].grad
+        assert g is not None, f'no gradient reached {k}'
+        want = float(z[f'ct_grad_norm/{k}'])
+        scale = max(want, 1e-3 * gmax)
+        fk = f'ct_grad_full/{k}'
+        if fk in z.files:
+            e_ref = float((torch.from_numpy(z[fk]).double() - g64).norm()) / scale
+            err = float((g.cpu().double() - g64).norm()) / scale
+        else:
+            e_ref = abs(want - float(g64.norm())) / scale
+            err = abs(float(g.double().norm()) - float(g64.norm())) / scale
+        assert err <= max(GTOL, 1.5 * e_ref), (k, err, e_ref)
+    m.zero_grad(set_to_none=True)
+
+
+@pytest.mark.gpu
+def test_gpu_continuous_sampler_steps_match_reference_sample():
+    """The first iterations of MolDiff.sample() in the continuous space, with the reference's own prior and noise draws injected:
+    every state of the chain against the reference's trajectory (free-running: the product's state feeds the next iteration)."""
+    z = U.gold('variants.npz')
+    bn, hei, bh = _cs_graph(z, 'cuda')
+    m = continuous('cuda')
+    ns = int(z['cs_nsteps'])
+    f = lambda k: torch.from_numpy(z[k]).cuda()
+
+    def noise(draw):
+        if draw == 0:
+            return f('cs_init_pos'), f('cs_init_node'), f('cs_init_halfedge')
+        j = draw - 1
+        return f(f'cs_{j}_eps_pos'), f(f'cs_{j}_eps_node'), f(f'cs_{j}_eps_halfedge')
+
+    sm = m.sampler(len(z['cs_sizes']), bn, hei, bh, noise=noise)
+    sm.init()
+    for j in range(ns):
+        sm.step(j)
+        st = sm.state()
+        for k in ('h_node', 'pos', 'h_halfedge'):
+            assert U.maxdiff(st[k], z[f'cs_{j}_{k}']) <= 1e-4 * (j + 1), (j, k, U.maxdiff(st[k], z[f'cs_{j}_{k}']))
+    res = sm.result()
+    for k, v in zip(('pred_node', 'pred_pos', 'pred_halfedge'), res['pred']):
+        assert U.maxdiff(v, z['cs_' + k]) <= 1e-3
+    assert res['traj'][0].shape == (1001, len(bn), 8) and res['traj'][2].shape == (1001, len(bh), 6)
+
+
+@pytest.mark.gpu
+def test_gpu_continuous_sampler_default_noise_is_reproducible_and_shard_invariant():
+    """Library noise (per-molecule Philox streams; class-feature normals by the inverse CDF): the same seed gives the same chain, and a
+    molecule's chain does not depend on what else is in the batch."""
+    m = continuous('cuda')
+    bn, hei, bh, _, _ = U.graph_from_sizes([5, 7, 4], 'cuda')
+
+    def run(bn, hei, bh, n, ids):
+        sm = m.sampler(n, bn, hei, bh, seed=11, return_traj=False, mol_ids=torch.tensor(ids))
+        sm.init()
+        for i in range(3):
+            sm.step(i)
+        return {k: v.clone() for k, v in sm.state().items()}
+
+    a, b = run(bn, hei, bh, 3, [0, 1, 2]), run(bn, hei, bh, 3, [0, 1, 2])
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.isfinite(a[k]).all()
+    bn1, hei1, bh1, _, _ = U.graph_from_sizes([7], 'cuda')
+    c = run(bn1, hei1, bh1, 1, [1])
+    assert U.maxdiff(c['pos'], a['pos'][5:12]) <= 1e-4 and U.maxdiff(c['h_node'], a['h_node'][5:12]) <= 1e-4
+    with pytest.raises(NotImplementedError):
+        m.sampler(3, bn, hei, bh, bond_predictor=None, guidance=['uncertainty', 1e-4])
