@@ -14,7 +14,10 @@
 #define MDX_WPS 1
 #endif
 #ifndef MDX_RING
-#define MDX_RING 8  // half-steps of 2 KiB in flight per wave
+#define MDX_RING 4  // half-steps of 2 KiB in flight per wave (seamless: 133.0 us per launch; 8: 135.5; the primed ring of 8: 135.6)
+#endif
+#ifndef MDX_SPLIT_SEAMLESS
+#define MDX_SPLIT_SEAMLESS 1  // the weight ring runs through GEMM boundaries (mdx_split.h); at 4 half-steps no GEMM of this kernel idles
 #endif
 #include "mdx_row.h"
 #include "mdx_split.h"

@@ -22,6 +22,9 @@
 #define MDX_RING 8  // half-steps of 2 KiB in flight per wave
 #endif
 #include "mdx_row.h"
+#ifndef MDX_SPLIT_SEAMLESS
+#define MDX_SPLIT_SEAMLESS 1  // the weight ring runs through GEMM boundaries (mdx_split.h)
+#endif
 #include "mdx_split.h"
 #include "mdx_edge2_plan.h"
 #include "../../include/moldiff_hip.h"

@@ -71,7 +71,7 @@ __device__ __forceinline__ void to_xs(XS<(FT + 1) / 2>& o, const f32x4 (&y)[FT][
 // half-step p = (ftp * KG + g) * 2 + h:  h = 0 the hi fragments of tiles (2 ftp, 2 ftp + 1) for k-group g, h = 1 their lo fragments
 // (scaled by 2^MDX_LO_SHIFT like the operand's lo halves).  Per tile pair: y += Whi Xhi directly; t += Whi Xlo + Wlo Xhi; y += t 2^-11.
 template <int KG, int FT>
-__device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, const WS& w, WRing& ring, const WS& wnext) {
+__device__ __forceinline__ void rgemm_s_primed(f32x4 (&y)[FT][RR], const XS<KG>& x, const WS& w, WRing& ring, const WS& wnext) {
   static_assert(FT % 2 == 0, "feature tiles come in pairs");
   constexpr int NP = (FT / 2) * KG * 2;
 #ifndef MDX_SPLIT_PRIME_AHEAD
@@ -141,6 +141,84 @@ __device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, con
   for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
     for (int rt = 0; rt < RR; ++rt) asm volatile("" : "+v"(y[ft][rt]));  // see rgemm (mdx_row.h)
+}
+
+// The same product with a ring that runs THROUGH the GEMM boundary (MDX_SPLIT_SEAMLESS builds: edge kernel A, mdx_edge2s.hip): the
+// slot a half-step frees is refilled at once with what the wave needs MDX_RING half-steps later -- this stream's, or, in the last
+// MDX_RING steps, the next stream's first half-steps -- so there is no second set of ring registers for the next stream's prime
+// (64 VGPRs at MDX_RING = 8, live exactly where the accumulators and both operand halves are: the kernel parked operands in AGPRs
+// for it, profiles/r4_split_phase_trace.txt) and every GEMM starts with its first MDX_RING half-steps in registers instead of 3.
+// The ring position must be the same at every GEMM entry, so a GEMM occupies a multiple of MDX_RING half-steps: the 4- and
+// 12-half-step ones run 4 idle steps that only turn the ring (their loads land in the stream pack's zero padding, MDX_RING_PAD).
+template <int KG, int FT>
+__device__ __forceinline__ void rgemm_s_seamless(f32x4 (&y)[FT][RR], const XS<KG>& x, const WS& w, WRing& ring, const WS& wnext) {
+  static_assert(FT % 2 == 0, "feature tiles come in pairs");
+  constexpr int NP = (FT / 2) * KG * 2;
+  constexpr int NPL = (NP + MDX_RING - 1) / MDX_RING * MDX_RING;  // half-steps of ring rotation
+  static_assert(NPL - NP <= 4, "idle steps read the pack's zero padding (4 half-steps)");
+  f32x4 t0[RR], t1[RR];
+  __builtin_amdgcn_s_setprio(0);
+  static_for<0, NPL>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    constexpr int ftp = p / (2 * KG), g = (p / 2) % KG, h = p % 2;
+    const h8 a0 = __builtin_bit_cast(h8, ring.a[p % MDX_RING][0]), a1 = __builtin_bit_cast(h8, ring.a[p % MDX_RING][1]);
+    if constexpr (!(MDX_ABL & 32)) {
+      if constexpr (p + MDX_RING < NPL) {
+        ring.a[p % MDX_RING][0] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING));
+        ring.a[p % MDX_RING][1] = ws_frag(w, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING) + 1);
+      } else {
+        ring.a[p % MDX_RING][0] = ws_frag(wnext, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING - NPL));
+        ring.a[p % MDX_RING][1] = ws_frag(wnext, 2 * ((MDX_ABL & 4) ? p % 4 : p + MDX_RING - NPL) + 1);
+      }
+    }
+    if constexpr (p >= NP) return;  // idle step
+    if constexpr (g == 0 && h == 0) {
+#pragma unroll
+      for (int rt = 0; rt < RR; ++rt) t0[rt] = t1[rt] = splat4(0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr ((MDX_ABL & 16) != 0 && (p % 8) != 0) return;
+    if constexpr (h == 0) {
+#pragma unroll
+      for (int rt = 0; rt < RR; ++rt) {
+        y[2 * ftp][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x.hi[g][rt], y[2 * ftp][rt], 0, 0, 0);
+        y[2 * ftp + 1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x.hi[g][rt], y[2 * ftp + 1][rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RR; ++rt) {
+        t0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x.lo[g][rt], t0[rt], 0, 0, 0);
+        t1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x.lo[g][rt], t1[rt], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < RR; ++rt) {
+        t0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x.hi[g][rt], t0[rt], 0, 0, 0);
+        t1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x.hi[g][rt], t1[rt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (g == KG - 1 && h == 1) {
+#pragma unroll
+      for (int rt = 0; rt < RR; ++rt) {
+        y[2 * ftp][rt] = y[2 * ftp][rt] + t0[rt] * splat4(MDX_LO_DOWN);
+        y[2 * ftp + 1][rt] = y[2 * ftp + 1][rt] + t1[rt] * splat4(MDX_LO_DOWN);
+      }
+    }
+  });
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int rt = 0; rt < RR; ++rt) asm volatile("" : "+v"(y[ft][rt]));
+}
+
+#ifndef MDX_SPLIT_SEAMLESS
+#define MDX_SPLIT_SEAMLESS 0
+#endif
+template <int KG, int FT>
+__device__ __forceinline__ void rgemm_s(f32x4 (&y)[FT][RR], const XS<KG>& x, const WS& w, WRing& ring, const WS& wnext) {
+  if constexpr (MDX_SPLIT_SEAMLESS) rgemm_s_seamless<KG, FT>(y, x, w, ring, wnext);
+  else rgemm_s_primed<KG, FT>(y, x, w, ring, wnext);
 }
 
 // the same with an fp32 operand in accumulator layout (KG16 tiles of 16 features): converted on the way in
