@@ -17,7 +17,7 @@ from torch.nn import Module
 from . import _lib
 from .common import MLP, GaussianSmearing
 from .diffusion import get_beta_schedule
-from .graph import NodeEdgeNet, _sig
+from .graph import NodeEdgeNet, _sig, synth_gates
 from .transition import ContigousTransition, GeneralCategoricalTransition
 
 
@@ -120,7 +120,7 @@ class BondPredictor(Module):
                              time_dim=self.time_dim, num_timesteps=self.num_timesteps,
                              num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
                              node_dim=e.node_dim, edge_dim=e.edge_dim, num_gaussians=e.distance_expansion.offset.numel(), smear_start=e.distance_expansion.start)
-            eng.upload(self.state_dict())
+            eng.upload({**self.state_dict(), **synth_gates(e, 'encoder.')})
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)
 

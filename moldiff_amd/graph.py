@@ -22,6 +22,38 @@ def _sig(module):
     return tuple((p.data_ptr(), p._version) for p in module.state_dict(keep_vars=True).values())
 
 
+GATE_OPEN = 32.0   # sigmoid(32) == 1.0f exactly (the division form and the exp2 / rcp form of the kernels alike)
+
+
+def synth_gates(net, prefix=''):
+    """use_gate=False (models/graph.py:21-22,123-124): the reference multiplies by no gate at all.  The fused kernels always evaluate
+    one, so a net built without gates is packed with PASS-THROUGH gate parameters under the keys a gated net would have: all weights
+    zero, LayerNorm (1, 0), last bias GATE_OPEN -> sigmoid(gate) == 1.0f and message * 1.0f is the message, bit for bit; in the
+    guidance backward sigmoid' == 0 exactly, so nothing flows through the synthetic path.  Costs the gate's GEMMs (no shipped config
+    pays it).  Returns {key: tensor} to be merged into the state_dict handed to the engine; {} for a gated net."""
+    if net.use_gate:
+        return {}
+    nd, ed = net.node_dim, net.edge_dim
+    out = {}
+
+    def mlp(pre, din, dhid, dout):
+        out[pre + '.net.0.weight'] = torch.zeros(dhid, din)
+        out[pre + '.net.0.bias'] = torch.zeros(dhid)
+        out[pre + '.net.1.weight'] = torch.ones(dhid)
+        out[pre + '.net.1.bias'] = torch.zeros(dhid)
+        out[pre + '.net.3.weight'] = torch.zeros(dout, dhid)
+        out[pre + '.net.3.bias'] = torch.full((dout,), GATE_OPEN)
+
+    for i in range(net.num_blocks):
+        mlp(f'{prefix}node_blocks_with_edge.{i}.gate', ed + nd + 1, nd, nd)
+        if net.update_edge:
+            for side in ('bond_ffn_left', 'bond_ffn_right'):
+                mlp(f'{prefix}edge_blocks.{i}.{side}.gate', ed + nd + 1, 32, ed)
+        if net.update_pos:
+            mlp(f'{prefix}pos_blocks.{i}.edge_lin.gate', 2 * ed + 1, 32, 1)
+    return out
+
+
 class _Block(Module):
     """Common plumbing: a block reaches the HIP engine through the NodeEdgeNet that owns it."""
     _owner = None
@@ -38,13 +70,12 @@ class _Block(Module):
 class NodeBlock(_Block):
     def __init__(self, node_dim, edge_dim, hidden_dim, use_gate):
         super().__init__()
-        if not use_gate:
-            raise NotImplementedError('use_gate=False is not built (both shipped configs gate)')
         self.use_gate, self.node_dim = use_gate, node_dim
         self.node_net = MLP(node_dim, hidden_dim, hidden_dim)
         self.edge_net = MLP(edge_dim, hidden_dim, hidden_dim)
         self.msg_net = Linear(hidden_dim, hidden_dim)
-        self.gate = MLP(edge_dim + node_dim + 1, hidden_dim, hidden_dim)  # +1: time
+        if use_gate:  # use_gate=False (models/graph.py:21-22,46-48): no gate module; the fused kernels get a pass-through one (synth_gates)
+            self.gate = MLP(edge_dim + node_dim + 1, hidden_dim, hidden_dim)  # +1: time
         self.centroid_lin = Linear(node_dim, hidden_dim)
         self.layer_norm = nn.LayerNorm(hidden_dim)
         self.act = nn.ReLU()
@@ -68,13 +99,12 @@ class BondFFN(_Block):
     def __init__(self, bond_dim, node_dim, inter_dim, use_gate, out_dim=None):
         super().__init__()
         out_dim = bond_dim if out_dim is None else out_dim
-        if not use_gate:
-            raise NotImplementedError('use_gate=False is not built')
         self.use_gate = use_gate
         self.bond_linear = Linear(bond_dim, inter_dim, bias=False)
         self.node_linear = Linear(node_dim, inter_dim, bias=False)
         self.inter_module = MLP(inter_dim, out_dim, inter_dim)
-        self.gate = MLP(bond_dim + node_dim + 1, out_dim, 32)  # +1: time
+        if use_gate:  # models/graph.py:123-124,138-140
+            self.gate = MLP(bond_dim + node_dim + 1, out_dim, 32)  # +1: time
 
     _side = -1  # 0 / 1 = bond_ffn_left / bond_ffn_right of an EdgeBlock (set by the owning NodeEdgeNet)
 
@@ -203,7 +233,7 @@ class NodeEdgeNet(Module):
             eng = _lib.Model(_lib.MDX_KIND_NET, num_blocks=self.num_blocks, cutoff=self.cutoff, update_pos=self.update_pos,
                              node_dim=self.node_dim, edge_dim=self.edge_dim,
                              num_gaussians=self.distance_expansion.offset.numel(), smear_start=self.distance_expansion.start)
-            eng.upload(self.state_dict())
+            eng.upload({**self.state_dict(), **synth_gates(self)})
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)
 

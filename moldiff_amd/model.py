@@ -26,7 +26,7 @@ GUIDANCE_TYPES = ('entropy', 'uncertainty', 'uncertainty_bond', 'entropy_bond', 
                   'crossent_bond')
 from .common import MLP, GaussianSmearing
 from .diffusion import get_beta_schedule
-from .graph import NodeEdgeNet, _sig
+from .graph import NodeEdgeNet, _sig, synth_gates
 from .transition import ContigousTransition, GeneralCategoricalTransition
 
 
@@ -91,7 +91,7 @@ class MolDiff(Module):
                              num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
                              node_dim=d.node_dim, edge_dim=d.edge_dim,
                              num_gaussians=d.distance_expansion.offset.numel(), smear_start=d.distance_expansion.start)
-            eng.upload(self.state_dict())
+            eng.upload({**self.state_dict(), **synth_gates(d, 'denoiser.')})
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)
 

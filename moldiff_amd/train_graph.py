@@ -95,10 +95,11 @@ def node_block(m, x, g, edge_attr, node_time):
     h_node = mlp(m.node_net, x)
     h_edge = mlp(m.edge_net, edge_attr)
     msg = T.linear(T.mul_gather(h_edge, h_node, g.right), m.msg_net.weight, m.msg_net.bias)
-    g0, ed = m.gate.net[0], edge_attr.shape[1]
-    per_node = T.linear(cat(x, node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
-    gt = mlp_from_pre(m.gate, T.linear(edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right)))
-    msg = T.gate(msg, gt)
+    if m.use_gate:   # models/graph.py:46-48
+        g0, ed = m.gate.net[0], edge_attr.shape[1]
+        per_node = T.linear(cat(x, node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
+        gt = mlp_from_pre(m.gate, T.linear(edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right)))
+        msg = T.gate(msg, gt)
     out = T.linear(x, m.centroid_lin.weight, m.centroid_lin.bias, addend=T.scatter_sum(msg, g.left))
     out = T.ln_relu(out, m.layer_norm.weight, m.layer_norm.bias, True)
     return T.linear(out, m.out_transform.weight, m.out_transform.bias)
@@ -106,9 +107,13 @@ def node_block(m, x, g, edge_attr, node_time):
 
 def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
     """BondFFN on (bond_in, node_in, time) where node_in is either node_rows[plan.index] (hoisted) or node_edges (E rows)."""
+    bond_feat = T.linear(bond_in, m.bond_linear.weight)
+    if not m.use_gate:   # models/graph.py:138-140: no gate, the inter module's output is the result
+        if node_edges is None:
+            return mlp(m.inter_module, T.mul_gather(bond_feat, T.linear(node_rows, m.node_linear.weight), plan))
+        return mlp(m.inter_module, T.mul(bond_feat, T.linear(node_edges, m.node_linear.weight)))
     g0, bd = m.gate.net[0], bond_in.shape[1]
     nd = g0.weight.shape[1] - bd - 1
-    bond_feat = T.linear(bond_in, m.bond_linear.weight)
     if node_edges is None:
         prod = T.mul_gather(bond_feat, T.linear(node_rows, m.node_linear.weight), plan)
         gate_node = T.gather(T.linear(node_rows, g0.weight[:, bd:bd + nd], keep32=True), plan)

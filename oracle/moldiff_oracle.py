@@ -175,8 +175,9 @@ def node_block(P, pre, x, edge_index, edge_attr, node_time):
     h = mlp(P, pre + '.node_net', x)
     he = mlp(P, pre + '.edge_net', edge_attr)
     m = lin(P, pre + '.msg_net', he * h[col])
-    g = mlp(P, pre + '.gate', torch.cat([edge_attr, x[col], node_time[col]], -1))
-    m = m * torch.sigmoid(g)
+    if pre + '.gate.net.0.weight' in P:   # use_gate (graph.py:21-22,46-48): a net built without gates has no such parameters
+        g = mlp(P, pre + '.gate', torch.cat([edge_attr, x[col], node_time[col]], -1))
+        m = m * torch.sigmoid(g)
     z = lin(P, pre + '.centroid_lin', x) + seg_sum(m, row, x.shape[0])
     w = P[pre + '.layer_norm.weight']
     z = F.layer_norm(z, (w.shape[0],), w, P[pre + '.layer_norm.bias'], 1e-5)
@@ -186,6 +187,8 @@ def node_block(P, pre, x, edge_index, edge_attr, node_time):
 def bond_ffn(P, pre, b, n, t):
     inter = lin(P, pre + '.bond_linear', b, bias=False) * lin(P, pre + '.node_linear', n, bias=False)
     inter = mlp(P, pre + '.inter_module', inter)
+    if pre + '.gate.net.0.weight' not in P:   # use_gate=False (graph.py:123-124,138-140)
+        return inter
     return inter * torch.sigmoid(mlp(P, pre + '.gate', torch.cat([b, n, t], -1)))
 
 

@@ -6,6 +6,7 @@ reference (oracle/make_goldens_variants.py -> tests/golden/variants.npz).
     position gradient where the clamp cuts it
   * categorical_space = 'continuous' (models/model.py:54-56,76-78,91-93,144-148,185-187,249-251,301-304): get_loss with pinned
     draws, and the first iterations of sample() with the reference's own draws
+  * use_gate = False (models/graph.py:21-22,46-48,123-124,138-140): forward, loss + gradients, the predictor's position gradient
 """
 import copy
 
@@ -24,6 +25,22 @@ GTOL = 1e-4   # parameter gradients, same rule as tests/test_loss.py::_check_par
 LTOL = 2e-5   # logits: the golden-forward tolerance of the bond predictor (tests/test_gpu_sampling.py)
 
 _models = {}
+
+
+def _check_gpos(g, want):
+    """Position gradient of a guidance objective through the 8-block predictor vs a golden from another fp32 arithmetic.
+    The two evaluate ~1e6 ReLU units each; a pre-activation within rounding of zero falls on different sides in the two and shifts the
+    atoms it feeds by a discrete ~1e-4 of the gradient scale (measured here: the SAME kernels against the layer operators on the
+    same inputs, positions jittered by 1e-4: 3 of 8 draws show one such event, 7.7e-5 .. 3.0e-4 of a 1.66 scale; the rest 2e-6;
+    DESIGN section 3.4, profiles/r4_split_delta_diag.txt).  An event moves every atom of ONE molecule, so on these small batches neither
+    the maximum nor the rms can carry a 1e-5 contract: 70 % of the atoms do (more than any one molecule leaves), the maximum gets room
+    for one event."""
+    want = torch.as_tensor(want).to(g.device)
+    scale = max(1.0, float(want.abs().max()))
+    d = (g - want).abs().max(-1).values.double()
+    q70 = float(torch.quantile(d, 0.70))
+    assert q70 <= 2e-5 * scale, q70
+    assert float(d.max()) <= 1e-3 * scale, float(d.max())
 
 
 def timefree(device='cpu'):
@@ -185,8 +202,7 @@ def test_gpu_predictor_position_gradient_with_smearing_start_matches_reference_a
     logits = mb(h, pos, args[2], args[4], args[5], args[6])
     assert U.maxdiff(logits, z['st_bond_logits']) <= 2e-5 * max(1.0, float(np.abs(z['st_bond_logits']).max()))
     (g,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), pos)
-    want = z['st_bond_gpos']
-    assert U.maxdiff(g, want) <= 1e-4 * max(1.0, float(np.abs(want).max())), U.maxdiff(g, want)
+    _check_gpos(g, z['st_bond_gpos'])
 
 
 @pytest.mark.gpu
@@ -370,3 +386,96 @@ def test_gpu_continuous_sampler_default_noise_is_reproducible_and_shard_invarian
     assert U.maxdiff(c['pos'], a['pos'][5:12]) <= 1e-4 and U.maxdiff(c['h_node'], a['h_node'][5:12]) <= 1e-4
     with pytest.raises(NotImplementedError):
         m.sampler(3, bn, hei, bh, bond_predictor=None, guidance=['uncertainty', 1e-4])
+
+
+# ---- use_gate = False -------------------------------------------------------------------------------------------------------------
+def _nogate_models(device):
+    key = 'nogate' + str(device)
+    if key not in _models:
+        cfg = copy.deepcopy(default_config('MolDiff_simple'))
+        cfg.denoiser.use_gate = False
+        md = M.MolDiff(cfg, 8, 6).eval()
+        md.load_state_dict(M.recipe_state_dict(md, 20230815), strict=True)
+        cfgp = copy.deepcopy(default_config('bondpred'))
+        cfgp.encoder.use_gate = False
+        mb = M.BondPredictor(cfgp, 8, 5).eval()
+        mb.load_state_dict(M.recipe_state_dict(mb, 20230816), strict=True)
+        _models[key] = (md.to(device), mb.to(device))
+    return _models[key]
+
+
+def _ng_case(device='cpu'):
+    z = U.gold('variants.npz')
+    bn, hei, bh, ei, be = U.graph_from_sizes([int(s) for s in z['ng_sizes']], device)
+    f = lambda k: torch.from_numpy(z[k]).to(device)
+    args = (f('ng_node_type'), f('ng_node_pos'), bn, f('ng_halfedge_type'), hei, bh, len(z['ng_sizes']))
+    noise = {'eps_pos': f('ng_eps_pos'), 'u_node': f('ng_u_node'), 'u_halfedge': f('ng_u_halfedge')}
+    return z, args, f('ng_t'), noise, (ei, be)
+
+
+def test_nogate_state_dict_and_oracle_match_the_reference_golden():
+    z, args, t, noise, (ei, be) = _ng_case()
+    md, mb = _nogate_models('cpu')
+    assert sorted(md.state_dict()) == [str(k) for k in z['ng_keys']] and not any('.gate.' in k for k in mb.state_dict())
+    P = U.params(md)
+    hh = torch.from_numpy(z['ng_h_half'])
+    with torch.no_grad():
+        fw = O.moldiff_forward(P, CFG_C, torch.from_numpy(z['ng_h_node']), args[1], args[2], torch.cat([hh, hh]), ei, be, t)
+        ls = O.moldiff_loss(P, CFG_C, U.tables(P) | {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')}},
+                            *args, t, noise)
+    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+        assert U.maxdiff(fw[k], z['ng_' + k]) <= 1e-6
+    for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+        assert abs(float(ls[k]) - float(z['ng_' + k])) <= 1e-6 * max(1.0, float(z['ng_' + k]))
+    # the pass-through gates the fused kernels are packed with open exactly
+    from moldiff_amd.graph import GATE_OPEN, synth_gates
+    assert float(torch.sigmoid(torch.tensor(GATE_OPEN))) == 1.0
+    extra = synth_gates(md.denoiser, 'denoiser.')
+    assert len(extra) == 6 * (1 + 2 + 1) * 6 and all('.gate.net.' in k for k in extra)
+    assert synth_gates(U.moldiff('MolDiff').denoiser) == {}
+
+
+@pytest.mark.gpu
+def test_gpu_nogate_forward_loss_and_gradients_match_reference():
+    z, args, t, noise, (ei, be) = _ng_case('cuda')
+    md, _ = _nogate_models('cuda')
+    hh = torch.from_numpy(z['ng_h_half']).cuda()
+    with torch.no_grad():
+        fw = md(torch.from_numpy(z['ng_h_node']).cuda(), args[1], args[2], torch.cat([hh, hh]), ei, be, t)
+        ev = md.get_loss(*args, time_step=t, noise=noise)
+    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+        assert U.maxdiff(fw[k], z['ng_' + k]) <= 1e-4, (k, U.maxdiff(fw[k], z['ng_' + k]))
+    md.zero_grad(set_to_none=True)
+    got = md.get_loss(*args, time_step=t, noise=noise)
+    for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+        want = float(z['ng_' + k])
+        assert abs(float(ev[k]) - want) <= RTOL * max(1.0, abs(want)), ('eval', k)
+        assert abs(float(got[k].detach()) - want) <= RTOL * max(1.0, abs(want)), ('train', k)
+    got['loss'].backward()
+    names = [k[len('ng_grad_norm/'):] for k in z.files if k.startswith('ng_grad_norm/')]
+    P = dict(md.named_parameters())
+    assert set(names) == {k for k, v in P.items() if v.requires_grad}
+    gmax = max(float(z[f'ng_grad_norm/{k}']) for k in names)
+    for k in names:
+        g = P[k].grad
+        assert g is not None, f'no gradient reached {k}'
+        want = float(z[f'ng_grad_norm/{k}'])
+        scale = max(want, 1e-3 * gmax)
+        err = abs(float(g.double().norm()) - want) / scale
+        fk = f'ng_grad_full/{k}'
+        if fk in z.files:
+            err = max(err, float((g - torch.from_numpy(z[fk]).to(g.device)).double().norm()) / scale)
+        assert err <= GTOL, (k, err)
+    md.zero_grad(set_to_none=True)
+
+
+@pytest.mark.gpu
+def test_gpu_nogate_predictor_position_gradient_matches_reference_autograd():
+    z, args, t, noise, (ei, be) = _ng_case('cuda')
+    _, mb = _nogate_models('cuda')
+    h = torch.nn.functional.one_hot(args[0], 8).float()
+    pos = args[1].clone().requires_grad_(True)
+    logits = mb(h, pos, args[2], ei, be, t)
+    assert U.maxdiff(logits, z['ng_bond_logits']) <= 2e-5 * max(1.0, float(np.abs(z['ng_bond_logits']).max()))
+    (g,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), pos)
+    _check_gpos(g, z['ng_bond_gpos'])
