@@ -741,7 +741,11 @@ def main():
             L = _lib.lib()
             name_a, name_g = (L.mdx_profile_kernel_name(k).decode() for k in (0, 3))
             out['roofline']['kernel_symbol'], out['aggregation']['kernel_symbol'] = name_a, name_g
+            # newest summary of THIS configuration first: the round-4 directory also holds summaries of the guided step and of the
+            # split-float16 build, which know other kernels
             pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_summary.json')))
+            pm = [f for f in pm if 'guided' not in os.path.basename(f)]
+            pm.sort(key=lambda f: ('split' in os.path.basename(f)) == ('matrix_path' in out))   # stable: the matching build's newest round last
             if pm and args.batch == 256 and not args.guided:
                 ks = json.load(open(pm[-1]))['kernels']
                 src = os.path.relpath(pm[-1], ROOT)
@@ -844,6 +848,17 @@ def main():
                 lineS['kernel_ms_per_step'] = {k: v[1] / 20 for k, v in profS.items() if v[0]}
                 lineS['roofline'] = roofline_split('edge_a', 'edge_a2s_kernel (split float16 build of edge kernel A, mdx_edge2s.hip)', FLOP_EDGE_A, ES, profS)
                 lineS['roofline_edge_b'] = roofline_split('edge_b', 'edge_b2s_kernel (split float16 build of edge kernel B)', FLOP_EDGE_B, ES, profS)
+                try:   # HBM traffic per launch of the split build's kernel A from ITS committed PMC passes (same rule as the headline's)
+                    import glob
+                    pat = 'r*_split_guided_pmc_summary.json' if cname == 'guided_split' else 'r*_split_pmc_summary.json'
+                    pmS = sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)))
+                    ksS = json.load(open(pmS[-1]))['kernels'] if pmS else {}
+                    hit = [k for k in ksS if k.startswith('edge_a2s_kernel<15>')]
+                    if hit and args.batch == 256:
+                        lineS['roofline']['traffic'] = ksS[hit[0]]['hbm_bytes_per_launch']
+                        lineS['roofline']['traffic_source'] = os.path.relpath(pmS[-1], ROOT) + ' (PMC passes of the split run; not measured in this run)'
+                except Exception:
+                    pass
                 exact = configs['simple' if cname == 'simple_split' else 'guided']
                 lineS['speedup_vs_exact_path'] = exact['ms_per_step'] / lineS['ms_per_step']
                 lineS['parity'] = ('tests/test_gpu_round4.py: the exact path\'s golden / fp64-arbitrated parity tests re-run on this path '
