@@ -26,31 +26,57 @@ GATE_OPEN = 32.0   # sigmoid(32) == 1.0f exactly (the division form and the exp2
 
 
 def synth_gates(net, prefix=''):
-    """use_gate=False (models/graph.py:21-22,123-124): the reference multiplies by no gate at all.  The fused kernels always evaluate
-    one, so a net built without gates is packed with PASS-THROUGH gate parameters under the keys a gated net would have: all weights
-    zero, LayerNorm (1, 0), last bias GATE_OPEN -> sigmoid(gate) == 1.0f and message * 1.0f is the message, bit for bit; in the
-    guidance backward sigmoid' == 0 exactly, so nothing flows through the synthetic path.  Costs the gate's GEMMs (no shipped config
-    pays it).  Returns {key: tensor} to be merged into the state_dict handed to the engine; {} for a gated net."""
-    if net.use_gate:
-        return {}
+    """Parameters the fused kernels need and a net built with `use_gate=False` or `update_edge=False` does not have, under the keys
+    a full net would carry; merged into the state_dict handed to the engine ({} for a full net).
+
+    use_gate=False (models/graph.py:21-22,123-124): the reference multiplies by no gate at all.  The kernels always evaluate one, so
+    they get PASS-THROUGH gates: all weights zero, LayerNorm (1, 0), last bias GATE_OPEN -> sigmoid(gate) == 1.0f and message * 1.0f
+    is the message, bit for bit; in the guidance backward sigmoid' == 0 exactly, so nothing flows through the synthetic path.
+
+    update_edge=False (models/graph.py:317-320,352-361): every block re-derives the edge features from the distances alone
+    (edge_embs is num_gaussians -> edge_dim and ignores the incoming features) and there is no EdgeBlock.  The kernels get edge_embs
+    weights with a ZERO block in front of the distance columns (0 * h_edge adds nothing) and all-zero EdgeBlocks, whose update
+    out_transform(relu(LayerNorm(0))) = 0 leaves the edge features as edge_embs made them.  Both cost the unused GEMMs; no shipped
+    config pays it."""
     nd, ed = net.node_dim, net.edge_dim
     out = {}
 
-    def mlp(pre, din, dhid, dout):
+    def mlp(pre, din, dhid, dout, last_bias=0.0):
         out[pre + '.net.0.weight'] = torch.zeros(dhid, din)
         out[pre + '.net.0.bias'] = torch.zeros(dhid)
         out[pre + '.net.1.weight'] = torch.ones(dhid)
         out[pre + '.net.1.bias'] = torch.zeros(dhid)
         out[pre + '.net.3.weight'] = torch.zeros(dout, dhid)
-        out[pre + '.net.3.bias'] = torch.full((dout,), GATE_OPEN)
+        out[pre + '.net.3.bias'] = torch.full((dout,), last_bias)
+
+    def lin(pre, dout, din, bias=True):
+        out[pre + '.weight'] = torch.zeros(dout, din)
+        if bias:
+            out[pre + '.bias'] = torch.zeros(dout)
 
     for i in range(net.num_blocks):
-        mlp(f'{prefix}node_blocks_with_edge.{i}.gate', ed + nd + 1, nd, nd)
+        if not net.use_gate:
+            mlp(f'{prefix}node_blocks_with_edge.{i}.gate', ed + nd + 1, nd, nd, GATE_OPEN)
+            if net.update_pos:
+                mlp(f'{prefix}pos_blocks.{i}.edge_lin.gate', 2 * ed + 1, 32, 1, GATE_OPEN)
         if net.update_edge:
+            if not net.use_gate:
+                for side in ('bond_ffn_left', 'bond_ffn_right'):
+                    mlp(f'{prefix}edge_blocks.{i}.{side}.gate', ed + nd + 1, 32, ed, GATE_OPEN)
+        else:
+            w = net.edge_embs[i].weight.detach().cpu().float()
+            out[f'{prefix}edge_embs.{i}.weight'] = torch.cat([torch.zeros(ed, ed), w], dim=1)
+            eb = f'{prefix}edge_blocks.{i}'
             for side in ('bond_ffn_left', 'bond_ffn_right'):
-                mlp(f'{prefix}edge_blocks.{i}.{side}.gate', ed + nd + 1, 32, ed)
-        if net.update_pos:
-            mlp(f'{prefix}pos_blocks.{i}.edge_lin.gate', 2 * ed + 1, 32, 1)
+                lin(f'{eb}.{side}.bond_linear', 2 * ed, ed, bias=False)
+                lin(f'{eb}.{side}.node_linear', 2 * ed, nd, bias=False)
+                mlp(f'{eb}.{side}.inter_module', 2 * ed, 2 * ed, ed)
+                mlp(f'{eb}.{side}.gate', ed + nd + 1, 32, ed)
+            lin(f'{eb}.node_ffn_left', ed, nd)
+            lin(f'{eb}.node_ffn_right', ed, nd)
+            lin(f'{eb}.self_ffn', ed, ed)
+            out[f'{eb}.layer_norm.weight'], out[f'{eb}.layer_norm.bias'] = torch.ones(ed), torch.zeros(ed)
+            lin(f'{eb}.out_transform', ed, ed)
     return out
 
 
@@ -198,9 +224,9 @@ class NodeEdgeNet(Module):
         self.distance_expansion = GaussianSmearing(start=start, stop=cutoff, num_gaussians=num_gaussians)
         self.update_edge = not ('update_edge' in kwargs and not kwargs['update_edge'])
         self.update_pos = not ('update_pos' in kwargs and not kwargs['update_pos'])
-        if not self.update_edge:
-            raise NotImplementedError('update_edge=False is not built (no shipped config uses it)')
-        input_edge_dim = edge_dim + num_gaussians
+        # update_edge=False (models/graph.py:317-320,352-361): edge features are re-derived from the distances in every block, there
+        # are no EdgeBlocks; the fused kernels get zero-update EdgeBlocks and a zero He-part of edge_embs (synth_params)
+        input_edge_dim = (edge_dim if self.update_edge else 0) + num_gaussians
         self.node_blocks_with_edge = ModuleList()
         self.edge_embs = ModuleList()
         self.edge_blocks = ModuleList()
@@ -209,7 +235,8 @@ class NodeEdgeNet(Module):
             self.node_blocks_with_edge.append(NodeBlock(node_dim=node_dim, edge_dim=edge_dim, hidden_dim=node_dim,
                                                         use_gate=use_gate))
             self.edge_embs.append(Linear(input_edge_dim, edge_dim))
-            self.edge_blocks.append(EdgeBlock(edge_dim=edge_dim, node_dim=node_dim, use_gate=use_gate))
+            if self.update_edge:
+                self.edge_blocks.append(EdgeBlock(edge_dim=edge_dim, node_dim=node_dim, use_gate=use_gate))
             if self.update_pos:
                 self.pos_blocks.append(PosUpdate(node_dim=node_dim, edge_dim=edge_dim, hidden_dim=edge_dim,
                                                  use_gate=use_gate))

@@ -17,7 +17,9 @@ REAL reference on CPU.  BUILD-CONTAINER ONLY (needs /root/reference, read-only).
   * `use_gate: false` (models/graph.py:21-22,46-48,123-124,138-140): MolDiff (simple config) without any gate MLP -- forward, get_loss
     with pinned draws (+ parameter-gradient norms) -- and the bond predictor without gates: logits and the reference's autograd
     gradient of the `uncertainty` objective w.r.t. the positions.
-Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 .. 20230816).
+  * `update_edge: false` (models/graph.py:317-320,352-361: edge features re-derived from the distances in every block, no EdgeBlocks):
+    the same set.
+Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 .. 20230818).
 """
 import itertools
 import json
@@ -246,79 +248,83 @@ def main():
     pins['variant_continuous_sample_steps'] = worst
     print('continuous space: oracle vs reference', {k: v for k, v in pins.items() if 'continuous' in k})
 
-    # ---- use_gate = False ------------------------------------------------------------------------------------------------------
+    # ---- use_gate = False ('ng') and update_edge = False ('ne'): the same recipe for both ------------------------------------------------
     from oracle.make_goldens_loss import pinned_randomness
-    cfg = ref_shim.load_yaml_cfg('configs/train/train_MolDiff_simple.yml')
-    cfg.model.denoiser.use_gate = False
-    mg = MolDiff(cfg.model, 8, 6).eval()
-    sd = mg.state_dict()
-    assert not any('.gate.' in k for k in sd)
-    shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
-    sd.update(O.recipe_state_dict(shapes, 20230815))
-    mg.load_state_dict(sd, strict=True)
-    Pn = {k: v.detach().clone() for k, v in mg.state_dict().items()}
-    out['ng_keys'] = np.array(sorted(sd))
-    sizes = [7, 5, 12, 9, 3]
-    bn, hei, bh, node_type, node_pos, half_type = batch(sizes, 109)
-    B = len(sizes)
-    g = np.random.Generator(np.random.PCG64(113))
-    t_half = torch.tensor([0, 437, 850])
-    eps_pos = torch.from_numpy(g.standard_normal((len(bn), 3)).astype(np.float32))
-    u_node = torch.from_numpy(g.random((len(bn), 8)).astype(np.float32))
-    u_half = torch.from_numpy(g.random((len(bh), 6)).astype(np.float32))
-    with pinned_randomness(t_half, eps_pos, [u_node, u_half]):
-        ref = mg.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
-    mg.zero_grad()
-    ref['loss'].backward()
-    ref_grads = {k: v.grad.detach().clone() for k, v in mg.named_parameters() if v.grad is not None}
-    t = torch.cat([t_half, 1000 - t_half - 1])[:B]
-    tabs = {'pos': {k: Pn['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')},
-            'node': {k: Pn['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
-            'edge': {k: Pn['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
-    Pg = {k: (v.clone().requires_grad_(True) if k in ref_grads else v) for k, v in Pn.items()}
-    orc = O.moldiff_loss(Pg, CFG, tabs, node_type, node_pos, bn, half_type, hei, bh, B, t, dict(eps_pos=eps_pos, u_node=u_node, u_halfedge=u_half))
-    orc['loss'].backward()
-    pins['variant_nogate_param_grads'] = max(float((Pg[k].grad - gg).abs().max()) for k, gg in ref_grads.items())
-    for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
-        pins[f'variant_nogate_{k}'] = abs(float(ref[k].detach()) - float(orc[k].detach()))
-        out[f'ng_{k}'] = np.float32(float(ref[k].detach()))
-    for k, gg in ref_grads.items():
-        out[f'ng_grad_norm/{k}'] = np.float64(gg.double().norm())
-        if gg.numel() <= 256:
-            out[f'ng_grad_full/{k}'] = gg.numpy()
-    out.update({'ng_sizes': np.array(sizes), 'ng_node_type': node_type.numpy(), 'ng_node_pos': node_pos.numpy(),
-                'ng_halfedge_type': half_type.numpy(), 'ng_t': t.numpy(), 'ng_eps_pos': eps_pos.numpy(), 'ng_u_node': u_node.numpy(),
-                'ng_u_halfedge': u_half.numpy()})
-    ei, be = torch.cat([hei, hei.flip(0)], 1), torch.cat([bh, bh])
-    h_node = torch.from_numpy(g.random((len(bn), 8)).astype(np.float32))
-    h_half = torch.from_numpy(g.random((len(bh), 6)).astype(np.float32))
-    with torch.no_grad():
-        fw = mg(h_node, node_pos, bn, torch.cat([h_half, h_half]), ei, be, t)
-        fo = O.moldiff_forward(Pn, CFG, h_node, node_pos, bn, torch.cat([h_half, h_half]), ei, be, t)
-    for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
-        pins[f'variant_nogate_{k}'] = float((fw[k] - fo[k]).abs().max())
-        out[f'ng_{k}'] = fw[k].numpy()
-    out.update({'ng_h_node': h_node.numpy(), 'ng_h_half': h_half.numpy()})
-    cfgp = ref_shim.load_yaml_cfg('configs/train/train_bondpred.yml')
-    cfgp.model.encoder.use_gate = False
-    mbg = BondPredictor(cfgp.model, 8, 5).eval()
-    sd = mbg.state_dict()
-    shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
-    sd.update(O.recipe_state_dict(shapes, 20230816))
-    mbg.load_state_dict(sd, strict=True)
-    Pq = {k: v.detach().clone() for k, v in mbg.state_dict().items()}
-    hn1 = torch.nn.functional.one_hot(node_type, 8).float()
-    pos = node_pos.clone().requires_grad_(True)
-    lg = mbg(hn1, pos, bn, ei, be, t)
-    (gpos,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lg, -1)).log().sum(), pos)
-    cfgb = dict(num_timesteps=1000, num_blocks=cfgp.model.encoder.num_blocks, cutoff=cfgp.model.encoder.cutoff)
-    po = node_pos.clone().requires_grad_(True)
-    lo = O.bondpred_forward(Pq, cfgb, hn1, po, bn, ei, be, t)
-    (go,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lo, -1)).log().sum(), po)
-    pins['variant_nogate_bond_logits'] = float((lg - lo).abs().max())
-    pins['variant_nogate_bond_gpos'] = float((gpos - go).abs().max())
-    out.update({'ng_bond_logits': lg.detach().numpy(), 'ng_bond_gpos': gpos.numpy()})
-    print('use_gate = False: oracle vs reference', {k: v for k, v in pins.items() if 'nogate' in k})
+    for tag, label, key, seeds, bseed in (('ng', 'use_gate = False', 'use_gate', (20230815, 20230816), 109),
+                                          ('ne', 'update_edge = False', 'update_edge', (20230817, 20230818), 127)):
+        cfg = ref_shim.load_yaml_cfg('configs/train/train_MolDiff_simple.yml')
+        cfg.model.denoiser[key] = False
+        mg = MolDiff(cfg.model, 8, 6).eval()
+        sd = mg.state_dict()
+        assert not any(('.gate.' in k) if tag == 'ng' else ('edge_blocks' in k) for k in sd)
+        shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+        sd.update(O.recipe_state_dict(shapes, seeds[0]))
+        mg.load_state_dict(sd, strict=True)
+        Pn = {k: v.detach().clone() for k, v in mg.state_dict().items()}
+        out[f'{tag}_keys'] = np.array(sorted(sd))
+        sizes = [7, 5, 12, 9, 3]
+        bn, hei, bh, node_type, node_pos, half_type = batch(sizes, bseed)
+        B = len(sizes)
+        g = np.random.Generator(np.random.PCG64(bseed + 4))
+        t_half = torch.tensor([0, 437, 850])
+        eps_pos = torch.from_numpy(g.standard_normal((len(bn), 3)).astype(np.float32))
+        u_node = torch.from_numpy(g.random((len(bn), 8)).astype(np.float32))
+        u_half = torch.from_numpy(g.random((len(bh), 6)).astype(np.float32))
+        with pinned_randomness(t_half, eps_pos, [u_node, u_half]):
+            ref = mg.get_loss(node_type, node_pos, bn, half_type, hei, bh, B)
+        mg.zero_grad()
+        ref['loss'].backward()
+        ref_grads = {k: v.grad.detach().clone() for k, v in mg.named_parameters() if v.grad is not None}
+        t = torch.cat([t_half, 1000 - t_half - 1])[:B]
+        tabs = {'pos': {k: Pn['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')},
+                'node': {k: Pn['node_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')},
+                'edge': {k: Pn['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
+        CFGV = dict(CFG, update_edge=(tag != 'ne'))
+        Pg = {k: (v.clone().requires_grad_(True) if k in ref_grads else v) for k, v in Pn.items()}
+        orc = O.moldiff_loss(Pg, CFGV, tabs, node_type, node_pos, bn, half_type, hei, bh, B, t, dict(eps_pos=eps_pos, u_node=u_node, u_halfedge=u_half))
+        orc['loss'].backward()
+        vt = 'nogate' if tag == 'ng' else 'noedge'
+        pins[f'variant_{vt}_param_grads'] = max(float((Pg[k].grad - gg).abs().max()) for k, gg in ref_grads.items())
+        for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
+            pins[f'variant_{vt}_{k}'] = abs(float(ref[k].detach()) - float(orc[k].detach()))
+            out[f'{tag}_{k}'] = np.float32(float(ref[k].detach()))
+        for k, gg in ref_grads.items():
+            out[f'{tag}_grad_norm/{k}'] = np.float64(gg.double().norm())
+            if gg.numel() <= 256:
+                out[f'{tag}_grad_full/{k}'] = gg.numpy()
+        out.update({f'{tag}_sizes': np.array(sizes), f'{tag}_node_type': node_type.numpy(), f'{tag}_node_pos': node_pos.numpy(),
+                    f'{tag}_halfedge_type': half_type.numpy(), f'{tag}_t': t.numpy(), f'{tag}_eps_pos': eps_pos.numpy(),
+                    f'{tag}_u_node': u_node.numpy(), f'{tag}_u_halfedge': u_half.numpy()})
+        ei, be = torch.cat([hei, hei.flip(0)], 1), torch.cat([bh, bh])
+        h_node = torch.from_numpy(g.random((len(bn), 8)).astype(np.float32))
+        h_half = torch.from_numpy(g.random((len(bh), 6)).astype(np.float32))
+        with torch.no_grad():
+            fw = mg(h_node, node_pos, bn, torch.cat([h_half, h_half]), ei, be, t)
+            fo = O.moldiff_forward(Pn, CFGV, h_node, node_pos, bn, torch.cat([h_half, h_half]), ei, be, t)
+        for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
+            pins[f'variant_{vt}_{k}'] = float((fw[k] - fo[k]).abs().max())
+            out[f'{tag}_{k}'] = fw[k].numpy()
+        out.update({f'{tag}_h_node': h_node.numpy(), f'{tag}_h_half': h_half.numpy()})
+        cfgp = ref_shim.load_yaml_cfg('configs/train/train_bondpred.yml')
+        cfgp.model.encoder[key] = False
+        mbg = BondPredictor(cfgp.model, 8, 5).eval()
+        sd = mbg.state_dict()
+        shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
+        sd.update(O.recipe_state_dict(shapes, seeds[1]))
+        mbg.load_state_dict(sd, strict=True)
+        Pq = {k: v.detach().clone() for k, v in mbg.state_dict().items()}
+        hn1 = torch.nn.functional.one_hot(node_type, 8).float()
+        pos = node_pos.clone().requires_grad_(True)
+        lg = mbg(hn1, pos, bn, ei, be, t)
+        (gpos,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lg, -1)).log().sum(), pos)
+        cfgb = dict(num_timesteps=1000, num_blocks=cfgp.model.encoder.num_blocks, cutoff=cfgp.model.encoder.cutoff, update_edge=(tag != 'ne'))
+        po = node_pos.clone().requires_grad_(True)
+        lo = O.bondpred_forward(Pq, cfgb, hn1, po, bn, ei, be, t)
+        (go,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lo, -1)).log().sum(), po)
+        pins[f'variant_{vt}_bond_logits'] = float((lg - lo).abs().max())
+        pins[f'variant_{vt}_bond_gpos'] = float((gpos - go).abs().max())
+        out.update({f'{tag}_bond_logits': lg.detach().numpy(), f'{tag}_bond_gpos': gpos.numpy()})
+        print(label + ': oracle vs reference', {k: v for k, v in pins.items() if vt in k})
 
     np.savez_compressed(os.path.join(OUT, 'variants.npz'), **out)
     pf = os.path.join(OUT, 'PINNING.json')

@@ -213,17 +213,19 @@ def pos_update(P, pre, h_node, h_edge, edge_index, rel, dist, edge_time):
 
 
 def node_edge_net(P, pre, h_node, pos, h_edge, edge_index, node_time, edge_time, *,
-                  num_blocks, cutoff, update_pos=True, num_gaussians=16, start=0.0):
-    """graph.py:348-374 (update_edge=True only, the two shipped configs).  `start`: GaussianSmearing's lower clamp (:330-333)."""
+                  num_blocks, cutoff, update_pos=True, num_gaussians=16, start=0.0, update_edge=True):
+    """graph.py:348-374.  `start`: GaussianSmearing's lower clamp (:330-333); update_edge=False (:352-361): the edge features of a block
+    are edge_embs(distance features) alone and there is no EdgeBlock."""
     off, coeff = P[pre + '.distance_expansion.offset'], P[pre + '.distance_expansion.coeff']
     for i in range(num_blocks):
         if update_pos or i == 0:
             rel = pos[edge_index[0]] - pos[edge_index[1]]
             dist = torch.norm(rel, dim=-1, p=2)
             dfeat = smear(dist, off, coeff, start, cutoff)
-        h_edge = lin(P, f'{pre}.edge_embs.{i}', torch.cat([h_edge, dfeat], -1))
+        h_edge = lin(P, f'{pre}.edge_embs.{i}', torch.cat([h_edge, dfeat], -1) if update_edge else dfeat)
         dn = node_block(P, f'{pre}.node_blocks_with_edge.{i}', h_node, edge_index, h_edge, node_time)
-        h_edge = h_edge + edge_block(P, f'{pre}.edge_blocks.{i}', h_edge, edge_index, h_node, edge_time)
+        if update_edge:
+            h_edge = h_edge + edge_block(P, f'{pre}.edge_blocks.{i}', h_edge, edge_index, h_node, edge_time)
         h_node = h_node + dn
         if update_pos:
             pos = pos + pos_update(P, f'{pre}.pos_blocks.{i}', h_node, h_edge, edge_index, rel, dist, edge_time)
@@ -242,7 +244,8 @@ def moldiff_forward(P, cfg, h_node_pert, pos_pert, batch_node, h_edge_pert, edge
     he = torch.cat([F.linear(h_edge_pert, P['edge_embedder.weight']), smear(te, toff, tco, 0.0, T)], -1)
     hn, pos, he = node_edge_net(P, 'denoiser', hn, pos_pert, he, edge_index,
                                 tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
-                                num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], start=cfg.get('start', 0.0))
+                                num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], start=cfg.get('start', 0.0),
+                                update_edge=cfg.get('update_edge', True))
     nh = he.shape[0] // 2
     return {'pred_node': mlp(P, 'node_decoder', hn),
             'pred_pos': pos,
@@ -266,7 +269,8 @@ def bondpred_forward(P, cfg, h_node, pos, batch_node, edge_index, batch_edge, t)
         te = torch.zeros(edge_index.shape[1], dtype=pos.dtype)
         T = 1
     hn, _, he = node_edge_net(P, 'encoder', hn, pos, he, edge_index, tn.unsqueeze(-1) / T, te.unsqueeze(-1) / T,
-                              num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], update_pos=False, start=cfg.get('start', 0.0))
+                              num_blocks=cfg['num_blocks'], cutoff=cfg['cutoff'], update_pos=False, start=cfg.get('start', 0.0),
+                              update_edge=cfg.get('update_edge', True))
     nh = he.shape[0] // 2
     ext = torch.cat([he[:nh] + he[nh:], hn[edge_index[0, :nh]] + hn[edge_index[1, :nh]]], -1)
     return mlp(P, 'edge_decoder', ext, layers=3)
@@ -453,12 +457,12 @@ def placeholder(n_graphs, max_size=None):
 def cat_add_noise(tab, v, t, batch, u):
     """GeneralCategoricalTransition.add_noise (transition.py:245-271): q(v_t | v_0) sample with the U[0,1) draw
     passed in.  -> (one-hot float, log one-hot of the sample, log one-hot of v_0)."""
-    K = tab['q_mats'].shape[-1]
-    log_v0 = torch.log(F.one_hot(v, K).float().clamp(min=1e-30))
+    K, dt = tab['q_mats'].shape[-1], tab['q_mats'].dtype   # (dt: float64 when a test arbitrates fp32 differences)
+    log_v0 = torch.log(F.one_hot(v, K).to(dt).clamp(min=1e-30))
     q = tab['q_mats'][t][batch]
     log_q = torch.log(torch.einsum('...i,...ij->...j', log_v0.exp(), q) + 1e-30).clamp_min(-32.)
     c = gumbel_argmax(log_q, u)
-    return F.one_hot(c, K).float(), torch.log(F.one_hot(c, K).float().clamp(min=1e-30)), log_v0
+    return F.one_hot(c, K).to(dt), torch.log(F.one_hot(c, K).to(dt).clamp(min=1e-30)), log_v0
 
 
 def moldiff_loss(P, cfg, tabs, node_type, node_pos, batch_node, halfedge_type, halfedge_index, batch_halfedge, num_mol,

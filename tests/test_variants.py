@@ -6,7 +6,8 @@ reference (oracle/make_goldens_variants.py -> tests/golden/variants.npz).
     position gradient where the clamp cuts it
   * categorical_space = 'continuous' (models/model.py:54-56,76-78,91-93,144-148,185-187,249-251,301-304): get_loss with pinned
     draws, and the first iterations of sample() with the reference's own draws
-  * use_gate = False (models/graph.py:21-22,46-48,123-124,138-140): forward, loss + gradients, the predictor's position gradient
+  * use_gate = False (models/graph.py:21-22,46-48,123-124,138-140) and update_edge = False (:317-320,352-361): forward, loss +
+    gradients, the predictor's position gradient
 """
 import copy
 
@@ -41,6 +42,37 @@ def _check_gpos(g, want):
     q70 = float(torch.quantile(d, 0.70))
     assert q70 <= 2e-5 * scale, q70
     assert float(d.max()) <= 1e-3 * scale, float(d.max())
+
+
+def _check_param_grads_f64(z, tag, module, loss64):
+    """Every parameter gradient of `module` (after backward) against the golden written by the reference, arbitrated in float64:
+    on these batches the reference's OWN fp32 gradients sit up to 9e-4 from the float64 evaluation of the same function (relative
+    measure of tests/test_loss.py), so the golden alone cannot carry the 1e-4 contract -- the rule of tests/test_gpu_fullsize.py
+    applies: |product - f64| <= max(contract, 1.5 x |reference fp32 - f64|).  loss64(P64) evaluates the oracle's loss on a float64 copy
+    of the parameters; `unreached` parameters (no golden) must have no or zero gradient.  Returns the set of unreached names."""
+    Pc = U.params(module)
+    P64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in Pc.items()}
+    P64 = {k: (v.requires_grad_(True) if (v.dtype.is_floating_point and not O.is_frozen_key(k)) else v) for k, v in P64.items()}
+    loss64(P64).backward()
+    names = [k[len(tag + '_grad_norm/'):] for k in z.files if k.startswith(tag + '_grad_norm/')]
+    P = dict(module.named_parameters())
+    unreached = {k for k, v in P.items() if v.requires_grad} - set(names)
+    assert all(P[k].grad is None or float(P[k].grad.abs().max()) == 0.0 for k in unreached)
+    gmax = max(float(z[f'{tag}_grad_norm/{k}']) for k in names)
+    for k in names:
+        g, g64 = P[k].grad, P64[k].grad
+        assert g is not None, f'no gradient reached {k}'
+        want = float(z[f'{tag}_grad_norm/{k}'])
+        scale = max(want, 1e-3 * gmax)
+        fk = f'{tag}_grad_full/{k}'
+        if fk in z.files:
+            e_ref = float((torch.from_numpy(z[fk]).double() - g64).norm()) / scale
+            err = float((g.cpu().double() - g64).norm()) / scale
+        else:
+            e_ref = abs(want - float(g64.norm())) / scale
+            err = abs(float(g.double().norm()) - float(g64.norm())) / scale
+        assert err <= max(GTOL, 1.5 * e_ref), (k, err, e_ref)
+    return unreached
 
 
 def timefree(device='cpu'):
@@ -307,31 +339,10 @@ def test_gpu_continuous_space_loss_and_gradients_match_reference():
         assert abs(float(ev[k]) - want) <= RTOL * max(1.0, abs(want)), ('eval', k, float(ev[k]), want)
         assert abs(float(got[k].detach()) - want) <= RTOL * max(1.0, abs(want)), ('train', k, float(got[k].detach()), want)
     got['loss'].backward()
-    # Gradients.  On this batch (30 x MSE on real-valued class features) the reference's OWN fp32 gradients sit up to 9e-4 from the
-    # float64 evaluation of the same function in the relative measure of tests/test_loss.py, so the golden alone cannot carry a 1e-4
-    # contract: the rule of tests/test_gpu_fullsize.py applies -- against float64, max(contract, 1.5 x |reference fp32 - float64|).
-    Pc = U.params(continuous())
-    P64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in Pc.items()}
-    P64 = {k: (v.requires_grad_(True) if (v.dtype.is_floating_point and not O.is_frozen_key(k)) else v) for k, v in P64.items()}
     a64 = [x.cpu().double() if (torch.is_tensor(x) and x.dtype.is_floating_point) else (x.cpu() if torch.is_tensor(x) else x) for x in args]
-    O.moldiff_loss_continuous(P64, CFG_C, _tabs(P64), [1., 4., 8.], *a64, t.cpu(), {k: v.cpu().double() for k, v in noise.items()})['loss'].backward()
-    names = [k[len('ct_grad_norm/'):] for k in z.files if k.startswith('ct_grad_norm/')]
-    P = dict(m.named_parameters())
-    assert set(names) == {k for k, v in P.items() if v.requires_grad}
-    gmax = max(float(z[f'ct_grad_norm/{k}']) for k in names)
-    for k in names:
-        g, g64 = P[k].grad, P64[k].grad
-        assert g is not None, f'no gradient reached {k}'
-        want = float(z[f'ct_grad_norm/{k}'])
-        scale = max(want, 1e-3 * gmax)
-        fk = f'ct_grad_full/{k}'
-        if fk in z.files:
-            e_ref = float((torch.from_numpy(z[fk]).double() - g64).norm()) / scale
-            err = float((g.cpu().double() - g64).norm()) / scale
-        else:
-            e_ref = abs(want - float(g64.norm())) / scale
-            err = abs(float(g.double().norm()) - float(g64.norm())) / scale
-        assert err <= max(GTOL, 1.5 * e_ref), (k, err, e_ref)
+    n64 = {k: v.cpu().double() for k, v in noise.items()}
+    unreached = _check_param_grads_f64(z, 'ct', m, lambda P64: O.moldiff_loss_continuous(P64, CFG_C, _tabs(P64), [1., 4., 8.], *a64, t.cpu(), n64)['loss'])
+    assert unreached == set()
     m.zero_grad(set_to_none=True)
 
 
@@ -388,94 +399,101 @@ def test_gpu_continuous_sampler_default_noise_is_reproducible_and_shard_invarian
         m.sampler(3, bn, hei, bh, bond_predictor=None, guidance=['uncertainty', 1e-4])
 
 
-# ---- use_gate = False -------------------------------------------------------------------------------------------------------------
-def _nogate_models(device):
-    key = 'nogate' + str(device)
+# ---- use_gate = False ('ng') / update_edge = False ('ne') --------------------------------------------------------------------------------
+VAR = {'ng': ('use_gate', (20230815, 20230816)), 'ne': ('update_edge', (20230817, 20230818))}
+
+
+def _var_models(tag, device):
+    key = tag + str(device)
     if key not in _models:
+        opt, seeds = VAR[tag]
         cfg = copy.deepcopy(default_config('MolDiff_simple'))
-        cfg.denoiser.use_gate = False
+        cfg.denoiser[opt] = False
         md = M.MolDiff(cfg, 8, 6).eval()
-        md.load_state_dict(M.recipe_state_dict(md, 20230815), strict=True)
+        md.load_state_dict(M.recipe_state_dict(md, seeds[0]), strict=True)
         cfgp = copy.deepcopy(default_config('bondpred'))
-        cfgp.encoder.use_gate = False
+        cfgp.encoder[opt] = False
         mb = M.BondPredictor(cfgp, 8, 5).eval()
-        mb.load_state_dict(M.recipe_state_dict(mb, 20230816), strict=True)
+        mb.load_state_dict(M.recipe_state_dict(mb, seeds[1]), strict=True)
         _models[key] = (md.to(device), mb.to(device))
     return _models[key]
 
 
-def _ng_case(device='cpu'):
+def _var_case(tag, device='cpu'):
     z = U.gold('variants.npz')
-    bn, hei, bh, ei, be = U.graph_from_sizes([int(s) for s in z['ng_sizes']], device)
-    f = lambda k: torch.from_numpy(z[k]).to(device)
-    args = (f('ng_node_type'), f('ng_node_pos'), bn, f('ng_halfedge_type'), hei, bh, len(z['ng_sizes']))
-    noise = {'eps_pos': f('ng_eps_pos'), 'u_node': f('ng_u_node'), 'u_halfedge': f('ng_u_halfedge')}
-    return z, args, f('ng_t'), noise, (ei, be)
+    bn, hei, bh, ei, be = U.graph_from_sizes([int(s) for s in z[tag + '_sizes']], device)
+    f = lambda k: torch.from_numpy(z[f'{tag}_{k}']).to(device)
+    args = (f('node_type'), f('node_pos'), bn, f('halfedge_type'), hei, bh, len(z[tag + '_sizes']))
+    noise = {'eps_pos': f('eps_pos'), 'u_node': f('u_node'), 'u_halfedge': f('u_halfedge')}
+    return z, args, f('t'), noise, (ei, be)
 
 
-def test_nogate_state_dict_and_oracle_match_the_reference_golden():
-    z, args, t, noise, (ei, be) = _ng_case()
-    md, mb = _nogate_models('cpu')
-    assert sorted(md.state_dict()) == [str(k) for k in z['ng_keys']] and not any('.gate.' in k for k in mb.state_dict())
+@pytest.mark.parametrize('tag', ['ng', 'ne'])
+def test_variant_state_dict_and_oracle_match_the_reference_golden(tag):
+    z, args, t, noise, (ei, be) = _var_case(tag)
+    md, mb = _var_models(tag, 'cpu')
+    assert sorted(md.state_dict()) == [str(k) for k in z[tag + '_keys']]
+    gone = '.gate.' if tag == 'ng' else 'edge_blocks'
+    assert not any(gone in k for k in mb.state_dict())
     P = U.params(md)
-    hh = torch.from_numpy(z['ng_h_half'])
+    cfg = dict(CFG_C, update_edge=(tag != 'ne'))
+    hh = torch.from_numpy(z[tag + '_h_half'])
     with torch.no_grad():
-        fw = O.moldiff_forward(P, CFG_C, torch.from_numpy(z['ng_h_node']), args[1], args[2], torch.cat([hh, hh]), ei, be, t)
-        ls = O.moldiff_loss(P, CFG_C, U.tables(P) | {'pos': {k: P['pos_transition.' + k] for k in ('coef_x0', 'coef_xt', 'std', 'alphas_bar')}},
-                            *args, t, noise)
+        fw = O.moldiff_forward(P, cfg, torch.from_numpy(z[tag + '_h_node']), args[1], args[2], torch.cat([hh, hh]), ei, be, t)
+        ls = O.moldiff_loss(P, cfg, U.tables(P), *args, t, noise)
     for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
-        assert U.maxdiff(fw[k], z['ng_' + k]) <= 1e-6
+        assert U.maxdiff(fw[k], z[f'{tag}_{k}']) <= 1e-6
     for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
-        assert abs(float(ls[k]) - float(z['ng_' + k])) <= 1e-6 * max(1.0, float(z['ng_' + k]))
-    # the pass-through gates the fused kernels are packed with open exactly
+        assert abs(float(ls[k]) - float(z[f'{tag}_{k}'])) <= 1e-6 * max(1.0, float(z[f'{tag}_{k}']))
+    # what the fused kernels are packed with on top of the module's own parameters
     from moldiff_amd.graph import GATE_OPEN, synth_gates
     assert float(torch.sigmoid(torch.tensor(GATE_OPEN))) == 1.0
     extra = synth_gates(md.denoiser, 'denoiser.')
-    assert len(extra) == 6 * (1 + 2 + 1) * 6 and all('.gate.net.' in k for k in extra)
+    if tag == 'ng':
+        assert len(extra) == 6 * (1 + 2 + 1) * 6 and all('.gate.net.' in k for k in extra)
+    else:
+        assert extra['denoiser.edge_embs.0.weight'].shape == (64, 80) and float(extra['denoiser.edge_embs.0.weight'][:, :64].abs().max()) == 0.0
+        assert torch.equal(extra['denoiser.edge_embs.0.weight'][:, 64:], md.denoiser.edge_embs[0].weight)
+        assert all(float(v.abs().max()) == 0.0 for k, v in extra.items() if 'edge_blocks' in k and 'layer_norm.weight' not in k and '.net.1.weight' not in k)
     assert synth_gates(U.moldiff('MolDiff').denoiser) == {}
 
 
 @pytest.mark.gpu
-def test_gpu_nogate_forward_loss_and_gradients_match_reference():
-    z, args, t, noise, (ei, be) = _ng_case('cuda')
-    md, _ = _nogate_models('cuda')
-    hh = torch.from_numpy(z['ng_h_half']).cuda()
+@pytest.mark.parametrize('tag', ['ng', 'ne'])
+def test_gpu_variant_forward_loss_and_gradients_match_reference(tag):
+    z, args, t, noise, (ei, be) = _var_case(tag, 'cuda')
+    md, _ = _var_models(tag, 'cuda')
+    hh = torch.from_numpy(z[tag + '_h_half']).cuda()
     with torch.no_grad():
-        fw = md(torch.from_numpy(z['ng_h_node']).cuda(), args[1], args[2], torch.cat([hh, hh]), ei, be, t)
+        fw = md(torch.from_numpy(z[tag + '_h_node']).cuda(), args[1], args[2], torch.cat([hh, hh]), ei, be, t)
         ev = md.get_loss(*args, time_step=t, noise=noise)
     for k in ('pred_node', 'pred_pos', 'pred_halfedge'):
-        assert U.maxdiff(fw[k], z['ng_' + k]) <= 1e-4, (k, U.maxdiff(fw[k], z['ng_' + k]))
+        assert U.maxdiff(fw[k], z[f'{tag}_{k}']) <= 1e-4, (k, U.maxdiff(fw[k], z[f'{tag}_{k}']))
     md.zero_grad(set_to_none=True)
     got = md.get_loss(*args, time_step=t, noise=noise)
     for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
-        want = float(z['ng_' + k])
+        want = float(z[f'{tag}_{k}'])
         assert abs(float(ev[k]) - want) <= RTOL * max(1.0, abs(want)), ('eval', k)
         assert abs(float(got[k].detach()) - want) <= RTOL * max(1.0, abs(want)), ('train', k)
     got['loss'].backward()
-    names = [k[len('ng_grad_norm/'):] for k in z.files if k.startswith('ng_grad_norm/')]
-    P = dict(md.named_parameters())
-    assert set(names) == {k for k, v in P.items() if v.requires_grad}
-    gmax = max(float(z[f'ng_grad_norm/{k}']) for k in names)
-    for k in names:
-        g = P[k].grad
-        assert g is not None, f'no gradient reached {k}'
-        want = float(z[f'ng_grad_norm/{k}'])
-        scale = max(want, 1e-3 * gmax)
-        err = abs(float(g.double().norm()) - want) / scale
-        fk = f'ng_grad_full/{k}'
-        if fk in z.files:
-            err = max(err, float((g - torch.from_numpy(z[fk]).to(g.device)).double().norm()) / scale)
-        assert err <= GTOL, (k, err)
+    a64 = [x.cpu().double() if (torch.is_tensor(x) and x.dtype.is_floating_point) else (x.cpu() if torch.is_tensor(x) else x) for x in args]
+    n64 = {k: v.cpu().double() for k, v in noise.items()}
+    cfg = dict(CFG_C, update_edge=(tag != 'ne'))
+    unreached = _check_param_grads_f64(z, tag, md, lambda P64: O.moldiff_loss(P64, cfg, U.tables(P64), *a64, t.cpu(), n64)['loss'])
+    # with update_edge=False the embedded edge features are never read: the reference's loss does not reach the embedder either
+    assert unreached == (set() if tag == 'ng' else {'edge_embedder.weight'})
     md.zero_grad(set_to_none=True)
 
 
 @pytest.mark.gpu
-def test_gpu_nogate_predictor_position_gradient_matches_reference_autograd():
-    z, args, t, noise, (ei, be) = _ng_case('cuda')
-    _, mb = _nogate_models('cuda')
+@pytest.mark.parametrize('tag', ['ng', 'ne'])
+def test_gpu_variant_predictor_position_gradient_matches_reference_autograd(tag):
+    z, args, t, noise, (ei, be) = _var_case(tag, 'cuda')
+    _, mb = _var_models(tag, 'cuda')
     h = torch.nn.functional.one_hot(args[0], 8).float()
     pos = args[1].clone().requires_grad_(True)
     logits = mb(h, pos, args[2], ei, be, t)
-    assert U.maxdiff(logits, z['ng_bond_logits']) <= 2e-5 * max(1.0, float(np.abs(z['ng_bond_logits']).max()))
+    want = z[tag + '_bond_logits']
+    assert U.maxdiff(logits, want) <= 2e-5 * max(1.0, float(np.abs(want).max()))
     (g,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), pos)
-    _check_gpos(g, z['ng_bond_gpos'])
+    _check_gpos(g, z[tag + '_bond_gpos'])
