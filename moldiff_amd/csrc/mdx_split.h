@@ -151,8 +151,9 @@ __device__ __forceinline__ void rgemm_s_primed(f32x4 (&y)[FT][RR], const XS<KG>&
 // The ring position must be the same at every GEMM entry, so a GEMM occupies a multiple of MDX_RING half-steps: the 4- and
 // 12-half-step ones run 4 idle steps that only turn the ring (their loads land in the stream pack's zero padding, MDX_RING_PAD).
 template <int KG, int FT>
-__device__ __forceinline__ void rgemm_s_seamless(f32x4 (&y)[FT][RR], const XS<KG>& x, const WS& w, WRing& ring, const WS& wnext) {
+__device__ __forceinline__ void rgemm_s_seamless(f32x4 (&y)[FT][RR], const XS<KG>& xin, const WS& w, WRing& ring, const WS& wnext) {
   static_assert(FT % 2 == 0, "feature tiles come in pairs");
+  const XS<KG>& x = xin;
   constexpr int NP = (FT / 2) * KG * 2;
   constexpr int NPL = (NP + MDX_RING - 1) / MDX_RING * MDX_RING;  // half-steps of ring rotation
   static_assert(NPL - NP <= 4, "idle steps read the pack's zero padding (4 half-steps)");
