@@ -231,6 +231,7 @@ __device__ __forceinline__ void gemm_split(f32x4 (&y)[16][R], const h8 (&xh)[8][
 
 // phase stamps of one wave (block 0, wave 0) in its second pass over the chain: [layer][0 start, 1 operand split, 2 GEMM, 3 LayerNorm]
 __device__ unsigned long long g_stamp[64];
+__device__ int g_desync = 0;
 #define STAMP(i)                                                                             \
   do {                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                       \
@@ -252,7 +253,9 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict
 #pragma unroll
     for (int rt = 0; rt < R; ++rt) x[g][rt] = *reinterpret_cast<const f32x4*>(X + (row0 + 16 * rt + c) * 256 + 16 * g + 4 * q);
   const WS ws{__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(W), 0, -1, 0x00020000), 16u * lane};
-  int m = 0;
+  // UB_DESYNC: every wave starts at its own matrix, so the four waves of a CU never stream the same weights at the same time (as in the
+  // real kernels, where waves sit at different layers) -- what the L1's cross-wave hits are worth
+  int m = g_desync ? __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 4 + wave) % nmat)) : 0;
 #pragma unroll 1
   for (int r = 0; r < reps; ++r) {
 #pragma unroll 1
@@ -463,6 +466,7 @@ static void run(const char* name, const Dev& d, const void* W, const Problem& P,
 }
 
 int main(int argc, char** argv) {
+  if (getenv("UB_DESYNC")) { int one = 1; hipMemcpyToSymbol(HIP_SYMBOL(g_desync), &one, sizeof(one)); }
   const int nmat = 6, nl_check = 6, nref = 128, sw = argc > 1 ? atoi(argv[1]) : 8;
   Problem P;
   P.nmat = nmat;
