@@ -1023,12 +1023,17 @@ int* wq_for(const mdx_graph_s* gc, hipStream_t s) {
   g->wq_stream[g->wq_n] = s;
   return g->wq + (size_t)MDX_WQ_SET_INTS * g->wq_n++;
 }
+// The split float16 forward kernels take the STATIC split: their waves then run identical programs from a common start and stay close
+// enough for the L1 to serve the weight fragments one wave pulled to the other three (tools/ubench_split.hip UB_DESYNC: 23 vs 29
+// cycles per MFMA), which is worth more to them than the queues' balance -- kernel A 373.5 vs 385.0 us per launch, kernel B 134.5 vs
+// 136.0 (profiles/r4_split_phase_trace.txt).  The exact kernels are bound by the matrix pipe and keep the queues (6.95 vs 6.96 ms per
+// step either way).  Results do not depend on the distribution (tests/test_gpu_round3.py static-vs-queue parity).
 int run_ea(const mdx_graph_s* g, EdgeAArgs a, hipStream_t s) {
-  a.wq = wq_for(g, s);
+  a.wq = (a.flags & EA_SPLIT) ? nullptr : wq_for(g, s);
   return launch_edge_a(a, s);
 }
 int run_eb(const mdx_graph_s* g, EdgeBArgs a, hipStream_t s) {
-  a.wq = wq_for(g, s);
+  a.wq = (a.flags & EB_SPLIT) ? nullptr : wq_for(g, s);
   return launch_edge_b(a, s);
 }
 
