@@ -343,14 +343,17 @@ int main() {
     ref_chain(P, hX.data() + (size_t)r * 256, nl_check, true, refLN.data() + (size_t)r * 256);
     ref_chain(P, hX.data() + (size_t)r * 256, 2, false, refNo.data() + (size_t)r * 256);
   }
-  std::vector<uint16_t> p4, p8;
+  std::vector<uint16_t> p2, p4, p8;
+  pack_tile<2>(P, p2);
   pack_tile<4>(P, p4);
   pack_tile<8>(P, p8);
   float *dX, *dout, *dgb;
-  void *dW4, *dW8;
+  void *dW2, *dW4, *dW8;
   hipMalloc(&dX, hX.size() * 4);
   hipMalloc(&dout, hX.size() * 4);
   hipMalloc(&dgb, P.gb.size() * 4);
+  hipMalloc(&dW2, p2.size() * 2);
+  hipMemcpy(dW2, p2.data(), p2.size() * 2, hipMemcpyHostToDevice);
   hipMalloc(&dW4, p4.size() * 2);
   hipMalloc(&dW8, p8.size() * 2);
   hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice);
@@ -358,6 +361,12 @@ int main() {
   hipMemcpy(dW4, p4.data(), p4.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dW8, p8.data(), p8.size() * 2, hipMemcpyHostToDevice);
   printf("workgroup-tile split chain (6 layers 256 -> 256, LayerNorm + ReLU); row-owner figures of the same chain: tools/ubench_split.hip\n");
+  // wave PAIRS: 32 rows, two waves with half of the output features each (64 accumulator registers per wave): 4 pairs per CU = 2 waves per
+  // SIMD at the weight stream of 32 rows x 1 wave
+  run<2, 2, 4, true, 4>("pair 32 rows, 2 waves", dX, dW2, dgb, dout, P, refLN, nl_check, nref);
+  run<2, 2, 8, true, 4>("pair 32 rows, 2 waves", dX, dW2, dgb, dout, P, refLN, nl_check, nref);
+  run<2, 2, 4, false, 4>("pair 32 rows, 2 waves, no LN", dX, dW2, dgb, dout, P, refNo, 2, nref);
+  run<4, 2, 4, true, 2>("pair 64 rows, 2 waves", dX, dW2, dgb, dout, P, refLN, nl_check, nref);
   run<4, 4, 4, true, 2>("tile 64 rows, 4 waves", dX, dW4, dgb, dout, P, refLN, nl_check, nref);
   run<4, 4, 8, true, 2>("tile 64 rows, 4 waves", dX, dW4, dgb, dout, P, refLN, nl_check, nref);
   run<2, 4, 4, true, 4>("tile 32 rows, 4 waves", dX, dW4, dgb, dout, P, refLN, nl_check, nref);
