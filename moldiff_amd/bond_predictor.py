@@ -69,7 +69,7 @@ class BondPredictor(Module):
         return d
 
     def __init__(self, config, num_node_types, num_edge_types, **kwargs):
-        # variants the kernels are not built for are rejected BEFORE any sub-module exists (INTEGRATION.md "unsupported variants")
+        # variants the kernels are not built for are rejected BEFORE any sub-module exists (INTEGRATION.md "Constructor variants beyond the shipped configs")
         if config.encoder.get('update_pos', True) if hasattr(config.encoder, 'get') else getattr(config.encoder, 'update_pos', True):
             raise NotImplementedError('the bond predictor kernels assume encoder.update_pos=False (the shipped config)')
         super().__init__()
