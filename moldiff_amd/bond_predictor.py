@@ -119,7 +119,7 @@ class BondPredictor(Module):
             eng = _lib.Model(_lib.MDX_KIND_BONDPRED, num_blocks=e.num_blocks, cutoff=e.cutoff, update_pos=False,
                              time_dim=self.time_dim, num_timesteps=self.num_timesteps,
                              num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
-                             node_dim=e.node_dim, edge_dim=e.edge_dim, num_gaussians=e.distance_expansion.offset.numel(), smear_start=e.distance_expansion.start)
+                             node_dim=e.node_dim, edge_dim=e.edge_dim, num_gaussians=16, smear_start=e.distance_expansion.start)
             eng.upload({**self.state_dict(), **synth_gates(e, 'encoder.')})
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)

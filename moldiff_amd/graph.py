@@ -22,6 +22,7 @@ def _sig(module):
     return tuple((p.data_ptr(), p._version) for p in module.state_dict(keep_vars=True).values())
 
 
+NG_KERNEL = 16     # distance gaussians the fused kernels evaluate; a net with fewer is packed with dead ones (synth_gates)
 GATE_OPEN = 32.0   # sigmoid(32) == 1.0f exactly (the division form and the exp2 / rcp form of the kernels alike)
 
 
@@ -40,6 +41,13 @@ def synth_gates(net, prefix=''):
     config pays it."""
     nd, ed = net.node_dim, net.edge_dim
     out = {}
+    # num_gaussians < 16 (models/graph.py:309-312): the kernels always evaluate 16 -- the missing ones get offset 0 / coeff 0 (value
+    # exp(0) = 1) and ZERO columns in every edge_embs weight, so they add exactly nothing
+    ng = net.distance_expansion.offset.numel()
+    if ng < NG_KERNEL:
+        for key in ('offset', 'coeff'):
+            v = getattr(net.distance_expansion, key).detach().cpu().float()
+            out[f'{prefix}distance_expansion.{key}'] = torch.cat([v, torch.zeros(NG_KERNEL - ng)])
 
     def mlp(pre, din, dhid, dout, last_bias=0.0):
         out[pre + '.net.0.weight'] = torch.zeros(dhid, din)
@@ -63,9 +71,12 @@ def synth_gates(net, prefix=''):
             if not net.use_gate:
                 for side in ('bond_ffn_left', 'bond_ffn_right'):
                     mlp(f'{prefix}edge_blocks.{i}.{side}.gate', ed + nd + 1, 32, ed, GATE_OPEN)
+            if ng < NG_KERNEL:
+                w = net.edge_embs[i].weight.detach().cpu().float()
+                out[f'{prefix}edge_embs.{i}.weight'] = torch.cat([w, torch.zeros(ed, NG_KERNEL - ng)], dim=1)
         else:
             w = net.edge_embs[i].weight.detach().cpu().float()
-            out[f'{prefix}edge_embs.{i}.weight'] = torch.cat([torch.zeros(ed, ed), w], dim=1)
+            out[f'{prefix}edge_embs.{i}.weight'] = torch.cat([torch.zeros(ed, ed), w, torch.zeros(ed, NG_KERNEL - ng)], dim=1)
             eb = f'{prefix}edge_blocks.{i}'
             for side in ('bond_ffn_left', 'bond_ffn_right'):
                 lin(f'{eb}.{side}.bond_linear', 2 * ed, ed, bias=False)
@@ -220,6 +231,8 @@ class NodeEdgeNet(Module):
         self.node_dim, self.edge_dim, self.num_blocks = node_dim, edge_dim, num_blocks
         self.cutoff, self.use_gate, self.kwargs = cutoff, use_gate, kwargs
         num_gaussians = kwargs.get('num_gaussians', 16)
+        if num_gaussians > NG_KERNEL:
+            raise NotImplementedError(f'num_gaussians > {NG_KERNEL} is not built (the kernels smear into one 16-wide feature tile)')
         start = kwargs.get('start', 0)
         self.distance_expansion = GaussianSmearing(start=start, stop=cutoff, num_gaussians=num_gaussians)
         self.update_edge = not ('update_edge' in kwargs and not kwargs['update_edge'])
@@ -259,7 +272,7 @@ class NodeEdgeNet(Module):
         if self._eng is None or sig != self._eng_sig:
             eng = _lib.Model(_lib.MDX_KIND_NET, num_blocks=self.num_blocks, cutoff=self.cutoff, update_pos=self.update_pos,
                              node_dim=self.node_dim, edge_dim=self.edge_dim,
-                             num_gaussians=self.distance_expansion.offset.numel(), smear_start=self.distance_expansion.start)
+                             num_gaussians=NG_KERNEL, smear_start=self.distance_expansion.start)
             eng.upload({**self.state_dict(), **synth_gates(self)})
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)

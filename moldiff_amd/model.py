@@ -90,7 +90,7 @@ class MolDiff(Module):
                              time_dim=self.config.diff.time_dim, num_timesteps=self.num_timesteps,
                              num_node_types=self.num_node_types, num_edge_types=self.num_edge_types,
                              node_dim=d.node_dim, edge_dim=d.edge_dim,
-                             num_gaussians=d.distance_expansion.offset.numel(), smear_start=d.distance_expansion.start)
+                             num_gaussians=16, smear_start=d.distance_expansion.start)
             eng.upload({**self.state_dict(), **synth_gates(d, 'denoiser.')})
             self._eng, self._eng_sig = eng, sig
         return self._eng.use_matrix_path(self.matrix_path)

@@ -19,7 +19,8 @@ REAL reference on CPU.  BUILD-CONTAINER ONLY (needs /root/reference, read-only).
     gradient of the `uncertainty` objective w.r.t. the positions.
   * `update_edge: false` (models/graph.py:317-320,352-361: edge features re-derived from the distances in every block, no EdgeBlocks):
     the same set.
-Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 .. 20230818).
+  * `num_gaussians: 8` (models/graph.py:309-312; fewer distance gaussians than the 16 of the shipped configs): the same set.
+Weights: the recipe of make_goldens.py applied to the variant's own state_dict (seeds 20230811 .. 20230820).
 """
 import itertools
 import json
@@ -250,13 +251,15 @@ def main():
 
     # ---- use_gate = False ('ng') and update_edge = False ('ne'): the same recipe for both ------------------------------------------------
     from oracle.make_goldens_loss import pinned_randomness
-    for tag, label, key, seeds, bseed in (('ng', 'use_gate = False', 'use_gate', (20230815, 20230816), 109),
-                                          ('ne', 'update_edge = False', 'update_edge', (20230817, 20230818), 127)):
+    for tag, label, key, val, seeds, bseed in (('ng', 'use_gate = False', 'use_gate', False, (20230815, 20230816), 109),
+                                               ('ne', 'update_edge = False', 'update_edge', False, (20230817, 20230818), 127),
+                                               ('g8', 'num_gaussians = 8', 'num_gaussians', 8, (20230819, 20230820), 131)):
         cfg = ref_shim.load_yaml_cfg('configs/train/train_MolDiff_simple.yml')
-        cfg.model.denoiser[key] = False
+        cfg.model.denoiser[key] = val
         mg = MolDiff(cfg.model, 8, 6).eval()
         sd = mg.state_dict()
-        assert not any(('.gate.' in k) if tag == 'ng' else ('edge_blocks' in k) for k in sd)
+        assert not any(('.gate.' in k) if tag == 'ng' else ('edge_blocks' in k) if tag == 'ne' else False for k in sd)
+        assert tag != 'g8' or sd['denoiser.edge_embs.0.weight'].shape == (64, 72)
         shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}
         sd.update(O.recipe_state_dict(shapes, seeds[0]))
         mg.load_state_dict(sd, strict=True)
@@ -283,7 +286,7 @@ def main():
         Pg = {k: (v.clone().requires_grad_(True) if k in ref_grads else v) for k, v in Pn.items()}
         orc = O.moldiff_loss(Pg, CFGV, tabs, node_type, node_pos, bn, half_type, hei, bh, B, t, dict(eps_pos=eps_pos, u_node=u_node, u_halfedge=u_half))
         orc['loss'].backward()
-        vt = 'nogate' if tag == 'ng' else 'noedge'
+        vt = {'ng': 'nogate', 'ne': 'noedge', 'g8': 'gauss8'}[tag]
         pins[f'variant_{vt}_param_grads'] = max(float((Pg[k].grad - gg).abs().max()) for k, gg in ref_grads.items())
         for k in ('loss', 'loss_pos', 'loss_node', 'loss_edge'):
             pins[f'variant_{vt}_{k}'] = abs(float(ref[k].detach()) - float(orc[k].detach()))
@@ -306,7 +309,7 @@ def main():
             out[f'{tag}_{k}'] = fw[k].numpy()
         out.update({f'{tag}_h_node': h_node.numpy(), f'{tag}_h_half': h_half.numpy()})
         cfgp = ref_shim.load_yaml_cfg('configs/train/train_bondpred.yml')
-        cfgp.model.encoder[key] = False
+        cfgp.model.encoder[key] = val
         mbg = BondPredictor(cfgp.model, 8, 5).eval()
         sd = mbg.state_dict()
         shapes = {k: tuple(v.shape) for k, v in sd.items() if not O.is_frozen_key(k)}

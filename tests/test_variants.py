@@ -6,8 +6,8 @@ reference (oracle/make_goldens_variants.py -> tests/golden/variants.npz).
     position gradient where the clamp cuts it
   * categorical_space = 'continuous' (models/model.py:54-56,76-78,91-93,144-148,185-187,249-251,301-304): get_loss with pinned
     draws, and the first iterations of sample() with the reference's own draws
-  * use_gate = False (models/graph.py:21-22,46-48,123-124,138-140) and update_edge = False (:317-320,352-361): forward, loss +
-    gradients, the predictor's position gradient
+  * use_gate = False (models/graph.py:21-22,46-48,123-124,138-140), update_edge = False (:317-320,352-361) and num_gaussians = 8
+    (:309-312): forward, loss + gradients, the predictor's position gradient
 """
 import copy
 
@@ -400,19 +400,20 @@ def test_gpu_continuous_sampler_default_noise_is_reproducible_and_shard_invarian
 
 
 # ---- use_gate = False ('ng') / update_edge = False ('ne') --------------------------------------------------------------------------------
-VAR = {'ng': ('use_gate', (20230815, 20230816)), 'ne': ('update_edge', (20230817, 20230818))}
+VAR = {'ng': ('use_gate', False, (20230815, 20230816)), 'ne': ('update_edge', False, (20230817, 20230818)),
+       'g8': ('num_gaussians', 8, (20230819, 20230820))}
 
 
 def _var_models(tag, device):
     key = tag + str(device)
     if key not in _models:
-        opt, seeds = VAR[tag]
+        opt, val, seeds = VAR[tag]
         cfg = copy.deepcopy(default_config('MolDiff_simple'))
-        cfg.denoiser[opt] = False
+        cfg.denoiser[opt] = val
         md = M.MolDiff(cfg, 8, 6).eval()
         md.load_state_dict(M.recipe_state_dict(md, seeds[0]), strict=True)
         cfgp = copy.deepcopy(default_config('bondpred'))
-        cfgp.encoder[opt] = False
+        cfgp.encoder[opt] = val
         mb = M.BondPredictor(cfgp, 8, 5).eval()
         mb.load_state_dict(M.recipe_state_dict(mb, seeds[1]), strict=True)
         _models[key] = (md.to(device), mb.to(device))
@@ -428,12 +429,12 @@ def _var_case(tag, device='cpu'):
     return z, args, f('t'), noise, (ei, be)
 
 
-@pytest.mark.parametrize('tag', ['ng', 'ne'])
+@pytest.mark.parametrize('tag', ['ng', 'ne', 'g8'])
 def test_variant_state_dict_and_oracle_match_the_reference_golden(tag):
     z, args, t, noise, (ei, be) = _var_case(tag)
     md, mb = _var_models(tag, 'cpu')
     assert sorted(md.state_dict()) == [str(k) for k in z[tag + '_keys']]
-    gone = '.gate.' if tag == 'ng' else 'edge_blocks'
+    gone = {'ng': '.gate.', 'ne': 'edge_blocks', 'g8': 'no such key'}[tag]
     assert not any(gone in k for k in mb.state_dict())
     P = U.params(md)
     cfg = dict(CFG_C, update_edge=(tag != 'ne'))
@@ -451,6 +452,11 @@ def test_variant_state_dict_and_oracle_match_the_reference_golden(tag):
     extra = synth_gates(md.denoiser, 'denoiser.')
     if tag == 'ng':
         assert len(extra) == 6 * (1 + 2 + 1) * 6 and all('.gate.net.' in k for k in extra)
+    elif tag == 'g8':   # dead gaussians: coeff 0 and zero weight columns
+        assert sorted(extra) == sorted(['denoiser.distance_expansion.offset', 'denoiser.distance_expansion.coeff'] + [f'denoiser.edge_embs.{i}.weight' for i in range(6)])
+        assert extra['denoiser.distance_expansion.coeff'].shape == (16,) and float(extra['denoiser.distance_expansion.coeff'][8:].abs().max()) == 0.0
+        w = extra['denoiser.edge_embs.3.weight']
+        assert w.shape == (64, 80) and float(w[:, 72:].abs().max()) == 0.0 and torch.equal(w[:, :72], md.denoiser.edge_embs[3].weight)
     else:
         assert extra['denoiser.edge_embs.0.weight'].shape == (64, 80) and float(extra['denoiser.edge_embs.0.weight'][:, :64].abs().max()) == 0.0
         assert torch.equal(extra['denoiser.edge_embs.0.weight'][:, 64:], md.denoiser.edge_embs[0].weight)
@@ -459,7 +465,7 @@ def test_variant_state_dict_and_oracle_match_the_reference_golden(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['ng', 'ne'])
+@pytest.mark.parametrize('tag', ['ng', 'ne', 'g8'])
 def test_gpu_variant_forward_loss_and_gradients_match_reference(tag):
     z, args, t, noise, (ei, be) = _var_case(tag, 'cuda')
     md, _ = _var_models(tag, 'cuda')
@@ -481,12 +487,12 @@ def test_gpu_variant_forward_loss_and_gradients_match_reference(tag):
     cfg = dict(CFG_C, update_edge=(tag != 'ne'))
     unreached = _check_param_grads_f64(z, tag, md, lambda P64: O.moldiff_loss(P64, cfg, U.tables(P64), *a64, t.cpu(), n64)['loss'])
     # with update_edge=False the embedded edge features are never read: the reference's loss does not reach the embedder either
-    assert unreached == (set() if tag == 'ng' else {'edge_embedder.weight'})
+    assert unreached == ({'edge_embedder.weight'} if tag == 'ne' else set())
     md.zero_grad(set_to_none=True)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['ng', 'ne'])
+@pytest.mark.parametrize('tag', ['ng', 'ne', 'g8'])
 def test_gpu_variant_predictor_position_gradient_matches_reference_autograd(tag):
     z, args, t, noise, (ei, be) = _var_case(tag, 'cuda')
     _, mb = _var_models(tag, 'cuda')
