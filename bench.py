@@ -788,6 +788,20 @@ def main():
                                           '(%.2f ms/step with that overhead); ms_per_step is the run without them' % (el3 / 20 * 1e3))
             line2['roofline_other'] = rb if tot_a >= tot_b else ra
             line2['kernel_ms_per_step_inline'] = {k: v[1] / 20 for k, v in prof3.items() if v[0]}
+            try:   # HBM traffic per launch from the guided step's own committed PMC passes (same rule as the headline's): the edge_a
+                # slot is 6 launches of kernel A and 8 of its tape variant per step -> their launch-weighted mean
+                import glob
+                pmG = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_guided_pmc_summary.json')) if 'split' not in os.path.basename(f))
+                ksG = json.load(open(pmG[-1]))['kernels'] if pmG and args.batch == 256 else {}
+                if all(k in ksG for k in ('edge_a2_kernel<15>', 'edge_a2_kernel<63>', 'edge_bwd2_kernel<true>')):
+                    srcG = os.path.relpath(pmG[-1], ROOT) + ' (PMC passes of the guided run; not measured in this run)'
+                    ta = (6 * ksG['edge_a2_kernel<15>']['hbm_bytes_per_launch'] + 8 * ksG['edge_a2_kernel<63>']['hbm_bytes_per_launch']) / 14
+                    tb = ksG['edge_bwd2_kernel<true>']['hbm_bytes_per_launch']
+                    for r_ in (line2['roofline'], line2['roofline_other']):
+                        r_['traffic'] = tb if 'edge_bwd2' in r_['kernel'] else ta
+                        r_['traffic_source'] = srcG
+            except Exception:
+                pass
             del sm3
         else:
             line2['roofline'] = roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, 2 * sm2.Eh, prof2)
