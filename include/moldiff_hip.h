@@ -158,6 +158,15 @@ int mdx_cat_posterior(const float* q_mats, const float* qT_onestep, int32_t K, i
 /* log_sample_categorical, diffusion.py:79-85 (u passed in) + onehot_encode, transition.py:255. */
 int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n, int64_t* cls, float* onehot,
                       void* stream);
+/* GeneralCategoricalTransition.sample_init, transition.py:331-339 (called at model.py:245-246): the prior draw.  The
+ * reference's logits there are FLOAT64 (log(init_prob + 1e-30).clamp_min(-32) of a float64 numpy array), so rand_like,
+ * the Gumbel transform of diffusion.py:79-85 and the argmax all run in float64; this entry point does the same.
+ * logits64: K (<= 8) doubles on the HOST (one row, the reference repeats it n times); u: (n,K) uniforms on the device,
+ * float64 when u_is_f64 else float32 (widened exactly); outputs (any may be NULL): cls (n) int64, onehot (n,K),
+ * log_onehot (n,K) = log(onehot.clamp(min=1e-30)) with log_off = the float32 log(1e-30) of the caller's libm,
+ * cls8 (n) one byte per row (compact trajectory frame). */
+int mdx_prior_draw(const double* logits64, int32_t K, const void* u, int32_t u_is_f64, int64_t n, int64_t* cls,
+                   float* onehot, float* log_onehot, float log_off, uint8_t* cls8, void* stream);
 /* dU/dlogits of the default 'uncertainty' guidance objective U = sum_h log sigmoid(-logsumexp_k logits[h,k])
  * (model.py:322-324); glogits (n,K).  Feed to mdx_bondpred_backward with scale = -guidance_scale to get delta. */
 int mdx_guidance_uncertainty_grad(const float* logits, int32_t K, int64_t n, float* glogits, void* stream);

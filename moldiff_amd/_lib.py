@@ -21,7 +21,7 @@ EXPORTS = [
     'mdx_graph_create', 'mdx_graph_destroy', 'mdx_graph_plan_host', 'mdx_workspace_bytes',
     'mdx_net_forward', 'mdx_node_block', 'mdx_edge_block', 'mdx_bond_ffn', 'mdx_pos_update', 'mdx_segment_sum',
     'mdx_moldiff_forward', 'mdx_sample_step', 'mdx_sample_step_full', 'mdx_bondpred_forward', 'mdx_bondpred_backward', 'mdx_bondpred_tape_bytes',
-    'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_noise',
+    'mdx_pos_posterior', 'mdx_cat_posterior', 'mdx_gumbel_argmax', 'mdx_prior_draw', 'mdx_noise',
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
     'mdx_profile_enable', 'mdx_profile_read', 'mdx_profile_kernel_name',
     'mdx_op_sgemm_nt', 'mdx_op_sgemm_tn', 'mdx_op_hgemm_nt', 'mdx_op_hgemm_tn', 'mdx_op_xgemm_nt', 'mdx_op_xgemm_tn', 'mdx_op_amp_adamw',
@@ -104,6 +104,7 @@ def lib():
         L.mdx_cat_posterior.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_prior_draw.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]
         L.mdx_noise.argtypes = [c_void_p, c_uint64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.mdx_guidance_uncertainty_grad.argtypes = [c_void_p, c_int32, c_int64, c_void_p, c_void_p]
         L.mdx_add_inplace.argtypes = [c_void_p, c_void_p, c_int64, c_void_p]
@@ -328,6 +329,22 @@ class default_matrix_path:
         _default_matrix_path = self.prev
 
 
+class pinned_matrix_path:
+    """Run a module's forward on the path a sampler resolved at construction, whatever the process default is by now: the
+    module's own `matrix_path` attribute is set for the duration of the block (its _engine() resolves that first)."""
+
+    def __init__(self, module, name):
+        self.module, self.name = module, name
+
+    def __enter__(self):
+        self.prev = self.module.matrix_path
+        self.module.matrix_path = self.name
+        return self
+
+    def __exit__(self, *exc):
+        self.module.matrix_path = self.prev
+
+
 def resolve_matrix_path(name):
     name = _default_matrix_path if name is None else name
     if name not in MATRIX_PATHS:
@@ -399,6 +416,25 @@ def cat_posterior(q_mats, qT, in0, log_vt, t, batch, is_logits=False):
     check(lib().mdx_cat_posterior(ptr(q_mats), ptr(qT), in0.shape[1], q_mats.shape[0], ptr(in0), int(is_logits),
                                   ptr(log_vt), ptr(t), ptr(batch), in0.shape[0], ptr(out), stream()))
     return out
+
+
+_LOG_EPS32 = None
+
+
+def prior_draw(init_prob, u, n, cls=None, onehot=None, log_onehot=None, cls8=None):
+    """GeneralCategoricalTransition.sample_init (models/transition.py:331-339): Gumbel-max in float64 on the float64 prior logits.
+    init_prob: float64 numpy (K); u: (n,K) device tensor, float64 or float32; outputs are written where given."""
+    global _LOG_EPS32
+    import numpy as np
+    _need_gpu(u)
+    if u.dtype not in (torch.float32, torch.float64) or not u.is_contiguous():
+        u = u.to(torch.float64).contiguous()
+    K = int(init_prob.shape[0])
+    lg = torch.log(torch.from_numpy(np.asarray(init_prob, dtype=np.float64)) + 1e-30).clamp_min(-32.).contiguous()   # float64, host
+    if _LOG_EPS32 is None:
+        _LOG_EPS32 = float(torch.log(torch.tensor([1e-30], dtype=torch.float32))[0])
+    check(lib().mdx_prior_draw(lg.data_ptr(), K, ptr(u), int(u.dtype == torch.float64), n, ptr(cls), ptr(onehot), ptr(log_onehot),
+                               _LOG_EPS32, ptr(cls8), stream()))
 
 
 def gumbel_argmax(logits, u, want_onehot=False):

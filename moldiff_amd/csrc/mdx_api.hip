@@ -556,6 +556,9 @@ int pack_model(mdx_model_s* m) {
   HIPCHK(hipMemcpy(m->arena, c.pk.host.data(), m->arena_floats * sizeof(float), hipMemcpyHostToDevice));
   for (auto& f : c.pk.fix) *f.first = m->arena + f.second;
   m->finalized = true;
+  // a handle re-finalized with weights the split path cannot hold falls back to the exact path instead of silently running
+  // float16 operands that overflowed at pack time (the caller's next mdx_model_set_matrix_path(split) is refused as usual)
+  if (!m->split_ok) m->matrix_path = MDX_MATRIX_EXACT_F32;
   return MDX_OK;
 }
 
@@ -1444,6 +1447,7 @@ extern "C" int mdx_bondpred_forward(mdx_model_t m, mdx_graph_t g, const float* h
   EmbedArgs ea{};
   ea.N = (int)g->N; ea.E = (int)g->E; ea.Kn = cf.num_node_types; ea.Ke = cf.num_edge_types; ea.time_dim = cf.time_dim;
   ea.T = std::max(cf.num_timesteps, 1); ea.nd_emb = MDX_ND - cf.time_dim; ea.ed_emb = MDX_ED - cf.time_dim; ea.xn = h_node; ea.xe = nullptr;
+  ea.zero_time = cf.num_timesteps == 0;  // time-free predictor: the reference replaces t by zeros (bond_predictor.py:141-144), whatever the caller passes
   ea.int2ref = g->int2ref; ea.l = g->left; ea.r = g->right; ea.node_graph = g->node_graph; ea.t = t; ea.Wn = m->Wn;
   ea.We = m->We; ea.toff = m->toff; ea.tcoef = m->tcoef; ea.Hn = w.Hn; ea.He = w.HeA; ea.tn = w.tn;
   ea.te = tape ? tp.te : w.te;
@@ -1617,6 +1621,14 @@ extern "C" int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K,
                                  void* stream) {
   if (K < 1 || n < 0 || (n > 0 && (!logits || !u))) return fail(MDX_ERR_ARG, "bad argument");
   launch_gumbel_argmax(logits, u, K, (int)n, cls, onehot, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
+extern "C" int mdx_prior_draw(const double* logits64, int32_t K, const void* u, int32_t u_is_f64, int64_t n, int64_t* cls,
+                              float* onehot, float* log_onehot, float log_off, uint8_t* cls8, void* stream) {
+  if (K < 1 || K > 8 || n < 0 || !logits64 || (n > 0 && !u)) return fail(MDX_ERR_ARG, "bad argument");
+  launch_prior_draw(logits64, K, u, u_is_f64 != 0, (int)n, cls, onehot, log_onehot, log_off, cls8, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return MDX_OK;
 }

@@ -340,6 +340,7 @@ struct EmbedArgs {
   const int *l, *r;       // internal
   const int* node_graph;  // (N)
   const int64_t* t;       // (B) device
+  int zero_time;          // != 0: the time-free bond predictor (num_timesteps == 0): t is ignored, every row's time is 0 (bond_predictor.py:141-144)
   const float *Wn, *We;   // node_embedder (nd_emb x Kn), edge_embedder (ed_emb x Ke or 2*Kn)
   const float *toff, *tcoef;  // time smearing tables
   float *Hn, *He, *tn, *te;   // outputs: (N,256) (E,64) (N) (E)
@@ -367,6 +368,8 @@ void launch_uncertainty_grad(const float* logits, int K, int n, float* glogits, 
 void launch_add_inplace(float* dst, const float* src, int n, hipStream_t s);
 void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int64_t* cls, float* onehot, hipStream_t s,
                           uint8_t* cls8 = nullptr);
+void launch_prior_draw(const double* logits64_host, int K, const void* u, bool u_f64, int n, int64_t* cls, float* onehot,
+                       float* log_onehot, float log_off, uint8_t* cls8, hipStream_t s);
 void launch_fill_i64(int64_t* p, int64_t v, int n, hipStream_t s);
 void launch_philox_noise(uint64_t seed, int step, const int* node_graph, const int* node_local, const int* he_graph,
                          const int* he_local, const int64_t* mol_ids, int N, int Eh, int Kn, int Ke, float* eps_pos,

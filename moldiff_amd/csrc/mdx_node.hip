@@ -237,7 +237,7 @@ __device__ __forceinline__ void embed_node_block(const EmbedArgs& a, int blk, fl
   for (int rep = 0; rep < EMB_NODE_REPS; ++rep) {   // 4 atoms per pass: the staged weight serves 16 atoms per workgroup
     const int v = (blk * EMB_NODE_REPS + rep) * (MDX_WG / 64) + (tid >> 6);
     if (v >= a.N) return;
-    const int64_t t = a.t[a.node_graph[v]];
+    const int64_t t = a.zero_time ? 0 : a.t[a.node_graph[v]];
     float x[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = k < Kn ? a.xn[(size_t)v * Kn + k] : 0.f;
@@ -277,7 +277,7 @@ __device__ __forceinline__ void embed_edge_block(const EmbedArgs& a, int blk, fl
   const int e = blk * (MDX_WG / 16) + (tid >> 4), f0 = 4 * (tid & 15);
   if (e >= a.E) return;
   const int nl = a.l[e], nr = a.r[e];
-  const int64_t t = a.t[a.node_graph[nl]];
+  const int64_t t = a.zero_time ? 0 : a.t[a.node_graph[nl]];
   float x[EMB_KMAX];
   if (a.xe) {
     int ref = a.int2ref ? a.int2ref[e] : e;

@@ -132,6 +132,35 @@ __global__ void gumbel_argmax_kernel(const float* __restrict__ logits, const flo
   gumbel_argmax_row(logits, u, K, n, cls, onehot, cls8, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// Prior draw of the categorical chain (reference models/transition.py:331-339 sample_init): Gumbel-max over the SAME K float64
+// logits log(init_prob + 1e-30).clamp_min(-32) for every row, the whole expression of diffusion.py:79-85 evaluated in float64
+// as the reference does at this one place (its logits tensor is float64, so rand_like / log / argmax are too).  The uniforms
+// are float64 (explicit, tests) or the float32 Philox draws of mdx_noise widened exactly.
+struct PriorLogits { double v[8]; };
+template <class U>
+__global__ void prior_draw_kernel(const PriorLogits lg, const U* __restrict__ u, int K, int n, int64_t* __restrict__ cls,
+                                  float* __restrict__ onehot, float* __restrict__ log_onehot, float log_off,
+                                  uint8_t* __restrict__ cls8) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = 0;
+  double bv = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double g = -log(-log((double)u[(size_t)i * K + k] + 1e-30) + 1e-30);
+    const double z = g + lg.v[k];
+    if (k == 0 || z > bv) {  // first maximum wins, like torch.argmax
+      bv = z;
+      best = k;
+    }
+  }
+  if (cls) cls[i] = best;
+  if (cls8) cls8[i] = (uint8_t)best;
+  for (int k = 0; k < K; ++k) {
+    if (onehot) onehot[(size_t)i * K + k] = (k == best) ? 1.f : 0.f;
+    if (log_onehot) log_onehot[(size_t)i * K + k] = (k == best) ? 0.f : log_off;  // log(onehot.clamp(min=1e-30)), transition.py:338
+  }
+}
+
 // The five transition launches of a sampling step (models/model.py:287-307) in one: thread i does position component i, atom
 // row i and half-edge row i through the same row functions as the stand-alone kernels (a row's posterior is written and read
 // back by the same thread).  MolDiff's class counts (8 atom types, 6 bond types) only; other counts take the separate kernels.
@@ -277,6 +306,16 @@ void launch_gumbel_argmax(const float* logits, const float* u, int K, int n, int
                           uint8_t* cls8) {
   if (n <= 0) return;
   hipLaunchKernelGGL(gumbel_argmax_kernel, dim3((n + 255) / 256), dim3(256), 0, s, logits, u, K, n, cls, onehot, cls8);
+}
+
+void launch_prior_draw(const double* logits64, int K, const void* u, bool u_f64, int n, int64_t* cls, float* onehot, float* log_onehot,
+                       float log_off, uint8_t* cls8, hipStream_t s) {
+  if (n <= 0) return;
+  PriorLogits lg{};
+  for (int k = 0; k < K && k < 8; ++k) lg.v[k] = logits64[k];
+  const dim3 g((n + 255) / 256), b(256);
+  if (u_f64) hipLaunchKernelGGL(prior_draw_kernel<double>, g, b, 0, s, lg, (const double*)u, K, n, cls, onehot, log_onehot, log_off, cls8);
+  else hipLaunchKernelGGL(prior_draw_kernel<float>, g, b, 0, s, lg, (const float*)u, K, n, cls, onehot, log_onehot, log_off, cls8);
 }
 
 namespace {

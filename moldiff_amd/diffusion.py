@@ -106,15 +106,30 @@ class deferred_class_checks:
             return None
         dev = torch.stack([m for m, _ in self.items])
         limits = [k for _, k in self.items]
-        host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+        # Multi-rank: every rank must fail in the SAME step, or the healthy ranks sit in the next gradient all-reduce until the
+        # collective's watchdog ends them.  One MAX all-reduce of a flag (a device op on the step's stream, no host round trip; every
+        # rank issues it at the same point of its step) tells everybody that somebody's batch is out of range.
+        import torch.distributed as dist
+        peers = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            peers = (dev >= torch.tensor(limits, dtype=dev.dtype, device=dev.device)).any().to(torch.int32).reshape(1)
+            dist.all_reduce(peers, op=dist.ReduceOp.MAX)
+            dev = torch.cat([dev, peers.to(dev.dtype)])
+        host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=dev.is_cuda)
         host.copy_(dev, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = None
+        if dev.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
 
         def verify():
-            ev.synchronize()
-            for m, k in zip(host.tolist(), limits):
+            if ev is not None:
+                ev.synchronize()
+            vals = host.tolist()
+            for m, k in zip(vals, limits):
                 assert m < k, f'Error: {m} >= {k}'
+            if peers is not None:
+                assert vals[-1] == 0, 'Error: class id out of range on another rank (models/diffusion.py:54 raised there)'
         return verify
 
 
@@ -127,8 +142,7 @@ def index_to_log_onehot(x, num_classes, checked=True):
             deferred_class_checks._active.items.append((x.max(), num_classes))
             # one_hot on an out-of-range id trips a device-side assert long before the postponed check would report it: encode
             # the clamped ids, so that the reference's AssertionError (one step later) is what the caller sees.  In a multi-rank run
-            # the rank that raises leaves its peers in that step's gradient all-reduce until the collective's watchdog ends them
-            # (an invalid-data error path; checking before the collective would need the host round trip this context avoids).
+            # finish() all-reduces the flag, so every rank raises in the same step.
             x = x.clamp(max=num_classes - 1)
         else:
             assert x.max().item() < num_classes, f'Error: {x.max().item()} >= {num_classes}'

@@ -88,6 +88,27 @@ def recipe_state_dict(module, seed):
     return sd
 
 
+def stress_state_dict(module, seed):
+    """Heavy-tailed "stress" weights on top of the base recipe (trained-weight parity cannot be pinned offline,
+    this probes what a trained checkpoint may hold that N(0, small) weights do not): every LayerNorm gain log-uniform in
+    [0.1, 30], every bias x 8, and block 2's two `out_transform` matrices x 16 so the residual streams reach 10^2 - 10^3.
+    Deterministic: its own PCG64 stream (seed + 1), keys in sorted order."""
+    sd = recipe_state_dict(module, seed)
+    g = np.random.Generator(np.random.PCG64(seed + 1))
+    for k in sorted(sd):
+        if is_frozen_key(k):
+            continue
+        w = sd[k]
+        if w.dim() == 1 and k.endswith('.weight'):      # LayerNorm gain
+            u = g.random(tuple(w.shape), dtype=np.float32)
+            sd[k] = torch.from_numpy(np.exp(np.float32(math.log(0.1)) + u * np.float32(math.log(30.0) - math.log(0.1))).astype(np.float32)).to(w.device)
+        elif w.dim() == 1:                              # bias
+            sd[k] = w * 8.0
+        elif '_blocks.2.out_transform.weight' in k:
+            sd[k] = w * 16.0
+    return sd
+
+
 def default_config(name):
     """Model hyper-parameters of the three shipped training configs (the `model:` section that a checkpoint
     carries as ckpt['config'].model): 'MolDiff' (configs/train/train_MolDiff.yml:1-36), 'MolDiff_simple'

@@ -289,6 +289,12 @@ class _Sampler:
         self.N, self.Eh = int(batch_node.numel()), int(batch_halfedge.numel())
         self.n_graphs = n_graphs
         self.eng = m._engine()
+        # The matrix path is state of the (shared) engine handle.  A sampler resolves it ONCE, here -- module attribute, else the
+        # process default in force at construction -- and re-applies it before every launch, so a sampler built inside
+        # `with default_matrix_path(...)` keeps its path after the context exits and another sampler / forward / get_loss on the
+        # same model cannot flip it under a live chain.
+        self._path = self.eng._path
+        self._bp_path = self.bp_eng._path if self.guidance is not None else None
         edge_index = torch.cat([halfedge_index, halfedge_index.flip(0)], dim=1)
         self.g = _lib.Graph(edge_index, batch_node, n_graphs, mol_ids)
         self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
@@ -344,20 +350,21 @@ class _Sampler:
     def init(self):
         """Prior draw (models/model.py:244-263): classes ~ init_prob by Gumbel-max, positions ~ N(0, I)."""
         m, L, dev = self.m, _lib.lib(), self.dev
+        u_n, u_h = self.u_n, self.u_h
         if self.noise is not None:
             e, a, b = self.noise(0)
-            self.eps.copy_(e); self.u_n.copy_(a); self.u_h.copy_(b)
+            self.eps.copy_(e)
+            u_n = a.to(dev).contiguous() if a.dtype == torch.float64 else self.u_n.copy_(a)
+            u_h = b.to(dev).contiguous() if b.dtype == torch.float64 else self.u_h.copy_(b)
         else:
             _lib.check(L.mdx_noise(self.g.h, ctypes.c_uint64(self.seed), 0, self.Kn, self.Ke, _lib.ptr(self.eps),
                                    _lib.ptr(self.u_n), _lib.ptr(self.u_h), _lib.stream()))
-        for tr, n, K, u, oh, ids, logs in ((m.node_transition, self.N, self.Kn, self.u_n, self.h_node, self.node_ids, self.log_node),
-                                           (m.edge_transition, self.Eh, self.Ke, self.u_h, self.h_half, self.half_ids, self.log_half)):
-            logit = torch.log(torch.from_numpy(tr.init_prob).float() + 1e-30).clamp_min(-32.).to(dev)
-            logit = logit.unsqueeze(0).repeat(n, 1).contiguous()
-            cls = torch.empty(n, dtype=torch.int64, device=dev)
-            _lib.check(L.mdx_gumbel_argmax(_lib.ptr(logit), _lib.ptr(u), K, n, _lib.ptr(cls), _lib.ptr(oh[0]), _lib.stream()))
-            ids[0].copy_(cls)
-            torch.log(oh[0].clamp(min=1e-30), out=logs[0])
+        # the prior draw is the one place where the reference computes in float64 (models/transition.py:331-339: its logits are a
+        # float64 numpy array moved to the device): mdx_prior_draw evaluates the Gumbel-max there in float64 too.  Explicit noise
+        # may be float64 (the reference's rand_like dtype at this point) or float32.
+        for tr, n, u, oh, ids, logs in ((m.node_transition, self.N, u_n, self.h_node, self.node_ids, self.log_node),
+                                        (m.edge_transition, self.Eh, u_h, self.h_half, self.half_ids, self.log_half)):
+            _lib.prior_draw(tr.init_prob, u, n, onehot=oh[0], log_onehot=logs[0], cls8=ids[0])
         self.pos_traj[0].copy_(self.eps)
         self.cur, self.lcur, self.pcur = 0, 0, 0
 
@@ -378,6 +385,9 @@ class _Sampler:
         nxt = _lib.MdxState(P(self.h_node[n]), P(self.pos_traj[pn]), P(self.h_half[n]), P(self.log_node[ln]), P(self.log_half[ln]))
         nz = _lib.MdxStepNoise(self.seed, draw, P(self.eps), P(self.u_n), P(self.u_h))
         ws, nb = self.g.workspace(self.dev)
+        self.eng.use_matrix_path(self._path)
+        if self._bp_path is not None:
+            self.bp_eng.use_matrix_path(self._bp_path)
         _lib.check(L.mdx_sample_step_full(self.eng.h, self.g.h, ctypes.byref(self.tables), T - 1 - i, P(self.bn), P(self.bh),
                                           ctypes.byref(cur), ctypes.byref(nxt), P(self.preds[0]), P(self.preds[1]), P(self.preds[2]),
                                           ctypes.byref(nz), P(self.t), P(self.node_ids[pn]), P(self.half_ids[pn]),
@@ -392,7 +402,7 @@ class _Sampler:
         the HIP backward of the predictor.  (The default 'uncertainty' objective lives inside mdx_sample_step_full.)"""
         g = self.g
         gui_type, scale = self.guidance
-        with torch.enable_grad():
+        with torch.enable_grad(), _lib.pinned_matrix_path(self.bp, self._bp_path):
             pos_in = pos.detach().clone().requires_grad_(True)
             pred = self.bp(h_node.detach(), pos_in, self.bn, self.edge_index, self.batch_edge, self.t[:self.n_graphs], _graph=g)
             sign = -1.0
@@ -477,6 +487,7 @@ class _ContinuousSampler:
         self.eps, self.u_n, self.u_h = torch.empty(self.N, 3, **f32), torch.empty(self.N, self.Kn, **f32), torch.empty(self.Eh, self.Ke, **f32)
         self.preds = None
         self.cur = 0
+        self._path = self.eng._path   # resolved once per sampler, like _Sampler
 
     def _frame(self, j):
         return j if self.return_traj else j % 2
@@ -504,7 +515,8 @@ class _ContinuousSampler:
         t = self.t[:self.n_graphs]
         e, a, b = self._draw(i + 1)
         h_node, pos, h_half = self.node_traj[c], self.pos_traj[c], self.half_traj[c]
-        preds = m.forward(h_node, pos, self.bn, torch.cat([h_half, h_half], dim=0), self.edge_index, self.batch_edge, t, _graph=self.g)
+        with _lib.pinned_matrix_path(m, self._path):
+            preds = m.forward(h_node, pos, self.bn, torch.cat([h_half, h_half], dim=0), self.edge_index, self.batch_edge, t, _graph=self.g)
         self.pos_traj[n].copy_(m.pos_transition.get_prev_from_recon(pos, preds['pred_pos'], t, self.bn, eps=e))
         self.node_traj[n].copy_(m.node_transition.get_prev_from_recon(h_node, preds['pred_node'], t, self.bn, eps=a))
         self.half_traj[n].copy_(m.edge_transition.get_prev_from_recon(h_half, preds['pred_halfedge'], t, self.bh, eps=b))

@@ -200,7 +200,8 @@ class Trainer:
             verify()
 
     def state_dict(self):
-        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr, 'amp_state': self.state.clone()}
+        return {'m': self.m, 'v': self.v, 'steps': self.steps, 'lr': self.lr, 'amp_state': self.state.clone(),
+                'amp_scaled': bool(self._scaled), 'precision': self.precision}
 
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v'])
@@ -211,7 +212,9 @@ class Trainer:
             # (its growth is disabled), a scaled mode must not start from the 1.0 an unscaled run stored
             if not self._scaled:
                 self.state[0], self.state[1] = 1.0, 0.0
-            elif float(sd['amp_state'][0]) == 1.0:
+            elif not sd.get('amp_scaled', float(sd['amp_state'][0]) != 1.0):
+                # written by an unscaled mode (checkpoints older than the 'amp_scaled' flag: inferred from a scale of exactly 1.0; a
+                # float16 run that legitimately backed off to 2^0 is told apart by the flag)
                 self.state[0], self.state[1] = 65536.0, 0.0
         else:
             self.state[2] = float(sd['steps'])

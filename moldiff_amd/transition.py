@@ -137,11 +137,15 @@ class GeneralCategoricalTransition(nn.Module):
         return mask * nll_v + (1 - mask) * kl_v
 
     def sample_init(self, n, u=None):
-        """Draw from the prior by Gumbel-max on float64 logits (the reference's dtype at this point)."""
+        """Draw from the prior by Gumbel-max on float64 logits (the reference's dtype at this point, models/transition.py:331-339):
+        one library call (``mdx_prior_draw``).  u: optional (n,K) uniforms, float64 or float32."""
         dev = self.q_mats.device
-        logits = torch.log(torch.from_numpy(self.init_prob) + self.eps).clamp_min(-32.).to(dev)
-        logits = logits.unsqueeze(0).repeat(n, 1)
+        K = self.num_classes
         if u is None:
-            u = torch.rand_like(logits)
-        cls = (logits - torch.log(-torch.log(u + 1e-30) + 1e-30)).argmax(dim=-1)
-        return cls, self.onehot_encode(cls), index_to_log_onehot(cls, self.num_classes, checked=False) if n > 0 else torch.zeros(0, self.num_classes, device=dev)
+            u = torch.rand(n, K, dtype=torch.float64, device=dev)
+        cls = torch.empty(n, dtype=torch.int64, device=dev)
+        oh = torch.empty(n, K, dtype=torch.float32, device=dev)
+        lg = torch.empty(n, K, dtype=torch.float32, device=dev)
+        if n > 0:
+            _lib.prior_draw(self.init_prob, u.to(dev), n, cls=cls, onehot=oh, log_onehot=lg)
+        return cls, oh, lg

@@ -582,6 +582,27 @@ def recipe_state_dict(shapes, seed):
     return out
 
 
+def stress_state_dict(shapes, seed):
+    """Heavy-tailed "stress" weights on top of the base recipe; the same transform as moldiff_amd.harness.stress_state_dict, restated (trained-weight parity cannot be pinned offline,
+    this probes what a trained checkpoint may hold that N(0, small) weights do not): every LayerNorm gain log-uniform in
+    [0.1, 30], every bias x 8, and block 2's two `out_transform` matrices x 16 so the residual streams reach 10^2 - 10^3.
+    Deterministic: its own PCG64 stream (seed + 1), keys in sorted order."""
+    sd = recipe_state_dict(shapes, seed)
+    g = np.random.Generator(np.random.PCG64(seed + 1))
+    for k in sorted(sd):
+        if is_frozen_key(k):
+            continue
+        w = sd[k]
+        if w.dim() == 1 and k.endswith('.weight'):      # LayerNorm gain
+            u = g.random(tuple(w.shape), dtype=np.float32)
+            sd[k] = torch.from_numpy(np.exp(np.float32(math.log(0.1)) + u * np.float32(math.log(30.0) - math.log(0.1))).astype(np.float32)).to(w.device)
+        elif w.dim() == 1:                              # bias
+            sd[k] = w * 8.0
+        elif '_blocks.2.out_transform.weight' in k:
+            sd[k] = w * 16.0
+    return sd
+
+
 # --------------------------------------------------------------------------------------
 # data side of the training loop (test infrastructure for moldiff_amd/data.py)
 # --------------------------------------------------------------------------------------

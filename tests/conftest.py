@@ -20,3 +20,22 @@ def pytest_configure(config):
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
 
+
+
+# ---- both matrix paths under ONE suite ------------------------------------------------------------------
+# A test marked `@pytest.mark.usefixtures('matrix_path')` (tests.util.both_paths) runs twice: on the exact fp32 MFMA path and on
+# the split float16 path, selected process-wide for the duration of the test (`moldiff_amd._lib.default_matrix_path`).  Same
+# assertions on both; where a tolerance depends on the path it reads `tests.util.current_matrix_path()` and says why.
+MATRIX_PATHS = ('exact_f32', 'split_f16')
+
+
+def pytest_generate_tests(metafunc):
+    if 'matrix_path' in metafunc.fixturenames:
+        metafunc.parametrize('matrix_path', MATRIX_PATHS, indirect=True)
+
+
+@pytest.fixture
+def matrix_path(request):
+    from moldiff_amd import _lib
+    with _lib.default_matrix_path(request.param):
+        yield request.param

@@ -154,3 +154,44 @@ def test_replicas_start_from_rank0_weights_even_with_different_init_streams():
     assert np.array_equal(a0, b0)               # rank 0 keeps its weights
     assert np.array_equal(a1, a0)               # rank 1 now holds them too ...
     assert np.array_equal(lin1, lin0)           # ... and the module's parameters are views of the synced buffer
+
+
+# ---- deferred class-range check: every rank fails in the same step ----------------------------------------------
+def _defer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from moldiff_amd.diffusion import deferred_class_checks
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    outcome = []
+    for bad_rank in (None, 1):              # a clean step, then a step in which ONLY rank 1 holds an out-of-range class id
+        with deferred_class_checks() as chk:
+            chk.items.append((torch.tensor(7 if rank != bad_rank else 9), 8))     # (max id of the batch, num_classes)
+            chk.items.append((torch.tensor(5), 6))
+        verify = chk.finish()
+        try:
+            verify()
+            outcome.append('ok')
+        except AssertionError as e:
+            outcome.append(str(e))
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_deferred_class_check_raises_on_every_rank_in_the_same_step():
+    """The rank with the bad batch raises the reference's AssertionError (models/diffusion.py:54); its peer raises too instead of
+    waiting in the next gradient all-reduce for a rank that has left."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_defer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == 'ok'
+    assert res[1][1] == 'Error: 9 >= 8'
+    assert 'another rank' in res[0][1]

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+@U.both_paths
 def test_bondpred_forward_vs_golden():
     g = U.gold('forward.npz')
     bn, hei, bh, ei, be = U.graph_from_sizes(g['sizes'])
@@ -26,6 +27,7 @@ def test_bondpred_forward_vs_golden():
     assert U.maxdiff(out, g['tmix_bond_logits']) < 2e-5
 
 
+@U.both_paths
 @pytest.mark.parametrize('tag', ['n12', 'n101'])
 def test_guidance_delta_vs_golden(tag):
     g = U.gold('guidance.npz')
@@ -43,6 +45,7 @@ def test_guidance_delta_vs_golden(tag):
     assert U.maxdiff(delta, ref) <= 1e-3 * float(np.abs(ref).max()) + 1e-9
 
 
+@U.both_paths
 def test_backward_of_arbitrary_logit_functional_vs_oracle_autograd():
     """Any scalar of the logits works (the other guidance types of model.py:317-359): random cotangent."""
     bn, hei, bh, ei, be = U.graph_from_sizes([6, 9, 4])
@@ -64,6 +67,7 @@ def test_backward_of_arbitrary_logit_functional_vs_oracle_autograd():
     assert U.maxdiff(got, ref) <= 1e-3 * float(ref.abs().max())
 
 
+@U.both_paths
 def test_guidance_gradient_with_distances_straddling_the_cutoff_vs_oracle_autograd():
     """The clamp of GaussianSmearing passes the gradient on the closed interval [0, cutoff] and blocks it beyond
     (torch.clamp's backward): pairs beyond the predictor's 20 A cutoff contribute nothing to dL/dpos through their own

@@ -24,6 +24,7 @@ def _fwd_inputs(sizes, seed):
     return bn, hei, bh, ei, be, xn, xh, pos, t
 
 
+@U.both_paths
 @pytest.mark.parametrize('sizes', [[1, 7, 2, 1, 0, 5], [2, 2], [3]])
 def test_forward_with_degenerate_molecules_matches_oracle(sizes):
     bn, hei, bh, ei, be, xn, xh, pos, t = _fwd_inputs(sizes, 3)
@@ -36,6 +37,7 @@ def test_forward_with_degenerate_molecules_matches_oracle(sizes):
     assert U.maxdiff(out['pred_pos'], ref['pred_pos']) < 1e-4
 
 
+@U.both_paths
 def test_molecule_larger_than_a_tile_matches_oracle():
     """n = 90: every node's run of 89 outgoing edges spans several 48-edge tiles; n = 64 is the old 'max'."""
     bn, hei, bh, ei, be, xn, xh, pos, t = _fwd_inputs([90, 64], 4)
@@ -49,6 +51,7 @@ def test_molecule_larger_than_a_tile_matches_oracle():
     assert U.maxdiff(out['pred_pos'], ref['pred_pos']) < 2e-4
 
 
+@U.both_paths
 def test_empty_batch_and_single_atom_batch_do_not_crash():
     m = U.moldiff('MolDiff_simple', DEV)
     for sizes in ([], [1], [1, 1, 1]):
@@ -63,6 +66,7 @@ def test_empty_batch_and_single_atom_batch_do_not_crash():
         assert st['h_halfedge'].shape == (0, 6)
 
 
+@U.both_paths
 def test_general_graph_not_molecule_layout():
     """NodeEdgeNet on an arbitrary directed graph given in shuffled edge order (ring + chords, asymmetric degrees):
     the kernels rely only on the CSR plan, not on the fully-connected triangular layout."""
@@ -86,6 +90,7 @@ def test_general_graph_not_molecule_layout():
     assert U.maxdiff(o[0], ref[0]) < 1e-4 and U.maxdiff(o[2], ref[2]) < 1e-4 and U.maxdiff(o[1], ref[1]) < 2e-4
 
 
+@U.both_paths
 def test_coincident_atoms_propagate_nan_like_the_reference():
     """G10 of SURVEY.md: w*rel/d/(d+1) with d == 0 gives NaN in the reference; it must not be 'fixed'."""
     bn, hei, bh, ei, be, xn, xh, pos, t = _fwd_inputs([4], 5)
@@ -127,6 +132,7 @@ def test_wrong_handle_kind_and_small_workspace_are_reported():
     assert rc == 3 and b'workspace too small' in _lib.lib().mdx_last_error()
 
 
+@U.both_paths
 def test_distance_smearing_clamps_at_the_cutoff_like_the_reference():
     """GaussianSmearing (models/common.py:233-237) clamps d to [0, cutoff] before the Gaussians: pairs beyond the denoiser's
     15 A cutoff (and well inside the first Gaussian, d ~ 1e-3) must give what the reference gives, through the FUSED path

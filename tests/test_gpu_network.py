@@ -55,6 +55,7 @@ def test_pos_update_vs_golden(i):
     assert U.maxdiff(out, g[f'posupdate{i}_out']) < 2e-5
 
 
+@U.both_paths
 @pytest.mark.parametrize('tag,sizes', [('n12', [5, 7]), ('n204', None)])
 def test_node_edge_net_vs_golden(tag, sizes):
     gd = U.gold('nodeedgenet.npz')
@@ -95,6 +96,7 @@ def test_segment_sum_matches_index_add():
             assert U.maxdiff(out, ref) < 1e-5
 
 
+@U.both_paths
 @pytest.mark.parametrize('tval', ['t999', 't500', 't0', 'tmix'])
 def test_moldiff_forward_vs_golden(tval):
     g = U.gold('forward.npz')

@@ -55,77 +55,9 @@ def test_split_path_is_selected_and_actually_differs_from_the_exact_path():
         _lib.default_matrix_path('fp8')
 
 
-@pytest.mark.parametrize('tv', ['t999', 't500', 't0', 'tmix'])
-def test_split_moldiff_forward_vs_reference_golden(split_path, tv):
-    from tests.test_gpu_network import test_moldiff_forward_vs_golden
-    test_moldiff_forward_vs_golden(tv)
-
-
-@pytest.mark.parametrize('tag,sizes', [('n12', [5, 7]), ('n204', None)])
-def test_split_node_edge_net_vs_reference_golden(split_path, tag, sizes):
-    from tests.test_gpu_network import test_node_edge_net_vs_golden
-    test_node_edge_net_vs_golden(tag, sizes)
-
-
-@pytest.mark.parametrize('window', ['hi', 'lo'])
-def test_split_step_replay_simple_vs_reference_golden(split_path, window):
-    """bit-exact class ids, positions / log-posteriors within the contract, fp64-arbitrated on the ill-conditioned window"""
-    from tests.test_gpu_sampling import _replay
-    _replay('MolDiff_simple', 'simple', window)
-
-
-@pytest.mark.parametrize('window', ['hi', 'lo'])
-def test_split_step_replay_guided_vs_reference_golden(split_path, window):
-    from tests.test_gpu_sampling import _replay
-    _replay('MolDiff', 'guided', window, guided=True)
-
-
-def test_split_one_full_size_step_matches_oracle(split_path):
-    """BASELINE config #2's own batch (256 molecules), fp64-arbitrated: max(contract, 1.5 |oracle32 - fp64|)."""
-    from tests.test_gpu_fullsize import test_one_full_size_step_matches_oracle
-    test_one_full_size_step_matches_oracle()
-
-
-def test_split_one_full_size_guided_step_matches_oracle(split_path):
-    """Every forward quantity under the exact path's own 1.5x rule.  The guidance increment's MAXIMUM error is a kink event on one
-    atom of the 6,279 (1.6e-6 where the exact path's own kink event on another atom is 7.6e-7 and the CPU fp32 oracle's 4.6e-7;
-    medians 1.3e-10 / 1.5e-10, profiles/r4_split_delta_diag.txt): that ONE clause gets 4x the oracle's own maximum instead of 2x (still
-    capped at 2e-6 absolute), rms asserted as for the exact path."""
-    from tests.test_gpu_fullsize import test_one_full_size_guided_step_matches_oracle
-    with U.tail_factor(4.0, key='delta'):
-        test_one_full_size_guided_step_matches_oracle()
-
-
-def test_split_free_running_chain_keeps_class_ids_for_20_steps(split_path):
-    from tests.test_gpu_round3 import test_free_running_chain_bit_equal_for_twenty_steps
-    test_free_running_chain_bit_equal_for_twenty_steps()
-
-
-def test_split_bond_predictor_logits_and_gradient_vs_golden(split_path):
-    from tests import test_gpu_bondpred as TB
-    TB.test_bondpred_forward_vs_golden()
-    for tag in ('n12', 'n101'):
-        TB.test_guidance_delta_vs_golden(tag)
-    TB.test_backward_of_arbitrary_logit_functional_vs_oracle_autograd()
-    TB.test_guidance_gradient_with_distances_straddling_the_cutoff_vs_oracle_autograd()
-
-
-@pytest.mark.parametrize('sizes', [[1, 7, 2, 1, 0, 5], [2, 2], [3]])
-def test_split_forward_with_degenerate_molecules_matches_oracle(split_path, sizes):
-    """single atoms (no edges), empty molecules, odd numbers of 16-row units per 32-row work item"""
-    from tests.test_gpu_edgecases import test_forward_with_degenerate_molecules_matches_oracle
-    test_forward_with_degenerate_molecules_matches_oracle(sizes)
-
-
-def test_split_edge_cases(split_path):
-    """a molecule whose node runs span several units, the empty / single-atom batches, a general (non-molecule) graph in shuffled edge
-    order, and NaN propagation from coincident atoms -- the exact path's edge-case tests on the split kernels"""
-    from tests import test_gpu_edgecases as TE
-    TE.test_molecule_larger_than_a_tile_matches_oracle()
-    TE.test_empty_batch_and_single_atom_batch_do_not_crash()
-    TE.test_general_graph_not_molecule_layout()
-    TE.test_coincident_atoms_propagate_nan_like_the_reference()
-    TE.test_distance_smearing_clamps_at_the_cutoff_like_the_reference()
+# (The exact path's parity tests used to be re-run here one by one under the split path.  Since round 5 every sampling-path test is
+# parametrized over BOTH matrix paths where it is defined -- tests/conftest.py `matrix_path`, `@U.both_paths` -- so the wrappers are
+# gone; what stays here is what is specific to the split path.)
 
 
 def test_split_path_refuses_weights_outside_float16_range():

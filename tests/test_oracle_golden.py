@@ -276,3 +276,37 @@ def test_pinning_record_says_bit_exact():
             assert d <= 2.0 ** -23, (name, d)
         else:
             assert d == 0.0, (name, d)
+
+
+def test_oracle_matches_reference_on_stress_weights():
+    """tests/golden/stress.npz (oracle/make_goldens_stress.py: the REAL reference with heavy-tailed weights -- LayerNorm gains up to
+    30, biases x 8, residual streams 10^2 - 10^3): the oracle's forward, bond logits, guidance increment and one guided loop
+    iteration, N = 12 and N = 101.  Outputs are O(10): tolerances relative to each quantity's scale."""
+    g = U.gold('stress.npz')
+    P, Pb = U.params(U.moldiff_stress()), U.params(U.bondpred_stress())
+    for tag in ('n12', 'n101'):
+        bn, hei, bh, ei, be = U.graph_from_sizes(g[f'{tag}_sizes'])
+        xn = F.one_hot(torch.from_numpy(g[f'{tag}_node_type']), 8).float()
+        xh = F.one_hot(torch.from_numpy(g[f'{tag}_halfedge_type']), 6).float()
+        pos, t = U.t32(g[f'{tag}_pos']), torch.from_numpy(g[f'{tag}_t'])
+        with torch.no_grad():
+            o = O.moldiff_forward(P, U.CFG, xn, pos, bn, torch.cat([xh, xh]), ei, be, t)
+        for k in o:
+            assert U.maxdiff(o[k], g[f'{tag}_{k}']) <= 1e-5 * max(1.0, float(np.abs(g[f'{tag}_{k}']).max())), (tag, k)
+        d, lg = O.guidance_delta(Pb, U.CFGB, xn, pos, bn, ei, be, t, 1e-4)
+        assert U.maxdiff(lg, g[f'{tag}_bond_logits']) <= 1e-5 * float(np.abs(g[f'{tag}_bond_logits']).max())
+        assert U.maxdiff(d, g[f'{tag}_delta']) <= 1e-8 + 1e-3 * float(np.abs(g[f'{tag}_delta']).max())
+        st = {'h_node': xn, 'pos': pos, 'h_halfedge': xh, 'log_node': U.t32(g[f'{tag}_step_log_node_in']),
+              'log_halfedge': U.t32(g[f'{tag}_step_log_halfedge_in'])}
+        noise = {k: U.t32(g[f'{tag}_step_{k}']) for k in ('eps_pos', 'u_node', 'u_halfedge')}
+        with torch.no_grad():
+            new, preds = O.sample_step(P, U.CFG, U.tables(P), st, {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh,
+                                                                    'n_graphs': len(g[f'{tag}_sizes'])}, int(g[f'{tag}_step']), noise,
+                                       Pb=Pb, cfgb=U.CFGB, guidance=['uncertainty', 1e-4])
+        assert U.maxdiff(new['pos'], g[f'{tag}_step_pos']) <= 1e-5 * max(1.0, float(np.abs(g[f'{tag}_step_pos']).max()))
+        assert U.maxdiff(new['log_node'], g[f'{tag}_step_log_node']) < 1e-4 and U.maxdiff(new['log_halfedge'], g[f'{tag}_step_log_halfedge']) < 1e-4
+        assert np.array_equal(new['node_type'].numpy(), g[f'{tag}_step_node_type'])
+        assert np.array_equal(new['halfedge_type'].numpy(), g[f'{tag}_step_halfedge_type'])
+    full = json.load(open(os.path.join(U.GOLD, 'PINNING.json')))
+    assert all(full[k] == 0.0 for k in ('stress_moldiff_forward', 'stress_guidance_logits', 'stress_sample_step_preds', 'stress_sample_step_pos'))
+    assert full['stress_guidance_delta'] <= 1e-8

@@ -173,6 +173,40 @@ def test_gpu_timefree_predictor_guidance_gradient_matches_oracle_autograd():
     assert U.maxdiff(g, go) <= 1e-4 * max(1.0, float(go.abs().max()))
 
 
+@pytest.mark.gpu
+def test_gpu_timefree_predictor_in_the_fused_guided_step_ignores_the_step_index():
+    """inside mdx_sample_step_full the predictor is handed the CURRENT step (e.g. 999); the time-free predictor must
+    replace it by zeros like the reference (models/bond_predictor.py:141-144).  The fused 'uncertainty' step == the denoiser step
+    plus the increment evaluated by hand through the Python forward (which passes t = None), and == the oracle's guided step."""
+    md, bp = U.moldiff('MolDiff', 'cuda'), timefree('cuda')
+    bn, hei, bh, ei, be = U.graph_from_sizes([6, 9, 4], 'cuda')
+    def run(**extra):
+        sm = md.sampler(3, bn, hei, bh, seed=5, **extra)
+        sm.init()
+        st0 = {k: v.clone() for k, v in sm.state().items()}
+        sm.step(0)
+        return st0, sm.state()['pos'].clone()
+    st0, plain = run()
+    _, fused = run(bond_predictor=bp, guidance=['uncertainty', 1e-4])
+    _, generic = run(bond_predictor=bp, guidance=['uncertainty_bond', 1e-4])   # a torch-expression objective: goes through forward(t)
+    pos_in = st0['pos'].clone().requires_grad_(True)
+    logits = bp(st0['h_node'], pos_in, bn, ei, be, None)
+    (gr,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), pos_in)
+    delta = -1e-4 * gr
+    assert float(delta.abs().max()) > 0
+    assert U.maxdiff(fused - plain, delta) <= 1e-3 * float(delta.abs().max()) + 2.5e-7
+    # the generic route hands forward() the step tensor (999): it must be ignored there too -- same logits as t = None
+    t999 = torch.full((3,), 999, dtype=torch.long, device='cuda')
+    assert torch.equal(bp(st0['h_node'], st0['pos'], bn, ei, be, t999), bp(st0['h_node'], st0['pos'], bn, ei, be, None))
+    assert float((generic - plain).abs().max()) > 0
+    # and the oracle's increment for the same state
+    Pb = U.params(timefree())
+    pc = st0['pos'].cpu().clone().requires_grad_(True)
+    lo = O.bondpred_forward(Pb, dict(num_timesteps=0, num_blocks=8, cutoff=20), st0['h_node'].cpu(), pc, bn.cpu(), ei.cpu(), be.cpu(), None)
+    (go,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(lo, -1)).log().sum(), pc)
+    assert U.maxdiff(fused - plain, -1e-4 * go) <= 1e-3 * float(go.abs().max()) * 1e-4 + 2.5e-7
+
+
 # ---- distance smearing with start != 0 -----------------------------------------------------------------------------------------
 def _start_models(device):
     key = 'start' + str(device)
