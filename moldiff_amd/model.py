@@ -13,6 +13,7 @@ containers only.  Differences a caller can see, all opt-in keyword arguments wit
 global generator, see DESIGN.md "noise").
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -324,7 +325,7 @@ class _Sampler:
             if self.guidance[0] == 'uncertainty':
                 # the default objective is part of the library call, with its own workspace; on request (overlap_guidance) it runs
                 # on a side stream concurrently with the denoiser's forward of the same step (both only read the step's input state)
-                self.side = torch.cuda.Stream(device=dev)
+                self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('MDX_SIDE_PRIORITY', '0')))
                 nbytes = _lib.lib().mdx_workspace_bytes(self.N, 2 * self.Eh)
                 self._ws2 = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
                 off = (-self._ws2.data_ptr()) % 256

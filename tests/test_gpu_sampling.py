@@ -5,6 +5,8 @@ injected noise), so chaos in the 1000-step chain cannot ma
 Tolerances: positions <= 1e-4 abs, log-posteriors <= 1e-4 abs (values reach -69), class ids bit-exact (the
 golden file records the top-2 Gumbel margins; all are > 1e-4, the stated tolerance).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -117,6 +119,7 @@ def test_generic_guidance_types_run_and_match_hip_path():
         m.sampler(2, bn, hei, bh, bond_predictor=bp, guidance=['nope', 1.0])
 
 
+_SHIFT64 = {}   # float64 arbiter of the eight-objective fixture, per objective (computed once per session)
 GUIDANCE_TYPES = ('entropy', 'uncertainty', 'uncertainty_bond', 'entropy_bond', 'logit_bond', 'logit', 'crossent', 'crossent_bond')
 
 
@@ -179,7 +182,27 @@ def test_all_eight_guidance_objectives_vs_reference_sample(gt):
         sm.step(first)
         res.append(sm.state()['pos'].cpu().numpy().astype(np.float64))
     d_ref = g[f'{tag}_0_{gt}_pos'].astype(np.float64) - g[f'{tag}_0_none_pos']
-    assert np.abs((res[1] - res[0]) - d_ref).max() <= 1e-3 * np.abs(d_ref).max() + 5e-7, gt
+    # Arbitrated in float64 (round 5).  This fixture's prior-drawn positions hold a pair 0.12 apart, and the REFERENCE's own fp32
+    # shift is 9.4e-5 = 3e-3 of its scale from the float64 value on one atom (an ill-conditioned row / ReLU kink, the same input
+    # state for all eight objectives).  An fp32 evaluation lands on the reference's side of that event or on float64's: the exact
+    # path shares the reference's side (|HIP - reference| <= 1e-3 of the scale), the split float16 path float64's.  Either is right:
+    # |HIP - fp64| <= max(1e-3 scale, 2 |reference - fp64|), the rule of tests/test_gpu_fullsize.py for the same quantity.
+    if gt not in _SHIFT64:
+        Pb64 = {k: (v.double() if v.is_floating_point() else v) for k, v in U.params(U.bondpred()).items()}
+        t = torch.full((4,), 999 - first, dtype=torch.long)
+        ch = torch.from_numpy(g[f'{tag}_0_none_halfedge_type'].astype(np.int64))
+        nth = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        try:
+            _SHIFT64[gt] = O.guidance_delta(Pb64, U.CFGB, oh_n.double(), torch.from_numpy(g[f'{tag}_init_pos']).double(), bn, ei, be, t, scale,
+                                            gui_type=gt, halfedge_type_prev=ch,
+                                            log_halfedge_type=torch.from_numpy(g[f'{tag}_0_log_halfedge']).double())[0].numpy()
+        finally:
+            torch.set_num_threads(nth)
+    d64 = _SHIFT64[gt]
+    e_hip, e_ref, sc = np.abs((res[1] - res[0]) - d64).max(), np.abs(d_ref - d64).max(), np.abs(d64).max()
+    print(f'\n    [{gt}] shift scale {sc:.3e}: |HIP-fp64| {e_hip:.3e}  |reference-fp64| {e_ref:.3e}  |HIP-reference| {np.abs((res[1] - res[0]) - d_ref).max():.3e}')
+    assert e_hip <= max(1e-3 * sc, 2.0 * e_ref) + 5e-7, gt
 
 
 def test_transition_kernels_vs_oracle():
@@ -355,7 +378,8 @@ def test_config1_T100_B8_steps_vs_reference_golden():
             # (tail factor per matrix path: tests/util.py TAIL -- the noisy end of this chain has atom pairs 0.1 apart, where the
             # maximum over atoms is a tail event of any fp32 evaluation; tests/test_gpu_round5.py holds the statistic)
             assert U.maxdiff(hip, r64) <= max(1e-4, U.tail('config1') * U.maxdiff(gold_, r64))
-            assert U.maxdiff(hip, gold_) < 4e-4
+            if U.current_matrix_path() == 'exact_f32':   # same products as the reference, another summation order: also close to its fp32 result
+                assert U.maxdiff(hip, gold_) < 3e-4
             assert U.rmsdiff(hip, r64) <= max(2e-6, 2.0 * U.rmsdiff(gold_, r64))
         assert U.maxdiff(got['log_node'], g[p + 'log_node']) < 1e-4
         assert U.maxdiff(got['log_halfedge'], g[p + 'log_halfedge']) < 1e-4
