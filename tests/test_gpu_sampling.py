@@ -123,6 +123,27 @@ _SHIFT64 = {}   # float64 arbiter of the eight-objective fixture, per objective 
 GUIDANCE_TYPES = ('entropy', 'uncertainty', 'uncertainty_bond', 'entropy_bond', 'logit_bond', 'logit', 'crossent', 'crossent_bond')
 
 
+def _shift64(g, gt):
+    """float64 arbiter of the eight-objective fixture (n101, first iteration): the guidance shift by the oracle in float64."""
+    tag = 'n101'
+    first, scale = int(g['first']), float(g['scale'])
+    bn, hei, bh, ei, be = U.graph_from_sizes(g[f'{tag}_sizes'])
+    oh_n = F.one_hot(torch.from_numpy(g[f'{tag}_init_node_type'].astype(np.int64)), 8).float()
+    if gt not in _SHIFT64:
+        Pb64 = {k: (v.double() if v.is_floating_point() else v) for k, v in U.params(U.bondpred()).items()}
+        t = torch.full((4,), 999 - first, dtype=torch.long)
+        ch = torch.from_numpy(g[f'{tag}_0_none_halfedge_type'].astype(np.int64))
+        nth = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        try:
+            _SHIFT64[gt] = O.guidance_delta(Pb64, U.CFGB, oh_n.double(), torch.from_numpy(g[f'{tag}_init_pos']).double(), bn, ei, be, t, scale,
+                                            gui_type=gt, halfedge_type_prev=ch,
+                                            log_halfedge_type=torch.from_numpy(g[f'{tag}_0_log_halfedge']).double())[0].numpy()
+        finally:
+            torch.set_num_threads(nth)
+    return _SHIFT64[gt]
+
+
 @U.both_paths
 @pytest.mark.parametrize('gt', GUIDANCE_TYPES)
 def test_all_eight_guidance_objectives_vs_reference_sample(gt):
@@ -162,11 +183,13 @@ def test_all_eight_guidance_objectives_vs_reference_sample(gt):
                 # the unguided part of the step obeys the 1e-4 position contract; the SHIFT is what this test is about
                 d_hip = got['pos'].cpu().numpy().astype(np.float64) - base
                 d_ref = ref.astype(np.float64) - base
-                assert np.abs(d_hip - d_ref).max() <= 1e-3 * shift + 1e-4, (tag, gt)
+                # (n101: + twice the reference's own distance from float64 on this ill-conditioned fixture, see the sharper clause below)
+                slack = 2.0 * np.abs(d_ref - _shift64(g, gt)).max() if tag == 'n101' else 0.0
+                assert np.abs(d_hip - d_ref).max() <= 1e-3 * shift + 1e-4 + slack, (tag, gt)
                 assert np.array_equal(got['h_halfedge'].argmax(-1).cpu().numpy(), g[f'{tag}_0_none_halfedge_type'])
                 assert np.array_equal(got['h_node'].argmax(-1).cpu().numpy(), g[f'{tag}_0_none_node_type'])
                 assert U.maxdiff(got['log_halfedge'], g[f'{tag}_0_log_halfedge']) < 1e-4
-            assert U.maxdiff(got['pos'], ref) <= 2e-4, (tag, gt, j)
+            assert U.maxdiff(got['pos'], ref) <= 2e-4 + (slack if j == 0 else 0.0), (tag, gt, j)
     # sharper: the shift alone, unguided step subtracted on the SAME device path (removes the denoiser's own 1e-4 budget)
     tag = 'n101'
     bn, hei, bh, ei, be = U.graph_from_sizes(g[f'{tag}_sizes'])
@@ -187,19 +210,7 @@ def test_all_eight_guidance_objectives_vs_reference_sample(gt):
     # state for all eight objectives).  An fp32 evaluation lands on the reference's side of that event or on float64's: the exact
     # path shares the reference's side (|HIP - reference| <= 1e-3 of the scale), the split float16 path float64's.  Either is right:
     # |HIP - fp64| <= max(1e-3 scale, 2 |reference - fp64|), the rule of tests/test_gpu_fullsize.py for the same quantity.
-    if gt not in _SHIFT64:
-        Pb64 = {k: (v.double() if v.is_floating_point() else v) for k, v in U.params(U.bondpred()).items()}
-        t = torch.full((4,), 999 - first, dtype=torch.long)
-        ch = torch.from_numpy(g[f'{tag}_0_none_halfedge_type'].astype(np.int64))
-        nth = torch.get_num_threads()
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
-        try:
-            _SHIFT64[gt] = O.guidance_delta(Pb64, U.CFGB, oh_n.double(), torch.from_numpy(g[f'{tag}_init_pos']).double(), bn, ei, be, t, scale,
-                                            gui_type=gt, halfedge_type_prev=ch,
-                                            log_halfedge_type=torch.from_numpy(g[f'{tag}_0_log_halfedge']).double())[0].numpy()
-        finally:
-            torch.set_num_threads(nth)
-    d64 = _SHIFT64[gt]
+    d64 = _shift64(g, gt)
     e_hip, e_ref, sc = np.abs((res[1] - res[0]) - d64).max(), np.abs(d_ref - d64).max(), np.abs(d64).max()
     print(f'\n    [{gt}] shift scale {sc:.3e}: |HIP-fp64| {e_hip:.3e}  |reference-fp64| {e_ref:.3e}  |HIP-reference| {np.abs((res[1] - res[0]) - d_ref).max():.3e}')
     assert e_hip <= max(1e-3 * sc, 2.0 * e_ref) + 5e-7, gt
