@@ -651,6 +651,11 @@ struct mdx_graph_s {
   // edge, rows), per-edge partial-row offset, per-node partial-row ranges
   const int32_t *units = nullptr, *epo = nullptr, *pbase = nullptr;
   int64_t nunits = 0, nparts = 0;
+  // the same in BY-RIGHT order (positions of col_eids), for the guidance backward's in-kernel sums of its by-right payloads
+  // (round 5): units_r (first col position, rows), epo_r per col position, pbase_r per node; col_left / col_right = the end
+  // points of edge col_eids[j] (so a tile's indices are independent loads)
+  const int32_t *units_r = nullptr, *epo_r = nullptr, *pbase_r = nullptr, *col_left = nullptr, *col_right = nullptr;
+  int64_t nunits_r = 0, nparts_r = 0;
   hipEvent_t ev_in = nullptr, ev_done = nullptr;  // stream hand-offs of mdx_sample_step_full's concurrent guidance chain
   // work-queue counter sets of the persistent edge kernels, one per launching stream (wq_for)
   int* wq = nullptr;
@@ -794,6 +799,36 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   g->nunits = (int64_t)units.size() / 2;
   g->nparts = pbase[N];
   const size_t o_un = add(units), o_epo = add(epo), o_pb = add(pbase);
+  // by-right twin: graph b owns the col positions col_ptr[node_ptr[b]] .. col_ptr[node_ptr[b+1]] (col_eids is ordered by right node)
+  std::vector<int32_t> units_r, epo_r(E), pbase_r(N + 1, 0), col_left(E), col_right(E);
+  for (int64_t j = 0; j < E; ++j) { col_left[j] = p.left[p.col_eids[j]]; col_right[j] = p.right[p.col_eids[j]]; }
+  for (int64_t b = 0; b < B; ++b) {
+    const int32_t j_lo = p.col_ptr[node_ptr[b]], j_hi = p.col_ptr[node_ptr[b + 1]];
+    for (int32_t j0 = j_lo; j0 < j_hi; j0 += 16) {
+      units_r.push_back(j0);
+      units_r.push_back(std::min<int32_t>(16, j_hi - j0));
+    }
+  }
+  {
+    const int64_t U = (int64_t)units_r.size() / 2;
+    int64_t u = 0;
+    for (int64_t v = 0; v < N; ++v) {
+      const int32_t r0 = p.col_ptr[v], r1 = p.col_ptr[v + 1];
+      int32_t pieces = 0, ufirst = 0;
+      if (r1 > r0) {
+        while (u + 1 < U && units_r[2 * (u + 1)] <= r0) ++u;
+        ufirst = (int32_t)u;
+        int64_t ul = u;
+        while (ul + 1 < U && units_r[2 * (ul + 1)] <= r1 - 1) ++ul;
+        pieces = (int32_t)(ul - u + 1);
+      }
+      pbase_r[v + 1] = pbase_r[v] + pieces;
+      for (int32_t j = r0; j < r1; ++j) epo_r[j] = pbase_r[v] - ufirst;
+    }
+  }
+  g->nunits_r = (int64_t)units_r.size() / 2;
+  g->nparts_r = pbase_r[N];
+  const size_t o_unr = add(units_r), o_epor = add(epo_r), o_pbr = add(pbase_r), o_cl = add(col_left), o_cr = add(col_right);
   std::vector<int32_t> half_of_int(E);
   for (int64_t i = 0; i < E; ++i) half_of_int[i] = Eh > 0 ? (int32_t)(p.int2ref[i] % Eh) : 0;
   const size_t o_hoi = add(half_of_int);
@@ -818,6 +853,8 @@ extern "C" int mdx_graph_create(int64_t N, int64_t E, const int64_t* ei, const i
   g->node_ptr = g->dev + o_np;
   g->he_ptr = g->dev + o_hp;
   g->units = g->dev + o_un; g->epo = g->dev + o_epo; g->pbase = g->dev + o_pb;
+  g->units_r = g->dev + o_unr; g->epo_r = g->dev + o_epor; g->pbase_r = g->dev + o_pbr; g->col_left = g->dev + o_cl;
+  g->col_right = g->dev + o_cr;
   g->wq = g->dev + o_wq;
   *out = g;
   return MDX_OK;
@@ -1562,6 +1599,8 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
     eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = et.wq;
     eb.split = split_bwd ? 1 : 0;
+    eb.units_r = g->units_r; eb.epo_r = g->epo_r; eb.col_eids = g->col_eids; eb.col_left = g->col_left; eb.col_right = g->col_right;
+    eb.nunits_r = (int)g->nunits_r;
     {
       ProfScope ps(PK_EDGE_BWD, s);
       if (split_bwd) {
@@ -1570,7 +1609,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     }
     {
       SegBwdArgs sr{};
-      sr.N = N; sr.row_ptr = g->row_ptr; sr.col_ptr = g->col_ptr; sr.col_eids = g->col_eids; sr.GH = GH; sr.GGX = tp.GGX;
+      sr.N = N; sr.row_ptr = g->row_ptr; sr.col_ptr = g->col_ptr; sr.col_eids = g->col_eids; sr.pbase_r = g->pbase_r; sr.GH = GH; sr.GGX = tp.GGX;
       sr.GNL0 = tp.GNL0; sr.GNL1 = tp.GNL1; sr.GGXS0 = tp.GGXS0; sr.GGXS1 = tp.GGXS1; sr.gH = gH; sr.GNT = GNT;
       launch_seg_reduce_bwd_block(sr, s);
     }

@@ -371,32 +371,34 @@ __global__ __launch_bounds__(MDX_WG) void seg_reduce_ld_kernel(const float* __re
 }
 
 // The six payload reductions that follow the backward edge kernel of a block, in one launch (13 waves per four nodes: GH and GGX
-// four waves each, the two (E,128) BondFFN payloads two each, the two (E,32) gate payloads half a wave each); and the two
+// four waves each, the two BondFFN payloads two each, the two gate payloads half a wave each).  Since round 5 the four by-right
+// payloads arrive as partial rows summed inside the edge kernel (a node's ~2.5 pieces are added here in order; the launch reads
+// ~140 MB instead of 515 MB at 256 molecules), the two by-left ones per edge as before; and the two
 // (E,64) reductions that follow the EdgeBlock-tail backward.  Same per-lane loop as seg_reduce_ld_kernel: same bits.
 __global__ __launch_bounds__(832) void seg_reduce_bwd_block_kernel(const SegBwdArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v0 = blockIdx.x * 4, N = a.N;
-  if (wave < 8) {  // (E,256) by right endpoint: dL/dH rows and the gate's node part
+  if (wave < 8) {  // (parts,256) partial rows of the by-right sums: dL/dH rows and the gate's node part
     const int v = v0 + (wave & 3);
     if (v >= N) return;
     if (wave < 4)
-      stg4(a.gH + (size_t)v * MDX_ND + 4 * lane, seg_sum_ld<256>(a.GH, a.col_ptr, a.col_eids, v, lane));
+      stg4(a.gH + (size_t)v * MDX_ND + 4 * lane, seg_sum_ld<256>(a.GH, a.pbase_r, nullptr, v, lane));
     else
-      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GX + 4 * lane, seg_sum_ld<256>(a.GGX, a.col_ptr, a.col_eids, v, lane));
-  } else if (wave < 12) {  // (E,128): left FFN by left endpoint, right FFN by right endpoint
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GX + 4 * lane, seg_sum_ld<256>(a.GGX, a.pbase_r, nullptr, v, lane));
+  } else if (wave < 12) {  // left FFN (E,128) per edge by left endpoint; right FFN: partial rows
     const int v = v0 + 2 * (wave & 1) + (lane >> 5), c4 = lane & 31;
     if (v >= N) return;
     if (wave < 10)
       stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_NLL + 4 * c4, seg_sum_ld<128>(a.GNL0, a.row_ptr, nullptr, v, c4));
     else
-      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_NLR + 4 * c4, seg_sum_ld<128>(a.GNL1, a.col_ptr, a.col_eids, v, c4));
-  } else {  // (E,32)
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_NLR + 4 * c4, seg_sum_ld<128>(a.GNL1, a.pbase_r, nullptr, v, c4));
+  } else {  // (.,32)
     const int v = v0 + ((lane & 31) >> 3), c4 = lane & 7;
     if (v >= N) return;
     if (lane < 32)
       stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GXL + 4 * c4, seg_sum_ld<32>(a.GGXS0, a.row_ptr, nullptr, v, c4));
     else
-      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GXR + 4 * c4, seg_sum_ld<32>(a.GGXS1, a.col_ptr, a.col_eids, v, c4));
+      stg4(a.GNT + (size_t)v * MDX_NTW + MDX_NT_GXR + 4 * c4, seg_sum_ld<32>(a.GGXS1, a.pbase_r, nullptr, v, c4));
   }
 }
 

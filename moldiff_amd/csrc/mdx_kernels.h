@@ -235,9 +235,16 @@ struct EdgeBwdArgs {
   const float* GNT;            // (N,960) gradient table: C cols = dL/d(aggr), NFL cols = A_l, NFR cols = A_r
   float* gHe_out;              // (E,64) dL/dHe_i
   float* gdist;                // (E) accumulated over blocks
-  float *GH, *GGX;             // (E,256) per-edge gradient payloads reduced by right endpoint
-  float* GNL[2];               // (E,128): left -> reduced by left, right -> by right
-  float* GGXS[2];              // (E,32)
+  // Gradient payloads for the node tables.  The kernel walks the edges in BY-RIGHT order (units of 16 positions of col_eids,
+  // aligned to each graph's first position like the forward's by-left units), so every payload that is reduced by the right end
+  // point -- GH, GGX, GNL[1], GGXS[1]: 672 of the 832 floats per edge -- is summed over each right node's run INSIDE the kernel
+  // (seg_sum_store, mdx_row.h) and leaves as one PARTIAL ROW per (node, unit) at row epo_r[j] + unit; the by-left payloads
+  // GNL[0], GGXS[0] stay per edge.  seg_reduce_bwd_block_kernel adds a node's ~2.5 partial rows in order (pbase_r).
+  float *GH, *GGX;             // (nparts_r,256) partial rows
+  float* GNL[2];               // [0]: (E,128) per edge, reduced by left afterwards; [1]: (nparts_r,128) partial rows
+  float* GGXS[2];              // [0]: (E,32) per edge; [1]: (nparts_r,32) partial rows
+  const int *units_r, *epo_r, *col_eids, *col_left, *col_right;  // by-right plan (mdx_graph_s)
+  int nunits_r;
   int* wq;                 // work-queue counters of the launch's stream (mdx_row.h WorkQ), nullptr = static unit split
   int split;               // 1: run the split float16 build (mdx_bwd2s.hip; needs the BondFFN tape)
   EdgeAW w;
@@ -288,6 +295,7 @@ void launch_bond_decode(const BondDecArgs& a, bool backward, hipStream_t s);
 struct SegBwdArgs {  // the payload reductions after the backward edge kernel (mdx_bondpred.hip)
   int N;
   const int *row_ptr, *col_ptr, *col_eids;
+  const int* pbase_r;  // partial-row ranges of the by-right payloads (GH, GGX, GNL1, GGXS1 hold partial rows)
   const float *GH, *GGX, *GNL0, *GNL1, *GGXS0, *GGXS1;
   float *gH, *GNT;
 };

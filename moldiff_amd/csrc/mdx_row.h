@@ -346,6 +346,25 @@ __device__ __forceinline__ RowTile load_tile_u(const int* __restrict__ l, const 
   return t;
 }
 
+// unit of the guidance backward (round 5): `cnt` (<= 16) positions from j0 of the BY-RIGHT edge order (col_eids); the tile's rows
+// are the edge ids found there, its end points come from the plan's col_left / col_right (independent loads), pf = epo_r
+template <int R = RR>
+__device__ __forceinline__ RowTile load_tile_r(const int* __restrict__ col_eids, const int* __restrict__ col_left,
+                                               const int* __restrict__ col_right, const float* __restrict__ te,
+                                               const int* __restrict__ epo_r, int j0, int cnt, int c) {
+  static_assert(R == 1, "one 16-row tile per wave");
+  RowTile t;
+  t.valid[0] = c < cnt;
+  const int j = t.valid[0] ? j0 + c : j0;  // clamped to the unit's first position (always a row of the same graph)
+  t.row[0] = col_eids[j];
+  t.li[0] = col_left[j];
+  t.ri[0] = col_right[j];
+  t.pf[0] = epo_r[j];
+  t.tt[0] = te[t.row[0]];
+  t.cnt = cnt;
+  return t;
+}
+
 // In-kernel segment sums of the EA_AGG kernels: y (accumulator layout: lane (q, c) holds features 16 ft + 4 q .. of row c) is
 // summed over runs of rows with equal `key` (sorted; the unit's first `cnt` rows are valid) and every run's sum is stored as ONE
 // row of `out` (FT*16 floats wide) at row index `prow` (taken from the run's rows; all rows of a run carry the same one).
@@ -355,45 +374,55 @@ __device__ __forceinline__ RowTile load_tile_u(const int* __restrict__ l, const 
 // (on this core VALU time is additive to MFMA time; a DPP scan of the 64 accumulator registers costs ~1,000 VALU issues per
 // unit, this ~50).  XOR swizzle of the 16-byte column by the row: writes (16 rows x 4 adjacent columns per instruction) and reads
 // (one row, 64 or 16 adjacent columns) are both bank-conflict free without padding, so the 16 KiB sigmoid parking area is reused.
+// first half: the tile goes to the wave's LDS area (XOR-swizzled 16-byte columns)
 template <int FT, int R = 1, int RT = 0>   // (R, RT: the tile is row tile RT of a wave that owns R of them)
-__device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][R], float* wbuf, int lane, int cnt, int key, int prow,
-                                              float* __restrict__ out) {
+__device__ __forceinline__ void seg_sum_put(const f32x4 (&y)[FT][R], float* wbuf, int lane) {
   constexpr int C4 = 4 * FT;  // 16-byte columns per row
-  static_assert(C4 == 64 || C4 == 16, "256- or 64-wide rows");
-  asm volatile("" : "+v"(lane));  // opaque per call: the 32 swizzled LDS addresses are cheap to rebuild and must not be hoisted out
+  static_assert(C4 == 64 || C4 == 32 || C4 == 16 || C4 == 8, "256-, 128-, 64- or 32-wide rows");
+  constexpr unsigned SWZ = C4 < 16 ? C4 - 1 : 15;  // rows are XOR-swizzled within the row's own columns
+  asm volatile("" : "+v"(lane));  // opaque per call: the swizzled LDS addresses are cheap to rebuild and must not be hoisted out
                                   // of the persistent loop (they would live in scratch)
   const int c = lane & 15, q = lane >> 4;
   char* base = reinterpret_cast<char*>(wbuf);
-  {
-    // physical column of (row c, column 4 ft + q) = (4 ft + q) ^ c = 16 (ft >> 2) + 4 ((ft & 3) ^ (c >> 2)) + (q ^ (c & 3)):
-    // four address registers, the rest is an immediate offset
-    const unsigned lo = (unsigned)(c * C4 + (q ^ (c & 3))) * 16u, cc = (unsigned)(c >> 2);
-    unsigned a4[4];
+  // physical column of (row c, column 4 ft + q) = (4 ft + q) ^ c = 16 (ft >> 2) + 4 ((ft & 3) ^ (c >> 2)) + (q ^ (c & 3)):
+  // four address registers, the rest is an immediate offset
+  const unsigned lo = (unsigned)(c * C4 + (q ^ (c & 3))) * 16u, cc = (unsigned)(c >> 2) & (SWZ >> 2);
+  unsigned a4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a4[j] = lo + (((unsigned)j ^ cc) << 6);
+  for (int j = 0; j < 4; ++j) a4[j] = lo + (((unsigned)j ^ cc) << 6);
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) *reinterpret_cast<f32x4*>(base + a4[ft & 3] + 256 * (ft >> 2)) = y[ft][RT];
-  }
+  for (int ft = 0; ft < FT; ++ft) *reinterpret_cast<f32x4*>(base + a4[ft & 3] + 256 * (ft >> 2)) = y[ft][RT];
   // lanes read what OTHER lanes of the wave wrote: DS operations of a wave execute in order, the compiler only has to keep them so
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+// second half: read the tile back transposed, sum each run in row order, store one row per run (may run any time before the area is
+// written again).  RB rows are in flight at a time (4 RB registers).
+template <int FT, int RB = 8>
+__device__ __forceinline__ void seg_sum_flush(float* wbuf, int lane, int cnt, int key, int prow, float* __restrict__ out) {
+  constexpr int C4 = 4 * FT;
+  constexpr unsigned SWZ = C4 < 16 ? C4 - 1 : 15;
+  static_assert(16 % RB == 0, "rows per burst");
+  asm volatile("" : "+v"(lane));
+  char* base = reinterpret_cast<char*>(wbuf);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int col = lane & (C4 - 1);
   const unsigned col16 = (unsigned)col * 16u;
   f32x4 acc = splat4(0.f);
   int k_r = __builtin_amdgcn_readlane(key, 0);
-  // eight rows at a time (32 registers in flight); every condition below is wave-uniform (scalar branches)
-  static_for<0, 2>([&](auto hc) {
+  // RB rows at a time; every condition below is wave-uniform (scalar branches)
+  static_for<0, 16 / RB>([&](auto hc) {
     constexpr int h = decltype(hc)::value;
-    if (8 * h < cnt) {
-      f32x4 v[8];
+    if (RB * h < cnt) {
+      f32x4 v[RB];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const f32x4*>(base + (col16 ^ (16u * (8 * h + r))) + (8 * h + r) * C4 * 16);
-      static_for<0, 8>([&](auto rc) {
-        constexpr int r = 8 * h + decltype(rc)::value;
+      for (int r = 0; r < RB; ++r) v[r] = *reinterpret_cast<const f32x4*>(base + (col16 ^ (16u * ((RB * h + r) & SWZ))) + (RB * h + r) * C4 * 16);
+      static_for<0, RB>([&](auto rc) {
+        constexpr int r = RB * h + decltype(rc)::value;
         const int k_next = __builtin_amdgcn_readlane(key, r < 15 ? r + 1 : 15);
         if (r < cnt) {
-          acc = acc + v[r - 8 * h];
+          acc = acc + v[r - RB * h];
           if (r + 1 == cnt || k_next != k_r) {  // last row of a run
             const int row = __builtin_amdgcn_readlane(prow, r);
             if ((C4 == 64 || lane < C4) && !(MDX_ABL & 1)) stg4(out + (size_t)row * (16 * FT) + 4 * col, acc);
@@ -405,6 +434,13 @@ __device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][R], float* wb
     }
   });
   __builtin_amdgcn_wave_barrier();  // the area is rewritten (parking, next unit) only after every lane has read it
+}
+
+template <int FT, int R = 1, int RT = 0>
+__device__ __forceinline__ void seg_sum_store(const f32x4 (&y)[FT][R], float* wbuf, int lane, int cnt, int key, int prow,
+                                              float* __restrict__ out) {
+  seg_sum_put<FT, R, RT>(y, wbuf, lane);
+  seg_sum_flush<FT>(wbuf, lane, cnt, key, prow, out);
 }
 
 template <int FT>

@@ -40,17 +40,18 @@ for s in (0, 1):
              (f'ffn{s}: sigmoid + store', 21 + o, 22 + o, 0)]
 
 
-PH_W = [('tile + SG, M, dL/daggr[l] loads + park', 0, 1, 0), ('msg^T GEMM 256->256', 1, 2, 2 * 256 * 256),
-        ('HE load, GH store, H[r] gather, He gather', 2, 3, 0), ('en W2^T GEMM 256->256', 3, 4, 2 * 256 * 256),
-        ('en W1 recompute 64->256', 4, 5, 2 * 64 * 256), ('LN backward 256', 5, 6, 0), ('en W1^T GEMM 256->64', 6, 7, 2 * 256 * 64),
-        ('unpark', 7, 8, 0), ('gate W2^T GEMM 256->256', 8, 9, 2 * 256 * 256), ('gx[r] gather + bias', 9, 10, 0),
-        ('gate W1 recompute 64->256', 10, 11, 2 * 64 * 256), ('LN backward 256 + GGX store', 11, 12, 0),
-        ('gate W1^T GEMM 256->64', 12, 13, 2 * 256 * 64),
-        ('ffn0 recompute', 13, 14, 2 * (64 * 128 + 128 * 128 + 128 * 64 + 64 * 32 + 32 * 64)),
+PH_W = [('tile + SG, M, dL/daggr[l] loads', 0, 1, 0), ('gate W2^T GEMM 256->256', 1, 2, 2 * 256 * 256),
+        ('gx[r], He gathers + bias', 2, 3, 0), ('gate W1 recompute 64->256', 3, 4, 2 * 64 * 256),
+        ('LN backward 256 + GGX segment sums', 4, 5, 0), ('gate W1^T GEMM 256->64', 5, 6, 2 * 256 * 64),
+        ('SG, dL/daggr[l] loads', 6, 7, 0), ('msg^T GEMM 256->256', 7, 8, 2 * 256 * 256),
+        ('HE load, H[r] gather, GH to LDS', 8, 9, 0), ('en W2^T GEMM 256->256', 9, 10, 2 * 256 * 256),
+        ('GH segment sums + en W1 recompute 64->256', 10, 11, 2 * 64 * 256), ('LN backward 256', 11, 12, 0),
+        ('en W1^T GEMM 256->64', 12, 13, 2 * 256 * 64),
+        ('ffn0 tape loads + gate recompute', 13, 14, 2 * (64 * 32 + 32 * 64)),
         ('ffn0 backward inter', 14, 15, 2 * (64 * 128 + 128 * 128 + 128 * 64)), ('ffn0 backward gate', 15, 21, 2 * (64 * 32 + 32 * 64)),
-        ('ffn1 recompute', 21, 17, 2 * (64 * 128 + 128 * 128 + 128 * 64 + 64 * 32 + 32 * 64)),
-        ('ffn1 backward inter', 17, 18, 2 * (64 * 128 + 128 * 128 + 128 * 64)), ('ffn1 backward gate', 18, 20, 2 * (64 * 32 + 32 * 64)),
-        ('emb backward + gdist', 20, 40, 2 * (64 * 64 + 64 * 32))]
+        ('ffn1 tape loads + gate recompute', 21, 17, 2 * (64 * 32 + 32 * 64)),
+        ('ffn1 backward inter + GNL1 segment sums', 17, 18, 2 * (64 * 128 + 128 * 128 + 128 * 64)),
+        ('ffn1 backward gate', 18, 20, 2 * (64 * 32 + 32 * 64)), ('emb backward + gdist', 20, 40, 2 * (64 * 64 + 64 * 32))]
 
 
 def main_bwd():
@@ -66,7 +67,7 @@ def main_bwd():
     torch.cuda.synchronize()
     E = 2 * ph['halfedge_index'].shape[1]
     rows = int(os.environ.get('MDX_BWD_ROWS', 16))
-    nunits = (E + rows - 1) // rows
+    nunits = (E + rows - 1) // rows + 256      # graph-aligned units of the by-right order: at most one more per molecule
     buf = torch.zeros(nunits * 48, dtype=torch.int64, device=dev)
     assert L.mdx_debug_set_trace_bwd(ctypes.c_void_p(buf.data_ptr())) == 0
     sm.step(3)
