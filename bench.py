@@ -44,10 +44,12 @@ T_STEPS = 1000
 _ORIG_ARGV = list(sys.argv[1:])   # main_train() strips --train before parsing; a self-launch must pass it on
 FLOP_EDGE_A = 617088        # per directed edge per launch (hoisted count, DESIGN.md / SURVEY Appendix D)
 FLOP_EDGE_B = 221184        # edge kernel B (EdgeBlock tail + PosUpdate): 2 * (2*64*64 + 2*64*256 + 2*64*32 + 256*256)
-# per directed edge per launch of the guidance backward's edge kernel (DESIGN.md section 3.3): EXECUTED flops.  Round 3 reads the
+# per directed edge per launch of the guidance backward's edge kernel (DESIGN.md section 3.2): EXECUTED flops.  Round 3 reads the
 # BondFFN intermediates from the tape instead of recomputing W_bl (64->128), W_1 (128->128) and W_2 (128->64) on both sides:
-# 829,440 - 2 * 2 * (64*128 + 128*128 + 128*64) = 698,368
-FLOP_EDGE_BWD = 698368
+# 829,440 - 2 * 2 * (64*128 + 128*128 + 128*64) = 698,368.  Round 5: the launch of block i > 0 also runs block i-1's EdgeBlock-tail backward
+# (3 GEMMs 64x64 = 24,576) and block 0's launch no longer forms dL/dHe_0 (8,192): averaged over a predictor's 8 launches
+# 698,368 + 7/8 * 24,576 - 1/8 * 8,192 = 718,848
+FLOP_EDGE_BWD = 718848
 EDGE_A_NAME = ('edge_a2_kernel<15> (row-owner fused per-edge MLP chain + in-kernel segment sums of its messages, 16 rows x 2 waves per '
                'SIMD, v_mfma_f32_16x16x4_f32)')
 EDGE_B_NAME = 'edge_b2_kernel (row-owner EdgeBlock tail + PosUpdate, v_mfma_f32_16x16x4_f32)'
@@ -412,7 +414,7 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
                         'flops_what': '3 x the hoisted forward count (forward, data gradient, weight gradient of every Linear)',
                         'traffic': None,
                         'note': 'whole-step fraction: the step is a chain of ~2,000 launches, half of its time HBM-bound row-wise passes '
-                                'between the GEMMs (DESIGN section 10)'},
+                                'between the GEMMs (DESIGN.md section 3.3, profiles/HISTORY.md section 10)'},
            'peak_hbm_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
            'loss_first_last': [float(losses[0]), float(losses[-1])]}
     return out, model, sizes

@@ -1566,7 +1566,7 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
   const mdx_config& cf = m->cfg;
   const int N = (int)g->N, E = (int)g->E;
   // scratch mapping onto the (now dead) forward workspace
-  float *gHn = w.Hn, *GNT = w.NT, *gH = w.H, *gHe = w.HeA, *gHe2 = w.HeB, *GU = w.FL, *GHEP = w.FR, *GH = w.M;
+  float *gHn = w.Hn, *GNT = w.NT, *gH = w.H, *gHe = w.HeA, *GU = w.FL, *GHEP = w.FR, *GH = w.M;
   HIPCHK(hipMemsetAsync(tp.gdist, 0, (size_t)std::max(E, 1) * 4, s));
   BondDecArgs da{};
   da.Eh = (int)g->Eh; da.Ke = cf.num_edge_types; da.He = tp.HeF; da.Hn = tp.HnF; da.ref2int = g->ref2int; da.left = g->left;
@@ -1581,24 +1581,39 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     const int nb_split = m->matrix_path == MDX_MATRIX_SPLIT_F16 ? NB_SPLIT : 0;
     nt.flags |= nb_split;
     launch_node_bwd(nt, s);
-    EdgeTailBwdArgs et{};
-    et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
-    et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
-    et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT; et.wq = wq_for(g, s);
-    et.ssWselfT = m->ebw[i].ss.WselfT; et.ssWoutT = m->ebw[i].ss.WoutT;
+    // EdgeBlock-tail backward: for the last block a launch of its own (its dL/dHe'' comes from the decoder); for every other
+    // block it ran inside block i + 1's edge kernel, fused behind that block's edge_embs backward (GU, GHEP are ready)
     const bool split_bwd = m->matrix_path == MDX_MATRIX_SPLIT_F16;
-    et.split = split_bwd ? 1 : 0;
-    if (split_bwd) launch_edge_tail_bwd2s(et, s);
-    else launch_edge_tail_bwd2(et, s);
+    int* wq = wq_for(g, s);
+    if (i == nb - 1) {
+      EdgeTailBwdArgs et{};
+      et.E = E; et.l = g->left; et.r = g->right; et.te = tp.te; et.Hep = k.Hep; et.gHe = gHe; et.SL = k.SL; et.SR = k.SR;
+      et.NT = k.NT; et.GU = GU; et.GHEP = GHEP; et.w = m->blocks[i].eb; et.WselfT = m->ebw[i].WselfT; et.WoutT = m->ebw[i].WoutT;
+      et.sWselfT = m->ebw[i].s.WselfT; et.sWoutT = m->ebw[i].s.WoutT; et.wq = wq;
+      et.ssWselfT = m->ebw[i].ss.WselfT; et.ssWoutT = m->ebw[i].ss.WoutT;
+      et.split = split_bwd ? 1 : 0;
+      if (split_bwd) launch_edge_tail_bwd2s(et, s);
+      else launch_edge_tail_bwd2(et, s);
+    }
     launch_seg_reduce_tail_block(GU, g->row_ptr, g->col_ptr, g->col_eids, GNT, N, s);
     EdgeBwdArgs eb{};
     eb.E = E; eb.l = g->left; eb.r = g->right; eb.te = tp.te; eb.pos = pos; eb.soff = m->soff; eb.scoef = m->scoef;
-    eb.cutoff = cf.cutoff; eb.smear_start = m->smear_start; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT; eb.gHe_out = gHe2;
+    eb.cutoff = cf.cutoff; eb.smear_start = m->smear_start; eb.Hep = k.Hep; eb.GHEP = GHEP; eb.H = k.H; eb.NT = k.NT; eb.GNT = GNT;
     eb.SG = k.SG; eb.HE = k.HE; eb.M = k.M;
     for (int sd = 0; sd < 2; ++sd) { eb.BL[sd] = k.BL[sd]; eb.H1[sd] = k.H1[sd]; eb.O[sd] = k.O[sd]; }
     eb.gdist = tp.gdist; eb.GH = GH; eb.GGX = tp.GGX; eb.GNL[0] = tp.GNL0; eb.GNL[1] = tp.GNL1; eb.GGXS[0] = tp.GGXS0;
-    eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = et.wq;
+    eb.GGXS[1] = tp.GGXS1; eb.w = m->blocks[i].ea; eb.wt = m->ebw[i]; eb.wq = wq;
     eb.split = split_bwd ? 1 : 0;
+    eb.fuse_tail = i > 0;
+    if (i > 0) {
+      const TapeBlock& kp = tp.b[i - 1];
+      const EdgeBW& wb = m->blocks[i - 1].eb;
+      eb.tHep = kp.Hep; eb.tSL = kp.SL; eb.tSR = kp.SR; eb.tNT = kp.NT; eb.tGU = GU; eb.tGHEP = GHEP;
+      eb.tWself = split_bwd ? wb.ss.Wself : wb.s.Wself;
+      eb.tWoutT = split_bwd ? m->ebw[i - 1].ss.WoutT : m->ebw[i - 1].s.WoutT;
+      eb.tWselfT = split_bwd ? m->ebw[i - 1].ss.WselfT : m->ebw[i - 1].s.WselfT;
+      eb.tbself = wb.bself; eb.tlng = wb.lng; eb.tlnb = wb.lnb;
+    }
     eb.units_r = g->units_r; eb.epo_r = g->epo_r; eb.col_eids = g->col_eids; eb.col_left = g->col_left; eb.col_right = g->col_right;
     eb.nunits_r = (int)g->nunits_r;
     {
@@ -1615,7 +1630,6 @@ extern "C" int mdx_bondpred_backward(mdx_model_t m, mdx_graph_t g, const float* 
     }
     nt.flags = NB_PRE | nb_split;
     launch_node_bwd(nt, s);
-    std::swap(gHe, gHe2);
   }
   launch_dist_to_pos(tp.gdist, pos, g->left, g->right, g->row_ptr, g->col_ptr, g->col_eids, tp.tmpE3, nullptr, gpos, scale, N,
                      E, cf.cutoff, s);

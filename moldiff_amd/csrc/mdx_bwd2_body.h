@@ -23,6 +23,7 @@
 constexpr int BW_FO = 32 + 7 * 256, BW_FS = 640;
 constexpr int BW_CONST_FLOATS = BW_FO + 2 * BW_FS;
 
+template <bool FUSE_TAIL>
 __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a, const int nunits, const WorkQ wq) {
   static_assert(RR == 1, "the in-kernel segment sums are written for one 16-row tile per wave");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,6 +90,13 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
   WRing ring;
   ring_prime(ring, W(wfirst));
 
+#ifdef MDX_BWD_PREFETCH
+  RowTile tnext;
+  {
+    const int2 ue0 = reinterpret_cast<const int2*>(a.units_r)[ubeg];
+    tnext = load_tile_r(a.col_eids, a.col_left, a.col_right, a.te, a.epo_r, ue0.x, ue0.y, c);
+  }
+#endif
 #pragma unroll 1
   for (int unit = ubeg;;) {
     int q = q0;
@@ -96,8 +104,12 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
     const int ureq = dyn ? wq_request(wp.line, lane) : 0;  // the next unit, consumed at the end of this one
     STAMPW(46);
     STAMPW(0);
+#ifdef MDX_BWD_PREFETCH
+    const RowTile t = tnext;
+#else
     const int2 ue = reinterpret_cast<const int2*>(a.units_r)[unit];
     const RowTile t = load_tile_r(a.col_eids, a.col_left, a.col_right, a.te, a.epo_r, ue.x, ue.y, c);
+#endif
     const int ucnt = __builtin_amdgcn_readfirstlane(t.cnt);
     const int prow = t.pf[0] + unit;  // the partial row of this lane's right node in this unit
     f32x4 hep[4][RR], ghe[4][RR];     // He' (tape) and the running dL/dHe'; the EdgeBlock tail's part (GHEP) is added at the very end
@@ -125,7 +137,8 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
       BW_GEMM(16, 16)(u, v, W(a.wt.BW_S.Wg2T), ring, W(a.w.BW_S.Wg1e));
       STAMPW(2);
       row_gather<16, RR>(v, a.NT + MDX_NT_GX, t.ri, MDX_NTW, q);
-      row_gather<4, RR>(hep, a.Hep, t.row, 64, q);
+      f32x4 hg[4][RR];  // He' for the gate's recompute; requested again under the message chain's second GEMM (not held across it)
+      row_gather<4, RR>(hg, a.Hep, t.row, 64, q);
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft) {
         const f32x4 b = lds4(c_bg1 + 16 * ft + 4 * q), wt = lds4(c_wtg1 + 16 * ft + 4 * q);
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
         for (int rt = 0; rt < RR; ++rt) v[ft][rt] = (b + v[ft][rt]) + splat4(t.tt[rt]) * wt;
       }
       STAMPW(3);
-      BW_GEMM(4, 16)(v, hep, W(a.w.BW_S.Wg1e), ring, W(a.wt.BW_S.Wg1eT));
+      BW_GEMM(4, 16)(v, hg, W(a.w.BW_S.Wg1e), ring, W(a.wt.BW_S.Wg1eT));
       STAMPW(4);
       {
         float rstd[RR];
@@ -141,11 +154,11 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
         row_ln_relu_bwd<16, RR>(u, v, rstd, c_gg, c_gb, q);
       }
       // dL/d gx[r]: summed over the unit's runs of equal right node (partial rows of GGX)
-      seg_sum_put<16>(u, wbuf, lane);
-      seg_sum_flush<16, 4>(wbuf, lane, ucnt, t.ri[0], prow, a.GGX);
+      seg_sum_put<16>(u, wbuf, lane);  // to the LDS area now, summed after the next GEMM (the writes retire under its MFMAs)
       row_zero<4, RR>(ghe);
       STAMPW(5);
       BW_GEMM(16, 4)(ghe, u, W(a.wt.BW_S.Wg1eT), ring, W(a.wt.BW_S.WmT));
+      seg_sum_flush<16, 4>(wbuf, lane, ucnt, t.ri[0], prow, a.GGX);
       STAMPW(6);
       // ---- message chain: d m0 = gm * sg (sigmoid(gate) is read again: the wave's LDS area stays free for the segment sums)
       row_gather<16, RR>(u, a.SG, t.row, MDX_ND, q);
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
         seg_sum_put<16>(u, wbuf, lane);  // GH goes to the LDS area now (u is free for the next GEMM) and is summed after it
         mul_inplace<16>(v, hr);
       }
+      row_gather<4, RR>(hep, a.Hep, t.row, 64, q);
       // through edge_net: he = W2 relu(LN(x)) + b2, x = W1 He' + b1
       row_zero<16, RR>(u);
       STAMPW(9);
@@ -285,11 +299,19 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
         row_ln_relu_bwd<2, RR>(ggg, xhg, rstdg, f_gg[s], f_gb[s], q);
         if constexpr (s == 1) seg_sum_store<2>(ggg, wbuf, lane, ucnt, t.ri[0], prow, a.GGXS[1]);
         else row_store<2, RR>(ggg, a.GGXS[0], t.row, t.valid, 32, q);
-        BW_GEMM(2, 4)(ghe, ggg, W(wts.Wg1eT), ring, W(s == 0 ? a.w.BW_S.ffn[1].Wg1e : a.wt.BW_S.WembHT));
+        BW_GEMM(2, 4)(ghe, ggg, W(wts.Wg1eT), ring, W(s == 0 ? a.w.BW_S.ffn[1].Wg1e : (FUSE_TAIL ? a.wt.BW_S.WembHT : a.wt.BW_S.WembDT)));
       }
     });
 
     STAMPW(20);
+#ifdef MDX_BWD_PREFETCH
+    // the next unit's indices travel under the edge_embs / tail GEMMs (the last unit of a wave repeats its own)
+    int unext = dyn ? wp.beg + wq_take(ureq) : unit + 1;
+    {
+      const int2 uen = reinterpret_cast<const int2*>(a.units_r)[unext < uend ? unext : unit];
+      tnext = load_tile_r(a.col_eids, a.col_left, a.col_right, a.te, a.epo_r, uen.x, uen.y, c);
+    }
+#endif
     // ---------------- edge_embs backward: He' = Wemb [He_i | D(d)] + b ----------------
     {
       f32x4 gi[4][RR];
@@ -298,12 +320,13 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
       for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
         for (int rt = 0; rt < RR; ++rt) ghe[ft][rt] = ghe[ft][rt] + gi[ft][rt];
-      row_zero<4, RR>(gi);
-      BW_GEMM(4, 4)(gi, ghe, W(a.wt.BW_S.WembHT), ring, W(a.wt.BW_S.WembDT));
-      row_store<4, RR>(gi, a.gHe_out, t.row, t.valid, 64, q);
+      if constexpr (FUSE_TAIL) {
+        row_zero<4, RR>(gi);
+        BW_GEMM(4, 4)(gi, ghe, W(a.wt.BW_S.WembHT), ring, W(a.wt.BW_S.WembDT));  // gi = dL/dHe''_{i-1}, stays in registers for the tail below
+      }
       f32x4 gd[2][RR];  // 16 distance features, padded to 32 by the pack
       row_zero<2, RR>(gd);
-      BW_GEMM(4, 2)(gd, ghe, W(a.wt.BW_S.WembDT), ring, W(wfirst));
+      BW_GEMM(4, 2)(gd, ghe, W(a.wt.BW_S.WembDT), ring, W(FUSE_TAIL ? a.tWself : wfirst));
       const f32x4 off = lds4(c_soff + 4 * q), coef = lds4(c_scoef + 4 * q);
 #pragma unroll
       for (int rt = 0; rt < RR; ++rt) {
@@ -323,10 +346,44 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
         sacc = red_q(sacc);
         if (q == 0 && t.valid[rt]) a.gdist[t.row[rt]] += (d >= a.smear_start && d <= a.cutoff) ? sacc : 0.f;  // clamp passes the gradient inside [start, stop]
       }
+      // ---------------- EdgeBlock tail of block i - 1, backward (models/graph.py:286-294 through autograd) ----------------
+      // He''_{i-1} = He'_{i-1} + out(relu(LN(u))),  u = self_ffn(He') + SL[l] + SR[r] + nfl[l] + nfr[r];  in: gi = dL/dHe''_{i-1}.
+      // Out: GU = dL/du (reduced per node by the caller) and GHEP = dL/dHe'' + self_ffn^T dL/du for block i - 1's own launch.
+      if constexpr (FUSE_TAIL) {
+        f32x4 hp[4][RR], u[4][RR];
+        row_gather<4, RR>(hp, a.tHep, t.row, 64, q);
+        {  // u's per-node part, in the forward's order of additions
+          f32x4 v1[4][RR], v2[4][RR], v3[4][RR];
+          row_gather<4, RR>(u, a.tSL, t.li, 64, q);
+          row_gather<4, RR>(v1, a.tSR, t.ri, 64, q);
+          row_gather<4, RR>(v2, a.tNT + MDX_NT_NFL, t.li, MDX_NTW, q);
+          row_gather<4, RR>(v3, a.tNT + MDX_NT_NFR, t.ri, MDX_NTW, q);
+#pragma unroll
+          for (int ft = 0; ft < 4; ++ft) {
+            const f32x4 bs = ldg4(a.tbself + 16 * ft + 4 * q);
+#pragma unroll
+            for (int rt = 0; rt < RR; ++rt) u[ft][rt] = (((u[ft][rt] + v1[ft][rt]) + v2[ft][rt]) + v3[ft][rt]) + bs;
+          }
+        }
+        BW_GEMM(4, 4)(u, hp, W(a.tWself), ring, W(a.tWoutT));
+        float rstd[RR];
+        row_ln_xhat<4, RR>(u, rstd);
+        f32x4 gy[4][RR];
+        row_zero<4, RR>(gy);
+        BW_GEMM(4, 4)(gy, gi, W(a.tWoutT), ring, W(a.tWselfT));
+        row_ln_relu_bwd<4, RR>(gy, u, rstd, a.tlng, a.tlnb, q);
+        row_store<4, RR>(gy, a.tGU, t.row, t.valid, 64, q);
+        BW_GEMM(4, 4)(gi, gy, W(a.tWselfT), ring, W(wfirst));
+        row_store<4, RR>(gi, a.tGHEP, t.row, t.valid, 64, q);
+      }
     }
     STAMPW(40);
     STAMPW(47);
+#ifdef MDX_BWD_PREFETCH
+    unit = unext;
+#else
     unit = dyn ? wp.beg + wq_take(ureq) : unit + 1;
+#endif
     if (unit >= uend) break;
   }
   if (dyn) wq_leave(wp, lane);

@@ -36,13 +36,15 @@ int launch_edge_bwd2s(const EdgeBwdArgs& a, hipStream_t s) {
   static bool attr = false;
   constexpr int lds = (4 * PARK_FLOATS + BW_CONST_FLOATS) * 4;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)edge_bwd2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)edge_bwd2s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)edge_bwd2s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   const int nunits = a.nunits_r;  // graph-aligned units of the by-right order (mdx_graph_s units_r)
   if (nunits <= 0) return 0;
   const int grid = std::min((nunits + 3) / 4, mdx_num_cus() * MDX_WPS);
   const WorkQ wq = make_workq(a.wq, nunits, grid, mdx_num_cus());
-  hipLaunchKernelGGL(edge_bwd2s_kernel, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
+  if (a.fuse_tail) hipLaunchKernelGGL(edge_bwd2s_kernel<true>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
+  else hipLaunchKernelGGL(edge_bwd2s_kernel<false>, dim3(grid), dim3(MDX_WG), lds, s, a, nunits, wq);
   return 0;
 }

@@ -233,7 +233,6 @@ struct EdgeBwdArgs {
   const float *SG, *HE, *M;    // tape (E,256): sigmoid(gate), edge_net output, gated message (M = msg_net(he*h[r]) * SG)
   const float *BL[2], *H1[2], *O[2];  // BondFFN tape (EdgeAArgs tBL / tH1 / tO); all null = recompute (tile kernels, A/B)
   const float* GNT;            // (N,960) gradient table: C cols = dL/d(aggr), NFL cols = A_l, NFR cols = A_r
-  float* gHe_out;              // (E,64) dL/dHe_i
   float* gdist;                // (E) accumulated over blocks
   // Gradient payloads for the node tables.  The kernel walks the edges in BY-RIGHT order (units of 16 positions of col_eids,
   // aligned to each graph's first position like the forward's by-left units), so every payload that is reduced by the right end
@@ -245,6 +244,15 @@ struct EdgeBwdArgs {
   float* GGXS[2];              // [0]: (E,32) per edge; [1]: (nparts_r,32) partial rows
   const int *units_r, *epo_r, *col_eids, *col_left, *col_right;  // by-right plan (mdx_graph_s)
   int nunits_r;
+  // EdgeBlock-tail backward of the PREVIOUS block (i - 1), fused behind this block's edge_embs backward for the same rows
+  // (round 5; it used to be a launch of its own that re-read dL/dHe'' from memory): tape and weights of block i - 1, outputs
+  // tGU (E,64) = dL/du and the rows of GHEP for block i - 1 (written over the rows of GHEP this unit has already consumed).
+  // fuse_tail = 0 (block 0): none of this is read, and dL/dHe_0 -- the gradient of the embedding, which nobody needs -- is not formed.
+  int fuse_tail;
+  const float *tHep, *tSL, *tSR, *tNT;
+  const float *tWself, *tWoutT, *tWselfT;   // stream packs in the build's format (BW_S)
+  const float *tbself, *tlng, *tlnb;
+  float *tGU, *tGHEP;
   int* wq;                 // work-queue counters of the launch's stream (mdx_row.h WorkQ), nullptr = static unit split
   int split;               // 1: run the split float16 build (mdx_bwd2s.hip; needs the BondFFN tape)
   EdgeAW w;
