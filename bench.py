@@ -705,8 +705,8 @@ def main():
                  'per_rank_ms_per_step': [float(x.item()) for x in per_rank], 'gather_first_ms': gt[0], 'gather_ms': gt[1],
                  'gather_rows': [int(nrows[0]), int(nrows[1])],
                  'gather_bytes': int(nrows[0]) * (8 + 3) * 4 + int(nrows[1]) * 6 * 4,
-                 'gather_what': 'one distributed.gather_pred of all ranks\' last-step predictions to rank 0 (1 size all_gather + 1 '
-                                'padded all_gather per tensor), max over ranks; happens once per 1000-step run, outside ms_per_step'}
+                 'gather_what': 'one distributed.gather_pred of all ranks\' last-step predictions to rank 0 (1 count all_gather + ONE padded '
+                                'gather-to-rank-0 of a flat buffer holding all three tensors), max over ranks; happens once per 1000-step run, outside ms_per_step'}
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world / (ms_per_step * T_STEPS / 1e3)
 
@@ -788,8 +788,8 @@ def main():
             el3, prof3 = run_chain(sm3, 20, 3, barrier)
             ra = roofline_mfma('edge_a', EDGE_A_NAME + ' (14 launches per guided step: 6 denoiser + 8 predictor blocks)', FLOP_EDGE_A,
                                2 * sm3.Eh, prof3)
-            rb = roofline_mfma('edge_bwd', 'edge_bwd2_kernel<true> (row-owner guidance backward: dgrad chain over the forward tape, first-layer recompute only, '
-                               'v_mfma_f32_16x16x4_f32)', FLOP_EDGE_BWD, 2 * sm3.Eh, prof3)
+            rb = roofline_mfma('edge_bwd', 'edge_bwd2_kernel (row-owner guidance backward in by-right edge order: dgrad chain over the forward tape, first-layer recompute '
+                               'only, in-kernel sums of the by-right payloads, previous block\'s EdgeBlock-tail backward fused; v_mfma_f32_16x16x4_f32)', FLOP_EDGE_BWD, 2 * sm3.Eh, prof3)
             tot_a, tot_b = prof3['edge_a'][1], prof3['edge_bwd'][1]
             line2['roofline'] = dict(ra if tot_a >= tot_b else rb,
                                      note='kernel durations from a 20-step run with hipEvent brackets on every block kernel '
@@ -804,7 +804,9 @@ def main():
                 if all(k in ksG for k in ('edge_a2_kernel<15>', 'edge_a2_kernel<63>', 'edge_bwd2_kernel<true>')):
                     srcG = os.path.relpath(pmG[-1], ROOT) + ' (PMC passes of the guided run; not measured in this run)'
                     ta = (6 * ksG['edge_a2_kernel<15>']['hbm_bytes_per_launch'] + 8 * ksG['edge_a2_kernel<63>']['hbm_bytes_per_launch']) / 14
-                    tb = ksG['edge_bwd2_kernel<true>']['hbm_bytes_per_launch']
+                    tb = ksG['edge_bwd2_kernel<true>']['hbm_bytes_per_launch']   # <true>: with the fused tail of block i-1 (7 of 8 launches)
+                    if 'edge_bwd2_kernel<false>' in ksG:
+                        tb = (7 * tb + ksG['edge_bwd2_kernel<false>']['hbm_bytes_per_launch']) / 8
                     for r_ in (line2['roofline'], line2['roofline_other']):
                         r_['traffic'] = tb if 'edge_bwd2' in r_['kernel'] else ta
                         r_['traffic_source'] = srcG

@@ -90,13 +90,6 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
   WRing ring;
   ring_prime(ring, W(wfirst));
 
-#ifdef MDX_BWD_PREFETCH
-  RowTile tnext;
-  {
-    const int2 ue0 = reinterpret_cast<const int2*>(a.units_r)[ubeg];
-    tnext = load_tile_r(a.col_eids, a.col_left, a.col_right, a.te, a.epo_r, ue0.x, ue0.y, c);
-  }
-#endif
 #pragma unroll 1
   for (int unit = ubeg;;) {
     int q = q0;
@@ -104,12 +97,8 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
     const int ureq = dyn ? wq_request(wp.line, lane) : 0;  // the next unit, consumed at the end of this one
     STAMPW(46);
     STAMPW(0);
-#ifdef MDX_BWD_PREFETCH
-    const RowTile t = tnext;
-#else
     const int2 ue = reinterpret_cast<const int2*>(a.units_r)[unit];
     const RowTile t = load_tile_r(a.col_eids, a.col_left, a.col_right, a.te, a.epo_r, ue.x, ue.y, c);
-#endif
     const int ucnt = __builtin_amdgcn_readfirstlane(t.cnt);
     const int prow = t.pf[0] + unit;  // the partial row of this lane's right node in this unit
     f32x4 hep[4][RR], ghe[4][RR];     // He' (tape) and the running dL/dHe'; the EdgeBlock tail's part (GHEP) is added at the very end
@@ -304,14 +293,6 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
     });
 
     STAMPW(20);
-#ifdef MDX_BWD_PREFETCH
-    // the next unit's indices travel under the edge_embs / tail GEMMs (the last unit of a wave repeats its own)
-    int unext = dyn ? wp.beg + wq_take(ureq) : unit + 1;
-    {
-      const int2 uen = reinterpret_cast<const int2*>(a.units_r)[unext < uend ? unext : unit];
-      tnext = load_tile_r(a.col_eids, a.col_left, a.col_right, a.te, a.epo_r, uen.x, uen.y, c);
-    }
-#endif
     // ---------------- edge_embs backward: He' = Wemb [He_i | D(d)] + b ----------------
     {
       f32x4 gi[4][RR];
@@ -379,11 +360,7 @@ __global__ __launch_bounds__(MDX_WG, MDX_WPS) void BW_KERNEL(const EdgeBwdArgs a
     }
     STAMPW(40);
     STAMPW(47);
-#ifdef MDX_BWD_PREFETCH
-    unit = unext;
-#else
     unit = dyn ? wp.beg + wq_take(ureq) : unit + 1;
-#endif
     if (unit >= uend) break;
   }
   if (dyn) wq_leave(wp, lane);
