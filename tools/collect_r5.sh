@@ -6,7 +6,7 @@
 #   r5_split_kernel_stats.csv / r5_split_guided_*   the same with MOLDIFF_MATRIX_PATH=split_f16
 #   r5_pmc_summary.json / r5_split_pmc_summary.json / r5_guided_* / r5_split_guided_*   tools/pmc_summary.py: three separate --pmc passes each
 #   r5_train_fp16_kernel_stats.csv             kernel statistics of 10 fp16 training steps
-#   r5_ubench_split.txt, r5_mfma_rounding.txt, r5_split_accuracy.txt, r5_split_delta_diag.txt   the split path's micro-benchmark and accuracy evidence
+#   r5_split_accuracy.txt, r5_parity_both_paths.txt (tail statistic, stress weights, eight objectives: both matrix paths vs float64), r5_trace_edge_bwd2.txt
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
@@ -31,8 +31,7 @@ rm -rf /tmp/prof_tr
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tr -o p -- python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 10 > $OUT/r5_train_bench_fp16_under_rocprof.json 2> /dev/null
 find /tmp/prof_tr -name "*kernel_stats.csv" -exec cp {} $OUT/r5_train_fp16_kernel_stats.csv \;
 cd $ROOT
-timeout 300 tools/ubench_split 8 > $OUT/r5_ubench_split.txt 2>&1
-timeout 60 tools/mfma_rounding > $OUT/r5_mfma_rounding.txt 2>&1
 python tools/split_accuracy.py > $OUT/r5_split_accuracy.txt 2>/dev/null
-python tools/split_delta_diag.py > $OUT/r5_split_delta_diag.txt 2>/dev/null
+python -m pytest tests/test_gpu_round5.py tests/test_gpu_sampling.py -q -m gpu -s -k "tail_statistic or stress or eight" 2>&1 | grep -v "^\s*$" > $OUT/r5_parity_both_paths.txt
+python tools/trace_edge2.py w > $OUT/r5_trace_edge_bwd2.txt 2>&1
 ls -la $OUT | grep r5_
