@@ -72,7 +72,12 @@ int mdx_model_finalize(mdx_model_t m);
  * reference computes them in fp32).  MDX_MATRIX_EXACT_F32 (default): fp32-input MFMA, bit-for-bit an fmaf chain.
  * MDX_MATRIX_SPLIT_F16 (opt-in): every operand split into float16 hi + lo halves (22 significand bits), three float16 MFMAs
  * per k-group with fp32 accumulation -- same parity tests, ~2x the matrix throughput.  Needs a finalized model; refused with
- * MDX_ERR_UNSUPPORTED if a weight lies outside float16's range (|w| >= 65504).  Takes effect on the next forward / step. */
+ * MDX_ERR_UNSUPPORTED if a weight lies outside float16's range (|w| >= 65504); a handle that is re-finalized with such weights
+ * drops back to the exact path.  ACTIVATION RANGE: operands of the per-edge layers must stay below 65504 in magnitude too -- only the
+ * weights can be checked at pack time.  LayerNorm outputs are bounded by their gains; the un-normalised operands are the pairwise
+ * products bond_linear(b) * node_linear(n) and edge_net(e) * node_net(h[col]) (graph.py:45,139) and the raw inputs of a bare
+ * NodeEdgeNet: beyond the range they become inf / NaN on this path where the exact path stays finite (NaN/inf are propagated
+ * silently, like the reference does).  tests/golden/stress.npz exercises 3.7e4.  Takes effect on the next forward / step. */
 #define MDX_MATRIX_EXACT_F32 0
 #define MDX_MATRIX_SPLIT_F16 1
 int mdx_model_set_matrix_path(mdx_model_t m, int32_t path);
