@@ -53,9 +53,8 @@ __global__ __launch_bounds__(MDX_WG, 2) void node_kernel(const NodeArgs a) {
     // partial rows of PR, SL through the by-right index list over FL), one (node, 4 features) per thread.  393 tiles leave 119 of the
     // chip's 512 workgroup slots free, so these run beside the tiles' GEMM chains instead of in front of them (as a prologue of every
     // tile they cost 10 us per launch).
-    static_assert(TN * 16 <= MDX_WG, "one thread per (node, float4) of a 64-wide row");
-    const int v = ((int)blockIdx.x - ntile) * TN + (tid >> 4), c4 = tid & 15;
-    if ((tid >> 4) < TN && v < N) {
+    const int v = ((int)blockIdx.x - ntile) * (MDX_WG / 16) + (tid >> 4), c4 = tid & 15;   // 16 nodes per workgroup, one thread per (node, float4)
+    if (v < N) {
       stg4(a.SR + (size_t)v * 64 + 4 * c4, seg_sum<64>(a.PR, a.pbase, nullptr, v, c4));
       stg4(a.SL + (size_t)v * 64 + 4 * c4, seg_sum<64>(a.FL, a.col_ptr, a.col_eids, v, c4));
     }
@@ -424,7 +423,7 @@ void launch_node(const NodeArgs& a, hipStream_t s) {
   }
   const int ntile = (a.N + TN - 1) / TN;
   // fused reduction: a second set of workgroups (ids >= ntile) computes the BondFFN sums beside the tiles
-  const int grid = ((a.flags & ND_MID) && a.P) ? 2 * ntile : ntile;
+  const int grid = ((a.flags & ND_MID) && a.P) ? ntile + (a.N + MDX_WG / 16 - 1) / (MDX_WG / 16) : ntile;
   hipLaunchKernelGGL(node_kernel, dim3(grid), dim3(MDX_WG), NODE_LDS_FLOATS * 4, s, a);
 }
 

@@ -17,6 +17,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import moldiff_amd._lib as _lib  # noqa: E402
+if os.environ.get('MDX_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['MDX_LIB'])   # an alternative build (tools/build_variant.sh)
 import bench  # noqa: E402
 import moldiff_amd as M  # noqa: E402
 from moldiff_amd.harness import default_config, placeholder_from_sizes  # noqa: E402
