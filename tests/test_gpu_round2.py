@@ -85,6 +85,7 @@ def test_compact_trajectory_expands_to_the_reference_layout():
     assert tuple(last[0].shape) == (1, N, 8) and torch.equal(last[0].dense()[0], frames[-1]['h_node'])
 
 
+@U.both_paths
 def test_one_call_step_from_c_abi_matches_the_separate_calls():
     """mdx_sample_step_full (time tensor + Philox draw + denoiser + posteriors + draws + concurrent guidance) against the
     same step assembled from the single-purpose entry points the way round 1's Python driver did it: bit-identical."""
@@ -153,6 +154,7 @@ def test_standalone_bond_ffn_vs_reference_golden(i):
     assert out_l.shape == (ea.shape[0], 1) and U.maxdiff(out_l, ref_l) < 2e-5
 
 
+@U.both_paths
 def test_config4_split_every_shard_equals_the_unsharded_batch():
     """BASELINE config #4: 2048 molecules over 8 ranks.  The eight 256-molecule slices of the entry point's cost-balanced
     order are run one after the other on this GPU (each through the HIP path, noise keyed by global molecule id) and

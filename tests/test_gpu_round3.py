@@ -70,6 +70,7 @@ def _guided_run(m, bp, sizes, mol_idx, seed, steps):
     return res
 
 
+@U.both_paths
 def test_config4_guided_shards_equal_the_unsharded_batch():
     """BASELINE config #4 with its own model: sample_MolDiff.yml = full model + bond-predictor guidance ['uncertainty', 1e-4], 2048
     molecules over 8 ranks.  The 2048 molecules are sampled as ONE guided batch (prior + 2 chain steps: denoiser, predictor forward
@@ -94,6 +95,7 @@ def test_config4_guided_shards_equal_the_unsharded_batch():
             assert torch.isfinite(got[1]).all()
 
 
+@U.both_paths
 def test_config4_guided_shard_step_matches_oracle():
     """One guided step of config #4's shard 0, oracle-checked.  A molecule's HIP result does not depend on its batch (previous
     test), so the oracle is run on the 24 molecules of the shard that matter most -- the 12 smallest (incl. n = 4) and the 12
@@ -137,6 +139,7 @@ def test_config4_guided_shard_step_matches_oracle():
             assert torch.equal(a, b), int(g)
 
 
+@U.both_paths
 def test_free_running_chain_bit_equal_for_twenty_steps():
     """Free-running (NOT teacher-forced) chains on identical explicit noise, HIP vs oracle: SURVEY 8(c) says class ids stay bit-equal
     for ~20 steps before fp32 chaos separates any two implementations (the reference differs from itself across thread counts).

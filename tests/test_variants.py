@@ -117,6 +117,7 @@ def test_oracle_timefree_predictor_matches_reference_golden():
     assert abs(float(loss) - float(z['tf_loss'])) <= 1e-6
 
 
+@U.both_paths
 @pytest.mark.gpu
 def test_gpu_timefree_predictor_forward_matches_reference_golden():
     z, sizes, args, (ei, be) = _tf_case('cuda')
@@ -155,6 +156,7 @@ def test_gpu_timefree_predictor_training_gradients_match_reference():
     m.zero_grad(set_to_none=True)
 
 
+@U.both_paths
 @pytest.mark.gpu
 def test_gpu_timefree_predictor_guidance_gradient_matches_oracle_autograd():
     """The hand-written d/d pos backward works for the variant too: d sum(log sigmoid(-logsumexp)) / d pos vs autograd through the oracle."""
@@ -173,6 +175,7 @@ def test_gpu_timefree_predictor_guidance_gradient_matches_oracle_autograd():
     assert U.maxdiff(g, go) <= 1e-4 * max(1.0, float(go.abs().max()))
 
 
+@U.both_paths
 @pytest.mark.gpu
 def test_gpu_timefree_predictor_in_the_fused_guided_step_ignores_the_step_index():
     """inside mdx_sample_step_full the predictor is handed the CURRENT step (e.g. 999); the time-free predictor must
@@ -248,6 +251,7 @@ def test_smearing_start_reaches_the_tables_and_the_oracle():
     assert U.maxdiff(other['pred_pos'], z['st_pred_pos']) > 1e-3
 
 
+@U.both_paths
 @pytest.mark.gpu
 def test_gpu_forward_with_smearing_start_matches_reference_golden():
     z, args, _ = _start_case('cuda')
@@ -258,6 +262,7 @@ def test_gpu_forward_with_smearing_start_matches_reference_golden():
         assert U.maxdiff(got[k], z[f'st_{k}']) <= 1e-4, (k, U.maxdiff(got[k], z[f'st_{k}']))
 
 
+@U.both_paths
 @pytest.mark.gpu
 def test_gpu_predictor_position_gradient_with_smearing_start_matches_reference_autograd():
     """d uncertainty / d pos from the hand-written backward vs the REFERENCE's autograd: below `start` the clamp passes nothing."""
@@ -380,6 +385,7 @@ def test_gpu_continuous_space_loss_and_gradients_match_reference():
     m.zero_grad(set_to_none=True)
 
 
+@U.both_paths
 @pytest.mark.gpu
 def test_gpu_continuous_sampler_steps_match_reference_sample():
     """The first iterations of MolDiff.sample() in the continuous space, with the reference's own prior and noise draws injected:
@@ -498,6 +504,7 @@ def test_variant_state_dict_and_oracle_match_the_reference_golden(tag):
     assert synth_gates(U.moldiff('MolDiff').denoiser) == {}
 
 
+@U.both_paths
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['ng', 'ne', 'g8'])
 def test_gpu_variant_forward_loss_and_gradients_match_reference(tag):
@@ -525,6 +532,7 @@ def test_gpu_variant_forward_loss_and_gradients_match_reference(tag):
     md.zero_grad(set_to_none=True)
 
 
+@U.both_paths
 @pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['ng', 'ne', 'g8'])
 def test_gpu_variant_predictor_position_gradient_matches_reference_autograd(tag):
