@@ -19,7 +19,7 @@ give-up rule (:106-108).  What differs, deliberately:
     number of GPUs;
   * with WORLD_SIZE > 1 every rank samples a contiguous slice of each batch's cost-balanced molecule order (noise keyed by
     global molecule id); per batch the last-step predictions travel to rank 0 as tensors (``distributed.gather_pred``:
-    one size all_gather + one padded all_gather each) and one 2-element all-reduce carries the loop condition.
+    one count all_gather + ONE padded gather-to-rank-0 of a flat buffer holding all three) and one 2-element all-reduce carries the loop condition.
 No pretrained checkpoint ships with the reference (Google-Drive download); ``--recipe-weights`` substitutes the
 deterministic synthetic weights used by the tests so the entry point can be exercised end to end.
 """
@@ -206,8 +206,8 @@ def main(argv=None):
                     with open(path, 'w') as f:
                         for info in frames:
                             f.write(mol_block(info) + '$$$$\n')
-        # the only data-path collective: this batch's last-step predictions to rank 0 (one size all_gather + one padded
-        # all_gather per tensor, RCCL over xGMI; about 2 MB per rank at 256 molecules)
+        # the only data-path collective: this batch's last-step predictions to rank 0 (one count all_gather + one padded
+        # gather-to-rank-0 of a flat buffer, RCCL over xGMI; about 2 MB per rank at 256 molecules)
         pred = out['pred']
         if dist is not None:
             pred = gather_pred([p.to(comm_dev) for p in pred], dst=0)
