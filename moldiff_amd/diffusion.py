@@ -102,17 +102,23 @@ class deferred_class_checks:
         deferred_class_checks._active = self.prev
 
     def finish(self):
-        if not self.items:
-            return None
-        dev = torch.stack([m for m, _ in self.items])
-        limits = [k for _, k in self.items]
-        # Multi-rank: every rank must fail in the SAME step, or the healthy ranks sit in the next gradient all-reduce until the
-        # collective's watchdog ends them.  One MAX all-reduce of a flag (a device op on the step's stream, no host round trip; every
-        # rank issues it at the same point of its step) tells everybody that somebody's batch is out of range.
         import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not self.items and not multi:
+            return None
+        limits = [k for _, k in self.items]
+        if self.items:
+            dev = torch.stack([m for m, _ in self.items])
+        else:   # nothing to check on this rank (empty batch): it still takes part in the collective below
+            dev = torch.zeros(0, dtype=torch.int64, device='cuda' if torch.cuda.is_available() else 'cpu')
+        # Multi-rank: every rank must fail in the SAME step, or the healthy ranks sit in the next gradient all-reduce until the
+        # collective's watchdog ends them.  One MAX all-reduce of a flag (a device op on the step's stream, no host round trip; EVERY
+        # rank issues it once per step at the same point, whatever its batch holds) tells everybody that somebody's batch is out of
+        # range.
         peers = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            peers = (dev >= torch.tensor(limits, dtype=dev.dtype, device=dev.device)).any().to(torch.int32).reshape(1)
+        if multi:
+            bad = (dev >= torch.tensor(limits, dtype=dev.dtype, device=dev.device)).any() if self.items else torch.zeros((), dtype=torch.bool, device=dev.device)
+            peers = bad.to(torch.int32).reshape(1)
             dist.all_reduce(peers, op=dist.ReduceOp.MAX)
             dev = torch.cat([dev, peers.to(dev.dtype)])
         host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=dev.is_cuda)
