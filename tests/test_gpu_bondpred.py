@@ -92,3 +92,42 @@ def test_guidance_gradient_with_distances_straddling_the_cutoff_vs_oracle_autogr
     ref, = torch.autograd.grad((ref_logits * cot).sum(), p)
     assert U.maxdiff(logits, ref_logits) < 2e-5
     assert U.maxdiff(got, ref) <= 1e-3 * float(ref.abs().max())
+
+
+@U.both_paths
+def test_guidance_gradient_on_a_sparse_shuffled_graph_vs_oracle_autograd():
+    """The backward walks the edges in BY-RIGHT order and sums its by-right payloads over each right node's run inside the kernel
+    (round 5): nothing in that may rely on the fully-connected molecule layout.  Two 'molecules' (13 and 20 atoms) whose half-edges
+    are a random 35 % subset of all pairs plus a ring, given in shuffled order -- irregular degrees (2..12 edges per atom), runs that
+    straddle the 16-row units -- logits and d(sum log sigmoid(-logsumexp))/d pos vs the oracle."""
+    r = U.rng(77)
+    sizes, off, pairs, bn = [13, 20], 0, [], []
+    for b, n in enumerate(sizes):
+        iu = np.stack(np.triu_indices(n, 1))
+        keep = r.random(iu.shape[1]) < 0.35
+        ring = np.stack([np.arange(n - 1), np.arange(1, n)])          # keeps every atom connected
+        he = np.unique(np.concatenate([iu[:, keep], ring], axis=1), axis=1)
+        he = he[:, r.permutation(he.shape[1])] + off
+        pairs.append(he)
+        bn += [b] * n
+        off += n
+    # half-edges grouped by molecule (batch_halfedge is non-decreasing like the reference's), shuffled inside each molecule
+    hei = torch.from_numpy(np.concatenate(pairs, axis=1)).long()
+    bn = torch.tensor(bn)
+    ei = torch.cat([hei, hei.flip(0)], 1)
+    be = bn[ei[0]]
+    N, Eh = len(bn), hei.shape[1]
+    xn = F.one_hot(torch.from_numpy(r.integers(0, 8, N)), 8).float()
+    pos0 = U.t32(r.standard_normal((N, 3), dtype=np.float32) * 2.0)
+    t = torch.tensor([120, 870])
+    m = U.bondpred(DEV)
+    pos = pos0.to(DEV).requires_grad_(True)
+    logits = m(xn.to(DEV), pos, bn.to(DEV), ei.to(DEV), be.to(DEV), t.to(DEV))
+    (got,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(logits, -1)).log().sum(), pos)
+    P = U.params(m)
+    p = pos0.clone().requires_grad_(True)
+    ref_logits = O.bondpred_forward(P, U.CFGB, xn, p, bn, ei, be, t)
+    (ref,) = torch.autograd.grad(torch.sigmoid(-torch.logsumexp(ref_logits, -1)).log().sum(), p)
+    assert logits.shape == (Eh, 5)
+    assert U.maxdiff(logits, ref_logits) < 2e-5
+    assert U.maxdiff(got, ref) <= 1e-3 * float(ref.abs().max())
