@@ -185,6 +185,92 @@ __device__ __forceinline__ void gemm_split2(f32x4 (&y)[16][R], const h8 (&xh)[8]
   });
 }
 
+// The shipped form with the operand conversion PIPELINED into the GEMM (round 5): k-group g + 1 is split into
+// its hi / lo halves while the first feature-tile pair's MFMAs of group g issue (the float16 MFMA co-executes with VALU work of the
+// same wave; the fp32 one does not).  Only the first of the eight passes over the k-groups can carry conversions -- every pass
+// needs all eight groups -- so at most 1/8 of the GEMM's MFMAs have VALU work next to them.  MODE 0: conversions placed in the MFMA
+// region, scheduling left to the compiler; MODE 1: forced interleave, one MFMA then VPM VALU instructions (sched_group_barrier).
+template <int R, int DEPTH, int MODE, int VPM = 10>
+__device__ __forceinline__ void gemm_split2_pipe(f32x4 (&y)[16][R], const f32x4 (&x)[16][R], const WS& w, int mbase) {
+  constexpr int KG = 8, NP = 8 * KG * 2;
+  h8 xh[8][R], xl[8][R];
+  auto conv = [&](auto gc, int rt0, int rt1) {
+    constexpr int g = decltype(gc)::value;
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt) {
+      if (rt < rt0 || rt >= rt1) continue;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float v = x[2 * g + t / 4][rt][t % 4];
+        const _Float16 h = (_Float16)v;
+        xh[g][rt][t] = h;
+        xl[g][rt][t] = (_Float16)((v - (float)h) * 2048.0f);
+      }
+    }
+  };
+  f32x4 ring[DEPTH][2];
+#pragma unroll
+  for (int p = 0; p < DEPTH; ++p) {
+    ring[p][0] = ws_frag(w, mbase + (2 * p) * 1024);
+    ring[p][1] = ws_frag(w, mbase + (2 * p + 1) * 1024);
+  }
+  conv(std::integral_constant<int, 0>{}, 0, R);
+  f32x4 t0[R], t1[R];
+  static_for<0, NP>([&](auto pc) {
+    constexpr int p = decltype(pc)::value, ftp = p / (2 * KG), g = (p / 2) % KG, h = p % 2;
+    const h8 a0 = __builtin_bit_cast(h8, ring[p % DEPTH][0]), a1 = __builtin_bit_cast(h8, ring[p % DEPTH][1]);
+    if constexpr (p + DEPTH < NP) {
+      ring[p % DEPTH][0] = ws_frag(w, mbase + (2 * (p + DEPTH)) * 1024);
+      ring[p % DEPTH][1] = ws_frag(w, mbase + (2 * (p + DEPTH) + 1) * 1024);
+    }
+    if constexpr (g == 0 && h == 0) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) t0[rt] = t1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr bool carry = ftp == 0 && g + 1 < KG;
+    if constexpr (carry) {  // group g + 1: the first half of the row tiles next to this half-step's MFMAs, the rest next to the other's
+      constexpr int half = (R + 1) / 2;
+      if constexpr (h == 0) conv(std::integral_constant<int, (g + 1 < KG ? g + 1 : 0)>{}, 0, half);
+      else conv(std::integral_constant<int, (g + 1 < KG ? g + 1 : 0)>{}, half, R);
+    }
+    if constexpr (h == 0) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        y[2 * ftp][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xh[g][rt], y[2 * ftp][rt], 0, 0, 0);
+        y[2 * ftp + 1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xh[g][rt], y[2 * ftp + 1][rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        t0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xl[g][rt], t0[rt], 0, 0, 0);
+        t1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xl[g][rt], t1[rt], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        t0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xh[g][rt], t0[rt], 0, 0, 0);
+        t1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xh[g][rt], t1[rt], 0, 0, 0);
+      }
+    }
+    if constexpr (carry && MODE == 1) {
+      constexpr int nm = h == 0 ? 4 * R : 2 * R;
+#pragma unroll
+      for (int i = 0; i < nm; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VPM VALU instructions of the conversion
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (g == KG - 1 && h == 1) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        y[2 * ftp][rt] = y[2 * ftp][rt] + t0[rt] * (1.0f / 2048.0f);
+        y[2 * ftp + 1][rt] = y[2 * ftp + 1][rt] + t1[rt] * (1.0f / 2048.0f);
+      }
+    }
+  });
+}
+
 // step p = ftp * 8 + g carries four 1-KiB fragments: hi(2ftp, g), hi(2ftp+1, g), lo(2ftp, g), lo(2ftp+1, g)
 // TERMS = 3: Whi Xhi + Whi Xlo + Wlo Xhi;  TERMS = 1: plain float16 (speed reference only)
 template <int R, int DEPTH, int TERMS>
@@ -239,6 +325,7 @@ __device__ int g_desync = 0;
     __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
 
+// KIND 6 / 7: the shipped split form with the operand conversion pipelined into the GEMM (compiler-scheduled / forced interleave);
 // KIND 0: exact fp32;  3: split float16, lo halves unscaled, one accumulator (first cut);  4: split float16 as shipped
 // (mdx_split.h: lo halves scaled by 2^11, cross terms in accumulators of their own);  1: plain float16 (one product)
 template <int KIND, int R, int DEPTH, int WPS, bool LN>
@@ -269,6 +356,8 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict
       STAMP(0);
       if constexpr (KIND == 0) {
         gemm_f32<R, DEPTH>(y, x, ws, mbase);
+      } else if constexpr (KIND == 6 || KIND == 7) {
+        gemm_split2_pipe<R, DEPTH, KIND - 6>(y, x, ws, mbase);
       } else if constexpr (KIND == 4 || KIND == 5) {
         h8 xh[8][R], xl[8][R];
         split_x<R>(x, xh, xl, 2048.0f);
@@ -519,6 +608,7 @@ int main(int argc, char** argv) {
   hipMemcpy(d.WsplitS, psS.data(), psS.size() * 2, hipMemcpyHostToDevice);
   const float eps = 1e-5f, epsS = 1e-5f * ldexpf(1.0f, 2 * sw);
   printf("weight scale 2^%d for the scaled split packs; reference = float64 chain of %d layers on %d rows\n", sw, nl_check, nref);
+  if (!getenv("UB_PIPE_ONLY")) {
   run<0, 1, 4, 2, true>("exact fp32 16x16x4", d, d.Wf32, P, eps, hX, refLN, nl_check, nref);
   run<0, 2, 4, 1, true>("exact fp32 16x16x4", d, d.Wf32, P, eps, hX, refLN, nl_check, nref);
   run<3, 1, 4, 2, true>("split f16 x3 (unscaled W)", d, d.Wsplit0, P, eps, hX, refLN, nl_check, nref);
@@ -526,8 +616,14 @@ int main(int argc, char** argv) {
   run<3, 1, 2, 2, true>("split f16 x3 (W * 2^sw)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
   run<3, 2, 2, 1, true>("split f16 x3 (W * 2^sw)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
   run<3, 2, 4, 1, true>("split f16 x3 (W * 2^sw)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
+  }
   run<4, 1, 4, 2, true>("SHIPPED: lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<4, 2, 4, 1, true>("SHIPPED: lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<6, 1, 4, 2, true>("pipelined conversion (compiler)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<6, 2, 4, 1, true>("pipelined conversion (compiler)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<7, 1, 4, 2, true>("pipelined conversion (interleave)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<7, 2, 4, 1, true>("pipelined conversion (interleave)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  if (getenv("UB_PIPE_ONLY")) return 0;
   run<5, 1, 4, 2, true>("variant: + Wlo Xlo (4 terms)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<5, 2, 4, 1, true>("variant: + Wlo Xlo (4 terms)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<1, 1, 4, 2, true>("plain f16 x1 (speed ref)", d, d.WsplitS, P, epsS, hX, refLN, nl_check, nref);
