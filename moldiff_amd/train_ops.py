@@ -536,10 +536,10 @@ class IndexPlan:
         _lib._need_gpu(index)
         self.index = index.detach().to(torch.int64).contiguous()
         self.n = int(n)
-        self.order = torch.sort(self.index, stable=True).indices.contiguous()
-        counts = torch.bincount(self.index, minlength=self.n)
-        self.ptr = torch.zeros(self.n + 1, dtype=torch.int64, device=index.device)
-        self.ptr[1:] = torch.cumsum(counts, 0)
+        srt = torch.sort(self.index, stable=True)
+        self.order = srt.indices.contiguous()
+        # segment starts from the sorted values (torch.bincount would read the maximum back to the host: a device sync per plan)
+        self.ptr = torch.searchsorted(srt.values, torch.arange(self.n + 1, dtype=torch.int64, device=index.device))
 
 
 def _gather_raw(x, plan, out_dtype=None):
