@@ -1872,11 +1872,49 @@ extern "C" int64_t mdx_op_ln_relu_bwd_rows(int64_t M) {  // partial rows mdx_op_
   return (nw + 3) / 4 * 4;
 }
 namespace {
-// One thread per output element: eight running sums over the partials k = z, z + 8, ... (z = 0..7), added up in the order z = 0..7 --
-// the association of the per-layer reduction kernels (and of this kernel's first form, which gave each z its own thread and read 128
-// contiguous bytes per half wave: 0.6 TB/s over ~850 MB per training step, 1.45 ms).  Here a wave reads 256 contiguous bytes per partial
-// and keeps eight independent loads in flight per lane.  The record table keeps its unit of 32 elements per block (`first_block`);
-// a workgroup takes eight of those.
+// One lane per FOUR consecutive output elements: eight running sums over the partials k = z, z + 8, ... (z = 0..7), added up in the
+// order z = 0..7 -- the association of the per-layer reduction kernels.  History: one thread per (element, z) read 128 contiguous bytes
+// per half wave (1.45 ms per training step); one thread per element with eight loads in flight: 1.13 ms -- and that time was not
+// bandwidth: a LayerNorm over the E edge rows leaves E / 16 partial rows, so ONE thread walked ~10,000 partials in a dependent chain
+// (1,250 iterations x ~0.9 us) while the weight records finished in a fraction of it.  The caller now splits a record with more than
+// 256 partials the way launch_reduce_partials does (chunk sums into scratch, `store` records; then a second launch over the chunk
+// sums), so no chain is longer than 32 + S/2048 iterations, and a lane takes four elements (one 16-byte load per partial when the
+// record's planes are 16-byte aligned) so a wave reads 1 KB per partial and the record look-up is paid once per 128 elements.
+// rkind bit 7: store the sum instead of adding it.  The record table's unit (`first_block`) is 128 elements per block.
+template <bool VEC>
+__device__ __forceinline__ f32x4 reduce_deferred_sum(const float* p, size_t pstride, int S, int ne) {
+  f32x4 acc[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) acc[z] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto ldp = [&](int k) -> f32x4 {
+    const float* q = p + (size_t)k * pstride;
+    if constexpr (VEC) {
+      return *reinterpret_cast<const f32x4*>(q);
+    } else {
+      f32x4 v{0.f, 0.f, 0.f, 0.f};
+      v[0] = q[0];
+      if (ne > 1) v[1] = q[1];
+      if (ne > 2) v[2] = q[2];
+      if (ne > 3) v[3] = q[3];
+      return v;
+    }
+  };
+  int k = 0;
+  for (; k + 8 <= S; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) v[z] = ldp(k + z);
+#pragma unroll
+    for (int z = 0; z < 8; ++z) acc[z] += v[z];
+  }
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (k + z < S) acc[z] += ldp(k + z);
+  f32x4 r{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int z = 0; z < 8; ++z) r += acc[z];
+  return r;
+}
 __global__ __launch_bounds__(256) void reduce_deferred_kernel(const int64_t* __restrict__ desc, int n, long long total_blocks) {
   const long long blk = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (blk >= total_blocks) return;
@@ -1891,26 +1929,21 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const int64_t* __r
   float* dst = reinterpret_cast<float*>(d[1]);
   const int S = (int)d[2], cols = (int)d[4], ld = (int)d[5];
   const size_t total = (size_t)d[3] * cols, pstride = (size_t)d[6];
-  const int rkind = (int)(d[7] & 255);
-  const size_t i = (size_t)(blk - (long long)(d[7] >> 8)) * 32 + (threadIdx.x & 31);
+  const int rkind = (int)(d[7] & 127);
+  const bool store = (d[7] & 128) != 0;
+  const size_t i = ((size_t)(blk - (long long)(d[7] >> 8)) * 32 + (threadIdx.x & 31)) * 4;
   if (i >= total) return;
-  float acc[8];
+  const int ne = (int)min((size_t)4, total - i);
+  const bool vec = ne == 4 && (pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0;
+  const f32x4 r = vec ? reduce_deferred_sum<true>(P + i, pstride, S, ne) : reduce_deferred_sum<false>(P + i, pstride, S, ne);
 #pragma unroll
-  for (int z = 0; z < 8; ++z) acc[z] = 0.f;
-  const float* p = P + i;
-  int k = 0;
-  for (; k + 8 <= S; k += 8) {
-#pragma unroll
-    for (int z = 0; z < 8; ++z) acc[z] += p[(size_t)(k + z) * pstride];
-  }
-#pragma unroll
-  for (int z = 0; z < 8; ++z)
-    if (k + z < S) acc[z] += p[(size_t)(k + z) * pstride];
-  float r = 0.f;
-#pragma unroll
-  for (int z = 0; z < 8; ++z) r += acc[z];
-  const size_t row = i / cols, col = i % cols;
-  dst[row * ld + col] += round_kind(r, rkind);
+  for (int e = 0; e < 4; ++e)
+    if (e < ne) {
+      const size_t row = (i + e) / cols, col = (i + e) % cols;
+      float* o = dst + row * ld + col;
+      const float x = round_kind(r[e], rkind);
+      *o = store ? x : *o + x;
+    }
 }
 }  // namespace
 extern "C" int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks, void* stream) {

@@ -119,7 +119,7 @@ class grad_sink:
         global _SINK
         f = self.flat
         self.prev = _SINK
-        _SINK = {'data': f.data.data_ptr(), 'grad': f.grad.data_ptr(), 'nbytes': f.data.numel() * 4, 'recs': [], 'keep': [], 'blocks': 0,
+        _SINK = {'data': f.data.data_ptr(), 'grad': f.grad.data_ptr(), 'nbytes': f.data.numel() * 4, 'recs': [], 'recs2': [], 'keep': [], 'blocks': 0, 'blocks2': 0,
                  'device': f.data.device, 'seen': set()}
         return self
 
@@ -140,28 +140,50 @@ def _sink_dst(t):
 
 def _sink_record(part_ptr, dst, S, rows, cols, ld, pstride, rkind, keep):
     sk = _SINK
-    # The reduction launch sums all records of a flush with plain (non-atomic) read-modify-writes, one workgroup per 32-element
+    # The reduction launch sums all records of a flush with plain (non-atomic) read-modify-writes, one half wave per 128-element
     # block of a record: two records for the SAME slot (a layer applied twice, tied weights, a second backward() inside one sink)
     # would race and lose a contribution.  A repeated destination therefore flushes what has been recorded first -- launches are
     # stream-ordered, so the second gradient is added on top of the first like autograd's AccumulateGrad would.
     if dst in sk['seen']:
         flush_grad_sink()
     sk['seen'].add(dst)
-    sk['recs'].append((part_ptr, dst, S, rows, cols, ld, pstride, rkind | (sk['blocks'] << 8)))
-    sk['blocks'] += (rows * cols + 31) // 32
+    if S > _RED_CHUNK:
+        # more partials than one chunk (a LayerNorm over the E edge rows leaves E / 16 partial rows): the two fixed-order stages of the
+        # per-layer reduction (csrc launch_reduce_partials) -- chunk sums into scratch in the first launch, their sum in a second one
+        nc, total = (S + _RED_CHUNK - 1) // _RED_CHUNK, rows * cols
+        scratch = torch.empty(nc * total, dtype=torch.float32, device=sk['device'])
+        for c in range(nc):
+            _sink_add(sk['recs'], 'blocks', part_ptr + 4 * c * _RED_CHUNK * pstride, scratch.data_ptr() + 4 * c * total,
+                      min(_RED_CHUNK, S - c * _RED_CHUNK), rows, cols, cols, pstride, 128)
+        _sink_add(sk['recs2'], 'blocks2', scratch.data_ptr(), dst, nc, rows, cols, ld, total, rkind)
+        sk['keep'].append(scratch)
+    else:
+        _sink_add(sk['recs'], 'blocks', part_ptr, dst, S, rows, cols, ld, pstride, rkind)
     sk['keep'].append(keep)
 
 
+_RED_CHUNK = 256     # = RED_CHUNK of csrc/mdx_train.hip
+
+
+def _sink_add(recs, counter, P, dst, S, rows, cols, ld, pstride, rkind):
+    sk = _SINK
+    recs.append((P, dst, S, rows, cols, ld, pstride, rkind | (sk[counter] << 8)))
+    sk[counter] += (rows * cols + 127) // 128
+
+
 def flush_grad_sink():
-    """one launch: every recorded gradient summed into its slot of the flat gradient buffer"""
+    """every recorded gradient summed into its slot of the flat gradient buffer: one launch, plus one over the chunk sums of the
+    records that had more than 256 partials"""
     sk = _SINK
     if sk is None or not sk['recs']:
         return
-    desc = torch.tensor(sk['recs'], dtype=torch.int64).to(sk['device'], non_blocking=True)
-    check(_L().mdx_op_reduce_deferred(ptr(desc), len(sk['recs']), sk['blocks'], stream()))
-    sk['keep'].append(desc)
-    # the partial buffers may be reused once the launch above has been enqueued (stream order); drop the references
-    sk['recs'], sk['keep'], sk['blocks'] = [], [], 0
+    for recs, counter in ((sk['recs'], 'blocks'), (sk['recs2'], 'blocks2')):
+        if recs:
+            desc = torch.tensor(recs, dtype=torch.int64).to(sk['device'], non_blocking=True)
+            check(_L().mdx_op_reduce_deferred(ptr(desc), len(recs), sk[counter], stream()))
+            sk['keep'].append(desc)
+    # the partial buffers may be reused once the launches above have been enqueued (stream order); drop the references
+    sk['recs'], sk['recs2'], sk['keep'], sk['blocks'], sk['blocks2'] = [], [], [], 0, 0
     sk['seen'] = set()
 
 

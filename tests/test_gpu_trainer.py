@@ -267,11 +267,13 @@ def test_fp16_loss_scale_follows_grad_scaler():
         assert U.maxdiff(p, r) <= 2e-6 * max(1.0, float(r.abs().max()))
 
 
+@pytest.mark.parametrize('sizes', [(7, 12, 5, 9, 16), (30, 40, 35, 45, 22)], ids=['small', 'two_stage'])
 @pytest.mark.parametrize('precision', ['f32', 'fp16'])
-def test_deferred_gradient_sink_equals_autograd_accumulation(precision):
+def test_deferred_gradient_sink_equals_autograd_accumulation(precision, sizes):
     """Trainer.step routes every weight / bias / LayerNorm gradient of the HIP operators around autograd: the split partials are
     summed into the flat gradient buffer by ONE launch (train_ops.grad_sink / mdx_op_reduce_deferred).  Same fixed summation order as
-    the per-layer reductions, so the flat gradient must equal what plain `loss.backward()` accumulates -- bit for bit in fp32."""
+    the per-layer reductions, so the flat gradient must equal what plain `loss.backward()` accumulates -- bit for bit in fp32.  'two_stage': 6,000 edge rows, so
+    the edge LayerNorms leave more than 256 partial rows and both routes take their two-stage form (chunk sums, then their sum)."""
     import copy
     from moldiff_amd import train_ops
     base = U.moldiff('MolDiff', DEV)
@@ -280,7 +282,7 @@ def test_deferred_gradient_sink_equals_autograd_accumulation(precision):
         if hasattr(mod, '_eng'):
             mod._eng, mod._eng_sig = None, None
     tr = Trainer(m, lr=0.0, max_grad_norm=None, precision=precision, init_scale=1.0)   # lr 0: the weights stay put
-    batch = _tiny_batch(21, sizes=(7, 12, 5, 9, 16))
+    batch = _tiny_batch(21, sizes=sizes)
     t = torch.tensor([5, 310, 640, 880, 999], device=DEV)
     g = U.rng(22)
     N, Eh = batch[1].shape[0], batch[3].shape[0]
