@@ -1012,8 +1012,16 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(const float* __restric
   }
 }
 
-// each wave walks `rows_per` consecutive rows: dx per row, and its own partial of dgamma / dbeta (registers) which it
-// writes to part[wave_global][2F] (dgamma first); the caller column-reduces `part`.
+// The four waves' partials of [dgamma | dbeta] (ln_sh[4][2F], dynamic LDS) -> ONE partial row per workgroup, waves added in the fixed
+// order ((0 + 1) + 2) + 3.  (Round 5: per-wave rows were 8 % of the backward's traffic and, read back, most of the deferred reduction's.)
+extern __shared__ __attribute__((aligned(16))) float ln_sh[];
+__device__ __forceinline__ void ln_part_combine(const float* sh, int F, float* __restrict__ row) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * F; i += 256) row[i] = ((sh[i] + sh[2 * F + i]) + sh[4 * F + i]) + sh[6 * F + i];
+}
+
+// each wave walks `rows_per` consecutive rows: dx per row, and its own partial of dgamma / dbeta (registers); the workgroup's four
+// partials are combined and written to part[blockIdx.x][2F] (dgamma first); the caller column-reduces `part`.
 __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int M, int F, int relu, int rows_per,
@@ -1061,10 +1069,11 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(const float* __restric
   for (int j = 0; j < LN_MAXJ; ++j) {
     const int f = lane + 64 * j;
     if (j < J && f < F) {
-      part[(size_t)wg * 2 * F + f] = dg[j];
-      part[(size_t)wg * 2 * F + F + f] = db[j];
+      ln_sh[(threadIdx.x >> 6) * 2 * F + f] = dg[j];
+      ln_sh[(threadIdx.x >> 6) * 2 * F + F + f] = db[j];
     }
   }
+  ln_part_combine(ln_sh, F, part + (size_t)blockIdx.x * 2 * F);
 }
 
 
@@ -1115,7 +1124,7 @@ __global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const TP x, const flo
   }
 }
 
-// backward: a wave walks `steps` consecutive row groups; dx per row; the wave's partial of dgamma / dbeta -> part[wave][2F]
+// backward: a wave walks `steps` consecutive row groups; dx per row; the workgroup's partial of dgamma / dbeta -> part[blockIdx.x][2F]
 template <int LPR>
 __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const TP dy, const TP x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -1172,9 +1181,11 @@ __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const TP dy, const TP
     db[k] = b;
   }
   if (sub == 0) {
-    stg4(part + (size_t)wg * 2 * F + 4 * c4, dg);
-    stg4(part + (size_t)wg * 2 * F + F + 4 * c4, db);
+    float* w = ln_sh + (threadIdx.x >> 6) * 2 * F;
+    *reinterpret_cast<f32x4*>(w + 4 * c4) = dg;
+    *reinterpret_cast<f32x4*>(w + F + 4 * c4) = db;
   }
+  ln_part_combine(ln_sh, F, part + (size_t)blockIdx.x * 2 * F);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1641,12 +1652,12 @@ extern "C" int mdx_op_ln_relu_bwd_t(const void* dyv, const void* xv, const float
   const TPW dx{dxv, (dt >> 2) & 1};
   const int RPW = MDX_LN_RPW;
   const int nw = (int)((M + RPW - 1) / RPW);     // waves
-  const int nwp = (nw + 3) / 4 * 4;              // rows of `part` actually written (whole workgroups)
+  const int nwp = (nw + 3) / 4 * 4;              // waves launched (whole workgroups); `part` gets one row per workgroup
   const bool al = tp_vec_ok(xv, x.h, 4) && tp_vec_ok(dyv, dy.h, 4) && tp_vec_ok(dxv, dx.h, 4) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
   bool done = false;
 #define MDX_LNB(LPR)                                                                                                              \
   case 4 * LPR:                                                                                                                   \
-    hipLaunchKernelGGL(ln_relu_bwd4_kernel<LPR>, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, dy, x, stats, gamma, beta, (int)M, relu, \
+    hipLaunchKernelGGL(ln_relu_bwd4_kernel<LPR>, dim3((unsigned)(nwp / 4)), dim3(256), 32 * F, s, dy, x, stats, gamma, beta, (int)M, relu, \
                        RPW, dx, ws);                                                                                              \
     done = true;                                                                                                                  \
     break;
@@ -1654,12 +1665,12 @@ extern "C" int mdx_op_ln_relu_bwd_t(const void* dyv, const void* xv, const float
 #undef MDX_LNB
   if (!done) {
     if (dt) return bad("ln_relu_bwd: half storage needs F in {32, 64, 128, 256} and aligned rows");
-    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 0, s, (const float*)dyv, (const float*)xv, stats, gamma, beta,
+    hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3((unsigned)(nwp / 4)), dim3(256), 32 * F, s, (const float*)dyv, (const float*)xv, stats, gamma, beta,
                        (int)M, F, relu, RPW, (float*)dxv, ws);
   }
-  // [dgamma | dbeta] = sum over the nwp per-wave partial rows, fixed-order parallel reduction (dgb == NULL: deferred, the partial
-  // rows stay in ws for mdx_op_reduce_deferred)
-  if (dgb) launch_reduce_partials(ws, nwp, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)nwp * 2 * F, s);
+  // [dgamma | dbeta] = sum over the nwp / 4 per-workgroup partial rows, fixed-order parallel reduction (dgb == NULL: deferred, the
+  // partial rows stay in ws for mdx_op_reduce_deferred)
+  if (dgb) launch_reduce_partials(ws, nwp / 4, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)(nwp / 4) * 2 * F, s);
   return launched();
 }
 extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
@@ -1667,8 +1678,8 @@ extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* 
   return mdx_op_ln_relu_bwd_t(dy, x, stats, gamma, beta, M, F, relu, dx, dgb, ws, 0, stream);
 }
 extern "C" size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F) {
-  const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW, nwp = (nw + 3) / 4 * 4;
-  return ((size_t)std::max<int64_t>(nwp, 1) * 2 * F + reduce_scratch_floats(nwp, 2 * F)) * sizeof(float);
+  const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW, nr = (nw + 3) / 4;   // one partial row per workgroup of four waves
+  return ((size_t)std::max<int64_t>(nr, 1) * 2 * F + reduce_scratch_floats(nr, 2 * F)) * sizeof(float);
 }
 
 extern "C" int mdx_op_ew_fwd_t(int32_t op, const void* a, const void* b, void* out, int64_t n, int32_t dt, void* stream) {
@@ -1869,7 +1880,7 @@ extern "C" int mdx_op_wgrad_layout(int64_t M, int64_t N, int64_t K, int32_t spli
 }
 extern "C" int64_t mdx_op_ln_relu_bwd_rows(int64_t M) {  // partial rows mdx_op_ln_relu_bwd leaves in ws ([rows][2F])
   const int64_t nw = (M + MDX_LN_RPW - 1) / MDX_LN_RPW;
-  return (nw + 3) / 4 * 4;
+  return (nw + 3) / 4;
 }
 namespace {
 // One lane per FOUR consecutive output elements: eight running sums over the partials k = z, z + 8, ... (z = 0..7), added up in the
