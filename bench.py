@@ -116,14 +116,29 @@ def build_bond_predictor():
     return bp
 
 
-def build_workload(batch, rank, device, kind='MolDiff_simple'):
-    import moldiff_amd as M
-    from moldiff_amd.harness import default_config, placeholder_from_sizes, GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
-    # the reference's size recipe (utils/transforms.py:128-131) with seed 2920 (= 2023 + sum(ord('./outputs')));
-    # rank r takes the r-th consecutive block of `batch` draws so every GPU gets a distinct, reproducible batch
+def rank_molecules(batch, rank, world=1):
+    """-> (sizes, global molecule ids) of the `batch` molecules rank `rank` samples.  The job is batch x world molecules whose sizes are
+    the first batch x world draws of the reference's size recipe (utils/transforms.py:128-131) with seed 2920 (= 2023 +
+    sum(ord('./outputs'))).  One rank: the draws in order.  Several ranks: the product's sharding (moldiff_amd/sample_drug3d.py:189) --
+    a contiguous slice of the serpentine-by-size order (distributed.balanced_order), so every GPU gets the same number of molecules
+    and, to 0.1 %, the same number of directed edges (consecutive blocks of draws differ by up to 4.8 % at 8 ranks, and the slowest
+    rank is the job's time).  world=None: the r-th consecutive block of draws (development tools, per-rank fixtures)."""
+    from moldiff_amd.harness import GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS
+    from moldiff_amd.distributed import balanced_order, shard_bounds
     np.random.seed(2920)
-    sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=batch * (rank + 1)).astype('int64')
-    sizes = sizes[batch * rank: batch * (rank + 1)]
+    if world is None or world == 1:
+        sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=batch * (rank + 1)).astype('int64')
+        return sizes[batch * rank: batch * (rank + 1)], np.arange(batch * rank, batch * (rank + 1), dtype=np.int64)
+    sizes = np.random.normal(GEOM_DRUGS_MEAN_ATOMS, GEOM_DRUGS_STD_ATOMS, size=batch * world).astype('int64')
+    order = balanced_order(sizes, world)
+    lo, hi = shard_bounds(len(sizes), world, rank)
+    return sizes[order[lo:hi]], order[lo:hi].astype(np.int64)
+
+
+def build_workload(batch, rank, device, kind='MolDiff_simple', world=1):
+    import moldiff_amd as M
+    from moldiff_amd.harness import default_config, placeholder_from_sizes
+    sizes, _ = rank_molecules(batch, rank, None if world == 1 else world)
     ph = placeholder_from_sizes(sizes, device)
     model = M.MolDiff(default_config(kind), 8, 6).eval()
     model.load_state_dict(M.recipe_state_dict(model, 20230807), strict=True)
@@ -638,14 +653,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def sampler_for(kind, batch, rk, **kw):
-        model, ph_cpu, sizes = build_workload(batch, rk, None, kind)
+    def sampler_for(kind, batch, rk, nranks=1, **kw):
+        model, ph_cpu, sizes = build_workload(batch, rk, None, kind, nranks)
         model = model.to(dev)
         gkw = {}
         if kind == 'MolDiff':
             gkw = dict(bond_predictor=build_bond_predictor().to(dev), guidance=['uncertainty', 1e-4])
         ph = {k: v.to(dev) for k, v in ph_cpu.items()}
-        mol_ids = np.arange(batch * rk, batch * (rk + 1), dtype=np.int64)
+        mol_ids = rank_molecules(batch, rk, None if nranks == 1 else nranks)[1]     # noise is keyed by the global molecule id
         sm = model.sampler(batch, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023, mol_ids=mol_ids,
                            return_traj=False, **gkw, **kw)
         sm.init()
@@ -658,14 +673,15 @@ def main():
                 'warmup': warmup,
                 'workload': ('sample_MolDiff.yml: full model + bond_predictor guidance [uncertainty, 1e-4], ' if kind == 'MolDiff'
                              else 'sample_MolDiff_simple.yml: no bond guidance, ') +
-                            'batch_size=%d molecules/GPU, T=1000 steps; sizes ~ reference recipe seed 2920 (rank 0: N=%d atoms, '
-                            'E=%d directed edges); recipe weights' % (args.batch, N, E),
+                            'batch_size=%d molecules/GPU, T=1000 steps; sizes ~ reference recipe seed 2920%s (rank 0: N=%d atoms, '
+                            'E=%d directed edges); recipe weights' % (args.batch, '' if nranks == 1 else
+                                ', the %d draws dealt to the ranks in serpentine order by size' % (args.batch * nranks), N, E),
                 'kernel_ms_per_step': {k: v[1] / steps for k, v in prof.items() if v[0]}}
         return line
 
     head_kind = 'MolDiff' if args.guided else 'MolDiff_simple'
     hkw = {'overlap_guidance': True} if (args.guided and os.environ.get('MDX_BENCH_OVERLAP')) else {}  # A/B: guidance on a side stream
-    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank, **hkw)
+    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank, world, **hkw)
     sizes_head = torch.bincount(ph_cpu['batch_node'], minlength=args.batch).numpy()
     N, E = sm.N, 2 * sm.Eh
     # Timed region: only the roofline kernel (edge kernel A) carries hipEvent brackets -- 25 event pairs per step on every kernel
