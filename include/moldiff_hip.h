@@ -374,9 +374,11 @@ int mdx_op_mul_gather_bwd_t(const void* g, const void* a, const void* t, const i
  * and mdx_op_ln_relu_bwd(_t) with dgb == NULL leave their split partials in the caller's buffer (layout: mdx_op_wgrad_layout -> number
  * of partials S and the float offset of the [S][N] bias partials; LayerNorm: mdx_op_ln_relu_bwd_rows(M) rows of 2F floats in ws).
  * mdx_op_reduce_deferred sums every record of a device table in ONE launch and ADDS it to its destination (a parameter's slot in a flat
- * gradient buffer): record = 8 x int64 {P, dst, S, rows, cols, ld, pstride, rkind | store << 7 | first_block << 8}
- * (store: write the sum instead of adding it -- the chunk sums of a record the caller splits at 256 partials); total_blocks = sum of
- * ceil(rows * cols / 128) (first_block counts the same 128-element blocks).  Same fixed summation order as the per-layer reduction kernels. */
+ * gradient buffer): record = 8 x int64 {P, dst, S, rows, cols, ld, pstride, rkind | chunked << 6 | store << 7 | first_block << 8};
+ * total_blocks = sum of ceil(rows * cols / 128) (x ceil(S / 256) for a chunked record; first_block counts the same blocks).  A record
+ * with S > 256 is given as `chunked`: the launch stores the sum of every 256 partials in the scratch planes behind them
+ * (P + (S + c) * pstride, which mdx_op_wgrad_layout / mdx_op_ln_relu_bwd_ws reserve), and the caller sums those ceil(S / 256) planes
+ * with a plain record {P + S * pstride, dst, ceil(S / 256), ...} in a second call.  Same fixed summation order as the per-layer reduction kernels. */
 int mdx_op_wgrad_layout(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t half, int64_t* S, int64_t* bias_off);
 int64_t mdx_op_ln_relu_bwd_rows(int64_t M);
 int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks, void* stream);

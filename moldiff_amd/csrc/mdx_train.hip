@@ -1888,10 +1888,11 @@ namespace {
 // per half wave (1.45 ms per training step); one thread per element with eight loads in flight: 1.13 ms -- and that time was not
 // bandwidth: a LayerNorm over the E edge rows leaves E / 16 partial rows, so ONE thread walked ~10,000 partials in a dependent chain
 // (1,250 iterations x ~0.9 us) while the weight records finished in a fraction of it.  The caller now splits a record with more than
-// 256 partials the way launch_reduce_partials does (chunk sums into scratch, `store` records; then a second launch over the chunk
-// sums), so no chain is longer than 32 + S/2048 iterations, and a lane takes four elements (one 16-byte load per partial when the
-// record's planes are 16-byte aligned) so a wave reads 1 KB per partial and the record look-up is paid once per 128 elements.
-// rkind bit 7: store the sum instead of adding it.  The record table's unit (`first_block`) is 128 elements per block.
+// 256 partials is summed the way launch_reduce_partials does it (chunk sums into the scratch planes behind the partials -- a `chunked`
+// record; then a second launch over the chunk sums), so no chain is longer than 32 + S/2048 iterations, and a lane takes four
+// elements (one 16-byte load per partial when the record's planes are 16-byte aligned) so a wave reads 1 KB per partial and the
+// record look-up is paid once per 128 elements.  rkind bit 6: chunked; bit 7: store the sum instead of adding it.  The record table's
+// unit (`first_block`) is 128 elements per block; a chunked record takes ceil(S / 256) times the blocks of a plain one.
 template <bool VEC>
 __device__ __forceinline__ f32x4 reduce_deferred_sum(const float* p, size_t pstride, int S, int ne) {
   f32x4 acc[8];
@@ -1938,11 +1939,27 @@ __global__ __launch_bounds__(256) void reduce_deferred_kernel(const int64_t* __r
   const int64_t* d = desc + 8 * lo;
   const float* P = reinterpret_cast<const float*>(d[0]);
   float* dst = reinterpret_cast<float*>(d[1]);
-  const int S = (int)d[2], cols = (int)d[4], ld = (int)d[5];
+  int S = (int)d[2], ld = (int)d[5];
+  const int cols = (int)d[4];
   const size_t total = (size_t)d[3] * cols, pstride = (size_t)d[6];
-  const int rkind = (int)(d[7] & 127);
-  const bool store = (d[7] & 128) != 0;
-  const size_t i = ((size_t)(blk - (long long)(d[7] >> 8)) * 32 + (threadIdx.x & 31)) * 4;
+  int rkind = (int)(d[7] & 63);
+  bool store = (d[7] & 128) != 0;
+  long long rel = blk - (long long)(d[7] >> 8);
+  if (d[7] & 64) {
+    // chunked record (S > RED_CHUNK): its blocks are [chunk][block]; chunk c sums partials 256 c .. 256 c + 255 and STORES the sum in
+    // the scratch plane c behind the partials (P + (S + c) * pstride: where launch_reduce_partials keeps its chunk sums, and what the
+    // workspace / wgrad layouts reserve).  The caller's second table sums those planes into dst.
+    const long long nblk = (long long)((total + 127) / 128);
+    const int chunk = (int)(rel / nblk);
+    rel -= chunk * nblk;
+    dst = const_cast<float*>(P) + ((size_t)S + chunk) * pstride;
+    P += (size_t)chunk * RED_CHUNK * pstride;
+    S = min(RED_CHUNK, S - chunk * RED_CHUNK);
+    ld = cols;
+    rkind = 0;
+    store = true;
+  }
+  const size_t i = ((size_t)rel * 32 + (threadIdx.x & 31)) * 4;
   if (i >= total) return;
   const int ne = (int)min((size_t)4, total - i);
   const bool vec = ne == 4 && (pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(P) & 15) == 0;

@@ -148,15 +148,12 @@ def _sink_record(part_ptr, dst, S, rows, cols, ld, pstride, rkind, keep):
         flush_grad_sink()
     sk['seen'].add(dst)
     if S > _RED_CHUNK:
-        # more partials than one chunk (a LayerNorm over the E edge rows leaves E / 16 partial rows): the two fixed-order stages of the
-        # per-layer reduction (csrc launch_reduce_partials) -- chunk sums into scratch in the first launch, their sum in a second one
-        nc, total = (S + _RED_CHUNK - 1) // _RED_CHUNK, rows * cols
-        scratch = torch.empty(nc * total, dtype=torch.float32, device=sk['device'])
-        for c in range(nc):
-            _sink_add(sk['recs'], 'blocks', part_ptr + 4 * c * _RED_CHUNK * pstride, scratch.data_ptr() + 4 * c * total,
-                      min(_RED_CHUNK, S - c * _RED_CHUNK), rows, cols, cols, pstride, 128)
-        _sink_add(sk['recs2'], 'blocks2', scratch.data_ptr(), dst, nc, rows, cols, ld, total, rkind)
-        sk['keep'].append(scratch)
+        # more partials than one chunk (a LayerNorm over the E edge rows leaves E / 64 partial rows): the two fixed-order stages of the
+        # per-layer reduction (csrc launch_reduce_partials) -- a `chunked` record (bit 6) makes the first launch store the sum of each
+        # chunk of 256 in the scratch planes the workspace / wgrad layouts keep right behind the partials; their sum is a second launch
+        nc = (S + _RED_CHUNK - 1) // _RED_CHUNK
+        _sink_add(sk['recs'], 'blocks', part_ptr, dst, S, rows, cols, ld, pstride, 64, nc)
+        _sink_add(sk['recs2'], 'blocks2', part_ptr + 4 * S * pstride, dst, nc, rows, cols, ld, pstride, rkind)
     else:
         _sink_add(sk['recs'], 'blocks', part_ptr, dst, S, rows, cols, ld, pstride, rkind)
     sk['keep'].append(keep)
@@ -165,10 +162,10 @@ def _sink_record(part_ptr, dst, S, rows, cols, ld, pstride, rkind, keep):
 _RED_CHUNK = 256     # = RED_CHUNK of csrc/mdx_train.hip
 
 
-def _sink_add(recs, counter, P, dst, S, rows, cols, ld, pstride, rkind):
+def _sink_add(recs, counter, P, dst, S, rows, cols, ld, pstride, rkind, nchunks=1):
     sk = _SINK
     recs.append((P, dst, S, rows, cols, ld, pstride, rkind | (sk[counter] << 8)))
-    sk[counter] += (rows * cols + 127) // 128
+    sk[counter] += nchunks * ((rows * cols + 127) // 128)
 
 
 def flush_grad_sink():
