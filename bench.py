@@ -725,6 +725,14 @@ def main():
                                 'gather-to-rank-0 of a flat buffer holding all three tensors), max over ranks; happens once per 1000-step run, outside ms_per_step'}
     ms_per_step = elapsed / args.steps * 1e3
     value = args.batch * world / (ms_per_step * T_STEPS / 1e3)
+    # a timing of garbage is worth nothing: after the timed region, every rank checks what its chain left behind
+    st, pr = sm.state(), sm.result()['pred']
+    ok = all(bool(torch.isfinite(p).all()) for p in pr) and bool(torch.isfinite(st['pos']).all())
+    ok = ok and bool((st['h_node'].sum(-1) == 1).all()) and bool((st['h_halfedge'].sum(-1) == 1).all())
+    ok = ok and float(st['pos'].abs().max()) < 1e3
+    if not ok:
+        raise SystemExit('bench.py: rank %d: the chain left non-finite predictions / positions or a state that is not one-hot after '
+                         '%d steps -- no line is reported for that' % (rank, args.steps + args.warmup))
 
     out = None
     if rank == 0:
@@ -743,6 +751,7 @@ def main():
             'aggregation': aggregation_line(N, E, prof_all, sizes_head, True),
             'kernel_ms_per_step': head['kernel_ms_per_step'], 'kernel_ms_note': head['kernel_ms_note'],
             'ranks_seen': 1, 'backend': backend_note or 'none',
+            'outputs_checked': 'after the timed region, on every rank: predictions and positions finite, |pos| < 1e3, atom / bond states one-hot',
         }
         from moldiff_amd import _lib as _lp
         if _lp.resolve_matrix_path(None) != 'exact_f32':
@@ -910,7 +919,7 @@ def main():
         # ---- BASELINE config #5's step (one optimisation step of train_MolDiff.yml at its own batch size) on the same line
         try:
             tr_lines = {}
-            for prec, st_, wu_ in (('fp16', 10, 3), ('f32', 5, 2)):
+            for prec, st_, wu_ in (('fp16', 20, 6), ('f32', 8, 3)):   # (6 warm-up steps: the caching allocator is still growing during the first 3-4)
                 tl, tmodel, tsizes = train_measure('MolDiff', prec, args.batch, st_, wu_, dev)
                 tl.pop('metric', None)
                 if prec == 'fp16' and not args.no_cpu_baseline:
