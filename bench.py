@@ -653,12 +653,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def sampler_for(kind, batch, rk, nranks=1, **kw):
+    def sampler_for(kind, batch, rk, nranks=1, bp_path=None, **kw):
         model, ph_cpu, sizes = build_workload(batch, rk, None, kind, nranks)
         model = model.to(dev)
         gkw = {}
         if kind == 'MolDiff':
             gkw = dict(bond_predictor=build_bond_predictor().to(dev), guidance=['uncertainty', 1e-4])
+            gkw['bond_predictor'].matrix_path = bp_path     # None: the process default, like the denoiser
         ph = {k: v.to(dev) for k, v in ph_cpu.items()}
         mol_ids = rank_molecules(batch, rk, None if nranks == 1 else nranks)[1]     # noise is keyed by the global molecule id
         sm = model.sampler(batch, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023, mol_ids=mol_ids,
@@ -916,19 +917,49 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:  # measurement extra: never fail the headline line
             configs['simple_split'] = {'error': repr(e)}
-        # ---- BASELINE config #5's step (one optimisation step of train_MolDiff.yml at its own batch size) on the same line
+        # ---- config #3 with ONLY the guidance predictor on the split path: the denoiser (what decides atom / bond classes and the
+        # posterior mean) stays on the exact fp32 MFMA; the predictor's forward + backward -- 61 % of the exact guided step -- produce an
+        # increment scaled by 1e-4 (bond_predictor.matrix_path = 'split_f16' / MOLDIFF_GUIDANCE_MATRIX_PATH)
         try:
+            msteps, mwarm = max(10, min(args.steps, 200)), min(args.warmup, 10)
+            smM, *_ = sampler_for('MolDiff', args.batch, 0, bp_path='split_f16')
+            elM, _ = run_chain(smM, msteps, mwarm, barrier, prof=0)
+            lineM = config_line('MolDiff', smM, msteps, mwarm, elM, {}, 1)
+            del smM
+            torch.cuda.empty_cache()
+            lineM['dtype'] = 'denoiser: f32 (fp32 MFMA); guidance predictor: ' + SPLIT_DTYPE
+            lineM['matrix_path'] = "denoiser exact_f32, bond_predictor.matrix_path = 'split_f16' (opt-in)"
+            lineM['speedup_vs_exact_path'] = configs['guided']['ms_per_step'] / lineM['ms_per_step']
+            lineM['parity'] = 'tests/test_gpu_fullsize.py::test_one_full_size_guided_step_mixed_paths_matches_oracle, tests/test_gpu_round5.py (mixed)'
+            lineM.pop('kernel_ms_per_step', None)
+            configs['guided_mixed'] = lineM
+        except Exception as e:
+            configs['guided_mixed'] = {'error': repr(e)}
+        # ---- BASELINE config #5's step (one optimisation step of train_MolDiff.yml at its own batch size) on the same line.  Measured
+        # by `python bench.py --train` in a FRESH process each: the step is issued launch by launch from Python (host time ~ GPU time), and
+        # at the end of this process -- process group, a dozen samplers and their streams behind it -- the same step takes the host 2-5 ms
+        # longer than in a process of its own (same box: 33.5 / 36.5 ms here against 31.1 / 32.2 there, profiles/HISTORY.md round 5).
+        try:
+            import subprocess
+            torch.cuda.empty_cache()
             tr_lines = {}
-            for prec, st_, wu_ in (('fp16', 20, 6), ('f32', 8, 3)):   # (6 warm-up steps: the caching allocator is still growing during the first 3-4)
-                tl, tmodel, tsizes = train_measure('MolDiff', prec, args.batch, st_, wu_, dev)
+            for prec, st_, wu_ in (('fp16', 20, 6), ('f32', 8, 3)):
+                cmd = [sys.executable, os.path.abspath(__file__), '--train', '--precision', prec, '--steps', str(st_), '--warmup', str(wu_),
+                       '--batch', str(args.batch), '--cpu-budget', str(min(args.cpu_budget, 15.0))]
+                if prec != 'fp16' or args.no_cpu_baseline:
+                    cmd.append('--no-cpu-baseline')
+                env = dict(os.environ)
+                for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+                    env.pop(k, None)
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                ln = [x for x in r.stdout.splitlines() if x.startswith('{')]
+                if r.returncode != 0 or not ln:
+                    raise RuntimeError('bench.py --train failed: ' + r.stderr[-500:])
+                tl = json.loads(ln[-1])
                 tl.pop('metric', None)
-                if prec == 'fp16' and not args.no_cpu_baseline:
-                    tl['cpu_baseline'] = train_cpu_baseline('MolDiff', tmodel, tsizes, min(args.cpu_budget, 15.0))
-                    tl['speedup_vs_cpu_baseline'] = tl['value'] / tl['cpu_baseline']['value']
                 tr_lines[prec] = tl
-                del tmodel
-                torch.cuda.empty_cache()
-            configs['train'] = dict(tr_lines['fp16'], what="config #5: train_MolDiff.yml's step (use_amp: True = precision 'fp16'), one GPU; "
+            configs['train'] = dict(tr_lines['fp16'], what="config #5: train_MolDiff.yml's step (use_amp: True = precision 'fp16'), one GPU, measured by "
+                                                           "`python bench.py --train --precision fp16` in a process of its own; "
                                                            "the 8-GPU data-parallel half adds one 22 MB all-reduce per step",
                                     f32=tr_lines['f32'])
         except Exception as e:

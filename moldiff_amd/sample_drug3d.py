@@ -100,6 +100,11 @@ def build_models(config, device, recipe):
         else:
             raise FileNotFoundError(bp_path)
         bond_predictor = bond_predictor.to(device).eval()
+        # MOLDIFF_GUIDANCE_MATRIX_PATH=split_f16: only the guidance predictor on the split float16 path, the denoiser stays where
+        # MOLDIFF_MATRIX_PATH puts it (exact fp32 by default) -- the 'mixed' configuration of DESIGN.md section 3.4
+        gpath = os.environ.get('MOLDIFF_GUIDANCE_MATRIX_PATH')
+        if gpath:
+            bond_predictor.matrix_path = _lib.resolve_matrix_path(gpath)
     if 'guidance' in config.sample:
         guidance = config.sample.guidance
     return model, bond_predictor, guidance

@@ -144,8 +144,31 @@ def test_one_full_size_guided_step_matches_oracle():
     """Config #3 at full size (full model, segment bond schedule, ['uncertainty', 1e-4] guidance through the 8-block bond
     predictor and its hand-written backward): one teacher-forced step at t = 500 against the oracle's autograd, in fp32 and
     arbitrated in fp64.  The guidance increment itself is also compared: within 1e-3 of its own scale."""
+    _full_size_guided_step(None)
+
+
+def test_one_full_size_guided_step_mixed_paths_matches_oracle():
+    """The same step with the denoiser on the exact fp32 path and ONLY the guidance predictor on the split float16 path
+    (`bond_predictor.matrix_path = 'split_f16'`: the predictor's forward + backward are 61 % of the exact guided step, and what they
+    produce is an increment scaled by 1e-4).  Same assertions; the increment's tail factor is the split path's."""
+    from moldiff_amd import _lib
+    with _lib.default_matrix_path('exact_f32'):
+        _full_size_guided_step('split_f16')
+
+
+def _full_size_guided_step(bp_path):
+    bp = U.bondpred(DEV)
+    old = bp.matrix_path
+    bp.matrix_path = bp_path          # None: follows the process default, like the denoiser
+    try:
+        _full_size_guided_step_body(bp, bp_path)
+    finally:
+        bp.matrix_path = old
+
+
+def _full_size_guided_step_body(bp, bp_path):
     ph, sizes = _workload('MolDiff')
-    m, bp = U.moldiff('MolDiff', DEV), U.bondpred(DEV)
+    m = U.moldiff('MolDiff', DEV)
     P, Pb = U.params(U.moldiff('MolDiff')), U.params(U.bondpred())
     st = _state(ph, 61)
     N, Eh = st['pos'].shape[0], st['h_halfedge'].shape[0]
@@ -182,7 +205,7 @@ def test_one_full_size_guided_step_matches_oracle():
     print(f'    guidance delta: max |delta| {scale:.3e}, |HIP-fp64| {e_hip:.3e}, |oracle32-fp64| {e_ref:.3e}')
     # a gradient through 8 blocks in a different (equally valid) summation order: within 2x the reference's own fp32 error,
     # and two orders of magnitude inside the 1e-4 position contract it feeds
-    assert e_hip <= max(1e-3 * scale, U.tail('delta') * e_ref) and e_hip <= 2e-6
+    assert e_hip <= max(1e-3 * scale, U.tail('delta', bp_path) * e_ref) and e_hip <= 2e-6
     # the maximum is set by isolated ReLU kink events (tests/util.py TAIL); the bulk: rms within 1e-4 of the increment's scale
     r_hip, r_ref = U.rmsdiff(delta, d64), U.rmsdiff(d32, d64)
     print(f'    guidance delta rms: |HIP-fp64| {r_hip:.3e}, |oracle32-fp64| {r_ref:.3e}')

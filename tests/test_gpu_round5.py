@@ -152,13 +152,28 @@ def _arbitrated(name, hip, gold_, r64, contract):
     assert U.rmsdiff(hip, r64) <= max(0.02 * contract * scale, 2.0 * U.rmsdiff(gold_, r64)), name
 
 
-@pytest.mark.parametrize('path', ['exact_f32', 'split_f16'])
+@pytest.mark.parametrize('path', ['exact_f32', 'split_f16', 'mixed'])
 @pytest.mark.parametrize('tag', ['n12', 'n101'])
 def test_stress_weights_forward_step_and_guidance_vs_reference_golden(path, tag):
     """tests/golden/stress.npz: the REAL reference with heavy-tailed weights (LayerNorm gains up to 30, biases x 8, one block's
     out_transform x 16; un-normalised pairwise products reach 4e4, the upper half of float16's range).  MolDiff.forward, the bond
-    logits, the guidance increment through the hand-written backward, and one guided loop iteration -- on BOTH matrix paths,
-    arbitrated in float64, class ids bit-exact."""
+    logits, the guidance increment through the hand-written backward, and one guided loop iteration -- on BOTH matrix paths and
+    on the 'mixed' configuration (denoiser exact fp32, only the guidance predictor split float16), arbitrated in float64, class ids
+    bit-exact."""
+    from moldiff_amd import _lib
+    if path == 'mixed':
+        bp_ = U.bondpred_stress(DEV)
+        old_path = bp_.matrix_path
+        bp_.matrix_path = 'split_f16'
+        try:
+            _stress_case('exact_f32', tag, 'mixed')
+        finally:
+            bp_.matrix_path = old_path
+    else:
+        _stress_case(path, tag, path)
+
+
+def _stress_case(path, tag, label):
     from moldiff_amd import _lib
     g = U.gold('stress.npz')
     md, bp = U.moldiff_stress(DEV), U.bondpred_stress(DEV)
@@ -172,7 +187,7 @@ def test_stress_weights_forward_step_and_guidance_vs_reference_golden(path, tag)
     with torch.no_grad():
         o64 = O.moldiff_forward(P64, U.CFG, xn.double(), pos.double(), bn, torch.cat([xh, xh]).double(), ei, be, t)
     d64, l64 = O.guidance_delta(Pb64, U.CFGB, xn.double(), pos.double(), bn, ei, be, t, 1e-4)
-    print(f'\n[stress weights, {tag}, {path}]')
+    print(f'\n[stress weights, {tag}, {label}]')
     with _lib.default_matrix_path(path):
         dargs = [a.to(DEV) for a in (xn, pos, bn, torch.cat([xh, xh]), ei, be, t)]
         with torch.no_grad():
@@ -200,6 +215,8 @@ def test_stress_weights_forward_step_and_guidance_vs_reference_golden(path, tag)
         sm.set_state(*(st[k].to(DEV) for k in ('h_node', 'pos', 'h_halfedge', 'log_node', 'log_halfedge')), frame=999 - step)
         sm.step(999 - step)
         got = sm.state()
+        if label == 'mixed':    # the sampler ran the denoiser on the exact path and the predictor on the split one
+            assert sm._path == 'exact_f32' and sm._bp_path == 'split_f16' and sm.eng._path == 'exact_f32' and sm.bp_eng._path == 'split_f16'
     with torch.no_grad():
         w64, p64 = O.sample_step(P64, U.CFG, U.tables(P64), {k: v.double() for k, v in st.items()},
                                  {'batch_node': bn, 'halfedge_index': hei, 'batch_halfedge': bh, 'n_graphs': B}, step,

@@ -117,8 +117,8 @@ TAIL = {
 }
 
 
-def tail(key):
-    return TAIL[key][current_matrix_path()]
+def tail(key, path=None):
+    return TAIL[key][path or current_matrix_path()]
 
 
 def rmsdiff(a, b):

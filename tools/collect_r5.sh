@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, via gpurun, from the repo root): bash tools/collect_r5.sh   -> gpurun_out/r5_*  (copy what is to be judged into profiles/)
 # Everything profiles/r5_* holds, taken at one HEAD on one box.  One pass per evidence kind; PMC passes never share a run with a trace.
-#   r5_bench.json                              python bench.py -- the driver's command (exact headline + configs.{simple,guided,simple_split,guided_split,train})
+#   r5_bench.json                              python bench.py -- the driver's command (exact headline + configs.{simple,guided,simple_split,guided_split,guided_mixed,train})
 #   r5_kernel_stats.csv / r5_guided_*          rocprofv3 --kernel-trace --stats, exact fp32 path (configs #2 / #3), + the JSON line of the same run
 #   r5_split_kernel_stats.csv / r5_split_guided_*   the same with MOLDIFF_MATRIX_PATH=split_f16
 #   r5_pmc_summary.json / r5_split_pmc_summary.json / r5_guided_* / r5_split_guided_*   tools/pmc_summary.py: three separate --pmc passes each
