@@ -357,6 +357,16 @@ int mdx_op_xgemm_nt_t(const void* A, int64_t lda, const float* B, int64_t ldb, c
                       void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out, int32_t dt, void* stream);
 int mdx_op_xgemm_tn_t(const void* G, int64_t ldg, const void* X, int64_t ldx, float* dW, int64_t ldw, float* db, int64_t M, int64_t N,
                       int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, int32_t dt, void* stream);
+/* Linear + LayerNorm(+ReLU) in ONE launch (common.MLP's first two layers, reference models/common.py:191-196; replaces
+ * F.linear + F.layer_norm + F.relu there): C = the Linear's result exactly as mdx_op_xgemm_nt_t stores it (the backward needs it),
+ * post (M,N; row stride ldp) = relu(LN(C)), stats (M,2) = mean, rstd -- what mdx_op_ln_relu_fwd_t would compute from C and what
+ * mdx_op_ln_relu_bwd_t reads.  dt bits: 0 A, 1 addend, 2 C, 3 post.  Built for float16 rows on the row-owner kernel only (A float16,
+ * M >= 1024, K in {32, 64, 128, 256}, N in {32, 64, 128, 256}: mdx_op_xgemm_nt_ln_supported); anything else returns
+ * MDX_ERR_UNSUPPORTED and the caller runs the two operators. */
+int mdx_op_xgemm_nt_ln_supported(int64_t M, int64_t N, int64_t K);
+int mdx_op_xgemm_nt_ln_t(const void* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const void* addend, int64_t ldd,
+                         void* C, int64_t ldc, const float* gamma, const float* beta, void* post, int64_t ldp, float* stats, int32_t relu,
+                         int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out, int32_t dt, void* stream);
 int mdx_op_ln_relu_fwd_t(const void* x, const float* gamma, const float* beta, int64_t M, int32_t F, int32_t relu, void* y, float* stats,
                          int32_t dt, void* stream);
 int mdx_op_ln_relu_bwd_t(const void* dy, const void* x, const float* stats, const float* gamma, const float* beta, int64_t M, int32_t F,

@@ -25,7 +25,7 @@ EXPORTS = [
     'mdx_guidance_uncertainty_grad', 'mdx_add_inplace', 'mdx_decode_output',
     'mdx_profile_enable', 'mdx_profile_read', 'mdx_profile_kernel_name',
     'mdx_op_sgemm_nt', 'mdx_op_sgemm_tn', 'mdx_op_hgemm_nt', 'mdx_op_hgemm_tn', 'mdx_op_xgemm_nt', 'mdx_op_xgemm_tn', 'mdx_op_amp_adamw',
-    'mdx_op_xgemm_nt_t', 'mdx_op_xgemm_tn_t', 'mdx_op_ln_relu_fwd_t', 'mdx_op_ln_relu_bwd_t', 'mdx_op_ew_fwd_t', 'mdx_op_ew_bwd_t',
+    'mdx_op_xgemm_nt_t', 'mdx_op_xgemm_nt_ln_t', 'mdx_op_xgemm_nt_ln_supported', 'mdx_op_xgemm_tn_t', 'mdx_op_ln_relu_fwd_t', 'mdx_op_ln_relu_bwd_t', 'mdx_op_ew_fwd_t', 'mdx_op_ew_bwd_t',
     'mdx_op_gather_rows_t', 'mdx_op_segsum_rows_t', 'mdx_op_mul_gather_fwd_t', 'mdx_op_mul_gather_bwd_t',
     'mdx_op_wgrad_layout', 'mdx_op_ln_relu_bwd_rows', 'mdx_op_reduce_deferred', 'mdx_op_transpose', 'mdx_op_transpose_batch', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_mul_gather_fwd', 'mdx_op_mul_gather_bwd', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
@@ -154,6 +154,9 @@ def lib():
                      'mul_gather_bwd'):
             base = getattr(L, 'mdx_op_' + name).argtypes
             getattr(L, 'mdx_op_' + name + '_t').argtypes = list(base[:-1]) + [c_int32, c_void_p]
+        L.mdx_op_xgemm_nt_ln_supported.argtypes = [c_int64, c_int64, c_int64]
+        L.mdx_op_xgemm_nt_ln_t.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_void_p, c_int32, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p]
         L.mdx_op_edge_geom_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_op_edge_geom_bwd.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_op_smear_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float, c_int64, c_void_p, c_void_p]

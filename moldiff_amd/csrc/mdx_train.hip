@@ -379,14 +379,37 @@ __global__ __launch_bounds__(256) void hgemm_nt_kernel(const TP A, int lda, cons
 // load in exactly that layout (no LDS round trip, no barrier in the loop), the next tile's rows are requested before the current
 // tile's MFMAs, weight fragments are conflict-free 16-byte LDS reads.  X is read once, Y written once.
 // Same products, same accumulation order per output as hgemm_nt_kernel (k ascending in chunks of 32): bit-identical results.
-template <int KT, int FT, bool ROUND>
+// LayerNorm(+ReLU) epilogue (round 5): the wave owns whole rows, so the LayerNorm that follows the Linear in every common.MLP
+// (reference models/common.py:191-196) is applied to the tile in registers -- the Linear's result is still stored (the backward needs
+// it), and so are the row statistics and the normalised, activated rows: what goes away is the LayerNorm launch and its read of the
+// Linear's result.  Same arithmetic as ln_relu_fwd4_kernel on the values the Linear stores (rounded first when it rounds).
+struct LnEpi {
+  const float *gamma, *beta;   // (N)
+  TPW post;                    // (M,N) relu(LN(C)), row stride ldp
+  int ldp;
+  float* stats;                // (M,2) mean, rstd
+  int relu;
+};
+__device__ __forceinline__ float sum_q4(float v) {   // sum over the four lanes c, c + 16, c + 32, c + 48 (every lane gets it)
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <int KT, int FT, bool ROUND, bool LN = false>
 __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                              const float* __restrict__ bias, const TP addend, int ldd, const TPW C,
-                                                             int ldc, int M) {
+                                                             int ldc, int M, const LnEpi ln = LnEpi{}) {
   constexpr int K = 32 * KT, N = 16 * FT, LD = K + 8;
   extern __shared__ __attribute__((aligned(16))) uint16_t hr_smem[];
   uint16_t* Ws = hr_smem;                                   // [N][LD] float16
-  float* bs = reinterpret_cast<float*>(hr_smem + N * LD);   // [N]
+  float* bs = reinterpret_cast<float*>(hr_smem + N * LD);   // [N] (+ [N] gamma, [N] beta with the LayerNorm epilogue)
+  if (LN)
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      bs[N + i] = ln.gamma[i];
+      bs[2 * N + i] = ln.beta[i];
+    }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -453,6 +476,33 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
 #pragma unroll
           for (int r = 0; r < 4; ++r) st1(C, o + r, v[r]);
         }
+        if (LN) acc[ft] = v;
+      }
+    }
+    if (LN) {   // (every lane takes part in the cross-lane sums; rows past M hold clamped duplicates and store nothing)
+      float sm = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) sm += (acc[ft][0] + acc[ft][1]) + (acc[ft][2] + acc[ft][3]);
+      const float mean = sum_q4(sm) * (1.0f / N);
+      float d2 = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        acc[ft] = acc[ft] - splat4(mean);
+        d2 = fmaf(acc[ft][0], acc[ft][0], fmaf(acc[ft][1], acc[ft][1], fmaf(acc[ft][2], acc[ft][2], fmaf(acc[ft][3], acc[ft][3], d2))));
+      }
+      const float rstd = 1.0f / sqrtf(sum_q4(d2) * (1.0f / N) + MDX_LN_EPS);
+      if (row < M) {
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+          const int col = 16 * ft + 4 * q;
+          f32x4 y = acc[ft] * splat4(rstd) * lds4(bs + N + col) + lds4(bs + 2 * N + col);
+          if (ln.relu) y = relu4(y);
+          st4(ln.post, (size_t)row * ln.ldp + col, y);
+        }
+        if (q == 0) {
+          ln.stats[2 * (size_t)row] = mean;
+          ln.stats[2 * (size_t)row + 1] = rstd;
+        }
       }
     }
 #pragma unroll
@@ -463,24 +513,24 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
 }  // namespace
 int mdx_num_cus();  // mdx_edge2.hip
 namespace {
-template <int KT, int FT, bool ROUND>
+template <int KT, int FT, bool ROUND, bool LN = false>
 static void launch_hgemm_nt_rows(const _Float16* A, int lda, const float* B, int ldb, const float* bias, const TP& addend, int ldd,
-                                 const TPW& C, int ldc, int M, hipStream_t s) {
-  constexpr int lds = 16 * FT * (32 * KT + 8) * 2 + 16 * FT * 4;
+                                 const TPW& C, int ldc, int M, hipStream_t s, const LnEpi& ln = LnEpi{}) {
+  constexpr int lds = 16 * FT * (32 * KT + 8) * 2 + 16 * FT * 4 * (LN ? 3 : 1);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)hgemm_nt_rows_kernel<KT, FT, ROUND>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)hgemm_nt_rows_kernel<KT, FT, ROUND, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr = true;
   }
   static int per_cu = 0;   // resident workgroups per CU: one where the weight fills the LDS, more for the narrow layers
   if (!per_cu) {
     int nb = 0;
-    per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hgemm_nt_rows_kernel<KT, FT, ROUND>, 512, lds) == hipSuccess && nb > 0)
+    per_cu = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hgemm_nt_rows_kernel<KT, FT, ROUND, LN>, 512, lds) == hipSuccess && nb > 0)
                  ? std::min(nb, 4) : 1;
   }
   const int ntiles = (M + 15) / 16;
   const int grid = std::max(1, std::min(mdx_num_cus() * per_cu, (ntiles + 7) / 8));
-  hipLaunchKernelGGL((hgemm_nt_rows_kernel<KT, FT, ROUND>), dim3(grid), dim3(512), lds, s, A, lda, B, ldb, bias, addend, ldd, C, ldc, M);
+  hipLaunchKernelGGL((hgemm_nt_rows_kernel<KT, FT, ROUND, LN>), dim3(grid), dim3(512), lds, s, A, lda, B, ldb, bias, addend, ldd, C, ldc, M, ln);
 }
 
 #ifdef MDX_EXPERIMENTAL
@@ -2051,6 +2101,51 @@ extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, in
   }
 #undef MDX_XNT3
 #undef MDX_XNT
+  return launched();
+}
+// Linear + LayerNorm(+ReLU) in one launch (float16 rows on the row-owner kernel only; anything else: MDX_ERR_UNSUPPORTED, the caller
+// runs the two operators).  C (M,N) = the Linear's result as mdx_op_xgemm_nt_t stores it, post (M,N) = relu(LN(C)) in the container
+// dt bit 3 names, stats (M,2) = mean, rstd: exactly what mdx_op_ln_relu_fwd_t would produce from C, and what mdx_op_ln_relu_bwd_t reads.
+static bool ln_rows_ok(const void* Av, int64_t lda, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t dt) {
+  const int kt = (int)(K / 32), ftn = (int)(N / 16);
+  return half_kind == 2 && (dt & 1) && M >= 1024 && K % 32 == 0 && N % 16 == 0 && (kt == 1 || kt == 2 || kt == 4 || kt == 8) &&
+         (ftn == 2 || ftn == 4 || ftn == 8 || ftn == 16) && (lda & 7) == 0 && (reinterpret_cast<uintptr_t>(Av) & 15) == 0;
+}
+extern "C" int mdx_op_xgemm_nt_ln_supported(int64_t M, int64_t N, int64_t K) {
+  return ln_rows_ok(nullptr, 8, M, N, K, 2, 1) ? 1 : 0;
+}
+extern "C" int mdx_op_xgemm_nt_ln_t(const void* Av, int64_t lda, const float* B, int64_t ldb, const float* bias, const void* addendv,
+                                    int64_t ldd, void* Cv, int64_t ldc, const float* gamma, const float* beta, void* postv, int64_t ldp,
+                                    float* stats, int32_t relu, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t round_out,
+                                    int32_t dt, void* stream) {
+  if (M <= 0 || N <= 0) return MDX_OK;
+  if (!Av || !B || !Cv || !gamma || !beta || !postv || !stats) return bad("xgemm_nt_ln: null operand");
+  if (!ln_rows_ok(Av, lda, M, N, K, half_kind, dt)) return mdx_set_error(MDX_ERR_UNSUPPORTED, "xgemm_nt_ln: shape / container not built (use xgemm_nt + ln_relu_fwd)");
+  const TP addend{addendv, (dt >> 1) & 1};
+  const TPW C{Cv, (dt >> 2) & 1};
+  const LnEpi ln{gamma, beta, TPW{postv, (dt >> 3) & 1}, (int)ldp, stats, relu};
+  if (!tp_vec_ok(postv, ln.post.h, ldp)) return bad("xgemm_nt_ln: post rows must be vector-aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const _Float16* Ah = reinterpret_cast<const _Float16*>(Av);
+  const int kt = (int)(K / 32), ftn = (int)(N / 16);
+#define MDX_HRL(KTv, FTv)                                                                                                              \
+  do {                                                                                                                                 \
+    if (round_out) launch_hgemm_nt_rows<KTv, FTv, true, true>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s, ln); \
+    else launch_hgemm_nt_rows<KTv, FTv, false, true>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s, ln);   \
+  } while (0)
+#define MDX_HRL_F(KTv)                      \
+  do {                                      \
+    if (ftn == 2) MDX_HRL(KTv, 2);          \
+    else if (ftn == 4) MDX_HRL(KTv, 4);     \
+    else if (ftn == 8) MDX_HRL(KTv, 8);     \
+    else MDX_HRL(KTv, 16);                  \
+  } while (0)
+  if (kt == 1) MDX_HRL_F(1);
+  else if (kt == 2) MDX_HRL_F(2);
+  else if (kt == 4) MDX_HRL_F(4);
+  else MDX_HRL_F(8);
+#undef MDX_HRL_F
+#undef MDX_HRL
   return launched();
 }
 extern "C" int mdx_op_xgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, const float* addend,

@@ -75,10 +75,23 @@ def mlp_from_pre(m, pre):
     return x
 
 
+def mlp_first(m, x, w, b, addend=None):
+    """common.MLP whose first Linear is given explicitly (a column slice of its weight + the other columns' product as `addend`, see
+    below): every Linear that a LayerNorm follows runs with the LayerNorm + ReLU in its epilogue (T.linear_ln_relu: one launch where
+    the fused kernel is built, the two operators otherwise)."""
+    mods, i = list(m.net), 0
+    while i + 1 < len(mods):
+        ln = mods[i + 1]
+        x = T.linear_ln_relu(x, w, b, ln.weight, ln.bias, addend=addend)
+        addend, i = None, i + 3
+        w, b = mods[i].weight, mods[i].bias
+    return T.linear(x, w, b, addend=addend)
+
+
 def mlp(m, x):
     """common.MLP: Linear -> (LayerNorm -> ReLU -> Linear)*"""
     first = m.net[0]
-    return mlp_from_pre(m, T.linear(x, first.weight, first.bias))
+    return mlp_first(m, x, first.weight, first.bias)
 
 
 def smear(gs, d):
@@ -98,10 +111,10 @@ def node_block(m, x, g, edge_attr, node_time):
     if m.use_gate:   # models/graph.py:46-48
         g0, ed = m.gate.net[0], edge_attr.shape[1]
         per_node = T.linear(cat(x, node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
-        gt = mlp_from_pre(m.gate, T.linear(edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right)))
+        gt = mlp_first(m.gate, edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right))
         msg = T.gate(msg, gt)
-    out = T.linear(x, m.centroid_lin.weight, m.centroid_lin.bias, addend=T.scatter_sum(msg, g.left))
-    out = T.ln_relu(out, m.layer_norm.weight, m.layer_norm.bias, True)
+    out = T.linear_ln_relu(x, m.centroid_lin.weight, m.centroid_lin.bias, m.layer_norm.weight, m.layer_norm.bias,
+                           addend=T.scatter_sum(msg, g.left))
     return T.linear(out, m.out_transform.weight, m.out_transform.bias)
 
 
@@ -121,8 +134,9 @@ def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
         prod = T.mul(bond_feat, T.linear(node_edges, m.node_linear.weight))
         gate_node = T.linear(node_edges, g0.weight[:, bd:bd + nd], keep32=True)
     inter = mlp(m.inter_module, prod)
-    pre = T.linear(bond_in, g0.weight[:, :bd], g0.bias, addend=T.linear(time, g0.weight[:, bd + nd:], None, addend=gate_node, keep32=True))
-    return T.gate(inter, mlp_from_pre(m.gate, pre))
+    gate = mlp_first(m.gate, bond_in, g0.weight[:, :bd], g0.bias,
+                     addend=T.linear(time, g0.weight[:, bd + nd:], None, addend=gate_node, keep32=True))
+    return T.gate(inter, gate)
 
 
 def edge_block(m, h_bond, g, h_node, bond_time):
@@ -131,8 +145,8 @@ def edge_block(m, h_bond, g, h_node, bond_time):
     sr = T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, bond_time, h_node, g.right), g.left)
     by_left = T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias, addend=sl)
     by_right = T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias, addend=sr)
-    h = T.linear(h_bond, m.self_ffn.weight, m.self_ffn.bias, addend=T.add(T.gather(by_left, g.left), T.gather(by_right, g.right)))
-    h = T.ln_relu(h, m.layer_norm.weight, m.layer_norm.bias, True)
+    h = T.linear_ln_relu(h_bond, m.self_ffn.weight, m.self_ffn.bias, m.layer_norm.weight, m.layer_norm.bias,
+                         addend=T.add(T.gather(by_left, g.left), T.gather(by_right, g.right)))
     return T.linear(h, m.out_transform.weight, m.out_transform.bias)
 
 

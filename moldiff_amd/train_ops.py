@@ -502,6 +502,80 @@ def ln_relu(x, gamma, beta, relu=True):
     return _LnRelu.apply(x, gamma, beta, relu)
 
 
+class _StageCtx:
+    """What _Linear / _LnRelu use of an autograd context, so that their backward bodies can run as the two halves of _LinearLnRelu's."""
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+
+_LN_OK = {}
+
+
+def linear_ln_ok(x, w, addend):
+    """Can Linear(x) -> LayerNorm -> ReLU take the fused launch (csrc mdx_op_xgemm_nt_ln_t)?  float16 mode, float16 rows of x, widths
+    the row-owner kernel is built for."""
+    if _AMP is None or _AMP[0] != 2 or x.dtype != torch.float16 or x.dim() != 2 or _store_dtype() != torch.float16:
+        return False
+    M, K = x.shape
+    N = w.shape[0]
+    key = (M >= 1024, N, K)
+    r = _LN_OK.get(key)
+    if r is None:
+        r = _LN_OK[key] = _L().mdx_op_xgemm_nt_ln_supported(M, N, K) == 1
+    return (r and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and w.stride(1) == 1
+            and (addend is None or (addend.dim() == 2 and addend.stride(1) == 1)))
+
+
+class _LinearLnRelu(torch.autograd.Function):
+    """relu(LayerNorm(Linear(x) + addend)) as one launch forward (the LayerNorm runs in the GEMM's epilogue, csrc hgemm_nt_rows_kernel
+    <.., LN>): the first two layers of every common.MLP (reference models/common.py:191-196).  The Linear's result and the row
+    statistics are stored for the backward, which is the LayerNorm's backward followed by the Linear's -- the bodies of _LnRelu and
+    _Linear, unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, addend, gamma, beta):
+        xc, wc = _rows(x), _rows(w)
+        M, K = xc.shape
+        N = wc.shape[0]
+        bc = _c(b) if b is not None else None
+        ac = _rows(addend) if addend is not None else None
+        g, bt = _c(gamma), _c(beta)
+        pre = torch.empty(M, N, dtype=torch.float16, device=xc.device)
+        post = torch.empty(M, N, dtype=torch.float16, device=xc.device)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=xc.device)
+        check(_L().mdx_op_xgemm_nt_ln_t(ptr(xc), xc.stride(0), ptr(wc), wc.stride(0), ptr(bc), ptr(ac), ac.stride(0) if ac is not None else 0,
+                                        ptr(pre), N, ptr(g), ptr(bt), ptr(post), N, ptr(stats), 1, M, N, K, _AMP[0], 1,
+                                        1 | (_h(ac) << 1) | 4 | 8, stream()))
+        lin, ln = _StageCtx(), _StageCtx()
+        lin.save_for_backward(xc, wc)
+        lin.has_bias, lin.has_addend = b is not None, addend is not None
+        lin.b_ref = b.detach() if b is not None else None
+        lin.x_dtype, lin.addend_dtype, lin.prec = x.dtype, (addend.dtype if addend is not None else None), _AMP
+        ln.save_for_backward(pre, g, bt, stats)
+        ln.relu, ln.x_dtype, ln.gb_ref = 1, torch.float16, (gamma.detach(), beta.detach())
+        ctx.lin, ctx.ln = lin, ln
+        return post
+
+    @staticmethod
+    def backward(ctx, gy):
+        need = ctx.needs_input_grad                       # x, w, b, addend, gamma, beta
+        lin, ln = ctx.lin, ctx.ln
+        ln.needs_input_grad = (True, need[4], need[5], False)
+        gpre, gg, gb_, _ = _LnRelu.backward(ln, gy)
+        lin.needs_input_grad = (need[0], need[1], need[2], need[3], False)
+        gx, gw, gb, ga, _ = _Linear.backward(lin, gpre)
+        ctx.lin = ctx.ln = None
+        return gx, gw, gb, ga, gg, gb_
+
+
+def linear_ln_relu(x, w, b, gamma, beta, addend=None):
+    """relu(LayerNorm(x @ w.T + b + addend)): one launch where the fused kernel is built, the two operators otherwise"""
+    if linear_ln_ok(x, w, addend):
+        return _LinearLnRelu.apply(x, w, b, addend, gamma, beta)
+    return ln_relu(linear(x, w, b, addend=addend), gamma, beta, True)
+
+
 class _Ew(torch.autograd.Function):
     @staticmethod
     def forward(ctx, op, a, b):

@@ -307,3 +307,63 @@ def test_float16_linear_on_many_rows_is_the_row_owner_kernel_and_equals_the_tile
     assert gx.dtype == torch.float16 and torch.equal(gx[lo:hi], gxs)
     ref = gy.double() @ w.half().double()
     assert bool(((gx.double() - ref).abs() <= ref.abs() * 2.0 ** -10 + 1e-3).all())
+
+
+@pytest.mark.parametrize('K,N', [(64, 256), (256, 256), (64, 32), (64, 64), (128, 128), (256, 64)])
+@pytest.mark.parametrize('addend_kind', [None, 'half', 'fp32'])
+def test_linear_with_layernorm_epilogue_equals_the_two_operators(K, N, addend_kind):
+    """relu(LayerNorm(Linear(x) + addend)) in ONE launch (csrc hgemm_nt_rows_kernel<.., LN>, train_ops.linear_ln_relu) against the
+    Linear launch followed by the LayerNorm launch: the Linear's stored result bit for bit (same products, same order), the row
+    statistics to fp32 rounding (another summation order over the row), the activated rows to one float16 ulp on a handful of
+    elements, and every gradient -- the backward is the two operators' own -- to the same."""
+    g = U.rng(K + 3 * N)
+    M = 5003                                                             # ragged: the last tile has 11 rows
+    h = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32)).to(DEV).half()
+    x0, w0, b0 = h(M, K), (h(N, K) * K ** -0.5).float(), h(N).float()
+    g0, be0 = (1 + 0.3 * h(N)).float(), (0.2 * h(N)).float()
+    a0 = None if addend_kind is None else (h(M, N) if addend_kind == 'half' else h(M, N).float())
+    gy = h(M, N)
+    res = []
+    for fused in (True, False):
+        x, w, b, gm, be = (t.detach().clone().requires_grad_(True) for t in (x0, w0, b0, g0, be0))
+        a = None if a0 is None else a0.detach().clone().requires_grad_(True)
+        with T.precision('fp16'):
+            assert T.linear_ln_ok(x, w, a)
+            if fused:
+                y = T.linear_ln_relu(x, w, b, gm, be, addend=a)
+                assert y.grad_fn.name().startswith('_LinearLnRelu')
+                pre, stats = y.grad_fn.ln.saved_tensors[0], y.grad_fn.ln.saved_tensors[3]
+            else:
+                pre_t = T.linear(x, w, b, addend=a)
+                y = T.ln_relu(pre_t, gm, be, True)
+                pre, stats = pre_t.detach(), y.grad_fn.saved_tensors[3]
+            y.backward(gy)
+        res.append(dict(y=y.detach(), pre=pre, stats=stats, gx=x.grad, gw=w.grad, gb=b.grad, gg=gm.grad, gbe=be.grad,
+                        ga=None if a is None else a.grad))
+    f, u = res
+    assert f['y'].dtype == torch.float16 and f['pre'].dtype == torch.float16
+    assert torch.equal(f['pre'], u['pre'])
+    assert _rel(f['stats'][:, 0], u['stats'][:, 0]) < 1e-5 and _rel(f['stats'][:, 1], u['stats'][:, 1]) < 1e-5
+    dy = (f['y'].float() - u['y'].float()).abs()
+    assert float(dy.max()) <= 2.0 ** -10 * float(u['y'].float().abs().max()) and float((dy > 0).float().mean()) < 1e-3
+    for k in ('gx', 'gw', 'gb', 'gg', 'gbe', 'ga'):
+        if f[k] is not None:
+            assert f[k].dtype == u[k].dtype and _rel(f[k], u[k]) < 2e-3, k
+    # and against float64 on the float16 operands
+    ref = F.relu(F.layer_norm(x0.double() @ w0.half().double().t() + b0.double() + (0 if a0 is None else a0.double()), (N,), g0.double(), be0.double()))
+    assert _rel(f['y'], ref) < 4e-3
+
+
+def test_linear_with_layernorm_epilogue_falls_back_where_the_fused_kernel_is_not_built():
+    """fp32 mode, few rows, odd widths: linear_ln_relu runs the two operators (same values as before the fused kernel existed)."""
+    g = U.rng(77)
+    x, w, b, gm, be = _leaf(g, 300, 80), _leaf(g, 48, 80, scale=0.1), _leaf(g, 48), _leaf(g, 48), _leaf(g, 48)
+    assert not T.linear_ln_ok(x, w, None)
+    y = T.linear_ln_relu(x, w, b, gm, be)
+    ref = F.relu(F.layer_norm(F.linear(x.double(), w.double(), b.double()), (48,), gm.double(), be.double()))
+    assert _rel(y, ref) < 5e-6
+    with T.precision('fp16'):
+        xs = x.detach().half()
+        assert not T.linear_ln_ok(xs, w, None)           # 300 rows, K = 80
+        y16 = T.linear_ln_relu(xs, w, b, gm, be)
+    assert _rel(y16, ref) < 2e-2
