@@ -32,6 +32,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tr -o p -- pyt
 find /tmp/prof_tr -name "*kernel_stats.csv" -exec cp {} $OUT/r5_train_fp16_kernel_stats.csv \;
 cd $ROOT
 python tools/split_accuracy.py > $OUT/r5_split_accuracy.txt 2>/dev/null
-python -m pytest tests/test_gpu_round5.py tests/test_gpu_sampling.py -q -m gpu -s -k "tail_statistic or stress or eight" 2>&1 | grep -v "^\s*$" > $OUT/r5_parity_both_paths.txt
+python -m pytest tests/test_gpu_round5.py tests/test_gpu_sampling.py tests/test_gpu_fullsize.py -q -m gpu -s -k "tail_statistic or stress or eight or mixed" 2>&1 | grep -v "^\s*$" > $OUT/r5_parity_both_paths.txt
 python tools/trace_edge2.py w > $OUT/r5_trace_edge_bwd2.txt 2>&1
 ls -la $OUT | grep r5_
