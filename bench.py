@@ -98,6 +98,113 @@ def emit(obj):
         os.write(_REAL_STDOUT, line)
 
 
+LINE_LIMIT = 6144     # bytes: the stdout line the driver parses stays below this; the full tree goes to bench_full.json + stderr
+
+
+def _num(x, sig=6):
+    if isinstance(x, float):
+        return float('%.*g' % (sig, x))
+    if isinstance(x, (list, tuple)):
+        return [_num(v, sig) for v in x]
+    if isinstance(x, dict):
+        return {k: _num(v, sig) for k, v in x.items()}
+    return x
+
+
+def _pick(d, keys, sig=6):
+    return {k: _num(d[k], sig) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _short(txt, n):
+    txt = str(txt)
+    return txt if len(txt) <= n else txt[:n - 3] + '...'
+
+
+def compact_line(full, full_path='bench_full.json'):
+    """The ONE stdout line (<= LINE_LIMIT bytes) from the full result tree: the contract's headline fields, `config`, `roofline`
+    (with `traffic`), `cpu_baseline`, and one-line summaries {ms_per_step, value, frac} of the other configurations.  Everything
+    else (kernel tables, notes, the per-configuration rooflines and CPU legs) lives in `full_path`.  Optional groups are dropped,
+    last first, should a line ever exceed the limit -- the contract fields never are."""
+    line = _pick(full, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling'), 8)
+    line['vs_baseline'] = full.get('vs_baseline')
+    line.update(_pick(full, ('dtype', 'data', 'matrix_path')))
+    line['dtype'] = _short(line.get('dtype', ''), 160)
+    cfg = dict(full.get('config', {}))
+    if 'workload' in cfg:
+        cfg['workload'] = _short(cfg['workload'], 420)
+    line['config'] = {k: _num(v) for k, v in cfg.items()}
+    rf = full.get('roofline') or {}
+    line['roofline'] = dict(_pick(rf, ('bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_ms', 'flops_per_launch', 'flops_per_edge',
+                                       'frac_of_fp32_mfma_peak')), traffic=_num(rf.get('traffic')))
+    line['roofline']['kernel'] = _short(rf.get('kernel_symbol') or rf.get('kernel', ''), 120)
+    if rf.get('traffic_source'):
+        line['roofline']['traffic_source'] = _short(rf['traffic_source'], 120)
+    cb = full.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = dict(_pick(cb, ('value', 'unit', 'cores', 'kind', 'ms_per_step', 'ms_per_step_scaled', 'sample_molecules',
+                                               'pinned_physical_cores', 'host_logical_cpus', 'reference_cpu_mol_s')),
+                                    sample=_short(cb.get('sample', ''), 360))
+    optional = []      # (key, value) in the order they are kept; dropped from the end if the line is too long
+    if 'sample_wall_s' in full:
+        optional.append(('sample_wall_s', _pick(full['sample_wall_s'], ('value', 'molecules_per_sec'))))
+    if 'configs' in full:
+        summ = {}
+        for name, c in full['configs'].items():
+            if 'error' in c:
+                summ[name] = {'error': _short(c['error'], 80)}
+                continue
+            e = _pick(c, ('ms_per_step', 'value', 'host_issue_ms_per_step', 'launches_per_step'))
+            r = c.get('roofline') or {}
+            if r.get('frac') is not None:
+                e['frac'] = _num(r['frac'])
+                e['kernel'] = _short(r.get('kernel', ''), 24).split(' ')[0]
+            ro = c.get('roofline_other') or {}
+            if ro.get('frac') is not None:
+                e['frac_' + _short(ro.get('kernel', 'other'), 24).split(' ')[0]] = _num(ro['frac'])
+            if 'cpu_baseline' in c:
+                e['cpu_value'] = _num(c['cpu_baseline'].get('value'))
+            if isinstance(c.get('f32'), dict):
+                e['f32_ms_per_step'] = _num(c['f32'].get('ms_per_step'))
+            summ[name] = e
+        optional.append(('configs', summ))
+    for k in ('roofline_edge_b', 'segment_sum', 'aggregation_large'):
+        if isinstance(full.get(k), dict) and full[k].get('frac') is not None:
+            e = _pick(full[k], ('bound', 'frac', 'achieved', 'avg_ms', 'unit', 'molecules', 'ms_per_step', 'molecules_per_sec'))
+            if 'unit' in e:
+                e['unit'] = _short(e['unit'], 8)
+            optional.append((k, e))
+    if 'kernel_ms_per_step' in full:
+        optional.append(('kernel_ms_per_step', _num(full['kernel_ms_per_step'])))
+    multi = _pick(full, ('ranks_seen', 'backend', 'per_rank_ms_per_step', 'gather_ms', 'gather_first_ms', 'gather_bytes', 'value_incl_gather'))
+    if multi:
+        optional.append(('multi', multi))
+    line['full'] = full_path
+    for k, v in optional:
+        line[k] = v
+    while len(json.dumps(line)) >= LINE_LIMIT and optional:
+        k, _ = optional.pop()
+        line.pop(k, None)
+        line['dropped'] = line.get('dropped', []) + [k]
+    if len(json.dumps(line)) >= LINE_LIMIT:   # contract fields alone can only get here through an absurd workload string
+        line['config']['workload'] = _short(line['config'].get('workload', ''), 120)
+        line.get('cpu_baseline', {}).pop('sample', None)
+    return line
+
+
+def emit_result(full, name='bench_full.json'):
+    """Full tree -> <repo>/bench_full.json (best effort) and stderr; the compact line -> stdout."""
+    path = os.path.join(ROOT, name)
+    try:
+        with open(path, 'w') as f:
+            json.dump(full, f, indent=1)
+            f.write('\n')
+    except OSError:
+        path = None
+    sys.stderr.write('BENCH_FULL ' + json.dumps(full) + '\n')
+    sys.stderr.flush()
+    emit(compact_line(full, name if path else 'stderr (BENCH_FULL line)'))
+
+
 def launch_env(args_gpus):
     """(world, rank, local_rank); starts the ranks when --gpus N > 1 was given to a plain `python bench.py`."""
     if 'WORLD_SIZE' not in os.environ and args_gpus > 1:
@@ -479,9 +586,11 @@ def _profile(L, k):
     return c.value, ms.value
 
 
-def run_chain(sm, steps, warmup, barrier, start=0, prof=1):
+def run_chain(sm, steps, warmup, barrier, start=0, prof=1, whole_run=False):
     """`warmup` untimed + `steps` timed iterations of the reverse chain; hipEvent kernel timing on during the timed region
     (`prof`: 1 = every kernel, 2 << k = kernel k only -- an event pair costs ~3.4 us of stream time).
+    whole_run (steps == T): the timed region is what MolDiff.sample runs after its one-off set-up -- the prior draw, then
+    iterations 0..T-1 writing trajectory frames 1..T -- so `value` IS n_graphs / wall of a sampling run.
     Returns (elapsed seconds, {kernel: (launches, total ms)})."""
     from moldiff_amd import _lib
     L = _lib.lib()
@@ -492,6 +601,10 @@ def run_chain(sm, steps, warmup, barrier, start=0, prof=1):
     barrier()
     L.mdx_profile_enable(prof)
     t0 = time.perf_counter()
+    if whole_run:
+        assert steps == T_STEPS
+        sm.init()
+        i = 0
     for _ in range(steps):
         sm.step(i % T_STEPS)
         i += 1
@@ -653,7 +766,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def sampler_for(kind, batch, rk, nranks=1, bp_path=None, **kw):
+    def sampler_for(kind, batch, rk, nranks=1, bp_path=None, traj=False, **kw):
         model, ph_cpu, sizes = build_workload(batch, rk, None, kind, nranks)
         model = model.to(dev)
         gkw = {}
@@ -663,7 +776,7 @@ def main():
         ph = {k: v.to(dev) for k, v in ph_cpu.items()}
         mol_ids = rank_molecules(batch, rk, None if nranks == 1 else nranks)[1]     # noise is keyed by the global molecule id
         sm = model.sampler(batch, ph['batch_node'], ph['halfedge_index'], ph['batch_halfedge'], seed=2023, mol_ids=mol_ids,
-                           return_traj=False, **gkw, **kw)
+                           return_traj=traj, **gkw, **kw)
         sm.init()
         return sm, model, ph, ph_cpu, gkw
 
@@ -682,13 +795,16 @@ def main():
 
     head_kind = 'MolDiff' if args.guided else 'MolDiff_simple'
     hkw = {'overlap_guidance': True} if (args.guided and os.environ.get('MDX_BENCH_OVERLAP')) else {}  # A/B: guidance on a side stream
-    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank, world, **hkw)
+    # the headline chain records the trajectory like a default model.sample() call (compact frames, moldiff_amd/traj.py): every
+    # step writes its frame, and with --steps 1000 the timed region is the prior draw + the complete run (run_chain whole_run)
+    whole = args.steps == T_STEPS
+    sm, model, ph, ph_cpu, gkw = sampler_for(head_kind, args.batch, rank, world, traj=True, **hkw)
     sizes_head = torch.bincount(ph_cpu['batch_node'], minlength=args.batch).numpy()
     N, E = sm.N, 2 * sm.Eh
     # Timed region: only the roofline kernel (edge kernel A) carries hipEvent brackets -- 25 event pairs per step on every kernel
     # cost 0.17 ms of a 7.3 ms step (tools/profile_overhead.py).  The other kernels' durations come from a short second pass
     # OUTSIDE the timed region (same chain, continued).
-    elapsed, prof = run_chain(sm, args.steps, args.warmup, barrier, prof=2 << 0)
+    elapsed, prof = run_chain(sm, args.steps, args.warmup, barrier, prof=2 << 0, whole_run=whole)
     _, prof_all = run_chain(sm, min(args.steps, 40), 0, barrier, start=args.steps + args.warmup)
     steps_all = min(args.steps, 40)
     multi = None
@@ -746,7 +862,10 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': head['workload'], 'molecules_per_gpu': args.batch, 'num_timesteps': T_STEPS,
-                       'parallelism': f'independent streams x{world}', 'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)'},
+                       'parallelism': f'independent streams x{world}', 'value_formula': 'batch*n_gpus / (ms_per_step*T/1000)',
+                       'timed_region': ('prior draw + all 1000 iterations with the trajectory recorded = one MolDiff.sample run after its one-off '
+                                        'set-up (graph plan, buffers)' if whole else
+                                        '%d iterations of the reverse chain, trajectory frames recorded as in MolDiff.sample' % args.steps)},
             'roofline': roofline_mfma('edge_a', EDGE_A_NAME, FLOP_EDGE_A, E, prof),
             'roofline_edge_b': roofline_mfma('edge_b', EDGE_B_NAME, FLOP_EDGE_B, E, prof_all),
             'aggregation': aggregation_line(N, E, prof_all, sizes_head, True),
@@ -794,6 +913,12 @@ def main():
             pass
 
     # ---- single-GPU extras, all OUTSIDE the headline's timed region --------------------------------------------------
+    if world == 1 and dist is not None:
+        # the single-rank group has done its work (barriers, the max-reduce, the gather); release it before the rank-0-only extras so
+        # that no communicator / watchdog is alive while the training measurement runs in processes of its own
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if world == 1 and not args.headline_only:
         configs = {'guided' if args.guided else 'simple': dict(head, roofline=out['roofline'])}
         out['segment_sum'] = segment_sum_line(sm, dev)
@@ -979,7 +1104,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        emit(out)
+        emit_result(out)
 
 
 if __name__ == '__main__':

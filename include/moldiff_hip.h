@@ -359,8 +359,8 @@ int mdx_op_xgemm_tn_t(const void* G, int64_t ldg, const void* X, int64_t ldx, fl
                       int64_t K, int32_t splits, float* partial, int32_t half_kind, int32_t round_out, int32_t dt, void* stream);
 /* Linear + LayerNorm(+ReLU) in ONE launch (common.MLP's first two layers, reference models/common.py:191-196; replaces
  * F.linear + F.layer_norm + F.relu there): C = the Linear's result exactly as mdx_op_xgemm_nt_t stores it (the backward needs it),
- * post (M,N; row stride ldp) = relu(LN(C)), stats (M,2) = mean, rstd -- what mdx_op_ln_relu_fwd_t would compute from C and what
- * mdx_op_ln_relu_bwd_t reads.  dt bits: 0 A, 1 addend, 2 C, 3 post.  Built for float16 rows on the row-owner kernel only (A float16,
+ * post (M,N; row stride ldp) = relu(LN(C)), stats (M,2) = mean, rstd -- mdx_op_ln_relu_fwd_t's formula on C in another summation order
+ * (equal to rounding, not bit for bit) and what mdx_op_ln_relu_bwd_t reads.  A float16 C requires round_out = 1.  dt bits: 0 A, 1 addend, 2 C, 3 post.  Built for float16 rows on the row-owner kernel only (A float16,
  * M >= 1024, K in {32, 64, 128, 256}, N in {32, 64, 128, 256}: mdx_op_xgemm_nt_ln_supported); anything else returns
  * MDX_ERR_UNSUPPORTED and the caller runs the two operators. */
 int mdx_op_xgemm_nt_ln_supported(int64_t M, int64_t N, int64_t K);

@@ -386,6 +386,15 @@ class Model:
             shape = (c_int64 * max(t.dim(), 1))(*t.shape)
             check(lib().mdx_model_set_param(self.h, k[len(prefix):].encode(), ptr(t), shape, t.dim()))
         check(lib().mdx_model_finalize(self.h))
+        # finalize drops a handle back to the exact path when the new weights cannot be held by the split packs (float16 range): the
+        # cached name must follow the handle, or a later use_matrix_path('split_f16') would be a silent no-op on the exact path
+        got = ctypes.c_int32()
+        check(lib().mdx_model_get_matrix_path(self.h, ctypes.byref(got)))
+        now = next(n for n, v in MATRIX_PATHS.items() if v == got.value)
+        if now != self._path:
+            was, self._path = self._path, now
+            raise RuntimeError(f"weights re-uploaded to a model on matrix path '{was}' cannot be held by it (|w| beyond the float16 "
+                               f"range); the handle is on '{now}' now -- select the path again explicitly if that is intended")
 
     def __del__(self):
         try:

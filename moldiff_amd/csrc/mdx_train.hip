@@ -2105,7 +2105,11 @@ extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, in
 }
 // Linear + LayerNorm(+ReLU) in one launch (float16 rows on the row-owner kernel only; anything else: MDX_ERR_UNSUPPORTED, the caller
 // runs the two operators).  C (M,N) = the Linear's result as mdx_op_xgemm_nt_t stores it, post (M,N) = relu(LN(C)) in the container
-// dt bit 3 names, stats (M,2) = mean, rstd: exactly what mdx_op_ln_relu_fwd_t would produce from C, and what mdx_op_ln_relu_bwd_t reads.
+// dt bit 3 names, stats (M,2) = mean, rstd: the SAME FORMULA as mdx_op_ln_relu_fwd_t applied to C, in a different summation order (a lane
+// sums its FT strided quads, then the four q-lanes are combined; the stand-alone operator sums LPR lanes of contiguous elements), so
+// the two agree to rounding (a few fp32 ulp on the statistics), not bit for bit -- which one runs depends on M >= 1024 only.  It is
+// what mdx_op_ln_relu_bwd_t reads.  A float16 C with round_out = 0 is refused: the LayerNorm would see the unrounded values while C
+// stores rounded ones.
 static bool ln_rows_ok(const void* Av, int64_t lda, int64_t M, int64_t N, int64_t K, int32_t half_kind, int32_t dt) {
   const int kt = (int)(K / 32), ftn = (int)(N / 16);
   return half_kind == 2 && (dt & 1) && M >= 1024 && K % 32 == 0 && N % 16 == 0 && (kt == 1 || kt == 2 || kt == 4 || kt == 8) &&
@@ -2121,6 +2125,7 @@ extern "C" int mdx_op_xgemm_nt_ln_t(const void* Av, int64_t lda, const float* B,
   if (M <= 0 || N <= 0) return MDX_OK;
   if (!Av || !B || !Cv || !gamma || !beta || !postv || !stats) return bad("xgemm_nt_ln: null operand");
   if (!ln_rows_ok(Av, lda, M, N, K, half_kind, dt)) return mdx_set_error(MDX_ERR_UNSUPPORTED, "xgemm_nt_ln: shape / container not built (use xgemm_nt + ln_relu_fwd)");
+  if (((dt >> 2) & 1) && !round_out) return mdx_set_error(MDX_ERR_UNSUPPORTED, "xgemm_nt_ln: a float16 C needs round_out (LN must see the stored values)");
   const TP addend{addendv, (dt >> 1) & 1};
   const TPW C{Cv, (dt >> 2) & 1};
   const LnEpi ln{gamma, beta, TPW{postv, (dt >> 3) & 1}, (int)ldp, stats, relu};

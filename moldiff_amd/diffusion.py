@@ -101,9 +101,13 @@ class deferred_class_checks:
     def __exit__(self, *a):
         deferred_class_checks._active = self.prev
 
-    def finish(self):
+    _limit_cache = {}
+
+    def finish(self, group=None):
+        """group: the process group the caller's gradient collectives run on (Trainer's `group`; None = WORLD).  The flag all-reduce
+        must pair with THAT group's ranks -- on a sub-group, ranks outside it never reach this point."""
         import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if not self.items and not multi:
             return None
         limits = [k for _, k in self.items]
@@ -117,9 +121,16 @@ class deferred_class_checks:
         # range.
         peers = None
         if multi:
-            bad = (dev >= torch.tensor(limits, dtype=dev.dtype, device=dev.device)).any() if self.items else torch.zeros((), dtype=torch.bool, device=dev.device)
+            if self.items:
+                key = (tuple(limits), dev.dtype, dev.device)     # the limits tensor is built once per (class counts, device): no H2D copy per step
+                lim = deferred_class_checks._limit_cache.get(key)
+                if lim is None:
+                    lim = deferred_class_checks._limit_cache[key] = torch.tensor(limits, dtype=dev.dtype, device=dev.device)
+                bad = (dev >= lim).any()
+            else:
+                bad = torch.zeros((), dtype=torch.bool, device=dev.device)
             peers = bad.to(torch.int32).reshape(1)
-            dist.all_reduce(peers, op=dist.ReduceOp.MAX)
+            dist.all_reduce(peers, op=dist.ReduceOp.MAX, group=group)
             dev = torch.cat([dev, peers.to(dev.dtype)])
         host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=dev.is_cuda)
         host.copy_(dev, non_blocking=True)

@@ -38,16 +38,19 @@ def balanced_order(n_nodes_list, world_size):
     return np.array([m for b in buckets for m in b], dtype=np.int64)
 
 
-def _gather_rows(flat, dst, group):
-    """(n_r,) payloads of different lengths -> list of (n_r,) tensors on `dst`, None elsewhere.  The row counts go to everybody
+def _gather_rows(flat, dst, group, extra=()):
+    """(n_r,) payloads of different lengths -> list of (n_r,) tensors on `dst`, None elsewhere.  The element counts go to everybody
     (8 bytes per rank: every rank needs the common padded length), the payload travels to `dst` ONLY (`dist.gather`: point-to-point
-    sends over xGMI with RCCL) -- an all_gather would move world_size times the bytes to ranks that drop them."""
+    sends over xGMI with RCCL) -- an all_gather would move world_size times the bytes to ranks that drop them.
+    extra: a few integers per rank that ride on the int64 count exchange (exact whatever the payload's dtype); with it the result
+    is (parts, [extra of rank 0, extra of rank 1, ...])."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
+    n = torch.tensor([flat.numel()] + [int(x) for x in extra], dtype=torch.int64, device=flat.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    extras = [[int(v) for v in c[1:].tolist()] for c in counts]
+    counts = [int(c[0].item()) for c in counts]
     pad = max(counts + [1])
     buf = torch.zeros(pad, dtype=flat.dtype, device=flat.device)
     buf[:flat.numel()] = flat
@@ -56,7 +59,8 @@ def _gather_rows(flat, dst, group):
     dist.gather(buf, gather_list=outs, dst=dst_global, group=group)
     if rank != dst:
         return None
-    return [o[:c] for o, c in zip(outs, counts)]
+    parts = [o[:c] for o, c in zip(outs, counts)]
+    return (parts, extras) if len(extra) else parts
 
 
 def gather_variable(t, dst=0, group=None):
@@ -71,19 +75,20 @@ def gather_variable(t, dst=0, group=None):
 def gather_pred(pred, dst=0, group=None):
     """pred = [pred_node (N_r,Kn), pred_pos (N_r,3), pred_halfedge (Eh_r,Ke)] -> concatenated over ranks on dst
     (rank order == global molecule order for contiguous shards).  The three tensors of a rank travel as ONE flat buffer headed by
-    their row counts: one count exchange + one gather-to-dst per batch (latency-bound at ~2 MB per rank: fewer, larger messages)."""
+    row counts: one count exchange + one gather-to-dst per batch (latency-bound at ~2 MB per rank: fewer, larger messages).  The row
+    counts travel as int64 with the count exchange, not in the payload, so they are exact for any prediction dtype; the three tensors
+    must share one dtype (they share the buffer)."""
     dt = pred[0].dtype
-    head = torch.tensor([float(p.shape[0]) for p in pred], dtype=dt, device=pred[0].device)   # exact in fp32 below 2^24 rows
-    if max(p.shape[0] for p in pred) >= 2 ** 24:
-        raise ValueError('gather_pred: more than 2^24 rows per rank')
-    parts = _gather_rows(torch.cat([head] + [p.contiguous().reshape(-1).to(dt) for p in pred]), dst, group)
-    if parts is None:
+    if any(p.dtype != dt for p in pred):
+        raise TypeError('gather_pred: the three prediction tensors must have one dtype, got %s' % [p.dtype for p in pred])
+    got = _gather_rows(torch.cat([p.contiguous().reshape(-1) for p in pred]), dst, group, extra=[p.shape[0] for p in pred])
+    if got is None:
         return None
+    parts, all_rows = got
     widths = [int(p.shape[1]) for p in pred]
     cols = [[] for _ in pred]
-    for flat in parts:
-        rows = [int(v) for v in flat[:len(pred)].tolist()]
-        off = len(pred)
+    for flat, rows in zip(parts, all_rows):
+        off = 0
         for j, (r, w) in enumerate(zip(rows, widths)):
             cols[j].append(flat[off:off + r * w].reshape(r, w))
             off += r * w

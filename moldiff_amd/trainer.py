@@ -186,7 +186,7 @@ class Trainer:
         with train_ops.grad_sink(self.flat), train_ops.transposed_params(self.wt):
             with train_ops.precision(self.precision), deferred_class_checks() as chk:
                 out = self.model.get_loss(*batch, **kw)
-            self._deferred = chk.finish()
+            self._deferred = chk.finish(group=self.group)
             gn = self.backward_and_step(out['loss'])
         res = {k: v.detach() for k, v in out.items()}
         res['grad_norm'] = gn

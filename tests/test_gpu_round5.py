@@ -121,22 +121,23 @@ def collect_tail_statistic(n_inputs=N_STAT, with_guidance=True, verbose=True):
             for p, d in res.items():
                 v = d[k]
                 if len(v):
-                    print(f'    {k:6s} {p:10s} median {np.median(v):.3f}  90% {np.quantile(v, 0.9):.3f}  max {v.max():.3f}  '
+                    print(f'    {k:6s} {p:10s} median {np.median(v):.3f}  90% {np.quantile(v, 0.9):.3f}  99% {np.quantile(v, 0.99):.3f}  max {v.max():.3f}  '
                           f'exceed 1.0: {(v > 1).sum()}  exceed 2.0: {(v > 2).sum()}')
     return res
 
 
 def test_split_path_tail_statistic_equals_the_exact_paths():
-    """The statistic behind the two per-path tolerances of the suite (tests/util.py TAIL): over 32 random ill-conditioned inputs
-    the split float16 path exceeds the exact path's own arbitrated bound no more often than the exact path does (+2 inputs), its
-    median and 90 % ratios are within 1.25x of the exact path's, and neither path's worst case passes 4x the bound."""
+    """The statistic behind the suite's tail factors (tests/util.py TAIL: ONE factor per quantity for both matrix paths): over 32 random
+    ill-conditioned inputs, both paths against the SAME bound (single-evaluation E_ref, i.e. the tightest form), the split float16
+    path exceeds it no more often than the exact path does (+2 inputs), its median and 90 % ratios are within 1.25x of the exact
+    path's, and neither path's worst case passes 2x the bound (the printed 99th percentile is the number the factors are read from)."""
     res = collect_tail_statistic()
     ex, sp = res['exact_f32'], res['split_f16']
     for k in ('pos', 'delta'):
         assert (sp[k] > 1).sum() <= (ex[k] > 1).sum() + 2, k
         assert np.median(sp[k]) <= 1.25 * np.median(ex[k]) + 0.02, k
         assert np.quantile(sp[k], 0.9) <= 1.25 * np.quantile(ex[k], 0.9) + 0.05, k
-        assert max(sp[k].max(), ex[k].max()) <= 4.0, k
+        assert max(sp[k].max(), ex[k].max()) <= 2.0, k
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -102,23 +102,96 @@ def tables(P):
             'edge': {k: P['edge_transition.' + k] for k in ('q_mats', 'transpopse_q_onestep_mats')}}
 
 
-# Tail factors of the fp64-arbitrated bounds  |HIP - fp64| <= max(contract, f * |oracle_fp32 - fp64|), per matrix path.
-# The MAXIMUM over atoms is a tail statistic: for positions it is set by a few ill-conditioned atoms (pairs ~0.1 apart), for the
-# guidance gradient by isolated ReLU kink events (a pre-activation that one fp32 evaluation puts 1e-8 on the other side of zero
-# than fp64 changes that atom's gradient discretely -- profiles/r4_split_delta_diag.txt).  Two fp32 arithmetics with the same error
-# DISTRIBUTION therefore differ in their maxima by small factors either way.  Every entry that is not the exact path's own factor
-# is justified by tests/test_gpu_round5.py::test_split_path_tail_statistic_equals_the_exact_paths, which measures over 32 random
-# ill-conditioned inputs how often EACH path exceeds the exact path's bound and asserts that the two behave alike; the rms of every
-# quantity is asserted next to each maximum.
+# Tail factors of the fp64-arbitrated bounds  |HIP - fp64| <= max(contract, f * E_ref),  ONE value per quantity for both matrix paths
+# (round 6; until round 5 the split float16 path had its own, looser, factors for two of them).
+#
+# E_ref is the fp32 REFERENCE ARITHMETIC's own distance from float64.  The MAXIMUM over atoms of that distance is a tail statistic:
+# for positions it is set by a few ill-conditioned atoms (pairs ~0.1 apart, w*rel/d/(d+1) in models/graph.py:393), for the guidance
+# gradient by isolated ReLU kink events (a LayerNorm->ReLU pre-activation that one fp32 evaluation puts 1e-8 on the other side of
+# zero than fp64 changes that atom's gradient discretely -- profiles/r4_split_delta_diag.txt).  WHICH atom trips depends on the
+# summation order, so a single fp32 evaluation (one golden, one oracle run) under-samples the tail: a legal re-association of the
+# same arithmetic -- the 8-wave node kernel of round 5, the split path, another BLAS -- lands on another atom and "exceeds" a bound
+# that was really a property of one fixture.  Where a bound is tail-limited, E_ref is therefore the maximum over several legal
+# summation orders of the fp32 oracle (`summation_order` / `fp32_error_over_orders` below: Linear reductions split in 2 and 4, segment
+# sums in reversed edge order, single-threaded evaluation), plus the reference's own golden where one exists.
+# The factors themselves come from tests/test_gpu_round5.py::test_split_path_tail_statistic_equals_the_exact_paths (32 random
+# ill-conditioned inputs, both paths against the same bound; the printed 99th percentile of the ratio stays below 1 for both).
 TAIL = {
-    'factor': {'exact_f32': 1.5, 'split_f16': 1.5},    # forward quantities of the teacher-forced steps
-    'delta': {'exact_f32': 2.0, 'split_f16': 4.0},     # maximum error of the guidance increment (kink events), test_gpu_fullsize.py
-    'config1': {'exact_f32': 1.5, 'split_f16': 3.0},   # BASELINE config #1's T = 100 replay (8 molecules, noisy end), test_gpu_sampling.py
+    'factor': 1.5,     # forward quantities of the teacher-forced steps
+    'delta': 2.0,      # maximum error of the guidance increment (kink events), test_gpu_fullsize.py
+    'config1': 1.5,    # BASELINE config #1's T = 100 replay (8 molecules, noisy end), test_gpu_sampling.py
 }
 
 
 def tail(key, path=None):
-    return TAIL[key][path or current_matrix_path()]
+    """One factor per quantity; `path` is accepted (and ignored) so call sites can keep naming the path they run on."""
+    return TAIL[key]
+
+
+SUMMATION_ORDERS = ('base', 'splitk2', 'reversed', 'splitk4_reversed', 'threads1')
+
+
+class summation_order:
+    """Evaluate the oracle in another LEGAL summation order of the same fp32 arithmetic (same products, same formulas):
+    'splitk2' / 'splitk4': every Linear's reduction over its input features is formed in 2 / 4 contiguous chunks that are then added
+                 (what a split-K or differently tiled GEMM does);
+    'reversed':  every segment sum (torch_scatter.scatter_sum's index-add) visits its source rows in reversed order;
+    'threads1':  single-threaded evaluation (ATen's reductions and index-adds chunk by thread count).
+    Only test code uses this; the oracle module itself is untouched outside the `with` block."""
+
+    def __init__(self, name):
+        assert name in SUMMATION_ORDERS, name
+        self.name = name
+
+    def __enter__(self):
+        self.saved = (O.lin, O.seg_sum, torch.get_num_threads())
+        name = self.name
+        nk = 4 if 'splitk4' in name else 2 if 'splitk2' in name else 1
+        if nk > 1:
+            def lin(P, pre, x, bias=True):
+                w = P[pre + '.weight']
+                b = P[pre + '.bias'] if bias else None
+                K = w.shape[1]
+                if K < 4 * nk:
+                    return F.linear(x, w, b)
+                cuts = [K * j // nk for j in range(nk + 1)]
+                y = F.linear(x[..., cuts[0]:cuts[1]], w[:, cuts[0]:cuts[1]])
+                for j in range(1, nk):
+                    y = y + F.linear(x[..., cuts[j]:cuts[j + 1]], w[:, cuts[j]:cuts[j + 1]])
+                return y + b if b is not None else y
+            O.lin = lin
+        if 'reversed' in name:
+            def seg_sum(src, index, n):
+                out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+                return out.index_add_(0, index.flip(0), src.flip(0))
+            O.seg_sum = seg_sum
+        if name == 'threads1':
+            torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *a):
+        O.lin, O.seg_sum = self.saved[0], self.saved[1]
+        torch.set_num_threads(self.saved[2])
+
+
+def fp32_error_over_orders(eval32, ref64, orders=SUMMATION_ORDERS, extra=()):
+    """max over legal summation orders of |fp32 oracle - fp64|, per quantity.
+    eval32() -> {name: tensor} (the fp32 oracle, called once inside each order); ref64: {name: tensor}; extra: further fp32 results
+    of the same arithmetic (the reference's golden).  Returns ({name: max error}, {name: [error per order]}); the result of the FIRST
+    order is kept in `fp32_error_over_orders.first` (callers that also want the plain fp32 oracle's output)."""
+    per = {k: [] for k in ref64}
+    for j, o in enumerate(orders):
+        with summation_order(o):
+            r = eval32()
+        if j == 0:
+            fp32_error_over_orders.first = r
+        for k in ref64:
+            per[k].append(maxdiff(r[k], ref64[k]))
+    for e in extra:
+        for k in ref64:
+            if k in e:
+                per[k].append(maxdiff(e[k], ref64[k]))
+    return {k: max(v) for k, v in per.items()}, per
 
 
 def rmsdiff(a, b):
