@@ -62,7 +62,7 @@ def _oracle_step(P, cfg, st, graph, step, noise, double=False, **guide):
 _ORACLE_CACHE = {}
 
 
-def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, pos_keys_extra=()):
+def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, pos_keys_extra=(), rel_scale=False):
     """SURVEY 8(c) tolerances, arbitrated in fp64.
 
     The contract: positions 1e-4, logits 2e-5 (pre-softmax network outputs), log-posteriors 1e-4, class ids bit-exact
@@ -70,7 +70,9 @@ def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, 
     amplifies fp32 rounding, so the reference's own fp32 result deviates from exact arithmetic by more than the contract on
     a few rows.  Each quantity therefore has to satisfy  |HIP - fp64| <= max(contract, 1.5 * |oracle_fp32 - fp64|):  within
     the contract, or as close to exact arithmetic as the reference's fp32 is (1.5x covers the different, equally valid,
-    summation orders of the two fp32 evaluations)."""
+    summation orders of the two fp32 evaluations).
+    rel_scale (stress weights: outputs are O(10), residual streams 10^2 - 10^3): the absolute contract, written for O(1) quantities,
+    is taken relative to each quantity's own scale max(1, max |fp64 value|), as tests/test_gpu_round5.py does for the small stress goldens."""
     report, counts = {}, {}
     for name, hip, r32, r64, tol in (
             ('pred_pos', gp[1], preds32['pred_pos'], preds64['pred_pos'], 1e-4),
@@ -79,6 +81,8 @@ def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, 
             ('pos', got['pos'], want32['pos'], want64['pos'], 1e-4),
             ('log_node', got['log_node'], want32['log_node'], want64['log_node'], 1e-4),
             ('log_halfedge', got['log_halfedge'], want32['log_halfedge'], want64['log_halfedge'], 1e-4)):
+        if rel_scale:
+            tol = tol * max(1.0, float(torch.as_tensor(r64).abs().max()))
         e_hip, e_ref = U.maxdiff(hip, r64), U.maxdiff(r32, r64)
         report[name] = (e_hip, e_ref, U.maxdiff(hip, r32))
         assert e_hip <= max(tol, U.tail('factor') * e_ref), f'{name}: |HIP-fp64| = {e_hip:.3e}, |oracle_fp32-fp64| = {e_ref:.3e}, contract {tol}'
@@ -101,11 +105,12 @@ def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, 
                                 ('halfedge', want64['log_halfedge'], noise['u_halfedge'].double(), got['h_halfedge'].argmax(-1))):
         z = log_p - torch.log(-torch.log(u + 1e-30) + 1e-30)
         top = z.topk(2, dim=-1).values
-        clear = (top[:, 0] - top[:, 1]) > 1e-4
+        margin = 1e-4 * (max(1.0, float(log_p.abs().max())) if rel_scale else 1.0)   # the log-posteriors' own contract
+        clear = (top[:, 0] - top[:, 1]) > margin
         n_close = int((~clear).sum())
-        print(f'    {part}: {n_close} of {clear.numel()} rows within the 1e-4 Gumbel margin (excused), '
+        print(f'    {part}: {n_close} of {clear.numel()} rows within the {margin:.1e} Gumbel margin (excused), '
               f'{int((cls[clear] != z.argmax(-1)[clear]).sum())} mismatches outside it')
-        assert n_close <= 2e-4 * clear.numel() + 2
+        assert n_close <= (2e-3 if rel_scale else 2e-4) * clear.numel() + 2
         assert torch.equal(cls[clear], z.argmax(-1)[clear])
     return report
 
@@ -114,9 +119,26 @@ def _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, 
 def test_one_full_size_step_matches_oracle():
     """Config #2 at full size: 256 molecules, step t = 600, explicit noise, one teacher-forced step against the oracle in fp32
     and fp64 (see _check_against_oracle for the tolerances)."""
+    _full_size_simple_step('recipe')
+
+
+@U.both_paths
+def test_one_full_size_step_with_stress_weights_matches_oracle():
+    """The same step with the heavy-tailed stress weights (harness.stress_state_dict: LayerNorm gains up to 30, biases x 8, one
+    block's out_transform x 16): 256 molecules put atom pairs ~0.1 apart AND gains of 30 into the same run, which neither the small
+    stress goldens (12 / 101 atoms) nor the recipe-weight full-size step does (reference models/graph.py:384-396 amplification,
+    models/common.py:181-201)."""
+    _full_size_simple_step('stress')
+
+
+def _full_size_simple_step(weights):
     ph, sizes = _workload()
-    m = U.moldiff('MolDiff_simple', DEV)
-    P = U.params(U.moldiff('MolDiff_simple'))
+    if weights == 'stress':
+        m = U.moldiff_stress(DEV, 'MolDiff_simple')
+        P = U.params(U.moldiff_stress('cpu', 'MolDiff_simple'))
+    else:
+        m = U.moldiff('MolDiff_simple', DEV)
+        P = U.params(U.moldiff('MolDiff_simple'))
     st = _state(ph, 31)
     N, Eh = st['pos'].shape[0], st['h_halfedge'].shape[0]
     g = U.rng(32)
@@ -133,10 +155,13 @@ def test_one_full_size_step_matches_oracle():
              'n_graphs': B}
     # (the oracle's two evaluations are deterministic functions of the seeds above: computed once per session, the split-path test of
     # tests/test_gpu_round4.py re-uses them)
-    if 'simple' not in _ORACLE_CACHE:
-        _ORACLE_CACHE['simple'] = (_oracle_step(P, U.CFG, st, graph, step, noise), _oracle_step(P, U.CFG, st, graph, step, noise, double=True))
-    (want32, preds32), (want64, preds64) = _ORACLE_CACHE['simple']
-    _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64)
+    ck = 'simple' if weights == 'recipe' else 'simple_stress'
+    if ck not in _ORACLE_CACHE:
+        _ORACLE_CACHE[ck] = (_oracle_step(P, U.CFG, st, graph, step, noise), _oracle_step(P, U.CFG, st, graph, step, noise, double=True))
+    (want32, preds32), (want64, preds64) = _ORACLE_CACHE[ck]
+    if weights == 'stress':
+        print(f'\n[stress weights at full size, config #2, {U.current_matrix_path()}]')
+    _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, rel_scale=(weights == 'stress'))
 
 
 @U.both_paths
@@ -156,20 +181,35 @@ def test_one_full_size_guided_step_mixed_paths_matches_oracle():
         _full_size_guided_step('split_f16')
 
 
-def _full_size_guided_step(bp_path):
-    bp = U.bondpred(DEV)
+@U.both_paths
+def test_one_full_size_guided_step_with_stress_weights_matches_oracle():
+    """Config #3's step at 256 molecules with the stress weights on denoiser AND predictor (see the config-#2 twin above): forward,
+    posteriors, class ids and the guidance increment through the hand-written backward, fp64-arbitrated, contract relative to each
+    quantity's scale."""
+    _full_size_guided_step(None, 'stress')
+
+
+def _full_size_guided_step(bp_path, weights='recipe'):
+    bp = U.bondpred_stress(DEV) if weights == 'stress' else U.bondpred(DEV)
     old = bp.matrix_path
     bp.matrix_path = bp_path          # None: follows the process default, like the denoiser
     try:
-        _full_size_guided_step_body(bp, bp_path)
+        _full_size_guided_step_body(bp, bp_path, weights)
     finally:
         bp.matrix_path = old
 
 
-def _full_size_guided_step_body(bp, bp_path):
+def _full_size_guided_step_body(bp, bp_path, weights='recipe'):
     ph, sizes = _workload('MolDiff')
-    m = U.moldiff('MolDiff', DEV)
-    P, Pb = U.params(U.moldiff('MolDiff')), U.params(U.bondpred())
+    stress = weights == 'stress'
+    sfx = '_stress' if stress else ''
+    if stress:
+        m = U.moldiff_stress(DEV)
+        P, Pb = U.params(U.moldiff_stress()), U.params(U.bondpred_stress())
+        print(f'\n[stress weights at full size, config #3, {bp_path or U.current_matrix_path()}]')
+    else:
+        m = U.moldiff('MolDiff', DEV)
+        P, Pb = U.params(U.moldiff('MolDiff')), U.params(U.bondpred())
     st = _state(ph, 61)
     N, Eh = st['pos'].shape[0], st['h_halfedge'].shape[0]
     g = U.rng(62)
@@ -186,24 +226,24 @@ def _full_size_guided_step_body(bp, bp_path):
     graph = {'batch_node': ph['batch_node'], 'halfedge_index': ph['halfedge_index'], 'batch_halfedge': ph['batch_halfedge'],
              'n_graphs': B}
     gd = dict(Pb=Pb, cfgb=U.CFGB, guidance=['uncertainty', 1e-4])
-    if 'guided' not in _ORACLE_CACHE:
-        _ORACLE_CACHE['guided'] = (_oracle_step(P, U.CFG, st, graph, step, noise, **gd), _oracle_step(P, U.CFG, st, graph, step, noise, double=True, **gd))
-    (want32, preds32), (want64, preds64) = _ORACLE_CACHE['guided']
-    _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64)
+    if 'guided' + sfx not in _ORACLE_CACHE:
+        _ORACLE_CACHE['guided' + sfx] = (_oracle_step(P, U.CFG, st, graph, step, noise, **gd), _oracle_step(P, U.CFG, st, graph, step, noise, double=True, **gd))
+    (want32, preds32), (want64, preds64) = _ORACLE_CACHE['guided' + sfx]
+    _check_against_oracle(got, gp, st, noise, want32, preds32, want64, preds64, rel_scale=stress)
     # the increment alone (oracle: new pos minus the unguided posterior mean + noise, evaluated in fp64)
     bn, hei, bh = graph['batch_node'], graph['halfedge_index'], graph['batch_halfedge']
     ei, be = torch.cat([hei, hei.flip(0)], 1), torch.cat([bh, bh])
     t = torch.full((B,), step, dtype=torch.long)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    if 'delta' not in _ORACLE_CACHE:
+    if 'delta' + sfx not in _ORACLE_CACHE:
         d64_ = O.guidance_delta(_f64(Pb), U.CFGB, st['h_node'].double(), st['pos'].double(), bn, ei, be, t, 1e-4)[0]
         # the fp32 reference arithmetic in four legal summation orders (tests/util.py TAIL): the increment's maximum error is a ReLU
         # kink event on ONE atom, and which atom trips depends on the order -- one evaluation under-samples that tail
         e_ref_, per_ = U.fp32_error_over_orders(
             lambda: {'delta': O.guidance_delta(Pb, U.CFGB, st['h_node'], st['pos'], bn, ei, be, t, 1e-4)[0]}, {'delta': d64_},
             orders=('base', 'splitk2', 'reversed', 'splitk4_reversed'))
-        _ORACLE_CACHE['delta'] = (d64_, U.fp32_error_over_orders.first['delta'], e_ref_['delta'], per_['delta'])
-    d64, d32, e_ref, per = _ORACLE_CACHE['delta']
+        _ORACLE_CACHE['delta' + sfx] = (d64_, U.fp32_error_over_orders.first['delta'], e_ref_['delta'], per_['delta'])
+    d64, d32, e_ref, per = _ORACLE_CACHE['delta' + sfx]
     scale = float(d64.abs().max())
     assert scale > 0
     e_hip = U.maxdiff(delta, d64)
@@ -212,7 +252,9 @@ def _full_size_guided_step_body(bp, bp_path):
     # a gradient through 8 blocks in a different (equally valid) summation order: within 2x the reference arithmetic's own fp32 error
     # (its maximum over the legal orders above; ONE factor for both matrix paths), and two orders of magnitude inside the 1e-4
     # position contract it feeds
-    assert e_hip <= max(1e-3 * scale, U.tail('delta') * e_ref) and e_hip <= 2e-6
+    # (absolute cap: 2e-6 with the recipe weights; the stress weights' increment is an order of magnitude larger -- capped at 1e-5,
+    # a tenth of the position contract)
+    assert e_hip <= max(1e-3 * scale, U.tail('delta') * e_ref) and e_hip <= (1e-5 if stress else 2e-6)
     # the maximum is set by isolated ReLU kink events (tests/util.py TAIL); the bulk: rms within 1e-4 of the increment's scale
     r_hip, r_ref = U.rmsdiff(delta, d64), U.rmsdiff(d32, d64)
     print(f'    guidance delta rms: |HIP-fp64| {r_hip:.3e}, |oracle32-fp64| {r_ref:.3e}')
