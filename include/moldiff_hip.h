@@ -393,6 +393,50 @@ int mdx_op_wgrad_layout(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t
 int64_t mdx_op_ln_relu_bwd_rows(int64_t M);
 int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks, void* stream);
 
+/* ---- fused row-owner training operators (round 6; csrc/mdx_train_fused.hip) ---------------------------------------------------------
+ * One forward and one backward launch for a whole BondFFN of the EdgeBlock in the float16 autocast arithmetic
+ * (replaces, for training, reference models/graph.py:133-141 -- bond_linear, the product with node_linear(h)[idx], the inter MLP
+ * models/common.py:191-198, the gate MLP on [bond | node | time] and the sigmoid product -- as called from models/graph.py:272-279,
+ * plus torch.autograd's backward through them).  Widths are those of the shipped networks: bond 64, inter 128, out 64, gate hidden 32.
+ * Row tensors are float16, row-major and dense unless a stride is given; weights are fp32 (N outputs x K inputs, row stride ld*, so
+ * column slices of a wider matrix are passed as they are); Wt is the gate's time COLUMN (element j at Wt[j * ldwt]).
+ * NL = node_linear(h_node) (N,128) float16 and GN = the node columns of the gate's first Linear applied to h_node (N,32) fp32 are
+ * computed per NODE by the caller (Linear(h[idx]) == Linear(h)[idx]); idx (E) selects the node whose features enter each row.
+ * Forward writes what the backward and the weight gradients read: prod (E,128), pre1 / post1 (E,128: before / after LayerNorm+ReLU
+ * of the inter MLP), inter (E,64), gpre / gpost (E,32), gate (E,64), out = inter * sigmoid(gate) (E,64). */
+typedef struct {
+  const void* X; int64_t ldx;                                            /* (E,64) float16, rows 16-byte aligned */
+  const float* Wb; int64_t ldwb;                                         /* bond_linear.weight (128,64) */
+  const float* Wi1; int64_t ldwi1; const float* bi1; const float* g1; const float* be1;   /* inter_module.net.0 (128,128) + bias, .1 LayerNorm(128) */
+  const float* Wi2; int64_t ldwi2; const float* bi2;                      /* inter_module.net.3 (64,128) + bias */
+  const float* Wg1; int64_t ldwg1; const float* bg1; const float* gg; const float* gbe;  /* gate.net.0 bond columns (32,64) + bias, .1 LayerNorm(32) */
+  const float* Wt; int64_t ldwt;                                         /* gate.net.0 time column (32) */
+  const float* Wg2; int64_t ldwg2; const float* bg2;                      /* gate.net.3 (64,32) + bias */
+  const void* NL; int64_t ldnl;                                          /* (N,128) float16 */
+  const float* GN; int64_t ldgn;                                         /* (N,32) fp32 */
+  const int64_t* idx;                                                    /* (E) */
+  const float* te;                                                       /* (E) the time input (already t / T) */
+  void *prod, *pre1, *post1, *inter, *gpre, *gpost, *gate, *out;         /* float16 outputs (inputs of the backward) */
+  int64_t E;
+} mdx_bondffn_args;
+/* Backward: gS (N,64; fp32, row stride ldgs) = dL/d scatter_sum(out, oidx); row e takes gS[oidx[e]] rounded to float16 (the gather the
+ * per-operator path's scatter_sum backward performs).  Writes the float16 row gradients the weight-gradient contractions read
+ * -- g_inter, g_gate (E,64), g_pre1, g_bf (E,128), g_gpre (E,32) -- plus g_x = dL/dX (E,64) and g_nl (E,128) = the per-edge dL/dNL rows
+ * (the caller sums them per node with mdx_op_segsum_rows_t; dL/dGN is the same sum of g_gpre).  lnp: mdx_op_bondffn_workgroups() rows
+ * of mdx_op_bondffn_lnp_floats() = 320 floats [d gamma1 | d beta1 (128 each) | d gamma_g | d beta_g (32 each)], one per workgroup,
+ * to be summed by the caller (mdx_op_reduce_deferred record: S = workgroups, pstride = 320). */
+typedef struct {
+  mdx_bondffn_args f;
+  const float* gS; int64_t ldgs;
+  const int64_t* oidx;
+  void *g_inter, *g_gate, *g_pre1, *g_bf, *g_nl, *g_gpre, *g_x;
+  float* lnp;
+} mdx_bondffn_bwd_args;
+int mdx_op_bondffn_fwd(const mdx_bondffn_args* a, void* stream);
+int mdx_op_bondffn_bwd(const mdx_bondffn_bwd_args* a, void* stream);
+int mdx_op_bondffn_workgroups(void);
+int mdx_op_bondffn_lnp_floats(void);
+
 /* One optimisation step with torch.cuda.amp.GradScaler semantics and ALL of its state on the device (no host round trip):
  * g = gradient of (S x loss).  state (16 floats): [0] loss scale S, [1] growth tracker, [2] optimizer steps taken, [3] steps skipped,
  * [4] unscaled squared gradient norm of this step (inf / nan if a gradient overflowed); [5..8] internal.  Finite: clip to max_norm

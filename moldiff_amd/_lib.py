@@ -30,6 +30,7 @@ EXPORTS = [
     'mdx_op_wgrad_layout', 'mdx_op_ln_relu_bwd_rows', 'mdx_op_reduce_deferred', 'mdx_op_transpose', 'mdx_op_transpose_batch', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_mul_gather_fwd', 'mdx_op_mul_gather_bwd', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
+    'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
 ]
 
 
@@ -50,6 +51,23 @@ class MdxGuidance(ctypes.Structure):   # == struct mdx_guidance
 
 class MdxStepNoise(ctypes.Structure):  # == struct mdx_step_noise
     _fields_ = [('seed', c_uint64), ('draw', c_int32), ('eps_pos', c_void_p), ('u_node', c_void_p), ('u_halfedge', c_void_p)]
+
+
+class MdxBondFfnArgs(ctypes.Structure):   # == mdx_bondffn_args
+    _fields_ = [('X', c_void_p), ('ldx', c_int64), ('Wb', c_void_p), ('ldwb', c_int64),
+                ('Wi1', c_void_p), ('ldwi1', c_int64), ('bi1', c_void_p), ('g1', c_void_p), ('be1', c_void_p),
+                ('Wi2', c_void_p), ('ldwi2', c_int64), ('bi2', c_void_p),
+                ('Wg1', c_void_p), ('ldwg1', c_int64), ('bg1', c_void_p), ('gg', c_void_p), ('gbe', c_void_p),
+                ('Wt', c_void_p), ('ldwt', c_int64), ('Wg2', c_void_p), ('ldwg2', c_int64), ('bg2', c_void_p),
+                ('NL', c_void_p), ('ldnl', c_int64), ('GN', c_void_p), ('ldgn', c_int64), ('idx', c_void_p), ('te', c_void_p),
+                ('prod', c_void_p), ('pre1', c_void_p), ('post1', c_void_p), ('inter', c_void_p), ('gpre', c_void_p), ('gpost', c_void_p),
+                ('gate', c_void_p), ('out', c_void_p), ('E', c_int64)]
+
+
+class MdxBondFfnBwdArgs(ctypes.Structure):   # == mdx_bondffn_bwd_args
+    _fields_ = [('f', MdxBondFfnArgs), ('gS', c_void_p), ('ldgs', c_int64), ('oidx', c_void_p),
+                ('g_inter', c_void_p), ('g_gate', c_void_p), ('g_pre1', c_void_p), ('g_bf', c_void_p), ('g_nl', c_void_p),
+                ('g_gpre', c_void_p), ('g_x', c_void_p), ('lnp', c_void_p)]
 
 
 class MdxConfig(ctypes.Structure):
@@ -166,6 +184,8 @@ def lib():
         L.mdx_op_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
         L.mdx_op_adamw.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                    c_int64, c_void_p, c_float, c_void_p]
+        L.mdx_op_bondffn_fwd.argtypes = [POINTER(MdxBondFfnArgs), c_void_p]
+        L.mdx_op_bondffn_bwd.argtypes = [POINTER(MdxBondFfnBwdArgs), c_void_p]
         _lib = L
     return _lib
 

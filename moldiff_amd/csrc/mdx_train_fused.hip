@@ -1,0 +1,556 @@
+// Row-owner FUSED training kernels (round 6): one forward and one backward launch for a whole BondFFN of the EdgeBlock
+// (reference models/graph.py:122-141 inside :268-283) in the float16 autocast arithmetic of the training path -- the per-operator
+// path of mdx_train.hip runs the same chain as 11 forward and ~28 backward launches with every intermediate making a round trip
+// through HBM.
+//
+//   bf    = bond_linear(X)                          (E,64) -> (E,128), no bias
+//   prod  = bf * NL[idx]                            NL = node_linear(h_node), hoisted to N rows by the caller
+//   inter = W_i2 relu(LN(W_i1 prod + b_i1)) + b_i2  common.MLP 128 -> 128 -> 64
+//   gate  = W_g2 relu(LN(W_g1e X + b_g1 + GN[idx] + t w_t)) + b_g2      common.MLP (64 + 256 + 1) -> 32 -> 64, node part hoisted
+//   out   = inter * sigmoid(gate)
+//
+// Design (the float16 row-owner scheme of hgemm_nt_rows_kernel, chained): a persistent workgroup of 8 waves per CU keeps EVERY
+// weight of the chain in LDS as float16 (80 KB forward, 99 KB backward); a wave owns 16-row tiles and needs nobody else: the first
+// layers take their activation operand straight from global memory (8 consecutive k of one row per lane = one 16-byte load), and
+// every later layer takes it from the previous layer's ACCUMULATORS: lane (q, c) of v_mfma_f32_16x16x32_f16's D holds features
+// 16 ft + 4 q .. + 3 of row c, the B operand of k-step ks wants 8 k-values of row c per lane -- tiles 2 ks and 2 ks + 1, rounded to
+// float16 (the value autocast's Linear would read anyway), with the k permutation  pos(k) = 32 (t / 2) + 8 q + 4 (t % 2) + s  for
+// k = 16 t + 4 q + s  baked into the LDS copy of the weight.  No LDS tile, no barrier in the loop; LayerNorm is wave-local.
+// Rounding points are those of the per-operator path (every Linear result, every product of two Linear results, the sigmoid).
+// Only what the weight gradients and the backward need is written out (float16): prod, the two pre-/post-LayerNorm pairs, inter, gate, out.
+//
+// Backward: dL/d(scatter_sum(out)) is gathered by the output index in the kernel; the data-gradient chain runs in registers; what
+// leaves are the row gradients the weight-gradient GEMMs contract (g_inter, g_gate, g_pre1, g_bf, g_gpre), dL/dX, the per-edge
+// dL/dNL rows (summed per node by the caller's segment sum) and one partial row of LayerNorm-parameter gradients per workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/moldiff_hip.h"
+#include "mdx_tile.h"
+
+int mdx_set_error(int code, const char* msg);  // mdx_api.hip
+
+namespace {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int BF_THREADS = 512, BF_WAVES = 8;
+constexpr int KB = 64, KI = 128, KO = 64, KG = 32;   // bond width, inter width, output width, gate hidden width
+constexpr int LDB = KB + 8, LDI = KI + 8, LDG = KG + 8, LDO = KO + 8;
+
+__device__ __forceinline__ float rh(float a) { return (float)(_Float16)a; }
+__device__ __forceinline__ f32x4 rh4(f32x4 v) {
+  f32x4 r = {rh(v[0]), rh(v[1]), rh(v[2]), rh(v[3])};
+  return r;
+}
+__device__ __forceinline__ uint2 pack4(f32x4 v) {   // four floats -> four float16 (RNE)
+  const f16x4_t h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ f32x4 unpack4(uint2 u) {
+  const f16x4_t h = __builtin_bit_cast(f16x4_t, u);
+  f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  return r;
+}
+__device__ __forceinline__ f16x8_t pair8(uint2 a, uint2 b) {   // B operand of one k-step from two packed feature tiles
+  const uint4 u = {a.x, a.y, b.x, b.y};
+  return __builtin_bit_cast(f16x8_t, u);
+}
+__device__ __forceinline__ f16x8_t lds8(const uint16_t* p) { return *reinterpret_cast<const f16x8_t*>(p); }
+__device__ __forceinline__ f32x4 ldh4(const _Float16* p) { return unpack4(*reinterpret_cast<const uint2*>(p)); }
+__device__ __forceinline__ void sth4(_Float16* p, uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
+__device__ __forceinline__ float sumq(float v) {   // sum over the four lanes c, c + 16, c + 32, c + 48 (every lane gets it)
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// position of natural input feature k in the LDS copy of a weight whose B operand is the previous layer's accumulators
+__device__ __forceinline__ int kperm(int k) {
+  const int t = k >> 4, q = (k & 15) >> 2, s = k & 3;
+  return 32 * (t >> 1) + 8 * q + 4 * (t & 1) + s;
+}
+// W (N outputs x K inputs, fp32, row stride ld) -> dst [N][K + 8] float16.  PERM: accumulator-fed layer (see kperm).
+template <int N, int K, bool PERM>
+__device__ __forceinline__ void stage_w(uint16_t* dst, const float* __restrict__ W, int ld, int tid) {
+  for (int i = tid; i < N * K; i += BF_THREADS) {
+    const int n = i / K, k = i % K;
+    dst[n * (K + 8) + (PERM ? kperm(k) : k)] = __builtin_bit_cast(uint16_t, (_Float16)W[(size_t)n * ld + k]);
+  }
+}
+// the TRANSPOSE of W (N x K): dst [K outputs][N + 8], for the data gradient  g_in[k] = sum_n g_out[n] W[n][k]
+template <int N, int K, bool PERM>
+__device__ __forceinline__ void stage_wt(uint16_t* dst, const float* __restrict__ W, int ld, int tid) {
+  for (int i = tid; i < N * K; i += BF_THREADS) {
+    const int n = i / K, k = i % K;
+    dst[k * (N + 8) + (PERM ? kperm(n) : n)] = __builtin_bit_cast(uint16_t, (_Float16)W[(size_t)n * ld + k]);
+  }
+}
+template <int N>
+__device__ __forceinline__ void stage_v(float* dst, const float* __restrict__ v, int stride, int tid, bool round_half = false) {
+  for (int i = tid; i < N; i += BF_THREADS) dst[i] = v ? (round_half ? rh(v[(size_t)i * stride]) : v[(size_t)i * stride]) : 0.f;
+}
+
+// y[ft] += W[16 ft + .][.] x   for FT output tiles over KS k-steps of 32; w = LDS weight + c * LD + 8 q; x[ks] the B operands
+template <int FT, int KS, int LD>
+__device__ __forceinline__ void mm(f32x4 (&y)[FT], const uint16_t* w, const f16x8_t (&x)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lds8(w + 16 * ft * LD + 32 * ks), x[ks], y[ft], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // one k-step's weight fragments at a time (hoisting them all spills)
+  }
+}
+template <int FT>
+__device__ __forceinline__ void zero(f32x4 (&y)[FT]) {
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) y[ft] = splat4(0.f);
+}
+
+// LayerNorm statistics of a row held as FT tiles of four features per lane (two-pass, biased variance: nn.LayerNorm)
+template <int FT>
+__device__ __forceinline__ void ln_stats(const f32x4 (&v)[FT], float& mean, float& rstd) {
+  constexpr float inv_n = 1.0f / (16 * FT);
+  float s = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) s += (v[ft][0] + v[ft][1]) + (v[ft][2] + v[ft][3]);
+  mean = sumq(s) * inv_n;
+  float d2 = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = v[ft][r] - mean;
+      d2 = fmaf(d, d, d2);
+    }
+  rstd = 1.0f / sqrtf(sumq(d2) * inv_n + MDX_LN_EPS);
+}
+
+struct FwdLds {   // offsets in uint16 units
+  static constexpr int WB = 0, WI1 = WB + KI * LDB, WI2 = WI1 + KI * LDI, WG1 = WI2 + KO * LDI, WG2 = WG1 + KG * LDB,
+                       END = WG2 + KO * LDG;
+  // fp32 constants behind the weights: bi1 g1 be1 (128 each) bi2 (64) bg1 gg gbe wt (32 each) bg2 (64)
+  static constexpr int C_BI1 = 0, C_G1 = 128, C_BE1 = 256, C_BI2 = 384, C_BG1 = 448, C_GG = 480, C_GBE = 512, C_WT = 544, C_BG2 = 576,
+                       C_END = 640;
+  static constexpr int BYTES = END * 2 + C_END * 4;
+};
+
+__global__ __launch_bounds__(BF_THREADS) void bondffn_fwd_kernel(const mdx_bondffn_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
+  uint16_t* S = bf_smem;
+  float* C = reinterpret_cast<float*>(bf_smem + FwdLds::END);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  stage_w<KI, KB, false>(S + FwdLds::WB, a.Wb, (int)a.ldwb, tid);
+  stage_w<KI, KI, true>(S + FwdLds::WI1, a.Wi1, (int)a.ldwi1, tid);
+  stage_w<KO, KI, true>(S + FwdLds::WI2, a.Wi2, (int)a.ldwi2, tid);
+  stage_w<KG, KB, false>(S + FwdLds::WG1, a.Wg1, (int)a.ldwg1, tid);
+  stage_w<KO, KG, true>(S + FwdLds::WG2, a.Wg2, (int)a.ldwg2, tid);
+  stage_v<128>(C + FwdLds::C_BI1, a.bi1, 1, tid); stage_v<128>(C + FwdLds::C_G1, a.g1, 1, tid); stage_v<128>(C + FwdLds::C_BE1, a.be1, 1, tid);
+  stage_v<64>(C + FwdLds::C_BI2, a.bi2, 1, tid); stage_v<32>(C + FwdLds::C_BG1, a.bg1, 1, tid); stage_v<32>(C + FwdLds::C_GG, a.gg, 1, tid);
+  stage_v<32>(C + FwdLds::C_GBE, a.gbe, 1, tid); stage_v<32>(C + FwdLds::C_WT, a.Wt, (int)a.ldwt, tid, true);
+  stage_v<64>(C + FwdLds::C_BG2, a.bg2, 1, tid);
+  __syncthreads();   // the only barrier
+
+  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * BF_WAVES;
+  const _Float16* X = reinterpret_cast<const _Float16*>(a.X);
+  const _Float16* NL = reinterpret_cast<const _Float16*>(a.NL);
+  const uint16_t* wb = S + FwdLds::WB + c * LDB + 8 * q;
+  const uint16_t* wi1 = S + FwdLds::WI1 + c * LDI + 8 * q;
+  const uint16_t* wi2 = S + FwdLds::WI2 + c * LDI + 8 * q;
+  const uint16_t* wg1 = S + FwdLds::WG1 + c * LDB + 8 * q;
+  const uint16_t* wg2 = S + FwdLds::WG2 + c * LDG + 8 * q;
+  _Float16* o_prod = reinterpret_cast<_Float16*>(a.prod);
+  _Float16* o_pre1 = reinterpret_cast<_Float16*>(a.pre1);
+  _Float16* o_post1 = reinterpret_cast<_Float16*>(a.post1);
+  _Float16* o_inter = reinterpret_cast<_Float16*>(a.inter);
+  _Float16* o_gpre = reinterpret_cast<_Float16*>(a.gpre);
+  _Float16* o_gpost = reinterpret_cast<_Float16*>(a.gpost);
+  _Float16* o_gate = reinterpret_cast<_Float16*>(a.gate);
+  _Float16* o_out = reinterpret_cast<_Float16*>(a.out);
+
+  int tile = blockIdx.x * BF_WAVES + wave;
+  uint4 xr[2], xn[2];
+  int64_t ni = 0, nin = 0;
+  float te = 0.f, ten = 0.f;
+  auto load = [&](uint4 (&d)[2], int64_t& n_, float& t_, int t) {
+    const int row = min(16 * t + c, E - 1);   // clamped: loads stay inside the matrices, stores are predicated
+    const _Float16* p = X + (size_t)row * a.ldx + 8 * q;
+    d[0] = *reinterpret_cast<const uint4*>(p);
+    d[1] = *reinterpret_cast<const uint4*>(p + 32);
+    n_ = a.idx[row];
+    t_ = a.te[row];
+  };
+  if (tile < ntiles) load(xr, ni, te, tile);
+#pragma unroll 1
+  for (; tile < ntiles; tile += nw) {
+    if (tile + nw < ntiles) load(xn, nin, ten, tile + nw);
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1);
+    const f16x8_t xb[2] = {__builtin_bit_cast(f16x8_t, xr[0]), __builtin_bit_cast(f16x8_t, xr[1])};
+    // ---- bond_linear, product with the node row
+    uint2 pk[8];
+    {
+      f32x4 nl[8];
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) nl[ft] = ldh4(NL + (size_t)ni * a.ldnl + 16 * ft + 4 * q);
+      f32x4 y[8];
+      zero<8>(y);
+      mm<8, 2, LDB>(y, wb, xb);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        pk[ft] = pack4(rh4(y[ft]) * nl[ft]);
+        if (ok) sth4(o_prod + r * KI + 16 * ft + 4 * q, pk[ft]);
+      }
+    }
+    // ---- inter module: Linear -> LayerNorm -> ReLU -> Linear
+    f32x4 inter[4];
+    {
+      const f16x8_t pb[4] = {pair8(pk[0], pk[1]), pair8(pk[2], pk[3]), pair8(pk[4], pk[5]), pair8(pk[6], pk[7])};
+      f32x4 y[8];
+      zero<8>(y);
+      mm<8, 4, LDI>(y, wi1, pb);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        y[ft] = rh4(y[ft] + lds4(C + FwdLds::C_BI1 + 16 * ft + 4 * q));
+        if (ok) sth4(o_pre1 + r * KI + 16 * ft + 4 * q, pack4(y[ft]));
+      }
+      float mean, rstd;
+      ln_stats<8>(y, mean, rstd);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        const f32x4 v = relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(C + FwdLds::C_G1 + 16 * ft + 4 * q) +
+                              lds4(C + FwdLds::C_BE1 + 16 * ft + 4 * q));
+        pk[ft] = pack4(v);
+        if (ok) sth4(o_post1 + r * KI + 16 * ft + 4 * q, pk[ft]);
+      }
+      const f16x8_t hb[4] = {pair8(pk[0], pk[1]), pair8(pk[2], pk[3]), pair8(pk[4], pk[5]), pair8(pk[6], pk[7])};
+      zero<4>(inter);
+      mm<4, 4, LDI>(inter, wi2, hb);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        inter[ft] = rh4(inter[ft] + lds4(C + FwdLds::C_BI2 + 16 * ft + 4 * q));
+        if (ok) sth4(o_inter + r * KO + 16 * ft + 4 * q, pack4(inter[ft]));
+      }
+    }
+    // ---- gate: Linear([X | node | t]) -> LayerNorm -> ReLU -> Linear; the node part arrives hoisted (GN rows), the time column is w_t t
+    {
+      f32x4 y[2];
+      zero<2>(y);
+      mm<2, 2, LDB>(y, wg1, xb);
+      const float th = rh(te);
+      uint2 pg[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 ad = ldg4(a.GN + (size_t)ni * a.ldgn + 16 * ft + 4 * q) + splat4(th) * lds4(C + FwdLds::C_WT + 16 * ft + 4 * q);
+        y[ft] = rh4((y[ft] + lds4(C + FwdLds::C_BG1 + 16 * ft + 4 * q)) + ad);
+        if (ok) sth4(o_gpre + r * KG + 16 * ft + 4 * q, pack4(y[ft]));
+      }
+      float mean, rstd;
+      ln_stats<2>(y, mean, rstd);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 v = relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(C + FwdLds::C_GG + 16 * ft + 4 * q) +
+                              lds4(C + FwdLds::C_GBE + 16 * ft + 4 * q));
+        pg[ft] = pack4(v);
+        if (ok) sth4(o_gpost + r * KG + 16 * ft + 4 * q, pg[ft]);
+      }
+      const f16x8_t gb[1] = {pair8(pg[0], pg[1])};
+      f32x4 g2[4];
+      zero<4>(g2);
+      mm<4, 1, LDG>(g2, wg2, gb);
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) {
+        g2[ft] = rh4(g2[ft] + lds4(C + FwdLds::C_BG2 + 16 * ft + 4 * q));
+        if (ok) {
+          sth4(o_gate + r * KO + 16 * ft + 4 * q, pack4(g2[ft]));
+          sth4(o_out + r * KO + 16 * ft + 4 * q, pack4(inter[ft] * rh4(sigmoid4(g2[ft]))));
+        }
+      }
+    }
+    xr[0] = xn[0]; xr[1] = xn[1]; ni = nin; te = ten;
+  }
+}
+
+struct BwdLds {
+  static constexpr int WI2T = 0, WI1T = WI2T + KI * LDO, WB = WI1T + KI * LDI, WBT = WB + KI * LDB, WG2T = WBT + KB * LDI,
+                       WG1T = WG2T + KG * LDO, END = WG1T + KB * LDG;
+  // fp32 constants: g1 be1 (128 each) gg gbe (32 each)
+  static constexpr int C_G1 = 0, C_BE1 = 128, C_GG = 256, C_GBE = 288, C_END = 320;
+  static constexpr int BYTES = END * 2 + C_END * 4;
+};
+constexpr int BF_LNP = 320;   // floats per partial row of LayerNorm-parameter gradients: dg1 | dbe1 (128 each) | dgg | dgbe (32 each)
+
+// g (dL/d relu(LN(x))) -> dL/dx in place; x holds the pre-LayerNorm values (float16-representable).  The row's LayerNorm-parameter
+// gradients are added to dgam / dbet (per lane: the lane's four features of each tile, summed over the wave's rows at the end).
+template <int FT>
+__device__ __forceinline__ void ln_relu_bwd(f32x4 (&g)[FT], f32x4 (&x)[FT], const float* gam, const float* bet, int q, bool ok,
+                                            f32x4 (&dgam)[FT], f32x4 (&dbet)[FT]) {
+  constexpr float inv_n = 1.0f / (16 * FT);
+  float mean, rstd;
+  ln_stats<FT>(x, mean, rstd);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    const f32x4 gm = lds4(gam + 16 * ft + 4 * q), bt = lds4(bet + 16 * ft + 4 * q);
+    x[ft] = (x[ft] - splat4(mean)) * splat4(rstd);      // x_hat, in place
+    const f32x4 y = x[ft] * gm + bt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float go = (ok && y[r] > 0.f) ? g[ft][r] : 0.f;
+      dgam[ft][r] = fmaf(go, x[ft][r], dgam[ft][r]);
+      dbet[ft][r] += go;
+      const float gh = go * gm[r];
+      g[ft][r] = gh;
+      s1 += gh;
+      s2 = fmaf(gh, x[ft][r], s2);
+    }
+  }
+  const float m1 = sumq(s1) * inv_n, m2 = sumq(s2) * inv_n;
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) g[ft] = (g[ft] - splat4(m1) - x[ft] * splat4(m2)) * splat4(rstd);
+}
+
+// sum over the 16 lanes of a DPP row (the wave's 16 rows c = 0..15 of one q); result in every lane of the row
+__device__ __forceinline__ float sum_c(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+__global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondffn_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
+  uint16_t* S = bf_smem;
+  float* C = reinterpret_cast<float*>(bf_smem + BwdLds::END);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  stage_wt<KO, KI, true>(S + BwdLds::WI2T, a.f.Wi2, (int)a.f.ldwi2, tid);    // (64 x 128)^T: 128 outputs over 64 inputs
+  stage_wt<KI, KI, true>(S + BwdLds::WI1T, a.f.Wi1, (int)a.f.ldwi1, tid);
+  stage_w<KI, KB, false>(S + BwdLds::WB, a.f.Wb, (int)a.f.ldwb, tid);         // recompute of bond_linear(X)
+  stage_wt<KI, KB, true>(S + BwdLds::WBT, a.f.Wb, (int)a.f.ldwb, tid);        // (128 x 64)^T: 64 outputs over 128 inputs
+  stage_wt<KO, KG, true>(S + BwdLds::WG2T, a.f.Wg2, (int)a.f.ldwg2, tid);     // (64 x 32)^T: 32 outputs over 64 inputs
+  stage_wt<KG, KB, true>(S + BwdLds::WG1T, a.f.Wg1, (int)a.f.ldwg1, tid);     // (32 x 64)^T: 64 outputs over 32 inputs
+  stage_v<128>(C + BwdLds::C_G1, a.f.g1, 1, tid); stage_v<128>(C + BwdLds::C_BE1, a.f.be1, 1, tid);
+  stage_v<32>(C + BwdLds::C_GG, a.f.gg, 1, tid); stage_v<32>(C + BwdLds::C_GBE, a.f.gbe, 1, tid);
+  __syncthreads();
+
+  const int E = (int)a.f.E, ntiles = (E + 15) >> 4, nw = gridDim.x * BF_WAVES;
+  const _Float16* X = reinterpret_cast<const _Float16*>(a.f.X);
+  const _Float16* NL = reinterpret_cast<const _Float16*>(a.f.NL);
+  const _Float16* s_pre1 = reinterpret_cast<const _Float16*>(a.f.pre1);
+  const _Float16* s_inter = reinterpret_cast<const _Float16*>(a.f.inter);
+  const _Float16* s_gpre = reinterpret_cast<const _Float16*>(a.f.gpre);
+  const _Float16* s_gate = reinterpret_cast<const _Float16*>(a.f.gate);
+  _Float16* o_ginter = reinterpret_cast<_Float16*>(a.g_inter);
+  _Float16* o_ggate = reinterpret_cast<_Float16*>(a.g_gate);
+  _Float16* o_gpre1 = reinterpret_cast<_Float16*>(a.g_pre1);
+  _Float16* o_gbf = reinterpret_cast<_Float16*>(a.g_bf);
+  _Float16* o_gnl = reinterpret_cast<_Float16*>(a.g_nl);
+  _Float16* o_ggpre = reinterpret_cast<_Float16*>(a.g_gpre);
+  _Float16* o_gx = reinterpret_cast<_Float16*>(a.g_x);
+  const uint16_t* wi2t = S + BwdLds::WI2T + c * LDO + 8 * q;
+  const uint16_t* wi1t = S + BwdLds::WI1T + c * LDI + 8 * q;
+  const uint16_t* wb = S + BwdLds::WB + c * LDB + 8 * q;
+  const uint16_t* wbt = S + BwdLds::WBT + c * LDI + 8 * q;
+  const uint16_t* wg2t = S + BwdLds::WG2T + c * LDO + 8 * q;
+  const uint16_t* wg1t = S + BwdLds::WG1T + c * LDG + 8 * q;
+
+  f32x4 dg1[8], db1[8], dgg[2], dgb[2];
+  zero<8>(dg1); zero<8>(db1); zero<2>(dgg); zero<2>(dgb);
+
+#pragma unroll 1
+  for (int tile = blockIdx.x * BF_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1);
+    const int64_t ni = a.f.idx[r], no = a.oidx[r];
+    uint4 xr[2];
+    {
+      const _Float16* p = X + r * a.f.ldx + 8 * q;
+      xr[0] = *reinterpret_cast<const uint4*>(p);
+      xr[1] = *reinterpret_cast<const uint4*>(p + 32);
+    }
+    // ---- out = inter * sigmoid(gate): the incoming gradient is dL/d(sum over the output node's rows), a float16 row per edge
+    uint2 pgi[4], pgg[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      const f32x4 g = rh4(ldg4(a.gS + (size_t)no * a.ldgs + 16 * ft + 4 * q));
+      const f32x4 it = ldh4(s_inter + r * KO + 16 * ft + 4 * q), sg = sigmoid4(ldh4(s_gate + r * KO + 16 * ft + 4 * q));
+      pgi[ft] = pack4(g * sg);
+      pgg[ft] = pack4(g * it * sg * (splat4(1.f) - sg));
+      if (ok) {
+        sth4(o_ginter + r * KO + 16 * ft + 4 * q, pgi[ft]);
+        sth4(o_ggate + r * KO + 16 * ft + 4 * q, pgg[ft]);
+      }
+    }
+    // ---- inter module backward
+    uint2 pgb[8];
+    {
+      f32x4 g[8], x[8];
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) x[ft] = ldh4(s_pre1 + r * KI + 16 * ft + 4 * q);
+      const f16x8_t b2[2] = {pair8(pgi[0], pgi[1]), pair8(pgi[2], pgi[3])};
+      zero<8>(g);
+      mm<8, 2, LDO>(g, wi2t, b2);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) g[ft] = rh4(g[ft]);
+      ln_relu_bwd<8>(g, x, C + BwdLds::C_G1, C + BwdLds::C_BE1, q, ok, dg1, db1);
+      uint2 pg[8];
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        pg[ft] = pack4(g[ft]);
+        if (ok) sth4(o_gpre1 + r * KI + 16 * ft + 4 * q, pg[ft]);
+      }
+      const f16x8_t b1[4] = {pair8(pg[0], pg[1]), pair8(pg[2], pg[3]), pair8(pg[4], pg[5]), pair8(pg[6], pg[7])};
+      zero<8>(g);
+      mm<8, 4, LDI>(g, wi1t, b1);     // dL/d prod
+      // prod = bf * nl:  d bf = gp * nl,  d nl = gp * bf  (bf = bond_linear(X) recomputed: 16 MFMAs against a 256-byte row of HBM traffic each way)
+      const f16x8_t xb[2] = {__builtin_bit_cast(f16x8_t, xr[0]), __builtin_bit_cast(f16x8_t, xr[1])};
+      zero<8>(x);
+      mm<8, 2, LDB>(x, wb, xb);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        const f32x4 gp = rh4(g[ft]), nl = ldh4(NL + (size_t)ni * a.f.ldnl + 16 * ft + 4 * q);
+        pgb[ft] = pack4(gp * nl);
+        if (ok) {
+          sth4(o_gbf + r * KI + 16 * ft + 4 * q, pgb[ft]);
+          sth4(o_gnl + r * KI + 16 * ft + 4 * q, pack4(gp * rh4(x[ft])));
+        }
+      }
+    }
+    // ---- gate backward
+    uint2 pgp[2];
+    {
+      f32x4 g[2], x[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) x[ft] = ldh4(s_gpre + r * KG + 16 * ft + 4 * q);
+      const f16x8_t b2[2] = {pair8(pgg[0], pgg[1]), pair8(pgg[2], pgg[3])};
+      zero<2>(g);
+      mm<2, 2, LDO>(g, wg2t, b2);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) g[ft] = rh4(g[ft]);
+      ln_relu_bwd<2>(g, x, C + BwdLds::C_GG, C + BwdLds::C_GBE, q, ok, dgg, dgb);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        pgp[ft] = pack4(g[ft]);
+        if (ok) sth4(o_ggpre + r * KG + 16 * ft + 4 * q, pgp[ft]);
+      }
+    }
+    // ---- dL/dX = bond_linear^T d bf + W_g1e^T d gate_pre  (two Linear data gradients, each a float16 tensor, summed in float16)
+    {
+      f32x4 g1[4], g2[4];
+      const f16x8_t bb[4] = {pair8(pgb[0], pgb[1]), pair8(pgb[2], pgb[3]), pair8(pgb[4], pgb[5]), pair8(pgb[6], pgb[7])};
+      zero<4>(g1);
+      mm<4, 4, LDI>(g1, wbt, bb);
+      const f16x8_t bg[1] = {pair8(pgp[0], pgp[1])};
+      zero<4>(g2);
+      mm<4, 1, LDG>(g2, wg1t, bg);
+      if (ok) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(g1[ft]) + rh4(g2[ft])));
+      }
+    }
+  }
+  // ---- LayerNorm-parameter gradients: lanes -> rows of the wave (DPP row sums) -> the workgroup's 8 waves (LDS, fixed order) -> one
+  // partial row per workgroup; the caller's deferred reduction sums the gridDim.x rows
+  __syncthreads();   // every wave is done with the weights: the LDS area is free
+  float* R = reinterpret_cast<float*>(bf_smem);
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float v1 = sum_c(dg1[ft][s]), v2 = sum_c(db1[ft][s]);
+      if (c == 0) {
+        R[wave * BF_LNP + 16 * ft + 4 * q + s] = v1;
+        R[wave * BF_LNP + 128 + 16 * ft + 4 * q + s] = v2;
+      }
+    }
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float v1 = sum_c(dgg[ft][s]), v2 = sum_c(dgb[ft][s]);
+      if (c == 0) {
+        R[wave * BF_LNP + 256 + 16 * ft + 4 * q + s] = v1;
+        R[wave * BF_LNP + 288 + 16 * ft + 4 * q + s] = v2;
+      }
+    }
+  __syncthreads();
+  for (int i = tid; i < BF_LNP; i += BF_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < BF_WAVES; ++w) s += R[w * BF_LNP + i];
+    a.lnp[(size_t)blockIdx.x * BF_LNP + i] = s;
+  }
+}
+
+int g_ncu = 0;
+int ncus() {
+  if (!g_ncu) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_ncu = p.multiProcessorCount;
+    if (g_ncu <= 0) g_ncu = 256;
+  }
+  return g_ncu;
+}
+bool g_attr_fwd = false, g_attr_bwd = false;
+
+int check_fwd(const mdx_bondffn_args& a, const char* who) {
+  if (a.E < 0) return mdx_set_error(MDX_ERR_ARG, "bondffn: negative row count");
+  if (!a.X || !a.Wb || !a.Wi1 || !a.Wi2 || !a.Wg1 || !a.Wg2 || !a.Wt || !a.NL || !a.GN || !a.idx || !a.te || !a.bi1 || !a.g1 || !a.be1 ||
+      !a.bi2 || !a.bg1 || !a.gg || !a.gbe || !a.bg2)
+    return mdx_set_error(MDX_ERR_ARG, "bondffn: null operand");
+  if ((a.ldx & 7) || (reinterpret_cast<uintptr_t>(a.X) & 15)) return mdx_set_error(MDX_ERR_ARG, "bondffn: X rows must be 16-byte aligned");
+  if ((a.ldnl & 3) || (reinterpret_cast<uintptr_t>(a.NL) & 7)) return mdx_set_error(MDX_ERR_ARG, "bondffn: NL rows must be 8-byte aligned");
+  if ((a.ldgn & 3) || (reinterpret_cast<uintptr_t>(a.GN) & 15)) return mdx_set_error(MDX_ERR_ARG, "bondffn: GN rows must be 16-byte aligned");
+  (void)who;
+  return MDX_OK;
+}
+
+}  // namespace
+
+extern "C" int mdx_op_bondffn_workgroups(void) { return ncus(); }
+extern "C" int mdx_op_bondffn_lnp_floats(void) { return BF_LNP; }
+
+extern "C" int mdx_op_bondffn_fwd(const mdx_bondffn_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "bondffn_fwd: null argument block");
+  if (a->E == 0) return MDX_OK;
+  if (int rc = check_fwd(*a, "fwd")) return rc;
+  if (!a->prod || !a->pre1 || !a->post1 || !a->inter || !a->gpre || !a->gpost || !a->gate || !a->out)
+    return mdx_set_error(MDX_ERR_ARG, "bondffn_fwd: null output");
+  if (!g_attr_fwd) {
+    if (hipFuncSetAttribute((const void*)bondffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FwdLds::BYTES) != hipSuccess)
+      return mdx_set_error(MDX_ERR_HIP, "bondffn_fwd: cannot reserve LDS");
+    g_attr_fwd = true;
+  }
+  const int ntiles = (int)((a->E + 15) / 16);
+  const int grid = std::max(1, std::min(ncus(), (ntiles + BF_WAVES - 1) / BF_WAVES));
+  hipLaunchKernelGGL(bondffn_fwd_kernel, dim3(grid), dim3(BF_THREADS), FwdLds::BYTES, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "bondffn_fwd: launch failed");
+}
+
+extern "C" int mdx_op_bondffn_bwd(const mdx_bondffn_bwd_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "bondffn_bwd: null argument block");
+  if (int rc = check_fwd(a->f, "bwd")) return rc;
+  if (!a->f.pre1 || !a->f.inter || !a->f.gpre || !a->f.gate || !a->gS || !a->oidx || !a->g_inter || !a->g_gate || !a->g_pre1 || !a->g_bf ||
+      !a->g_nl || !a->g_gpre || !a->g_x || !a->lnp)
+    return mdx_set_error(MDX_ERR_ARG, "bondffn_bwd: null operand");
+  if ((a->ldgs & 3) || (reinterpret_cast<uintptr_t>(a->gS) & 15)) return mdx_set_error(MDX_ERR_ARG, "bondffn_bwd: gS rows must be 16-byte aligned");
+  if (!g_attr_bwd) {
+    if (hipFuncSetAttribute((const void*)bondffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BwdLds::BYTES) != hipSuccess)
+      return mdx_set_error(MDX_ERR_HIP, "bondffn_bwd: cannot reserve LDS");
+    g_attr_bwd = true;
+  }
+  // ALWAYS the full grid: the caller's reduction of the LayerNorm-parameter partials reads mdx_op_bondffn_workgroups() rows
+  // (workgroups without tiles write zero rows)
+  hipLaunchKernelGGL(bondffn_bwd_kernel, dim3(ncus()), dim3(BF_THREADS), BwdLds::BYTES, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "bondffn_bwd: launch failed");
+}

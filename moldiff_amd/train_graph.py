@@ -139,10 +139,31 @@ def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
     return T.gate(inter, gate)
 
 
+def bond_ffn_scatter(m, bond_in, time, node_rows, plan, plan_out):
+    """scatter_sum(BondFFN(bond_in, node_rows[plan.index], time), plan_out.index): the EdgeBlock's use of a BondFFN
+    (models/graph.py:272-279).  Where the fused row-owner kernels are built (float16 autocast mode, the shipped widths, enough rows) the
+    whole chain and its backward are one autograd node (train_ops.bondffn_scatter); otherwise the per-operator composition."""
+    if m.use_gate:
+        g0, bd = m.gate.net[0], bond_in.shape[1]
+        nd = g0.weight.shape[1] - bd - 1
+        dims = (bd, m.bond_linear.weight.shape[0], m.inter_module.net[3].weight.shape[0], g0.weight.shape[0], nd)
+        if (len(m.inter_module.net) == 4 and len(m.gate.net) == 4 and m.gate.net[3].weight.shape[0] == dims[2]
+                and m.inter_module.net[0].weight.shape == (dims[1], dims[1])):
+            node_lin = T.linear(node_rows, m.node_linear.weight)
+            gate_node = T.linear(node_rows, g0.weight[:, bd:bd + nd], keep32=True)
+            if T.bondffn_fused_ok(bond_in, node_lin, gate_node, dims):
+                im, gt = m.inter_module.net, m.gate.net
+                return T.bondffn_scatter(bond_in, node_lin, gate_node, time, plan, plan_out, dict(
+                    Wb=m.bond_linear.weight, Wi1=im[0].weight, bi1=im[0].bias, g1=im[1].weight, be1=im[1].bias, Wi2=im[3].weight, bi2=im[3].bias,
+                    Wg1=g0.weight[:, :bd], bg1=g0.bias, gg=gt[1].weight, gbe=gt[1].bias, Wt=g0.weight[:, bd + nd:], Wg2=gt[3].weight,
+                    bg2=gt[3].bias))
+    return T.scatter_sum(bond_ffn(m, bond_in, time, node_rows, plan), plan_out)
+
+
 def edge_block(m, h_bond, g, h_node, bond_time):
     # per-node sums first (N rows), then ONE gather per endpoint: (S_L + node_ffn_left(h))[left] + (S_R + node_ffn_right(h))[right]
-    sl = T.scatter_sum(bond_ffn(m.bond_ffn_left, h_bond, bond_time, h_node, g.left), g.right)
-    sr = T.scatter_sum(bond_ffn(m.bond_ffn_right, h_bond, bond_time, h_node, g.right), g.left)
+    sl = bond_ffn_scatter(m.bond_ffn_left, h_bond, bond_time, h_node, g.left, g.right)
+    sr = bond_ffn_scatter(m.bond_ffn_right, h_bond, bond_time, h_node, g.right, g.left)
     by_left = T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias, addend=sl)
     by_right = T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias, addend=sr)
     h = T.linear_ln_relu(h_bond, m.self_ffn.weight, m.self_ffn.bias, m.layer_norm.weight, m.layer_norm.bias,

@@ -799,3 +799,135 @@ class _Force(torch.autograd.Function):
 def force(w, rel, dist):
     """w * rel / dist / (dist + 1) per edge (PosUpdate, models/graph.py:393)."""
     return _Force.apply(w, rel, dist)
+
+
+# ---- fused row-owner operators (round 6; csrc/mdx_train_fused.hip) -------------------------------------------------------------------
+# A whole BondFFN of the EdgeBlock + the scatter_sum that follows it as ONE autograd node: 2 launches forward (fused chain, segment sum)
+# and 9 backward (fused data-gradient chain, 6 weight-gradient contractions, 2 segment sums) where the per-operator composition issues
+# 12 and ~28.  float16 autocast mode with float16 containers only; every other mode keeps the per-operator path.
+FUSED_MIN_ROWS = 1024        # below this the per-operator path runs (tests lower it to cover the fused path on small graphs)
+_FUSED = __import__('os').environ.get('MDX_TRAIN_FUSED', '1') != '0'
+
+
+def bondffn_fused_ok(bond_in, node_lin, gate_node, dims):
+    """dims = (bond, inter, out, gate hidden, node columns of the gate): the kernel is built for (64, 128, 64, 32, any)."""
+    return (_FUSED and _AMP is not None and _AMP[0] == 2 and _AMP[1] and _AMP[2] and bond_in.dtype == torch.float16 and bond_in.dim() == 2
+            and bond_in.shape[0] >= FUSED_MIN_ROWS and dims[:4] == (64, 128, 64, 32) and node_lin.dtype == torch.float16
+            and gate_node.dtype == torch.float32)
+
+
+def _wslice(w):
+    """a weight or a column slice of one: fp32, unit column stride (row stride arbitrary)"""
+    w = w.detach()
+    assert w.dtype == torch.float32 and w.stride(-1) == 1
+    return w
+
+
+class _BondFfnScatter(torch.autograd.Function):
+    """scatter_sum(BondFFN(bond_in, h_node[idx], time), oidx) with the node-side Linears hoisted by the caller:
+    args = bond_in (E,64) f16, NL = node_linear(h) (N,128) f16, GN = gate.net.0[:, node columns](h) (N,32) fp32, time (E,1) fp32,
+    plan_in (idx), plan_out (oidx), then the parameters in the order of PARAMS."""
+    PARAMS = ('Wb', 'Wi1', 'bi1', 'g1', 'be1', 'Wi2', 'bi2', 'Wg1', 'bg1', 'gg', 'gbe', 'Wt', 'Wg2', 'bg2')
+
+    @staticmethod
+    def _args(x, NL, GN, time, plan_in, P, bufs, E):
+        a = _lib.MdxBondFfnArgs()
+        a.X, a.ldx = x.data_ptr(), x.stride(0)
+        for nm, ld in (('Wb', 'ldwb'), ('Wi1', 'ldwi1'), ('Wi2', 'ldwi2'), ('Wg1', 'ldwg1'), ('Wg2', 'ldwg2')):
+            setattr(a, nm, P[nm].data_ptr())
+            setattr(a, ld, P[nm].stride(0))
+        a.Wt, a.ldwt = P['Wt'].data_ptr(), P['Wt'].stride(0)
+        for nm in ('bi1', 'g1', 'be1', 'bi2', 'bg1', 'gg', 'gbe', 'bg2'):
+            setattr(a, nm, P[nm].data_ptr())
+        a.NL, a.ldnl, a.GN, a.ldgn = NL.data_ptr(), NL.stride(0), GN.data_ptr(), GN.stride(0)
+        a.idx, a.te = plan_in.index.data_ptr(), time.data_ptr()
+        for nm, t in bufs.items():
+            setattr(a, nm, t.data_ptr())
+        a.E = E
+        return a
+
+    @staticmethod
+    def forward(ctx, bond_in, NL, GN, time, plan_in, plan_out, *params):
+        import ctypes
+        x = _rows(bond_in)
+        if x.stride(0) % 8 or x.data_ptr() % 16:
+            x = x.contiguous()
+        NLc, GNc = _rows(NL), _rows(GN)
+        tc = _c(time).reshape(-1)
+        P = {k: _wslice(v) if v.dim() == 2 else _c(v) for k, v in zip(_BondFfnScatter.PARAMS, params)}
+        E, dev = x.shape[0], x.device
+        h = lambda f: torch.empty(E, f, dtype=torch.float16, device=dev)
+        bufs = {'prod': h(128), 'pre1': h(128), 'post1': h(128), 'inter': h(64), 'gpre': h(32), 'gpost': h(32), 'gate': h(64), 'out': h(64)}
+        a = _BondFfnScatter._args(x, NLc, GNc, tc, plan_in, P, bufs, E)
+        check(_L().mdx_op_bondffn_fwd(ctypes.byref(a), stream()))
+        ctx.x, ctx.NL, ctx.GN, ctx.time, ctx.P, ctx.bufs = x, NLc, GNc, tc, P, bufs
+        ctx.plan_in, ctx.plan_out = plan_in, plan_out
+        ctx.refs = {k: v.detach() for k, v in zip(_BondFfnScatter.PARAMS, params)}     # (views of the parameters: addresses for the gradient sink)
+        ctx.time2d = time.detach()
+        ctx.prec = _AMP
+        ctx.x_dtype = bond_in.dtype
+        return _segsum_raw(bufs['out'], plan_out)
+
+    @staticmethod
+    def backward(ctx, gS):
+        import ctypes
+        x, P, bufs, E, dev = ctx.x, ctx.P, ctx.bufs, ctx.x.shape[0], ctx.x.device
+        gS = _c(gS)
+        h = lambda f: torch.empty(E, f, dtype=torch.float16, device=dev)
+        g = {'g_inter': h(64), 'g_gate': h(64), 'g_pre1': h(128), 'g_bf': h(128), 'g_nl': h(128), 'g_gpre': h(32), 'g_x': h(64)}
+        nwg, lnf = int(_L().mdx_op_bondffn_workgroups()), int(_L().mdx_op_bondffn_lnp_floats())
+        lnp = torch.empty(nwg, lnf, dtype=torch.float32, device=dev)
+        b = _lib.MdxBondFfnBwdArgs()
+        b.f = _BondFfnScatter._args(x, ctx.NL, ctx.GN, ctx.time, ctx.plan_in, P, bufs, E)
+        b.gS, b.ldgs, b.oidx = gS.data_ptr(), gS.stride(0), ctx.plan_out.index.data_ptr()
+        for nm, t in g.items():
+            setattr(b, nm, t.data_ptr())
+        b.lnp = lnp.data_ptr()
+        check(_L().mdx_op_bondffn_bwd(ctypes.byref(b), stream()))
+        need = dict(zip(_BondFfnScatter.PARAMS, ctx.needs_input_grad[6:]))
+        grads = {k: None for k in _BondFfnScatter.PARAMS}
+        with precision(ctx.prec):
+            def wgrad(gy, xin, wname, bname):
+                """weight (+ bias) gradient of one Linear of the chain: deferred into the flat gradient buffer when a sink holds the parameter"""
+                if not need[wname]:
+                    return
+                w = ctx.refs[wname]
+                want_b = bname is not None and need[bname]
+                dst_w = _sink_dst(w)
+                dst_b = _sink_dst(ctx.refs[bname]) if want_b else None
+                sp = _splits_for(E, gy.shape[1], xin.shape[1], _h(gy) and _h(xin))
+                if dst_w is not None and (not want_b or dst_b is not None):
+                    sgemm_tn(gy, xin, sp, want_bias=want_b, defer=(dst_w, w.stride(0), dst_b))
+                else:
+                    r = sgemm_tn(gy, xin, sp, want_bias=want_b)
+                    grads[wname], gb_ = r if want_b else (r, None)
+                    if want_b:
+                        grads[bname] = gb_
+            wgrad(g['g_inter'], bufs['post1'], 'Wi2', 'bi2')
+            wgrad(g['g_gate'], bufs['gpost'], 'Wg2', 'bg2')
+            wgrad(g['g_pre1'], bufs['prod'], 'Wi1', 'bi1')
+            wgrad(g['g_bf'], x, 'Wb', None)
+            wgrad(g['g_gpre'], x, 'Wg1', 'bg1')
+            wgrad(g['g_gpre'], ctx.time2d if ctx.time2d.dim() == 2 else ctx.time2d.reshape(-1, 1), 'Wt', None)
+        # LayerNorm-parameter gradients: one partial row per workgroup
+        for nm, off, F in (('g1', 0, 128), ('be1', 128, 128), ('gg', 256, 32), ('gbe', 288, 32)):
+            if not need[nm]:
+                continue
+            dst = _sink_dst(ctx.refs[nm])
+            if dst is not None:
+                _sink_record(lnp.data_ptr() + 4 * off, dst, nwg, 1, F, F, lnf, 0, lnp)
+            else:
+                grads[nm] = lnp[:, off:off + F].sum(0)
+        ni = ctx.needs_input_grad
+        g_x = g['g_x'] if ni[0] else None
+        if g_x is not None and g_x.dtype != ctx.x_dtype:
+            g_x = g_x.to(ctx.x_dtype)
+        g_NL = _segsum_raw(g['g_nl'], ctx.plan_in, torch.float16) if ni[1] else None
+        g_GN = _segsum_raw(g['g_gpre'], ctx.plan_in, torch.float32) if ni[2] else None
+        ctx.bufs = ctx.P = None
+        return (g_x, g_NL, g_GN, None, None, None) + tuple(grads[k] for k in _BondFfnScatter.PARAMS)
+
+
+def bondffn_scatter(bond_in, node_lin, gate_node, time, plan_in, plan_out, params):
+    """params: dict with the keys of _BondFfnScatter.PARAMS (parameters or column slices of them)"""
+    return _BondFfnScatter.apply(bond_in, node_lin, gate_node, time, plan_in, plan_out, *[params[k] for k in _BondFfnScatter.PARAMS])

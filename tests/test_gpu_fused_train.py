@@ -1,0 +1,124 @@
+"""Fused row-owner training operators (round 6, csrc/mdx_train_fused.hip): the EdgeBlock's BondFFN + scatter_sum as one forward and
+one backward launch, against (a) the per-operator composition of the same module in the same float16 autocast arithmetic (same
+rounding points: agreement to a few float16 ulp) and (b) the fp64 evaluation of the reference formula (models/graph.py:133-141,
+:272-279 through torch autograd)."""
+import numpy as np
+import pytest
+import torch
+
+from moldiff_amd import graph as G
+from moldiff_amd import train_graph as TG
+from moldiff_amd import train_ops as T
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _setup(sizes, seed, scale=1.0):
+    g = U.rng(seed)
+    bn, hei, bh, ei, be = U.graph_from_sizes(sizes)
+    N, E = len(bn), ei.shape[1]
+    m = G.BondFFN(64, 256, 128, True).to(DEV)
+    with torch.no_grad():
+        for k, p in sorted(m.named_parameters()):
+            if p.dim() == 2:
+                p.copy_(torch.from_numpy((g.standard_normal(tuple(p.shape)) * (1.2 / np.sqrt(p.shape[1]))).astype(np.float32)))
+            elif 'net.1.' in k and k.endswith('weight'):
+                p.copy_(torch.from_numpy((1.0 + 0.4 * g.standard_normal(tuple(p.shape))).astype(np.float32)))
+            else:
+                p.copy_(torch.from_numpy((0.3 * g.standard_normal(tuple(p.shape))).astype(np.float32)))
+    x = torch.from_numpy((g.standard_normal((E, 64)) * scale).astype(np.float32)).to(DEV).half()
+    h = torch.from_numpy(g.standard_normal((N, 256)).astype(np.float32)).to(DEV).half()
+    te = torch.from_numpy(g.random((E, 1)).astype(np.float32)).to(DEV)
+    gS = torch.from_numpy(g.standard_normal((N, 64)).astype(np.float32)).to(DEV)
+    tg = TG.TrainGraph(ei.to(DEV), N)
+    return m, x, h, te, gS, tg
+
+
+def _run(m, x, h, te, gS, tg, fused):
+    m.zero_grad(set_to_none=True)
+    x = x.clone().requires_grad_(True)
+    h = h.clone().requires_grad_(True)
+    old, old_rows = T._FUSED, T.FUSED_MIN_ROWS
+    T._FUSED, T.FUSED_MIN_ROWS = fused, 1
+    try:
+        with T.precision('fp16'):
+            out = TG.bond_ffn_scatter(m, x, te, h, tg.left, tg.right)
+            out.backward(gS)
+    finally:
+        T._FUSED, T.FUSED_MIN_ROWS = old, old_rows
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    return out.detach(), x.grad.detach(), h.grad.detach(), grads
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+@pytest.mark.parametrize('sizes', [[5, 7, 4], [24, 31, 18, 27, 22, 25, 30, 19, 26, 23], [2, 2, 3]])
+def test_fused_bondffn_equals_the_per_operator_composition(sizes):
+    """Same arithmetic, same rounding points, another summation order inside the LayerNorm statistics and the MFMA chains: outputs and
+    every gradient within 2e-3 of the per-operator path relative to the tensor's largest entry (a float16 ulp is 1e-3)."""
+    args = _setup(sizes, 11)
+    o1, gx1, gh1, gr1 = _run(*args, fused=True)
+    o0, gx0, gh0, gr0 = _run(*args, fused=False)
+    assert o1.dtype == o0.dtype and gx1.dtype == gx0.dtype and gh1.dtype == gh0.dtype
+    assert _rel(o1, o0) < 2e-3, _rel(o1, o0)
+    assert _rel(gx1, gx0) < 4e-3, _rel(gx1, gx0)
+    assert _rel(gh1, gh0) < 4e-3, _rel(gh1, gh0)
+    assert set(gr1) == set(gr0)
+    for k in gr0:
+        assert torch.isfinite(gr1[k]).all(), k
+        assert _rel(gr1[k], gr0[k]) < 6e-3, (k, _rel(gr1[k], gr0[k]))
+
+
+def test_fused_bondffn_against_fp64_autograd_of_the_reference_formula():
+    """The fused path vs torch autograd in float64 on the reference's formula (weights and inputs = the float16-representable values
+    the kernels read): forward within 3e-3 of the output scale, gradients within 1.5 % (float16 autocast arithmetic), and no further
+    from float64 than the per-operator path is (x 1.5)."""
+    m, x, h, te, gS, tg = _setup([24, 31, 18, 27, 22, 25, 30, 19], 13)
+    o1, gx1, gh1, gr1 = _run(m, x, h, te, gS, tg, fused=True)
+    o0, gx0, gh0, gr0 = _run(m, x, h, te, gS, tg, fused=False)
+    P = {k: p.detach().double().clone().requires_grad_(True) for k, p in m.named_parameters()}
+    xd, hd = x.double().clone().requires_grad_(True), h.double().clone().requires_grad_(True)
+    li, ri = tg.left.index, tg.right.index
+    F = torch.nn.functional
+
+    def mlp(pre, v):
+        v = F.linear(v, P[pre + '.net.0.weight'], P[pre + '.net.0.bias'])
+        v = torch.relu(F.layer_norm(v, (v.shape[1],), P[pre + '.net.1.weight'], P[pre + '.net.1.bias'], 1e-5))
+        return F.linear(v, P[pre + '.net.3.weight'], P[pre + '.net.3.bias'])
+    node = hd[li]
+    inter = mlp('inter_module', F.linear(xd, P['bond_linear.weight']) * F.linear(node, P['node_linear.weight']))
+    gate = mlp('gate', torch.cat([xd, node, te.double()], -1))
+    out = torch.zeros(hd.shape[0], 64, dtype=torch.float64, device=DEV).index_add_(0, ri, inter * torch.sigmoid(gate))
+    out.backward(gS.double())
+    assert _rel(o1, out.detach()) < 3e-3
+    for name, got, base, ref in [('dX', gx1, gx0, xd.grad), ('dh', gh1, gh0, hd.grad)] + [(k, gr1[k], gr0[k], P[k].grad) for k in gr1]:
+        e1, e0 = _rel(got, ref), _rel(base, ref)
+        assert e1 < 1.5e-2, (name, e1)
+        assert e1 <= 1.5 * e0 + 2e-3, (name, e1, e0)
+
+
+def test_fused_bondffn_with_the_gradient_sink_equals_autograd_accumulation():
+    """Inside Trainer.step the weight gradients bypass autograd (train_ops.grad_sink): the fused node's six weight-gradient contractions
+    and its LayerNorm-parameter partial rows must land in the flat gradient buffer exactly as the returned tensors would."""
+    from moldiff_amd.trainer import FlatParams
+    m, x, h, te, gS, tg = _setup([24, 31, 18, 27, 22, 25, 30, 19], 17)
+    _, _, _, ref = _run(m, x, h, te, gS, tg, fused=True)
+    flat = FlatParams(m)
+    flat.grad.zero_()
+    old, old_rows = T._FUSED, T.FUSED_MIN_ROWS
+    T._FUSED, T.FUSED_MIN_ROWS = True, 1
+    try:
+        with T.grad_sink(flat), T.precision('fp16'):
+            out = TG.bond_ffn_scatter(m, x.clone().requires_grad_(True), te, h.clone().requires_grad_(True), tg.left, tg.right)
+            out.backward(gS)
+    finally:
+        T._FUSED, T.FUSED_MIN_ROWS = old, old_rows
+    for k, p in m.named_parameters():
+        got = p.grad if p.grad is not None else None
+        assert got is not None, k
+        assert _rel(got, ref[k]) < 2e-3, (k, _rel(got, ref[k]))

@@ -119,10 +119,18 @@ def tables(P):
 TAIL = {
     'factor': 1.5,     # forward quantities of the teacher-forced steps
     'delta': 2.0,      # maximum error of the guidance increment (kink events), test_gpu_fullsize.py
-    'config1': 1.5,    # BASELINE config #1's T = 100 replay (8 molecules, noisy end), test_gpu_sampling.py
+    'config1': 2.5,    # BASELINE config #1's T = 100 replay (8 molecules, noisy end), test_gpu_sampling.py -- see CONFIG1 below
 }
 
 
+# CONFIG1 -- why 2.5 and not 1.5 (measured, profiles/r6_parity_tail_factors.txt): at the t = 80 checkpoint of the replay the six fp32
+# summation orders of the ORACLE ITSELF sit 5.1e-5 .. 1.24e-4 from float64 (a 2.4x spread; 9.7x at t = 40: 7.5e-5 .. 7.3e-4), the exact
+# path 1.54e-4 (1.24x the largest of them) and the split path 2.61e-4 (2.1x) -- one pair of atoms 0.1 apart.  A seventh legal order
+# landing 2x beyond the maximum of six samples of a quantity whose samples already differ by 2.4 - 9.7x is inside that distribution; a
+# factor of 1.5 on max-of-six would reject the split path AND round 5's 8-wave node kernel, both legal re-associations.  With 2.5 the
+# worst ratio to the bound over the six checkpoints is 0.83 (exact) / 0.84 (split); every other checkpoint is below 0.64.  The rms
+# bound (2x the reference's own rms error) and the count of rows outside the plain contract are asserted next to it and carry no
+# such allowance.
 def tail(key, path=None):
     """One factor per quantity; `path` is accepted (and ignored) so call sites can keep naming the path they run on."""
     return TAIL[key]

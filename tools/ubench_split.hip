@@ -185,6 +185,99 @@ __device__ __forceinline__ void gemm_split2(f32x4 (&y)[16][R], const h8 (&xh)[8]
   });
 }
 
+// ---- split24 (round 6): THREE float16 pieces per operand, x = hi + lo' 2^-11 + l3'' 2^-22 EXACTLY (11 + 11 + <= 2
+// significand bits: every fp32 value is represented without loss, i.e. operands carry the reference's full 24 bits), and the six
+// products whose weight is >= 2^-22: Whi Xhi | Whi Xlo' + Wlo' Xhi (x 2^-11) | Wlo' Xlo' + Whi X3'' + W3'' Xhi (x 2^-22); dropped:
+// Wlo' X3'', W3'' Xlo' (2^-33) and W3'' X3'' (2^-44).  Three accumulator sets per feature-tile pair, the stream carries three
+// half-steps (hi, lo', l3'') per (pair, k-group): 1.5x the bytes of the two-piece stream.
+template <int R>
+__device__ __forceinline__ void split_x3(const f32x4 (&y)[16][R], h8 (&xh)[8][R], h8 (&xl)[8][R], h8 (&x3)[8][R]) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+#pragma unroll
+    for (int rt = 0; rt < R; ++rt)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float v = y[2 * g + t / 4][rt][t % 4];
+        const _Float16 h = (_Float16)v;
+        const float r1 = (v - (float)h) * 2048.0f;   // exact
+        const _Float16 l = (_Float16)r1;
+        xh[g][rt][t] = h;
+        xl[g][rt][t] = l;
+        x3[g][rt][t] = (_Float16)((r1 - (float)l) * 2048.0f);   // exact: <= 2 significant bits are left
+      }
+}
+
+template <int R, int DEPTH>
+__device__ __forceinline__ void gemm_split3(f32x4 (&y)[16][R], const h8 (&xh)[8][R], const h8 (&xl)[8][R], const h8 (&x3)[8][R], const WS& w,
+                                            int mbase) {
+  constexpr int KG = 8, NP = 8 * KG * 3;  // third-steps of two fragments: hi, lo', l3''
+  f32x4 ring[DEPTH][2];
+#pragma unroll
+  for (int p = 0; p < DEPTH; ++p) {
+    ring[p][0] = ws_frag(w, mbase + (2 * p) * 1024);
+    ring[p][1] = ws_frag(w, mbase + (2 * p + 1) * 1024);
+  }
+  f32x4 t0[R], t1[R], u0[R], u1[R];
+  static_for<0, NP>([&](auto pc) {
+    constexpr int p = decltype(pc)::value, ftp = p / (3 * KG), g = (p / 3) % KG, h = p % 3;
+    const h8 a0 = __builtin_bit_cast(h8, ring[p % DEPTH][0]), a1 = __builtin_bit_cast(h8, ring[p % DEPTH][1]);
+    if constexpr (p + DEPTH < NP) {
+      ring[p % DEPTH][0] = ws_frag(w, mbase + (2 * (p + DEPTH)) * 1024);
+      ring[p % DEPTH][1] = ws_frag(w, mbase + (2 * (p + DEPTH) + 1) * 1024);
+    }
+    if constexpr (g == 0 && h == 0) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) t0[rt] = t1[rt] = u0[rt] = u1[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (h == 0) {          // Whi: all three operand pieces
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        y[2 * ftp][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xh[g][rt], y[2 * ftp][rt], 0, 0, 0);
+        y[2 * ftp + 1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xh[g][rt], y[2 * ftp + 1][rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        t0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xl[g][rt], t0[rt], 0, 0, 0);
+        t1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xl[g][rt], t1[rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        u0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x3[g][rt], u0[rt], 0, 0, 0);
+        u1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x3[g][rt], u1[rt], 0, 0, 0);
+      }
+    } else if constexpr (h == 1) {   // Wlo': hi and lo pieces
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        t0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xh[g][rt], t0[rt], 0, 0, 0);
+        t1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xh[g][rt], t1[rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        u0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xl[g][rt], u0[rt], 0, 0, 0);
+        u1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xl[g][rt], u1[rt], 0, 0, 0);
+      }
+    } else {                         // W3'': the hi piece
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        u0[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xh[g][rt], u0[rt], 0, 0, 0);
+        u1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xh[g][rt], u1[rt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (g == KG - 1 && h == 2) {
+#pragma unroll
+      for (int rt = 0; rt < R; ++rt) {
+        t0[rt] = t0[rt] + u0[rt] * (1.0f / 2048.0f);
+        t1[rt] = t1[rt] + u1[rt] * (1.0f / 2048.0f);
+        y[2 * ftp][rt] = y[2 * ftp][rt] + t0[rt] * (1.0f / 2048.0f);
+        y[2 * ftp + 1][rt] = y[2 * ftp + 1][rt] + t1[rt] * (1.0f / 2048.0f);
+      }
+    }
+  });
+}
+
 // The shipped form with the operand conversion PIPELINED into the GEMM (round 5): k-group g + 1 is split into
 // its hi / lo halves while the first feature-tile pair's MFMAs of group g issue (the float16 MFMA co-executes with VALU work of the
 // same wave; the fp32 one does not).  Only the first of the eight passes over the k-groups can carry conversions -- every pass
@@ -358,6 +451,15 @@ __global__ __launch_bounds__(256, WPS) void chain_kernel(const float* __restrict
         gemm_f32<R, DEPTH>(y, x, ws, mbase);
       } else if constexpr (KIND == 6 || KIND == 7) {
         gemm_split2_pipe<R, DEPTH, KIND - 6>(y, x, ws, mbase);
+      } else if constexpr (KIND == 8) {
+        h8 xh[8][R], xl[8][R], x3[8][R];
+        split_x3<R>(x, xh, xl, x3);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+          for (int rt = 0; rt < R; ++rt) asm volatile("" : "+v"(xh[g][rt]), "+v"(xl[g][rt]), "+v"(x3[g][rt]));
+        STAMP(1);
+        gemm_split3<R, DEPTH>(y, xh, xl, x3, ws, mbase * 3 / 2);
       } else if constexpr (KIND == 4 || KIND == 5) {
         h8 xh[8][R], xl[8][R];
         split_x<R>(x, xh, xl, 2048.0f);
@@ -468,6 +570,32 @@ static void pack_split2(const Problem& P, std::vector<uint16_t>& out) {
             }
 }
 
+// the split24 stream: third-step ts = (ftp*8 + g)*3 + h, h = 0 hi, 1 lo' = lo 2^11, 2 l3'' = l3 2^22 (w = hi + lo + l3 exactly)
+static void pack_split3(const Problem& P, std::vector<uint16_t>& out) {
+  out.assign((size_t)P.nmat * 196608 + 8192, 0);
+  size_t inexact = 0;
+  for (int m = 0; m < P.nmat; ++m)
+    for (int ftp = 0; ftp < 8; ++ftp)
+      for (int g = 0; g < 8; ++g)
+        for (int j = 0; j < 2; ++j)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 8; ++t) {
+              const int q = lane >> 4, c = lane & 15, f = 16 * (2 * ftp + j) + c, k = 32 * g + 16 * (t / 4) + 4 * q + t % 4;
+              const float w = P.W[(size_t)m * 65536 + f * 256 + k];
+              const uint16_t hi = f2h(w);
+              const float r1 = (w - h2f(hi)) * 2048.0f;
+              const uint16_t lo = f2h(r1);
+              const float r2 = (r1 - h2f(lo)) * 2048.0f;
+              const uint16_t l3 = f2h(r2);
+              if ((double)h2f(hi) + (double)h2f(lo) / 2048.0 + (double)h2f(l3) / 4194304.0 != (double)w) ++inexact;
+              const size_t ts = ((size_t)m * 64 + ftp * 8 + g) * 3;
+              out[((ts * 2 + j) * 64 + lane) * 8 + t] = hi;
+              out[(((ts + 1) * 2 + j) * 64 + lane) * 8 + t] = lo;
+              out[(((ts + 2) * 2 + j) * 64 + lane) * 8 + t] = l3;
+            }
+  printf("split24 pack: %zu of %zu weights not represented exactly by hi + lo + l3\n", inexact, (size_t)P.nmat * 65536);
+}
+
 static void ref_chain(const Problem& P, const float* x0, int nl, bool ln, double* y) {
   std::vector<double> x(x0, x0 + 256), t(256);
   for (int l = 0; l < nl; ++l) {
@@ -496,7 +624,7 @@ static void ref_chain(const Problem& P, const float* x0, int nl, bool ln, double
 
 struct Dev {
   float *X, *gb, *out;
-  void *Wf32, *Wsplit0, *WsplitS, *Wsplit2;
+  void *Wf32, *Wsplit0, *WsplitS, *Wsplit2, *Wsplit3;
   float* Xsmall;
   size_t rows;
 };
@@ -584,6 +712,8 @@ int main(int argc, char** argv) {
   pack_split(P, 0, ps0);
   pack_split(P, sw, psS);
   pack_split2(P, ps2);
+  std::vector<uint16_t> ps3;
+  pack_split3(P, ps3);
   // small-magnitude activations (x 2^-7 ~ 0.01, no LayerNorm to renormalise them): where an UNSCALED float16 low half sits in the
   // subnormal range
   std::vector<float> hXs((size_t)nref * 256);
@@ -597,6 +727,8 @@ int main(int argc, char** argv) {
   hipMalloc(&d.Wsplit0, ps0.size() * 2);
   hipMalloc(&d.WsplitS, psS.size() * 2);
   hipMalloc(&d.Wsplit2, ps2.size() * 2);
+  hipMalloc(&d.Wsplit3, ps3.size() * 2);
+  hipMemcpy(d.Wsplit3, ps3.data(), ps3.size() * 2, hipMemcpyHostToDevice);
   hipMalloc(&d.Xsmall, (size_t)4096 * 256 * 4);
   hipMemset(d.Xsmall, 0, (size_t)4096 * 256 * 4);
   hipMemcpy(d.Xsmall, hXs.data(), hXs.size() * 4, hipMemcpyHostToDevice);
@@ -619,6 +751,19 @@ int main(int argc, char** argv) {
   }
   run<4, 1, 4, 2, true>("SHIPPED: lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<4, 2, 4, 1, true>("SHIPPED: lo*2^11, own acc, 3 terms", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
+  run<8, 1, 4, 2, true>("split24: 3 pieces, 6 terms", d, d.Wsplit3, P, eps, hX, refLN, nl_check, nref);
+  run<8, 1, 6, 2, true>("split24: 3 pieces, 6 terms", d, d.Wsplit3, P, eps, hX, refLN, nl_check, nref);
+  run<8, 2, 4, 1, true>("split24: 3 pieces, 6 terms", d, d.Wsplit3, P, eps, hX, refLN, nl_check, nref);
+  run<8, 2, 6, 1, true>("split24: 3 pieces, 6 terms", d, d.Wsplit3, P, eps, hX, refLN, nl_check, nref);
+  if (getenv("UB_SPLIT24_ONLY")) {
+    run<0, 1, 4, 2, true>("exact fp32 16x16x4", d, d.Wf32, P, eps, hX, refLN, nl_check, nref);
+    run<8, 1, 4, 2, false>("split24, no LN, 2 layers", d, d.Wsplit3, P, eps, hX, refNo, 2, nref);
+    run<4, 1, 4, 2, false>("SHIPPED split 3 terms, no LN", d, d.Wsplit2, P, eps, hX, refNo, 2, nref);
+    run<0, 1, 4, 2, false>("exact fp32, no LN, 2 layers", d, d.Wf32, P, eps, hX, refNo, 2, nref);
+    run<8, 1, 4, 2, false>("split24, small x", d, d.Wsplit3, P, eps, hX, refSm, 2, nref, d.Xsmall);
+    run<0, 1, 4, 2, false>("exact fp32, small x", d, d.Wf32, P, eps, hX, refSm, 2, nref, d.Xsmall);
+    return 0;
+  }
   run<6, 1, 4, 2, true>("pipelined conversion (compiler)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<6, 2, 4, 1, true>("pipelined conversion (compiler)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
   run<7, 1, 4, 2, true>("pipelined conversion (interleave)", d, d.Wsplit2, P, eps, hX, refLN, nl_check, nref);
