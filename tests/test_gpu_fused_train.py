@@ -52,6 +52,12 @@ def _run(m, x, h, te, gS, tg, fused):
     return out.detach(), x.grad.detach(), h.grad.detach(), grads
 
 
+def _rel2(a, b):
+    """relative L2 distance"""
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
 def _rel(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
@@ -75,9 +81,12 @@ def test_fused_bondffn_equals_the_per_operator_composition(sizes):
 
 
 def test_fused_bondffn_against_fp64_autograd_of_the_reference_formula():
-    """The fused path vs torch autograd in float64 on the reference's formula (weights and inputs = the float16-representable values
-    the kernels read): forward within 3e-3 of the output scale, gradients within 1.5 % (float16 autocast arithmetic), and no further
-    from float64 than the per-operator path is (x 1.5)."""
+    """The fused path vs torch autograd in float64 on the reference's formula: forward within 3e-3 of the output scale.  Gradients: in
+    float16 arithmetic ~1e-3 of the 800 k LayerNorm->ReLU pre-activations of this batch land on the other side of zero than in float64,
+    and each such kink event changes its row's gradient discretely -- the MAXIMUM over rows is therefore O(10 %) for ANY float16
+    evaluation (measured 18 % on dL/dX for both paths, to four digits the same number: the fused kernels take the per-operator path's
+    rounding points, so they flip the same units).  Asserted: relative L2 distance to float64 below 6 % and equal to the per-operator
+    path's within 2 % of it, i.e. the fused node is as far from exact arithmetic as autocast's own arithmetic, not further."""
     m, x, h, te, gS, tg = _setup([24, 31, 18, 27, 22, 25, 30, 19], 13)
     o1, gx1, gh1, gr1 = _run(m, x, h, te, gS, tg, fused=True)
     o0, gx0, gh0, gr0 = _run(m, x, h, te, gS, tg, fused=False)
@@ -96,10 +105,14 @@ def test_fused_bondffn_against_fp64_autograd_of_the_reference_formula():
     out = torch.zeros(hd.shape[0], 64, dtype=torch.float64, device=DEV).index_add_(0, ri, inter * torch.sigmoid(gate))
     out.backward(gS.double())
     assert _rel(o1, out.detach()) < 3e-3
-    for name, got, base, ref in [('dX', gx1, gx0, xd.grad), ('dh', gh1, gh0, hd.grad)] + [(k, gr1[k], gr0[k], P[k].grad) for k in gr1]:
-        e1, e0 = _rel(got, ref), _rel(base, ref)
-        assert e1 < 1.5e-2, (name, e1)
-        assert e1 <= 1.5 * e0 + 2e-3, (name, e1, e0)
+    rows = [('dX', gx1, gx0, xd.grad), ('dh', gh1, gh0, hd.grad)] + [(k, gr1[k], gr0[k], P[k].grad) for k in gr1]
+    errs = [(name, _rel2(got, ref), _rel2(base, ref), _rel(got, ref), _rel(base, ref)) for name, got, base, ref in rows]
+    print('\n[fused BondFFN vs fp64]  tensor: relative L2 fused, per-operator | max-norm fused, per-operator')
+    for name, e1, e0, m1, m0 in errs:
+        print(f'    {name:28s} {e1:.3e}  {e0:.3e} | {m1:.3e}  {m0:.3e}')
+    for name, e1, e0, m1, m0 in errs:
+        assert e1 < 6e-2, (name, e1)
+        assert e1 <= 1.02 * e0 + 1e-4, (name, e1, e0)
 
 
 def test_fused_bondffn_with_the_gradient_sink_equals_autograd_accumulation():
