@@ -175,9 +175,9 @@ def compact_line(full, full_path='bench_full.json'):
             optional.append((k, e))
     if 'kernel_ms_per_step' in full:
         optional.append(('kernel_ms_per_step', _num(full['kernel_ms_per_step'])))
-    multi = _pick(full, ('ranks_seen', 'backend', 'per_rank_ms_per_step', 'gather_ms', 'gather_first_ms', 'gather_bytes', 'value_incl_gather'))
-    if multi:
-        optional.append(('multi', multi))
+    # the process-group fields stay top-level keys (the multi-rank tests and the SCALE run read them there)
+    line.update(_pick(full, ('ranks_seen', 'backend', 'per_rank_ms_per_step', 'gather_ms', 'gather_first_ms', 'gather_rows', 'gather_bytes',
+                             'value_incl_gather')))
     line['full'] = full_path
     for k, v in optional:
         line[k] = v

@@ -432,6 +432,29 @@ typedef struct {
   void *g_inter, *g_gate, *g_pre1, *g_bf, *g_nl, *g_gpre, *g_x;
   float* lnp;
 } mdx_bondffn_bwd_args;
+/* EdgeBlock tail + residual in one launch (replaces, for training, reference models/graph.py:281-294 and the `h_edge + ...` of :360):
+ * out = H + out_transform(relu(LN(self_ffn(H) + BL[il] + BR[ir]))), BL / BR (N,64) float16 = the per-node sums S_L + node_ffn_left(h),
+ * S_R + node_ffn_right(h).  pre / post (E,64): the LayerNorm's input / relu(output), kept for the backward and out_transform's weight
+ * gradient.  Backward: g_out (E,64) float16 -> g_pre (E,64) = dL/d pre (self_ffn's weight gradient operand; summed per node by il / ir it
+ * is dL/dBL / dL/dBR), g_h = g_out + self_ffn^T g_pre, lnp: mdx_op_bondffn_workgroups() rows of 128 floats [d gamma | d beta]. */
+typedef struct {
+  const void* H; int64_t ldh;
+  const void* BL; int64_t ldbl; const void* BR; int64_t ldbr;
+  const int64_t* il; const int64_t* ir;
+  const float* Ws; int64_t ldws; const float* bs; const float* lng; const float* lnb;
+  const float* Wo; int64_t ldwo; const float* bo;
+  void *pre, *post, *out;
+  int64_t E;
+} mdx_edge_tail_args;
+typedef struct {
+  mdx_edge_tail_args f;
+  const void* g_out; int64_t ldg;
+  void *g_pre, *g_h;
+  float* lnp;
+} mdx_edge_tail_bwd_args;
+int mdx_op_edge_tail_fwd(const mdx_edge_tail_args* a, void* stream);
+int mdx_op_edge_tail_bwd(const mdx_edge_tail_bwd_args* a, void* stream);
+int mdx_op_edge_tail_lnp_floats(void);
 int mdx_op_bondffn_fwd(const mdx_bondffn_args* a, void* stream);
 int mdx_op_bondffn_bwd(const mdx_bondffn_bwd_args* a, void* stream);
 int mdx_op_bondffn_workgroups(void);

@@ -31,6 +31,7 @@ EXPORTS = [
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_mul_gather_fwd', 'mdx_op_mul_gather_bwd', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
+    'mdx_op_edge_tail_fwd', 'mdx_op_edge_tail_bwd', 'mdx_op_edge_tail_lnp_floats',
 ]
 
 
@@ -68,6 +69,16 @@ class MdxBondFfnBwdArgs(ctypes.Structure):   # == mdx_bondffn_bwd_args
     _fields_ = [('f', MdxBondFfnArgs), ('gS', c_void_p), ('ldgs', c_int64), ('oidx', c_void_p),
                 ('g_inter', c_void_p), ('g_gate', c_void_p), ('g_pre1', c_void_p), ('g_bf', c_void_p), ('g_nl', c_void_p),
                 ('g_gpre', c_void_p), ('g_x', c_void_p), ('lnp', c_void_p)]
+
+
+class MdxEdgeTailArgs(ctypes.Structure):   # == mdx_edge_tail_args
+    _fields_ = [('H', c_void_p), ('ldh', c_int64), ('BL', c_void_p), ('ldbl', c_int64), ('BR', c_void_p), ('ldbr', c_int64),
+                ('il', c_void_p), ('ir', c_void_p), ('Ws', c_void_p), ('ldws', c_int64), ('bs', c_void_p), ('lng', c_void_p), ('lnb', c_void_p),
+                ('Wo', c_void_p), ('ldwo', c_int64), ('bo', c_void_p), ('pre', c_void_p), ('post', c_void_p), ('out', c_void_p), ('E', c_int64)]
+
+
+class MdxEdgeTailBwdArgs(ctypes.Structure):   # == mdx_edge_tail_bwd_args
+    _fields_ = [('f', MdxEdgeTailArgs), ('g_out', c_void_p), ('ldg', c_int64), ('g_pre', c_void_p), ('g_h', c_void_p), ('lnp', c_void_p)]
 
 
 class MdxConfig(ctypes.Structure):
@@ -186,6 +197,8 @@ def lib():
                                    c_int64, c_void_p, c_float, c_void_p]
         L.mdx_op_bondffn_fwd.argtypes = [POINTER(MdxBondFfnArgs), c_void_p]
         L.mdx_op_bondffn_bwd.argtypes = [POINTER(MdxBondFfnBwdArgs), c_void_p]
+        L.mdx_op_edge_tail_fwd.argtypes = [POINTER(MdxEdgeTailArgs), c_void_p]
+        L.mdx_op_edge_tail_bwd.argtypes = [POINTER(MdxEdgeTailBwdArgs), c_void_p]
         _lib = L
     return _lib
 

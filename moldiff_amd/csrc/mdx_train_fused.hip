@@ -37,7 +37,11 @@ namespace {
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
+#ifndef MDX_BF_FWD_THREADS
+#define MDX_BF_FWD_THREADS 768   // forward: 12 waves per CU (135 VGPRs: three waves per SIMD fit); backward: 8 (256 VGPRs)
+#endif
 constexpr int BF_THREADS = 512, BF_WAVES = 8;
+constexpr int BF_FWD_THREADS = MDX_BF_FWD_THREADS, BF_FWD_WAVES = BF_FWD_THREADS / 64;
 constexpr int KB = 64, KI = 128, KO = 64, KG = 32;   // bond width, inter width, output width, gate hidden width
 constexpr int LDB = KB + 8, LDI = KI + 8, LDG = KG + 8, LDO = KO + 8;
 
@@ -76,23 +80,23 @@ __device__ __forceinline__ int kperm(int k) {
 }
 // W (N outputs x K inputs, fp32, row stride ld) -> dst [N][K + 8] float16.  PERM: accumulator-fed layer (see kperm).
 template <int N, int K, bool PERM>
-__device__ __forceinline__ void stage_w(uint16_t* dst, const float* __restrict__ W, int ld, int tid) {
-  for (int i = tid; i < N * K; i += BF_THREADS) {
+__device__ __forceinline__ void stage_w(uint16_t* dst, const float* __restrict__ W, int ld, int tid, int nt = BF_THREADS) {
+  for (int i = tid; i < N * K; i += nt) {
     const int n = i / K, k = i % K;
     dst[n * (K + 8) + (PERM ? kperm(k) : k)] = __builtin_bit_cast(uint16_t, (_Float16)W[(size_t)n * ld + k]);
   }
 }
 // the TRANSPOSE of W (N x K): dst [K outputs][N + 8], for the data gradient  g_in[k] = sum_n g_out[n] W[n][k]
 template <int N, int K, bool PERM>
-__device__ __forceinline__ void stage_wt(uint16_t* dst, const float* __restrict__ W, int ld, int tid) {
-  for (int i = tid; i < N * K; i += BF_THREADS) {
+__device__ __forceinline__ void stage_wt(uint16_t* dst, const float* __restrict__ W, int ld, int tid, int nt = BF_THREADS) {
+  for (int i = tid; i < N * K; i += nt) {
     const int n = i / K, k = i % K;
     dst[k * (N + 8) + (PERM ? kperm(n) : n)] = __builtin_bit_cast(uint16_t, (_Float16)W[(size_t)n * ld + k]);
   }
 }
 template <int N>
-__device__ __forceinline__ void stage_v(float* dst, const float* __restrict__ v, int stride, int tid, bool round_half = false) {
-  for (int i = tid; i < N; i += BF_THREADS) dst[i] = v ? (round_half ? rh(v[(size_t)i * stride]) : v[(size_t)i * stride]) : 0.f;
+__device__ __forceinline__ void stage_v(float* dst, const float* __restrict__ v, int stride, int tid, bool round_half = false, int nt = BF_THREADS) {
+  for (int i = tid; i < N; i += nt) dst[i] = v ? (round_half ? rh(v[(size_t)i * stride]) : v[(size_t)i * stride]) : 0.f;
 }
 
 // y[ft] += W[16 ft + .][.] x   for FT output tiles over KS k-steps of 32; w = LDS weight + c * LD + 8 q; x[ks] the B operands
@@ -139,24 +143,24 @@ struct FwdLds {   // offsets in uint16 units
   static constexpr int BYTES = END * 2 + C_END * 4;
 };
 
-__global__ __launch_bounds__(BF_THREADS) void bondffn_fwd_kernel(const mdx_bondffn_args a) {
+__global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_bondffn_args a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
   uint16_t* S = bf_smem;
   float* C = reinterpret_cast<float*>(bf_smem + FwdLds::END);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  stage_w<KI, KB, false>(S + FwdLds::WB, a.Wb, (int)a.ldwb, tid);
-  stage_w<KI, KI, true>(S + FwdLds::WI1, a.Wi1, (int)a.ldwi1, tid);
-  stage_w<KO, KI, true>(S + FwdLds::WI2, a.Wi2, (int)a.ldwi2, tid);
-  stage_w<KG, KB, false>(S + FwdLds::WG1, a.Wg1, (int)a.ldwg1, tid);
-  stage_w<KO, KG, true>(S + FwdLds::WG2, a.Wg2, (int)a.ldwg2, tid);
-  stage_v<128>(C + FwdLds::C_BI1, a.bi1, 1, tid); stage_v<128>(C + FwdLds::C_G1, a.g1, 1, tid); stage_v<128>(C + FwdLds::C_BE1, a.be1, 1, tid);
-  stage_v<64>(C + FwdLds::C_BI2, a.bi2, 1, tid); stage_v<32>(C + FwdLds::C_BG1, a.bg1, 1, tid); stage_v<32>(C + FwdLds::C_GG, a.gg, 1, tid);
-  stage_v<32>(C + FwdLds::C_GBE, a.gbe, 1, tid); stage_v<32>(C + FwdLds::C_WT, a.Wt, (int)a.ldwt, tid, true);
-  stage_v<64>(C + FwdLds::C_BG2, a.bg2, 1, tid);
+  stage_w<KI, KB, false>(S + FwdLds::WB, a.Wb, (int)a.ldwb, tid, BF_FWD_THREADS);
+  stage_w<KI, KI, true>(S + FwdLds::WI1, a.Wi1, (int)a.ldwi1, tid, BF_FWD_THREADS);
+  stage_w<KO, KI, true>(S + FwdLds::WI2, a.Wi2, (int)a.ldwi2, tid, BF_FWD_THREADS);
+  stage_w<KG, KB, false>(S + FwdLds::WG1, a.Wg1, (int)a.ldwg1, tid, BF_FWD_THREADS);
+  stage_w<KO, KG, true>(S + FwdLds::WG2, a.Wg2, (int)a.ldwg2, tid, BF_FWD_THREADS);
+  stage_v<128>(C + FwdLds::C_BI1, a.bi1, 1, tid, false, BF_FWD_THREADS); stage_v<128>(C + FwdLds::C_G1, a.g1, 1, tid, false, BF_FWD_THREADS); stage_v<128>(C + FwdLds::C_BE1, a.be1, 1, tid, false, BF_FWD_THREADS);
+  stage_v<64>(C + FwdLds::C_BI2, a.bi2, 1, tid, false, BF_FWD_THREADS); stage_v<32>(C + FwdLds::C_BG1, a.bg1, 1, tid, false, BF_FWD_THREADS); stage_v<32>(C + FwdLds::C_GG, a.gg, 1, tid, false, BF_FWD_THREADS);
+  stage_v<32>(C + FwdLds::C_GBE, a.gbe, 1, tid, false, BF_FWD_THREADS); stage_v<32>(C + FwdLds::C_WT, a.Wt, (int)a.ldwt, tid, true, BF_FWD_THREADS);
+  stage_v<64>(C + FwdLds::C_BG2, a.bg2, 1, tid, false, BF_FWD_THREADS);
   __syncthreads();   // the only barrier
 
-  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * BF_WAVES;
+  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * BF_FWD_WAVES;
   const _Float16* X = reinterpret_cast<const _Float16*>(a.X);
   const _Float16* NL = reinterpret_cast<const _Float16*>(a.NL);
   const uint16_t* wb = S + FwdLds::WB + c * LDB + 8 * q;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_fwd_kernel(const mdx_bondf
   _Float16* o_gate = reinterpret_cast<_Float16*>(a.gate);
   _Float16* o_out = reinterpret_cast<_Float16*>(a.out);
 
-  int tile = blockIdx.x * BF_WAVES + wave;
+  int tile = blockIdx.x * BF_FWD_WAVES + wave;
   uint4 xr[2], xn[2];
   int64_t ni = 0, nin = 0;
   float te = 0.f, ten = 0.f;
@@ -491,6 +495,152 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// EdgeBlock tail + residual (reference models/graph.py:281-294 and the `h_edge = h_edge + ...` of :360): per row
+//   pre = self_ffn(h) + (BL[l] + BR[r]);  new = h + out_transform(relu(LN(pre)))
+// with BL = S_L + node_ffn_left(h_node), BR = S_R + node_ffn_right(h_node) computed per NODE by the caller.  One launch instead of
+// gather, gather, add, Linear+LayerNorm, Linear, add; backward: one launch + the two weight-gradient contractions + two segment sums.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int ET_THREADS = 512, ET_WAVES = 8, ET_LNP = 128;
+struct EtLds {
+  static constexpr int WS = 0, WO = WS + KB * LDB, END = WO + KB * LDB;
+  static constexpr int C_BS = 0, C_G = 64, C_B = 128, C_BO = 192, C_END = 256;
+  static constexpr int BYTES = END * 2 + C_END * 4;
+};
+
+__global__ __launch_bounds__(ET_THREADS) void edge_tail_fwd_kernel(const mdx_edge_tail_args a) {
+  __shared__ __attribute__((aligned(16))) uint16_t S[EtLds::END];
+  __shared__ __attribute__((aligned(16))) float C[EtLds::C_END];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  stage_w<KB, KB, false>(S + EtLds::WS, a.Ws, (int)a.ldws, tid);
+  stage_w<KB, KB, true>(S + EtLds::WO, a.Wo, (int)a.ldwo, tid);
+  stage_v<64>(C + EtLds::C_BS, a.bs, 1, tid); stage_v<64>(C + EtLds::C_G, a.lng, 1, tid); stage_v<64>(C + EtLds::C_B, a.lnb, 1, tid);
+  stage_v<64>(C + EtLds::C_BO, a.bo, 1, tid);
+  __syncthreads();
+  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * ET_WAVES;
+  const _Float16* H = reinterpret_cast<const _Float16*>(a.H);
+  const _Float16* BL = reinterpret_cast<const _Float16*>(a.BL);
+  const _Float16* BR = reinterpret_cast<const _Float16*>(a.BR);
+  _Float16* o_pre = reinterpret_cast<_Float16*>(a.pre);
+  _Float16* o_post = reinterpret_cast<_Float16*>(a.post);
+  _Float16* o_out = reinterpret_cast<_Float16*>(a.out);
+  const uint16_t* ws = S + EtLds::WS + c * LDB + 8 * q;
+  const uint16_t* wo = S + EtLds::WO + c * LDB + 8 * q;
+#pragma unroll 1
+  for (int tile = blockIdx.x * ET_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1);
+    const _Float16* p = H + r * a.ldh + 8 * q;
+    const uint4 x0 = *reinterpret_cast<const uint4*>(p), x1 = *reinterpret_cast<const uint4*>(p + 32);
+    const int64_t il = a.il[r], ir = a.ir[r];
+    f32x4 ad[4], hres[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      ad[ft] = rh4(ldh4(BL + (size_t)il * a.ldbl + 16 * ft + 4 * q) + ldh4(BR + (size_t)ir * a.ldbr + 16 * ft + 4 * q));
+      hres[ft] = ldh4(H + r * a.ldh + 16 * ft + 4 * q);
+    }
+    const f16x8_t xb[2] = {__builtin_bit_cast(f16x8_t, x0), __builtin_bit_cast(f16x8_t, x1)};
+    f32x4 y[4];
+    zero<4>(y);
+    mm<4, 2, LDB>(y, ws, xb);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      y[ft] = rh4((y[ft] + lds4(C + EtLds::C_BS + 16 * ft + 4 * q)) + ad[ft]);
+      if (ok) sth4(o_pre + r * KB + 16 * ft + 4 * q, pack4(y[ft]));
+    }
+    float mean, rstd;
+    ln_stats<4>(y, mean, rstd);
+    uint2 pk[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      pk[ft] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(C + EtLds::C_G + 16 * ft + 4 * q) + lds4(C + EtLds::C_B + 16 * ft + 4 * q)));
+      if (ok) sth4(o_post + r * KB + 16 * ft + 4 * q, pk[ft]);
+    }
+    const f16x8_t hb[2] = {pair8(pk[0], pk[1]), pair8(pk[2], pk[3])};
+    zero<4>(y);
+    mm<4, 2, LDB>(y, wo, hb);
+    if (ok) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft)
+        sth4(o_out + r * KB + 16 * ft + 4 * q, pack4(hres[ft] + rh4(y[ft] + lds4(C + EtLds::C_BO + 16 * ft + 4 * q))));
+    }
+  }
+}
+
+__global__ __launch_bounds__(ET_THREADS) void edge_tail_bwd_kernel(const mdx_edge_tail_bwd_args a) {
+  __shared__ __attribute__((aligned(16))) uint16_t S[EtLds::END];
+  __shared__ __attribute__((aligned(16))) float C[ET_WAVES * ET_LNP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  stage_wt<KB, KB, true>(S + EtLds::WS, a.f.Ws, (int)a.f.ldws, tid);   // self_ffn^T
+  stage_wt<KB, KB, true>(S + EtLds::WO, a.f.Wo, (int)a.f.ldwo, tid);   // out_transform^T
+  stage_v<64>(C + 0, a.f.lng, 1, tid); stage_v<64>(C + 64, a.f.lnb, 1, tid);
+  __syncthreads();
+  const int E = (int)a.f.E, ntiles = (E + 15) >> 4, nw = gridDim.x * ET_WAVES;
+  const _Float16* G = reinterpret_cast<const _Float16*>(a.g_out);
+  const _Float16* s_pre = reinterpret_cast<const _Float16*>(a.f.pre);
+  _Float16* o_gpre = reinterpret_cast<_Float16*>(a.g_pre);
+  _Float16* o_gh = reinterpret_cast<_Float16*>(a.g_h);
+  const uint16_t* wst = S + EtLds::WS + c * LDB + 8 * q;
+  const uint16_t* wot = S + EtLds::WO + c * LDB + 8 * q;
+  f32x4 dg[4], db[4];
+  zero<4>(dg); zero<4>(db);
+#pragma unroll 1
+  for (int tile = blockIdx.x * ET_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1);
+    uint2 pg[4];
+    f32x4 x[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      pg[ft] = *reinterpret_cast<const uint2*>(G + r * a.ldg + 16 * ft + 4 * q);
+      x[ft] = ldh4(s_pre + r * KB + 16 * ft + 4 * q);
+    }
+    const f16x8_t gb[2] = {pair8(pg[0], pg[1]), pair8(pg[2], pg[3])};
+    f32x4 g[4];
+    zero<4>(g);
+    mm<4, 2, LDB>(g, wot, gb);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) g[ft] = rh4(g[ft]);
+    ln_relu_bwd<4>(g, x, C + 0, C + 64, q, ok, dg, db);
+    uint2 pp[4];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+      pp[ft] = pack4(g[ft]);
+      if (ok) sth4(o_gpre + r * KB + 16 * ft + 4 * q, pp[ft]);
+    }
+    const f16x8_t pb[2] = {pair8(pp[0], pp[1]), pair8(pp[2], pp[3])};
+    zero<4>(g);
+    mm<4, 2, LDB>(g, wst, pb);
+    if (ok) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) sth4(o_gh + r * KB + 16 * ft + 4 * q, pack4(unpack4(pg[ft]) + rh4(g[ft])));   // residual + self_ffn^T
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float v1 = sum_c(dg[ft][s]), v2 = sum_c(db[ft][s]);
+      if (c == 0) {
+        C[wave * ET_LNP + 16 * ft + 4 * q + s] = v1;
+        C[wave * ET_LNP + 64 + 16 * ft + 4 * q + s] = v2;
+      }
+    }
+  __syncthreads();
+  for (int i = tid; i < ET_LNP; i += ET_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ET_WAVES; ++w) s += C[w * ET_LNP + i];
+    a.lnp[(size_t)blockIdx.x * ET_LNP + i] = s;
+  }
+}
+
 int g_ncu = 0;
 int ncus() {
   if (!g_ncu) {
@@ -515,6 +665,15 @@ int check_fwd(const mdx_bondffn_args& a, const char* who) {
   return MDX_OK;
 }
 
+int check_tail(const mdx_edge_tail_args& a) {
+  if (a.E < 0) return mdx_set_error(MDX_ERR_ARG, "edge_tail: negative row count");
+  if (!a.H || !a.BL || !a.BR || !a.il || !a.ir || !a.Ws || !a.bs || !a.lng || !a.lnb || !a.Wo || !a.bo) return mdx_set_error(MDX_ERR_ARG, "edge_tail: null operand");
+  if ((a.ldh & 7) || (reinterpret_cast<uintptr_t>(a.H) & 15)) return mdx_set_error(MDX_ERR_ARG, "edge_tail: H rows must be 16-byte aligned");
+  if ((a.ldbl & 3) || (a.ldbr & 3) || (reinterpret_cast<uintptr_t>(a.BL) & 7) || (reinterpret_cast<uintptr_t>(a.BR) & 7))
+    return mdx_set_error(MDX_ERR_ARG, "edge_tail: node rows must be 8-byte aligned");
+  return MDX_OK;
+}
+
 }  // namespace
 
 extern "C" int mdx_op_bondffn_workgroups(void) { return ncus(); }
@@ -532,8 +691,8 @@ extern "C" int mdx_op_bondffn_fwd(const mdx_bondffn_args* a, void* stream) {
     g_attr_fwd = true;
   }
   const int ntiles = (int)((a->E + 15) / 16);
-  const int grid = std::max(1, std::min(ncus(), (ntiles + BF_WAVES - 1) / BF_WAVES));
-  hipLaunchKernelGGL(bondffn_fwd_kernel, dim3(grid), dim3(BF_THREADS), FwdLds::BYTES, (hipStream_t)stream, *a);
+  const int grid = std::max(1, std::min(ncus(), (ntiles + BF_FWD_WAVES - 1) / BF_FWD_WAVES));
+  hipLaunchKernelGGL(bondffn_fwd_kernel, dim3(grid), dim3(BF_FWD_THREADS), FwdLds::BYTES, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "bondffn_fwd: launch failed");
 }
 
@@ -553,4 +712,27 @@ extern "C" int mdx_op_bondffn_bwd(const mdx_bondffn_bwd_args* a, void* stream) {
   // (workgroups without tiles write zero rows)
   hipLaunchKernelGGL(bondffn_bwd_kernel, dim3(ncus()), dim3(BF_THREADS), BwdLds::BYTES, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "bondffn_bwd: launch failed");
+}
+
+extern "C" int mdx_op_edge_tail_lnp_floats(void) { return ET_LNP; }
+
+extern "C" int mdx_op_edge_tail_fwd(const mdx_edge_tail_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "edge_tail_fwd: null argument block");
+  if (a->E == 0) return MDX_OK;
+  if (int rc = check_tail(*a)) return rc;
+  if (!a->pre || !a->post || !a->out) return mdx_set_error(MDX_ERR_ARG, "edge_tail_fwd: null output");
+  const int ntiles = (int)((a->E + 15) / 16);
+  const int grid = std::max(1, std::min(2 * ncus(), (ntiles + ET_WAVES - 1) / ET_WAVES));
+  hipLaunchKernelGGL(edge_tail_fwd_kernel, dim3(grid), dim3(ET_THREADS), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "edge_tail_fwd: launch failed");
+}
+
+/* always mdx_op_bondffn_workgroups() workgroups: that many partial rows of LayerNorm-parameter gradients (128 floats: d gamma | d beta) */
+extern "C" int mdx_op_edge_tail_bwd(const mdx_edge_tail_bwd_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "edge_tail_bwd: null argument block");
+  if (int rc = check_tail(a->f)) return rc;
+  if (!a->f.pre || !a->g_out || !a->g_pre || !a->g_h || !a->lnp) return mdx_set_error(MDX_ERR_ARG, "edge_tail_bwd: null operand");
+  if ((a->ldg & 3) || (reinterpret_cast<uintptr_t>(a->g_out) & 7)) return mdx_set_error(MDX_ERR_ARG, "edge_tail_bwd: gradient rows must be 8-byte aligned");
+  hipLaunchKernelGGL(edge_tail_bwd_kernel, dim3(ncus()), dim3(ET_THREADS), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "edge_tail_bwd: launch failed");
 }

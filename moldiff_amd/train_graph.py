@@ -160,15 +160,22 @@ def bond_ffn_scatter(m, bond_in, time, node_rows, plan, plan_out):
     return T.scatter_sum(bond_ffn(m, bond_in, time, node_rows, plan), plan_out)
 
 
-def edge_block(m, h_bond, g, h_node, bond_time):
+def edge_block(m, h_bond, g, h_node, bond_time, residual=False):
+    """EdgeBlock.forward; residual=True returns h_bond + EdgeBlock(h_bond) (the caller's `h_edge = h_edge + ...`, models/graph.py:360),
+    which the fused tail kernel forms in the same launch."""
     # per-node sums first (N rows), then ONE gather per endpoint: (S_L + node_ffn_left(h))[left] + (S_R + node_ffn_right(h))[right]
     sl = bond_ffn_scatter(m.bond_ffn_left, h_bond, bond_time, h_node, g.left, g.right)
     sr = bond_ffn_scatter(m.bond_ffn_right, h_bond, bond_time, h_node, g.right, g.left)
     by_left = T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias, addend=sl)
     by_right = T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias, addend=sr)
+    if residual and T.edge_tail_fused_ok(h_bond, by_left, by_right) and m.self_ffn.weight.shape == (64, 64):
+        return T.edge_tail(h_bond, by_left, by_right, g.left, g.right, dict(
+            Ws=m.self_ffn.weight, bs=m.self_ffn.bias, lng=m.layer_norm.weight, lnb=m.layer_norm.bias, Wo=m.out_transform.weight,
+            bo=m.out_transform.bias))
     h = T.linear_ln_relu(h_bond, m.self_ffn.weight, m.self_ffn.bias, m.layer_norm.weight, m.layer_norm.bias,
                          addend=T.add(T.gather(by_left, g.left), T.gather(by_right, g.right)))
-    return T.linear(h, m.out_transform.weight, m.out_transform.bias)
+    out = T.linear(h, m.out_transform.weight, m.out_transform.bias)
+    return T.add(h_bond, out) if residual else out
 
 
 def pos_update(m, h_node, h_edge, g, rel, dist, edge_time):
@@ -188,7 +195,7 @@ def node_edge_net(net, h_node, pos, h_edge, g, node_time, edge_time):
         upd = node_block(net.node_blocks_with_edge[i], h_node, g, h_edge, node_time)
         if net.update_edge:
             # (the edge stream is re-embedded by a Linear in every block, graph.py:357: it IS a float16 tensor under autocast)
-            h_edge = T.add(h_edge, edge_block(net.edge_blocks[i], h_edge, g, h_node, edge_time))
+            h_edge = edge_block(net.edge_blocks[i], h_edge, g, h_node, edge_time, residual=True)
         h_node = res_add(h_node, upd)
         if net.update_pos:
             pos = T.add(pos, pos_update(net.pos_blocks[i], h_node, h_edge, g, rel, dist, edge_time))

@@ -805,7 +805,7 @@ def force(w, rel, dist):
 # A whole BondFFN of the EdgeBlock + the scatter_sum that follows it as ONE autograd node: 2 launches forward (fused chain, segment sum)
 # and 9 backward (fused data-gradient chain, 6 weight-gradient contractions, 2 segment sums) where the per-operator composition issues
 # 12 and ~28.  float16 autocast mode with float16 containers only; every other mode keeps the per-operator path.
-FUSED_MIN_ROWS = 1024        # below this the per-operator path runs (tests lower it to cover the fused path on small graphs)
+FUSED_MIN_ROWS = int(__import__('os').environ.get('MDX_TRAIN_FUSED_MIN_ROWS', '1024'))   # below this the per-operator path runs (tests lower it to cover the fused path on small graphs)
 _FUSED = __import__('os').environ.get('MDX_TRAIN_FUSED', '1') != '0'
 
 
@@ -887,22 +887,7 @@ class _BondFfnScatter(torch.autograd.Function):
         need = dict(zip(_BondFfnScatter.PARAMS, ctx.needs_input_grad[6:]))
         grads = {k: None for k in _BondFfnScatter.PARAMS}
         with precision(ctx.prec):
-            def wgrad(gy, xin, wname, bname):
-                """weight (+ bias) gradient of one Linear of the chain: deferred into the flat gradient buffer when a sink holds the parameter"""
-                if not need[wname]:
-                    return
-                w = ctx.refs[wname]
-                want_b = bname is not None and need[bname]
-                dst_w = _sink_dst(w)
-                dst_b = _sink_dst(ctx.refs[bname]) if want_b else None
-                sp = _splits_for(E, gy.shape[1], xin.shape[1], _h(gy) and _h(xin))
-                if dst_w is not None and (not want_b or dst_b is not None):
-                    sgemm_tn(gy, xin, sp, want_bias=want_b, defer=(dst_w, w.stride(0), dst_b))
-                else:
-                    r = sgemm_tn(gy, xin, sp, want_bias=want_b)
-                    grads[wname], gb_ = r if want_b else (r, None)
-                    if want_b:
-                        grads[bname] = gb_
+            wgrad = lambda gy, xin, wname, bname: _wgrad_into(grads, need, ctx.refs, E, gy, xin, wname, bname)
             wgrad(g['g_inter'], bufs['post1'], 'Wi2', 'bi2')
             wgrad(g['g_gate'], bufs['gpost'], 'Wg2', 'bg2')
             wgrad(g['g_pre1'], bufs['prod'], 'Wi1', 'bi1')
@@ -931,3 +916,108 @@ class _BondFfnScatter(torch.autograd.Function):
 def bondffn_scatter(bond_in, node_lin, gate_node, time, plan_in, plan_out, params):
     """params: dict with the keys of _BondFfnScatter.PARAMS (parameters or column slices of them)"""
     return _BondFfnScatter.apply(bond_in, node_lin, gate_node, time, plan_in, plan_out, *[params[k] for k in _BondFfnScatter.PARAMS])
+
+
+def _wgrad_into(grads, need, refs, E, gy, xin, wname, bname):
+    """weight (+ bias) gradient of one Linear inside a fused node: deferred into the flat gradient buffer when a sink holds the parameter,
+    else returned through `grads`"""
+    if not need[wname]:
+        return
+    w = refs[wname]
+    want_b = bname is not None and need[bname]
+    dst_w = _sink_dst(w)
+    dst_b = _sink_dst(refs[bname]) if want_b else None
+    sp = _splits_for(E, gy.shape[1], xin.shape[1], _h(gy) and _h(xin))
+    if dst_w is not None and (not want_b or dst_b is not None):
+        sgemm_tn(gy, xin, sp, want_bias=want_b, defer=(dst_w, w.stride(0), dst_b))
+    else:
+        r = sgemm_tn(gy, xin, sp, want_bias=want_b)
+        grads[wname], gb_ = r if want_b else (r, None)
+        if want_b:
+            grads[bname] = gb_
+
+
+_FUSED_TAIL = __import__('os').environ.get('MDX_TRAIN_FUSED_TAIL', '1') != '0'
+
+
+def edge_tail_fused_ok(h_bond, by_left, by_right):
+    return (_FUSED and _FUSED_TAIL and _AMP is not None and _AMP[0] == 2 and _AMP[1] and _AMP[2] and h_bond.dtype == torch.float16 and h_bond.dim() == 2
+            and h_bond.shape[1] == 64 and h_bond.shape[0] >= FUSED_MIN_ROWS and by_left.dtype == torch.float16 and by_right.dtype == torch.float16
+            and by_left.shape[1] == 64 and by_right.shape[1] == 64)
+
+
+class _EdgeTail(torch.autograd.Function):
+    """h + out_transform(relu(LN(self_ffn(h) + BL[left] + BR[right]))) (models/graph.py:281-294 + the residual of :360) as one node:
+    args = h (E,64) f16, BL, BR (N,64) f16, plan_left, plan_right, then PARAMS."""
+    PARAMS = ('Ws', 'bs', 'lng', 'lnb', 'Wo', 'bo')
+
+    @staticmethod
+    def _args(x, BL, BR, pl, pr, P, pre, post, out, E):
+        a = _lib.MdxEdgeTailArgs()
+        a.H, a.ldh, a.BL, a.ldbl, a.BR, a.ldbr = x.data_ptr(), x.stride(0), BL.data_ptr(), BL.stride(0), BR.data_ptr(), BR.stride(0)
+        a.il, a.ir = pl.index.data_ptr(), pr.index.data_ptr()
+        a.Ws, a.ldws, a.Wo, a.ldwo = P['Ws'].data_ptr(), P['Ws'].stride(0), P['Wo'].data_ptr(), P['Wo'].stride(0)
+        for nm in ('bs', 'lng', 'lnb', 'bo'):
+            setattr(a, nm, P[nm].data_ptr())
+        a.pre, a.post, a.out = pre.data_ptr(), post.data_ptr(), (out.data_ptr() if out is not None else None)
+        a.E = E
+        return a
+
+    @staticmethod
+    def forward(ctx, h, BL, BR, plan_l, plan_r, *params):
+        import ctypes
+        x = _rows(h)
+        if x.stride(0) % 8 or x.data_ptr() % 16:
+            x = x.contiguous()
+        BLc, BRc = _rows(BL), _rows(BR)
+        P = {k: _wslice(v) if v.dim() == 2 else _c(v) for k, v in zip(_EdgeTail.PARAMS, params)}
+        E, dev = x.shape[0], x.device
+        pre, post, out = (torch.empty(E, 64, dtype=torch.float16, device=dev) for _ in range(3))
+        a = _EdgeTail._args(x, BLc, BRc, plan_l, plan_r, P, pre, post, out, E)
+        check(_L().mdx_op_edge_tail_fwd(ctypes.byref(a), stream()))
+        ctx.x, ctx.BL, ctx.BR, ctx.P, ctx.pre, ctx.post = x, BLc, BRc, P, pre, post
+        ctx.plan_l, ctx.plan_r, ctx.prec, ctx.x_dtype = plan_l, plan_r, _AMP, h.dtype
+        ctx.refs = {k: v.detach() for k, v in zip(_EdgeTail.PARAMS, params)}
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes
+        x, P, E, dev = ctx.x, ctx.P, ctx.x.shape[0], ctx.x.device
+        g_out = _rows(g_out)
+        if g_out.dtype != torch.float16:
+            g_out = g_out.to(torch.float16)
+        if g_out.stride(0) % 4 or g_out.data_ptr() % 8:
+            g_out = g_out.contiguous()
+        g_pre, g_h = torch.empty(E, 64, dtype=torch.float16, device=dev), torch.empty(E, 64, dtype=torch.float16, device=dev)
+        nwg, lnf = int(_L().mdx_op_bondffn_workgroups()), int(_L().mdx_op_edge_tail_lnp_floats())
+        lnp = torch.empty(nwg, lnf, dtype=torch.float32, device=dev)
+        b = _lib.MdxEdgeTailBwdArgs()
+        b.f = _EdgeTail._args(x, ctx.BL, ctx.BR, ctx.plan_l, ctx.plan_r, P, ctx.pre, ctx.post, None, E)
+        b.g_out, b.ldg, b.g_pre, b.g_h, b.lnp = g_out.data_ptr(), g_out.stride(0), g_pre.data_ptr(), g_h.data_ptr(), lnp.data_ptr()
+        check(_L().mdx_op_edge_tail_bwd(ctypes.byref(b), stream()))
+        need = dict(zip(_EdgeTail.PARAMS, ctx.needs_input_grad[5:]))
+        grads = {k: None for k in _EdgeTail.PARAMS}
+        with precision(ctx.prec):
+            _wgrad_into(grads, need, ctx.refs, E, g_out, ctx.post, 'Wo', 'bo')
+            _wgrad_into(grads, need, ctx.refs, E, g_pre, x, 'Ws', 'bs')
+        for nm, off in (('lng', 0), ('lnb', 64)):
+            if not need[nm]:
+                continue
+            dst = _sink_dst(ctx.refs[nm])
+            if dst is not None:
+                _sink_record(lnp.data_ptr() + 4 * off, dst, nwg, 1, 64, 64, lnf, 0, lnp)
+            else:
+                grads[nm] = lnp[:, off:off + 64].sum(0)
+        ni = ctx.needs_input_grad
+        gh = g_h if ni[0] else None
+        if gh is not None and gh.dtype != ctx.x_dtype:
+            gh = gh.to(ctx.x_dtype)
+        gBL = _segsum_raw(g_pre, ctx.plan_l, torch.float16) if ni[1] else None
+        gBR = _segsum_raw(g_pre, ctx.plan_r, torch.float16) if ni[2] else None
+        ctx.pre = ctx.post = ctx.P = None
+        return (gh, gBL, gBR, None, None) + tuple(grads[k] for k in _EdgeTail.PARAMS)
+
+
+def edge_tail(h, by_left, by_right, plan_l, plan_r, params):
+    return _EdgeTail.apply(h, by_left, by_right, plan_l, plan_r, *[params[k] for k in _EdgeTail.PARAMS])

@@ -135,3 +135,56 @@ def test_fused_bondffn_with_the_gradient_sink_equals_autograd_accumulation():
         got = p.grad if p.grad is not None else None
         assert got is not None, k
         assert _rel(got, ref[k]) < 2e-3, (k, _rel(got, ref[k]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# EdgeBlock (two fused BondFFNs + the fused tail with the residual) against the per-operator composition
+# ---------------------------------------------------------------------------------------------------------------------------
+def _edge_block_run(m, x, h, te, g_out, tg, fused):
+    m.zero_grad(set_to_none=True)
+    x = x.clone().requires_grad_(True)
+    h = h.clone().requires_grad_(True)
+    old, old_rows = T._FUSED, T.FUSED_MIN_ROWS
+    T._FUSED, T.FUSED_MIN_ROWS = fused, 1
+    try:
+        with T.precision('fp16'):
+            out = TG.edge_block(m, x, tg, h, te, residual=True)
+            out.backward(g_out)
+    finally:
+        T._FUSED, T.FUSED_MIN_ROWS = old, old_rows
+    return out.detach(), x.grad.detach(), h.grad.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize('sizes', [[5, 7, 4], [24, 31, 18, 27, 22, 25, 30, 19, 26, 23]])
+def test_fused_edge_block_with_residual_equals_the_per_operator_composition(sizes):
+    """h + EdgeBlock(h) (models/graph.py:268-294, :360) with both BondFFNs and the tail fused vs the per-operator path in the same float16
+    arithmetic: output within 2 float16 ulp of its scale; gradients within 1 % in L2 (individual rows may sit on different sides of a ReLU kink once the
+    two paths' LayerNorm statistics differ in the last bit)."""
+    g = U.rng(23)
+    bn, hei, bh, ei, be = U.graph_from_sizes(sizes)
+    N, E = len(bn), ei.shape[1]
+    m = G.EdgeBlock(64, 256).to(DEV)
+    with torch.no_grad():
+        for k, p in sorted(m.named_parameters()):
+            if p.dim() == 2:
+                p.copy_(torch.from_numpy((g.standard_normal(tuple(p.shape)) * (1.0 / np.sqrt(p.shape[1]))).astype(np.float32)))
+            elif ('net.1.' in k or 'layer_norm' in k) and k.endswith('weight'):
+                p.copy_(torch.from_numpy((1.0 + 0.3 * g.standard_normal(tuple(p.shape))).astype(np.float32)))
+            else:
+                p.copy_(torch.from_numpy((0.2 * g.standard_normal(tuple(p.shape))).astype(np.float32)))
+    x = torch.from_numpy(g.standard_normal((E, 64)).astype(np.float32)).to(DEV).half()
+    h = torch.from_numpy(g.standard_normal((N, 256)).astype(np.float32)).to(DEV).half()
+    te = torch.from_numpy(g.random((E, 1)).astype(np.float32)).to(DEV)
+    g_out = torch.from_numpy(g.standard_normal((E, 64)).astype(np.float32)).to(DEV).half()
+    tg = TG.TrainGraph(ei.to(DEV), N)
+    o1, gx1, gh1, gr1 = _edge_block_run(m, x, h, te, g_out, tg, True)
+    o0, gx0, gh0, gr0 = _edge_block_run(m, x, h, te, g_out, tg, False)
+    assert o1.dtype == o0.dtype == torch.float16 and gx1.dtype == gx0.dtype
+    print(f'\n[fused EdgeBlock vs per-operator] out max {_rel(o1, o0):.2e}  dX L2 {_rel2(gx1, gx0):.2e}  dh L2 {_rel2(gh1, gh0):.2e}')
+    for k in gr0:
+        print(f'    {k:40s} L2 {_rel2(gr1[k], gr0[k]):.2e}')
+    assert _rel(o1, o0) < 3e-3, _rel(o1, o0)
+    assert _rel2(gx1, gx0) < 1e-2 and _rel2(gh1, gh0) < 1e-2, (_rel2(gx1, gx0), _rel2(gh1, gh0))
+    for k in gr0:
+        assert torch.isfinite(gr1[k]).all(), k
+        assert _rel2(gr1[k], gr0[k]) < 1e-2, (k, _rel2(gr1[k], gr0[k]))
