@@ -177,7 +177,7 @@ def compact_line(full, full_path='bench_full.json'):
         optional.append(('kernel_ms_per_step', _num(full['kernel_ms_per_step'])))
     # the process-group fields stay top-level keys (the multi-rank tests and the SCALE run read them there)
     line.update(_pick(full, ('ranks_seen', 'backend', 'per_rank_ms_per_step', 'gather_ms', 'gather_first_ms', 'gather_rows', 'gather_bytes',
-                             'value_incl_gather')))
+                             'value_incl_gather'), 8))     # (same digits as ms_per_step: it is the maximum of per_rank_ms_per_step)
     line['full'] = full_path
     for k, v in optional:
         line[k] = v

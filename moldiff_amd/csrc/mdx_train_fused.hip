@@ -293,31 +293,55 @@ constexpr int BF_LNP = 320;   // floats per partial row of LayerNorm-parameter g
 // g (dL/d relu(LN(x))) -> dL/dx in place; x holds the pre-LayerNorm values (float16-representable).  The row's LayerNorm-parameter
 // gradients are added to dgam / dbet (per lane: the lane's four features of each tile, summed over the wave's rows at the end).
 template <int FT>
-__device__ __forceinline__ void ln_relu_bwd(f32x4 (&g)[FT], f32x4 (&x)[FT], const float* gam, const float* bet, int q, bool ok,
+__device__ __forceinline__ void ln_relu_bwd(f32x4 (&g)[FT], const uint2 (&xp)[FT], const float* gam, const float* bet, int q, bool ok,
                                             f32x4 (&dgam)[FT], f32x4 (&dbet)[FT]) {
+  // x arrives PACKED (float16, as stored): 2 registers per tile instead of 4 across the two reductions -- the kernel sits at the
+  // 256-register limit of two waves per SIMD, and the float16 MFMA co-executes with the extra conversions
   constexpr float inv_n = 1.0f / (16 * FT);
   float mean, rstd;
-  ln_stats<FT>(x, mean, rstd);
+  {
+    float sm = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      const f32x4 v = unpack4(xp[ft]);
+      sm += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    mean = sumq(sm) * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      const f32x4 v = unpack4(xp[ft]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[r] - mean;
+        d2 = fmaf(d, d, d2);
+      }
+    }
+    rstd = 1.0f / sqrtf(sumq(d2) * inv_n + MDX_LN_EPS);
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft) {
     const f32x4 gm = lds4(gam + 16 * ft + 4 * q), bt = lds4(bet + 16 * ft + 4 * q);
-    x[ft] = (x[ft] - splat4(mean)) * splat4(rstd);      // x_hat, in place
-    const f32x4 y = x[ft] * gm + bt;
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    const f32x4 y = xh * gm + bt;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float go = (ok && y[r] > 0.f) ? g[ft][r] : 0.f;
-      dgam[ft][r] = fmaf(go, x[ft][r], dgam[ft][r]);
+      dgam[ft][r] = fmaf(go, xh[r], dgam[ft][r]);
       dbet[ft][r] += go;
       const float gh = go * gm[r];
       g[ft][r] = gh;
       s1 += gh;
-      s2 = fmaf(gh, x[ft][r], s2);
+      s2 = fmaf(gh, xh[r], s2);
     }
   }
   const float m1 = sumq(s1) * inv_n, m2 = sumq(s2) * inv_n;
 #pragma unroll
-  for (int ft = 0; ft < FT; ++ft) g[ft] = (g[ft] - splat4(m1) - x[ft] * splat4(m2)) * splat4(rstd);
+  for (int ft = 0; ft < FT; ++ft) {
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    g[ft] = (g[ft] - splat4(m1) - xh * splat4(m2)) * splat4(rstd);
+  }
 }
 
 // sum over the 16 lanes of a DPP row (the wave's 16 rows c = 0..15 of one q); result in every lane of the row
@@ -394,18 +418,20 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
         sth4(o_ggate + r * KO + 16 * ft + 4 * q, pgg[ft]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- inter module backward
     uint2 pgb[8];
     {
-      f32x4 g[8], x[8];
+      f32x4 g[8];
+      uint2 xp[8];
 #pragma unroll
-      for (int ft = 0; ft < 8; ++ft) x[ft] = ldh4(s_pre1 + r * KI + 16 * ft + 4 * q);
+      for (int ft = 0; ft < 8; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(s_pre1 + r * KI + 16 * ft + 4 * q);
       const f16x8_t b2[2] = {pair8(pgi[0], pgi[1]), pair8(pgi[2], pgi[3])};
       zero<8>(g);
       mm<8, 2, LDO>(g, wi2t, b2);
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) g[ft] = rh4(g[ft]);
-      ln_relu_bwd<8>(g, x, C + BwdLds::C_G1, C + BwdLds::C_BE1, q, ok, dg1, db1);
+      ln_relu_bwd<8>(g, xp, C + BwdLds::C_G1, C + BwdLds::C_BE1, q, ok, dg1, db1);
       uint2 pg[8];
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) {
@@ -415,8 +441,10 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
       const f16x8_t b1[4] = {pair8(pg[0], pg[1]), pair8(pg[2], pg[3]), pair8(pg[4], pg[5]), pair8(pg[6], pg[7])};
       zero<8>(g);
       mm<8, 4, LDI>(g, wi1t, b1);     // dL/d prod
+      __builtin_amdgcn_sched_barrier(0);
       // prod = bf * nl:  d bf = gp * nl,  d nl = gp * bf  (bf = bond_linear(X) recomputed: 16 MFMAs against a 256-byte row of HBM traffic each way)
       const f16x8_t xb[2] = {__builtin_bit_cast(f16x8_t, xr[0]), __builtin_bit_cast(f16x8_t, xr[1])};
+      f32x4 x[8];
       zero<8>(x);
       mm<8, 2, LDB>(x, wb, xb);
 #pragma unroll
@@ -429,12 +457,14 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- gate backward
     uint2 pgp[2];
     {
-      f32x4 g[2], x[2];
+      f32x4 g[2];
+      uint2 x[2];
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) x[ft] = ldh4(s_gpre + r * KG + 16 * ft + 4 * q);
+      for (int ft = 0; ft < 2; ++ft) x[ft] = *reinterpret_cast<const uint2*>(s_gpre + r * KG + 16 * ft + 4 * q);
       const f16x8_t b2[2] = {pair8(pgg[0], pgg[1]), pair8(pgg[2], pgg[3])};
       zero<2>(g);
       mm<2, 2, LDO>(g, wg2t, b2);
@@ -447,6 +477,7 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
         if (ok) sth4(o_ggpre + r * KG + 16 * ft + 4 * q, pgp[ft]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     // ---- dL/dX = bond_linear^T d bf + W_g1e^T d gate_pre  (two Linear data gradients, each a float16 tensor, summed in float16)
     {
       f32x4 g1[4], g2[4];
@@ -593,12 +624,11 @@ __global__ __launch_bounds__(ET_THREADS) void edge_tail_bwd_kernel(const mdx_edg
     const int row = 16 * tile + c;
     const bool ok = row < E;
     const size_t r = (size_t)min(row, E - 1);
-    uint2 pg[4];
-    f32x4 x[4];
+    uint2 pg[4], x[4];
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
       pg[ft] = *reinterpret_cast<const uint2*>(G + r * a.ldg + 16 * ft + 4 * q);
-      x[ft] = ldh4(s_pre + r * KB + 16 * ft + 4 * q);
+      x[ft] = *reinterpret_cast<const uint2*>(s_pre + r * KB + 16 * ft + 4 * q);
     }
     const f16x8_t gb[2] = {pair8(pg[0], pg[1]), pair8(pg[2], pg[3])};
     f32x4 g[4];

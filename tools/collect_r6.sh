@@ -6,7 +6,7 @@
 #   r6_kernel_stats.csv / r6_guided_*          rocprofv3 --kernel-trace --stats, exact fp32 path (configs #2 / #3), + the JSON line of the same run
 #   r6_pmc_summary.json / r6_guided_pmc_summary.json    tools/pmc_summary.py: three separate --pmc passes each
 #   r6_train_fp16_kernel_stats.csv             kernel statistics of 10 fp16 training steps (fused EdgeBlock kernels on) + the unfused twin
-#   r6_kernel_resources.txt                    registers / scratch / LDS of every kernel of the library
+#   (profiles/r6_kernel_resources.txt is produced on the build host: tools/resusage.sh over every csrc/*.hip)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out
@@ -31,5 +31,4 @@ for v in 1 0; do
   find /tmp/prof_tr -name "*kernel_stats.csv" -exec cp {} $OUT/r6_train_fp16_kernel_stats$sfx.csv \;
 done
 cd $ROOT
-bash tools/resusage.sh > $OUT/r6_kernel_resources.txt 2>&1
 ls -la $OUT | grep r6_
