@@ -452,6 +452,35 @@ typedef struct {
   void *g_pre, *g_h;
   float* lnp;
 } mdx_edge_tail_bwd_args;
+/* PosUpdate, front of its BondFFN (replaces, for training, reference models/graph.py:388-390 with :133-141 up to the inter MLP's input):
+ * a = LF[il] * RF[ir] (LF / RF (N,64) float16 = left_lin_edge(h), right_lin_edge(h), hoisted), prod = bond_linear(X) * node_linear(a)
+ * (E,256), gate = gate MLP on [X | a | t] (E,1).  Weights: Wb, Wn (256,64); Wg1x, Wg1a (32,64) and Wt (32) = the bond / node / time
+ * columns of gate.net.0; Wg2 (32) / bg2 (1) = gate.net.3.  Outputs (float16): a (E,64), prod (E,256), gpre / gpost (E,32), gate (E).
+ * Backward: g_prod (E,256; row stride ldgp), g_gate (E) -> g_bf, g_nf (E,256) = dL/d bond_linear(X), dL/d node_linear(a); g_gpre (E,32);
+ * g_x (E,64) = dL/dX; g_lf, g_rf (E,64) = the per-edge dL/dLF[il], dL/dRF[ir] rows (summed per node by the caller); lnp:
+ * mdx_op_bondffn_workgroups() rows of 64 floats [d gamma | d beta] of the gate's LayerNorm. */
+typedef struct {
+  const void* X; int64_t ldx;
+  const void* LF; int64_t ldlf; const void* RF; int64_t ldrf;
+  const int64_t* il; const int64_t* ir;
+  const float* te;
+  const float* Wb; int64_t ldwb; const float* Wn; int64_t ldwn;
+  const float* Wg1x; int64_t ldwg1x; const float* Wg1a; int64_t ldwg1a; const float* Wt; int64_t ldwt;
+  const float* bg1; const float* gg; const float* gbe;
+  const float* Wg2; const float* bg2;
+  void *a, *prod, *gpre, *gpost, *gate;
+  int64_t E;
+} mdx_posffn_args;
+typedef struct {
+  mdx_posffn_args f;
+  const void* g_prod; int64_t ldgp;
+  const void* g_gate;
+  void *g_bf, *g_nf, *g_gpre, *g_x, *g_lf, *g_rf;
+  float* lnp;
+} mdx_posffn_bwd_args;
+int mdx_op_posffn_fwd(const mdx_posffn_args* a, void* stream);
+int mdx_op_posffn_bwd(const mdx_posffn_bwd_args* a, void* stream);
+int mdx_op_posffn_lnp_floats(void);
 int mdx_op_edge_tail_fwd(const mdx_edge_tail_args* a, void* stream);
 int mdx_op_edge_tail_bwd(const mdx_edge_tail_bwd_args* a, void* stream);
 int mdx_op_edge_tail_lnp_floats(void);

@@ -32,6 +32,7 @@ EXPORTS = [
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
     'mdx_op_edge_tail_fwd', 'mdx_op_edge_tail_bwd', 'mdx_op_edge_tail_lnp_floats',
+    'mdx_op_posffn_fwd', 'mdx_op_posffn_bwd', 'mdx_op_posffn_lnp_floats',
 ]
 
 
@@ -79,6 +80,19 @@ class MdxEdgeTailArgs(ctypes.Structure):   # == mdx_edge_tail_args
 
 class MdxEdgeTailBwdArgs(ctypes.Structure):   # == mdx_edge_tail_bwd_args
     _fields_ = [('f', MdxEdgeTailArgs), ('g_out', c_void_p), ('ldg', c_int64), ('g_pre', c_void_p), ('g_h', c_void_p), ('lnp', c_void_p)]
+
+
+class MdxPosFfnArgs(ctypes.Structure):   # == mdx_posffn_args
+    _fields_ = [('X', c_void_p), ('ldx', c_int64), ('LF', c_void_p), ('ldlf', c_int64), ('RF', c_void_p), ('ldrf', c_int64),
+                ('il', c_void_p), ('ir', c_void_p), ('te', c_void_p), ('Wb', c_void_p), ('ldwb', c_int64), ('Wn', c_void_p), ('ldwn', c_int64),
+                ('Wg1x', c_void_p), ('ldwg1x', c_int64), ('Wg1a', c_void_p), ('ldwg1a', c_int64), ('Wt', c_void_p), ('ldwt', c_int64),
+                ('bg1', c_void_p), ('gg', c_void_p), ('gbe', c_void_p), ('Wg2', c_void_p), ('bg2', c_void_p),
+                ('a', c_void_p), ('prod', c_void_p), ('gpre', c_void_p), ('gpost', c_void_p), ('gate', c_void_p), ('E', c_int64)]
+
+
+class MdxPosFfnBwdArgs(ctypes.Structure):   # == mdx_posffn_bwd_args
+    _fields_ = [('f', MdxPosFfnArgs), ('g_prod', c_void_p), ('ldgp', c_int64), ('g_gate', c_void_p), ('g_bf', c_void_p), ('g_nf', c_void_p),
+                ('g_gpre', c_void_p), ('g_x', c_void_p), ('g_lf', c_void_p), ('g_rf', c_void_p), ('lnp', c_void_p)]
 
 
 class MdxConfig(ctypes.Structure):
@@ -199,6 +213,8 @@ def lib():
         L.mdx_op_bondffn_bwd.argtypes = [POINTER(MdxBondFfnBwdArgs), c_void_p]
         L.mdx_op_edge_tail_fwd.argtypes = [POINTER(MdxEdgeTailArgs), c_void_p]
         L.mdx_op_edge_tail_bwd.argtypes = [POINTER(MdxEdgeTailBwdArgs), c_void_p]
+        L.mdx_op_posffn_fwd.argtypes = [POINTER(MdxPosFfnArgs), c_void_p]
+        L.mdx_op_posffn_bwd.argtypes = [POINTER(MdxPosFfnBwdArgs), c_void_p]
         _lib = L
     return _lib
 

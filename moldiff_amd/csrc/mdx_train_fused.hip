@@ -671,6 +671,260 @@ __global__ __launch_bounds__(ET_THREADS) void edge_tail_bwd_kernel(const mdx_edg
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// PosUpdate, front of its BondFFN (reference models/graph.py:384-392 with :133-141, bond 64 / node 64 / inter 256 / out 1):
+//   a    = left_lin_edge(h)[l] * right_lin_edge(h)[r]                      (the two per-node MLPs are hoisted by the caller: LF, RF)
+//   prod = bond_linear(X) * node_linear(a)                                 (E,256): input of the inter MLP (its 256 x 256 Linear + LayerNorm
+//                                                                           stays the per-operator launch: the weight does not fit LDS beside these)
+//   gate = W_g2 relu(LN(W_g1x X + W_g1a a + t w_t + b)) + b_g2             (E,1)
+// One launch instead of gather, mul_gather, 2 Linears, mul, 2 partial Linears, Linear+LayerNorm, Linear; backward: one launch + six
+// weight-gradient contractions + two segment sums.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int PF_THREADS = 512, PF_WAVES = 8, PF_LNP = 64, KW = 256, LDW = KW + 8;
+struct PfLds {   // forward: Wb, Wn (256 x 64), Wg1x, Wg1a (32 x 64)
+  static constexpr int WB = 0, WN = WB + KW * LDB, WGX = WN + KW * LDB, WGA = WGX + KG * LDB, END = WGA + KG * LDB;
+  static constexpr int C_BG1 = 0, C_GG = 32, C_GBE = 64, C_WT = 96, C_WG2 = 128, C_END = 160;
+  static constexpr int BYTES = END * 2 + C_END * 4;
+};
+struct PbLds {   // backward: Wb, Wn (recompute), their transposes (64 x 256), the gate's first-layer transposes (64 x 32)
+  static constexpr int WB = 0, WN = WB + KW * LDB, WBT = WN + KW * LDB, WNT = WBT + KB * LDW, WGXT = WNT + KB * LDW, WGAT = WGXT + KB * LDG,
+                       END = WGAT + KB * LDG;
+  static constexpr int C_GG = 0, C_GBE = 32, C_WG2 = 64, C_END = 96;
+  static constexpr int BYTES = END * 2 + C_END * 4 + PF_WAVES * PF_LNP * 4;
+};
+
+// a = LF[il] * RF[ir] as the B operand of the Linears that read it (8 consecutive features of row c per lane and k-step), float16
+__device__ __forceinline__ void load_a(f16x8_t (&ab)[2], uint4 (&araw)[2], const _Float16* LF, size_t ol, const _Float16* RF, size_t orr, int q) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const f16x8_t l = *reinterpret_cast<const f16x8_t*>(LF + ol + 32 * ks + 8 * q), r = *reinterpret_cast<const f16x8_t*>(RF + orr + 32 * ks + 8 * q);
+    f16x8_t p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = (_Float16)((float)l[j] * (float)r[j]);
+    ab[ks] = p;
+    araw[ks] = __builtin_bit_cast(uint4, p);
+  }
+}
+
+__global__ __launch_bounds__(PF_THREADS) void posffn_fwd_kernel(const mdx_posffn_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
+  uint16_t* S = bf_smem;
+  float* C = reinterpret_cast<float*>(bf_smem + PfLds::END);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  stage_w<KW, KB, false>(S + PfLds::WB, a.Wb, (int)a.ldwb, tid);
+  stage_w<KW, KB, false>(S + PfLds::WN, a.Wn, (int)a.ldwn, tid);
+  stage_w<KG, KB, false>(S + PfLds::WGX, a.Wg1x, (int)a.ldwg1x, tid);
+  stage_w<KG, KB, false>(S + PfLds::WGA, a.Wg1a, (int)a.ldwg1a, tid);
+  stage_v<32>(C + PfLds::C_BG1, a.bg1, 1, tid); stage_v<32>(C + PfLds::C_GG, a.gg, 1, tid); stage_v<32>(C + PfLds::C_GBE, a.gbe, 1, tid);
+  stage_v<32>(C + PfLds::C_WT, a.Wt, (int)a.ldwt, tid, true); stage_v<32>(C + PfLds::C_WG2, a.Wg2, 1, tid, true);
+  __syncthreads();
+  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * PF_WAVES;
+  const _Float16* X = reinterpret_cast<const _Float16*>(a.X);
+  const _Float16* LF = reinterpret_cast<const _Float16*>(a.LF);
+  const _Float16* RF = reinterpret_cast<const _Float16*>(a.RF);
+  _Float16* o_a = reinterpret_cast<_Float16*>(a.a);
+  _Float16* o_prod = reinterpret_cast<_Float16*>(a.prod);
+  _Float16* o_gpre = reinterpret_cast<_Float16*>(a.gpre);
+  _Float16* o_gpost = reinterpret_cast<_Float16*>(a.gpost);
+  _Float16* o_gate = reinterpret_cast<_Float16*>(a.gate);
+  const uint16_t* wb = S + PfLds::WB + c * LDB + 8 * q;
+  const uint16_t* wn = S + PfLds::WN + c * LDB + 8 * q;
+  const uint16_t* wgx = S + PfLds::WGX + c * LDB + 8 * q;
+  const uint16_t* wga = S + PfLds::WGA + c * LDB + 8 * q;
+  const float bg2 = a.bg2 ? a.bg2[0] : 0.f;
+#pragma unroll 1
+  for (int tile = blockIdx.x * PF_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1);
+    const _Float16* px = X + r * a.ldx + 8 * q;
+    const f16x8_t xb[2] = {*reinterpret_cast<const f16x8_t*>(px), *reinterpret_cast<const f16x8_t*>(px + 32)};
+    f16x8_t ab[2];
+    uint4 araw[2];
+    load_a(ab, araw, LF, (size_t)a.il[r] * a.ldlf, RF, (size_t)a.ir[r] * a.ldrf, q);
+    const float th = rh(a.te[r]);
+    if (ok) {
+      *reinterpret_cast<uint4*>(o_a + r * KB + 8 * q) = araw[0];
+      *reinterpret_cast<uint4*>(o_a + r * KB + 32 + 8 * q) = araw[1];
+    }
+    // ---- prod = bond_linear(X) * node_linear(a), 128 features at a time
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 yb[8], yn[8];
+      zero<8>(yb); zero<8>(yn);
+      mm<8, 2, LDB>(yb, wb + 128 * h * LDB, xb);
+      mm<8, 2, LDB>(yn, wn + 128 * h * LDB, ab);
+      if (ok) {
+#pragma unroll
+        for (int ft = 0; ft < 8; ++ft) sth4(o_prod + r * KW + 128 * h + 16 * ft + 4 * q, pack4(rh4(yb[ft]) * rh4(yn[ft])));
+      }
+    }
+    // ---- gate: the node (a) and time columns of its first Linear are an fp32 addend of the bond columns' product, like the per-operator path
+    {
+      f32x4 gx[2], ga[2];
+      zero<2>(gx); zero<2>(ga);
+      mm<2, 2, LDB>(gx, wgx, xb);
+      mm<2, 2, LDB>(ga, wga, ab);
+      uint2 pg[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 ad = splat4(th) * lds4(C + PfLds::C_WT + 16 * ft + 4 * q) + ga[ft];
+        gx[ft] = rh4((gx[ft] + lds4(C + PfLds::C_BG1 + 16 * ft + 4 * q)) + ad);
+        if (ok) sth4(o_gpre + r * KG + 16 * ft + 4 * q, pack4(gx[ft]));
+      }
+      float mean, rstd;
+      ln_stats<2>(gx, mean, rstd);
+      float dot = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        const f32x4 v = rh4(relu4((gx[ft] - splat4(mean)) * splat4(rstd) * lds4(C + PfLds::C_GG + 16 * ft + 4 * q) + lds4(C + PfLds::C_GBE + 16 * ft + 4 * q)));
+        pg[ft] = pack4(v);
+        if (ok) sth4(o_gpost + r * KG + 16 * ft + 4 * q, pg[ft]);
+        const f32x4 w2 = lds4(C + PfLds::C_WG2 + 16 * ft + 4 * q);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dot = fmaf(v[s], w2[s], dot);
+      }
+      dot = sumq(dot);
+      if (ok && q == 0) o_gate[r] = (_Float16)(dot + bg2);
+    }
+  }
+}
+
+__global__ __launch_bounds__(PF_THREADS) void posffn_bwd_kernel(const mdx_posffn_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
+  uint16_t* S = bf_smem;
+  float* C = reinterpret_cast<float*>(bf_smem + PbLds::END);
+  float* R = C + PbLds::C_END;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  stage_w<KW, KB, false>(S + PbLds::WB, a.f.Wb, (int)a.f.ldwb, tid);
+  stage_w<KW, KB, false>(S + PbLds::WN, a.f.Wn, (int)a.f.ldwn, tid);
+  stage_wt<KW, KB, true>(S + PbLds::WBT, a.f.Wb, (int)a.f.ldwb, tid);        // (256 x 64)^T: 64 outputs over 256 inputs
+  stage_wt<KW, KB, true>(S + PbLds::WNT, a.f.Wn, (int)a.f.ldwn, tid);
+  stage_wt<KG, KB, true>(S + PbLds::WGXT, a.f.Wg1x, (int)a.f.ldwg1x, tid);   // (32 x 64)^T: 64 outputs over 32 inputs
+  stage_wt<KG, KB, true>(S + PbLds::WGAT, a.f.Wg1a, (int)a.f.ldwg1a, tid);
+  stage_v<32>(C + PbLds::C_GG, a.f.gg, 1, tid); stage_v<32>(C + PbLds::C_GBE, a.f.gbe, 1, tid); stage_v<32>(C + PbLds::C_WG2, a.f.Wg2, 1, tid, true);
+  __syncthreads();
+  const int E = (int)a.f.E, ntiles = (E + 15) >> 4, nw = gridDim.x * PF_WAVES;
+  const _Float16* X = reinterpret_cast<const _Float16*>(a.f.X);
+  const _Float16* LF = reinterpret_cast<const _Float16*>(a.f.LF);
+  const _Float16* RF = reinterpret_cast<const _Float16*>(a.f.RF);
+  const _Float16* GP = reinterpret_cast<const _Float16*>(a.g_prod);
+  const _Float16* GG = reinterpret_cast<const _Float16*>(a.g_gate);
+  const _Float16* s_gpre = reinterpret_cast<const _Float16*>(a.f.gpre);
+  _Float16* o_gbf = reinterpret_cast<_Float16*>(a.g_bf);
+  _Float16* o_gnf = reinterpret_cast<_Float16*>(a.g_nf);
+  _Float16* o_ggpre = reinterpret_cast<_Float16*>(a.g_gpre);
+  _Float16* o_gx = reinterpret_cast<_Float16*>(a.g_x);
+  _Float16* o_glf = reinterpret_cast<_Float16*>(a.g_lf);
+  _Float16* o_grf = reinterpret_cast<_Float16*>(a.g_rf);
+  const uint16_t* wb = S + PbLds::WB + c * LDB + 8 * q;
+  const uint16_t* wn = S + PbLds::WN + c * LDB + 8 * q;
+  const uint16_t* wbt = S + PbLds::WBT + c * LDW + 8 * q;
+  const uint16_t* wnt = S + PbLds::WNT + c * LDW + 8 * q;
+  const uint16_t* wgxt = S + PbLds::WGXT + c * LDG + 8 * q;
+  const uint16_t* wgat = S + PbLds::WGAT + c * LDG + 8 * q;
+  f32x4 dgg[2], dgb[2];
+  zero<2>(dgg); zero<2>(dgb);
+#pragma unroll 1
+  for (int tile = blockIdx.x * PF_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1);
+    const size_t ol = (size_t)a.f.il[r] * a.f.ldlf, orr = (size_t)a.f.ir[r] * a.f.ldrf;
+    const _Float16* px = X + r * a.f.ldx + 8 * q;
+    const f16x8_t xb[2] = {*reinterpret_cast<const f16x8_t*>(px), *reinterpret_cast<const f16x8_t*>(px + 32)};
+    f16x8_t ab[2];
+    uint4 araw[2];
+    load_a(ab, araw, LF, ol, RF, orr, q);
+    // ---- prod = bf * nf:  d bf = g * nf,  d nf = g * bf  (both Linears recomputed: 64 MFMAs against 2 KB per edge of HBM traffic)
+    uint2 pgb[16], pgn[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 yb[8], yn[8];
+      zero<8>(yb); zero<8>(yn);
+      mm<8, 2, LDB>(yb, wb + 128 * h * LDB, xb);
+      mm<8, 2, LDB>(yn, wn + 128 * h * LDB, ab);
+#pragma unroll
+      for (int ft = 0; ft < 8; ++ft) {
+        const f32x4 g = ldh4(GP + r * a.ldgp + 128 * h + 16 * ft + 4 * q);
+        pgb[8 * h + ft] = pack4(g * rh4(yn[ft]));
+        pgn[8 * h + ft] = pack4(g * rh4(yb[ft]));
+        if (ok) {
+          sth4(o_gbf + r * KW + 128 * h + 16 * ft + 4 * q, pgb[8 * h + ft]);
+          sth4(o_gnf + r * KW + 128 * h + 16 * ft + 4 * q, pgn[8 * h + ft]);
+        }
+      }
+    }
+    f32x4 gx1[4], ga1[4];
+    {
+      f16x8_t bb[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bb[ks] = pair8(pgb[2 * ks], pgb[2 * ks + 1]);
+      zero<4>(gx1);
+      mm<4, 8, LDW>(gx1, wbt, bb);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bb[ks] = pair8(pgn[2 * ks], pgn[2 * ks + 1]);
+      zero<4>(ga1);
+      mm<4, 8, LDW>(ga1, wnt, bb);
+    }
+    // ---- gate backward: gate = w_g2 . relu(LN(gpre)) + b
+    uint2 pgp[2];
+    {
+      const float gg = (float)GG[r];
+      f32x4 g[2];
+      uint2 xp[2];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        xp[ft] = *reinterpret_cast<const uint2*>(s_gpre + r * KG + 16 * ft + 4 * q);
+        g[ft] = rh4(splat4(gg) * lds4(C + PbLds::C_WG2 + 16 * ft + 4 * q));
+      }
+      ln_relu_bwd<2>(g, xp, C + PbLds::C_GG, C + PbLds::C_GBE, q, ok, dgg, dgb);
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        pgp[ft] = pack4(g[ft]);
+        if (ok) sth4(o_ggpre + r * KG + 16 * ft + 4 * q, pgp[ft]);
+      }
+    }
+    {
+      const f16x8_t bg[1] = {pair8(pgp[0], pgp[1])};
+      f32x4 gx2[4], ga2[4];
+      zero<4>(gx2); zero<4>(ga2);
+      mm<4, 1, LDG>(gx2, wgxt, bg);
+      mm<4, 1, LDG>(ga2, wgat, bg);
+      if (ok) {
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+          sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx1[ft]) + rh4(gx2[ft])));
+          const f32x4 ga = rh4(rh4(ga1[ft]) + rh4(ga2[ft]));
+          sth4(o_glf + r * KB + 16 * ft + 4 * q, pack4(ga * ldh4(RF + orr + 16 * ft + 4 * q)));
+          sth4(o_grf + r * KB + 16 * ft + 4 * q, pack4(ga * ldh4(LF + ol + 16 * ft + 4 * q)));
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float v1 = sum_c(dgg[ft][s]), v2 = sum_c(dgb[ft][s]);
+      if (c == 0) {
+        R[wave * PF_LNP + 16 * ft + 4 * q + s] = v1;
+        R[wave * PF_LNP + 32 + 16 * ft + 4 * q + s] = v2;
+      }
+    }
+  __syncthreads();
+  for (int i = tid; i < PF_LNP; i += PF_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < PF_WAVES; ++w) s += R[w * PF_LNP + i];
+    a.lnp[(size_t)blockIdx.x * PF_LNP + i] = s;
+  }
+}
+
 int g_ncu = 0;
 int ncus() {
   if (!g_ncu) {
@@ -765,4 +1019,48 @@ extern "C" int mdx_op_edge_tail_bwd(const mdx_edge_tail_bwd_args* a, void* strea
   if ((a->ldg & 3) || (reinterpret_cast<uintptr_t>(a->g_out) & 7)) return mdx_set_error(MDX_ERR_ARG, "edge_tail_bwd: gradient rows must be 8-byte aligned");
   hipLaunchKernelGGL(edge_tail_bwd_kernel, dim3(ncus()), dim3(ET_THREADS), 0, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "edge_tail_bwd: launch failed");
+}
+
+extern "C" int mdx_op_posffn_lnp_floats(void) { return PF_LNP; }
+
+static int check_posffn(const mdx_posffn_args& a) {
+  if (a.E < 0) return mdx_set_error(MDX_ERR_ARG, "posffn: negative row count");
+  if (!a.X || !a.LF || !a.RF || !a.il || !a.ir || !a.te || !a.Wb || !a.Wn || !a.Wg1x || !a.Wg1a || !a.Wt || !a.bg1 || !a.gg || !a.gbe || !a.Wg2)
+    return mdx_set_error(MDX_ERR_ARG, "posffn: null operand");
+  if ((a.ldx & 7) || (a.ldlf & 7) || (a.ldrf & 7) || (reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.LF) & 15) ||
+      (reinterpret_cast<uintptr_t>(a.RF) & 15))
+    return mdx_set_error(MDX_ERR_ARG, "posffn: X / LF / RF rows must be 16-byte aligned");
+  return MDX_OK;
+}
+static bool g_attr_pf = false, g_attr_pb = false;
+
+extern "C" int mdx_op_posffn_fwd(const mdx_posffn_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "posffn_fwd: null argument block");
+  if (a->E == 0) return MDX_OK;
+  if (int rc = check_posffn(*a)) return rc;
+  if (!a->a || !a->prod || !a->gpre || !a->gpost || !a->gate) return mdx_set_error(MDX_ERR_ARG, "posffn_fwd: null output");
+  if (!g_attr_pf) {
+    if (hipFuncSetAttribute((const void*)posffn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PfLds::BYTES) != hipSuccess)
+      return mdx_set_error(MDX_ERR_HIP, "posffn_fwd: cannot reserve LDS");
+    g_attr_pf = true;
+  }
+  const int ntiles = (int)((a->E + 15) / 16);
+  const int grid = std::max(1, std::min(ncus(), (ntiles + PF_WAVES - 1) / PF_WAVES));
+  hipLaunchKernelGGL(posffn_fwd_kernel, dim3(grid), dim3(PF_THREADS), PfLds::BYTES, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "posffn_fwd: launch failed");
+}
+
+extern "C" int mdx_op_posffn_bwd(const mdx_posffn_bwd_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "posffn_bwd: null argument block");
+  if (int rc = check_posffn(a->f)) return rc;
+  if (!a->f.gpre || !a->g_prod || !a->g_gate || !a->g_bf || !a->g_nf || !a->g_gpre || !a->g_x || !a->g_lf || !a->g_rf || !a->lnp)
+    return mdx_set_error(MDX_ERR_ARG, "posffn_bwd: null operand");
+  if ((a->ldgp & 3) || (reinterpret_cast<uintptr_t>(a->g_prod) & 7)) return mdx_set_error(MDX_ERR_ARG, "posffn_bwd: gradient rows must be 8-byte aligned");
+  if (!g_attr_pb) {
+    if (hipFuncSetAttribute((const void*)posffn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PbLds::BYTES) != hipSuccess)
+      return mdx_set_error(MDX_ERR_HIP, "posffn_bwd: cannot reserve LDS");
+    g_attr_pb = true;
+  }
+  hipLaunchKernelGGL(posffn_bwd_kernel, dim3(ncus()), dim3(PF_THREADS), PbLds::BYTES, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "posffn_bwd: launch failed");
 }

@@ -179,8 +179,23 @@ def edge_block(m, h_bond, g, h_node, bond_time, residual=False):
 
 
 def pos_update(m, h_node, h_edge, g, rel, dist, edge_time):
-    lf = T.gather(mlp(m.left_lin_edge, h_node), g.left)
-    w = bond_ffn(m.edge_lin, h_edge, edge_time, node_edges=T.mul_gather(lf, mlp(m.right_lin_edge, h_node), g.right))
+    lf_n, rf_n = mlp(m.left_lin_edge, h_node), mlp(m.right_lin_edge, h_node)
+    ff = m.edge_lin
+    if ff.use_gate and len(ff.inter_module.net) == 4 and len(ff.gate.net) == 4:
+        g0, bd = ff.gate.net[0], h_edge.shape[1]
+        nd = g0.weight.shape[1] - bd - 1
+        dims = (bd, nd, ff.bond_linear.weight.shape[0], g0.weight.shape[0], ff.gate.net[3].weight.shape[0])
+        if ff.node_linear.weight.shape[1] == nd and T.posffn_fused_ok(h_edge, lf_n, rf_n, dims):
+            # round 6: gather, product, the two first Linears, the gate MLP in one launch; the inter MLP's 256 x 256 Linear + LayerNorm
+            # and its 256 -> 1 Linear stay the per-operator launches
+            gt = ff.gate.net
+            prod, gate = T.posffn_front(h_edge, lf_n, rf_n, edge_time, g.left, g.right, dict(
+                Wb=ff.bond_linear.weight, Wn=ff.node_linear.weight, Wg1x=g0.weight[:, :bd], Wg1a=g0.weight[:, bd:bd + nd],
+                Wt=g0.weight[:, bd + nd:], bg1=g0.bias, gg=gt[1].weight, gbe=gt[1].bias, Wg2=gt[3].weight, bg2=gt[3].bias))
+            w = T.gate(mlp(ff.inter_module, prod), gate)
+            return T.scatter_sum(T.force(w, rel, dist), g.left)
+    lf = T.gather(lf_n, g.left)
+    w = bond_ffn(ff, h_edge, edge_time, node_edges=T.mul_gather(lf, rf_n, g.right))
     return T.scatter_sum(T.force(w, rel, dist), g.left)
 
 

@@ -1021,3 +1021,103 @@ class _EdgeTail(torch.autograd.Function):
 
 def edge_tail(h, by_left, by_right, plan_l, plan_r, params):
     return _EdgeTail.apply(h, by_left, by_right, plan_l, plan_r, *[params[k] for k in _EdgeTail.PARAMS])
+
+
+_FUSED_POS = __import__('os').environ.get('MDX_TRAIN_FUSED_POS', '1') != '0'
+
+
+def posffn_fused_ok(h_edge, lf, rf, dims):
+    """dims = (bond, node, inter, gate hidden, out): the kernel is built for PosUpdate's BondFFN (64, 64, 256, 32, 1)"""
+    return (_FUSED and _FUSED_POS and _AMP is not None and _AMP[0] == 2 and _AMP[1] and _AMP[2] and h_edge.dtype == torch.float16 and h_edge.dim() == 2
+            and h_edge.shape[0] >= FUSED_MIN_ROWS and dims == (64, 64, 256, 32, 1) and lf.dtype == torch.float16 and rf.dtype == torch.float16
+            and lf.shape[1] == 64 and rf.shape[1] == 64)
+
+
+class _PosFfnFront(torch.autograd.Function):
+    """(prod, gate) of PosUpdate's BondFFN (models/graph.py:388-390 with :133-141): prod = bond_linear(h_edge) * node_linear(a) (E,256),
+    gate = gate MLP([h_edge | a | t]) (E,1), a = LF[left] * RF[right].  args = h_edge (E,64) f16, LF, RF (N,64) f16, time (E,1) fp32,
+    plan_left, plan_right, then PARAMS."""
+    PARAMS = ('Wb', 'Wn', 'Wg1x', 'Wg1a', 'Wt', 'bg1', 'gg', 'gbe', 'Wg2', 'bg2')
+
+    @staticmethod
+    def _args(x, LF, RF, tc, pl, pr, P, bufs, E):
+        a = _lib.MdxPosFfnArgs()
+        a.X, a.ldx, a.LF, a.ldlf, a.RF, a.ldrf = x.data_ptr(), x.stride(0), LF.data_ptr(), LF.stride(0), RF.data_ptr(), RF.stride(0)
+        a.il, a.ir, a.te = pl.index.data_ptr(), pr.index.data_ptr(), tc.data_ptr()
+        for nm, ld in (('Wb', 'ldwb'), ('Wn', 'ldwn'), ('Wg1x', 'ldwg1x'), ('Wg1a', 'ldwg1a'), ('Wt', 'ldwt')):
+            setattr(a, nm, P[nm].data_ptr())
+            setattr(a, ld, P[nm].stride(0))
+        for nm in ('bg1', 'gg', 'gbe', 'Wg2', 'bg2'):
+            setattr(a, nm, P[nm].data_ptr())
+        for nm, t in bufs.items():
+            setattr(a, nm, t.data_ptr())
+        a.E = E
+        return a
+
+    @staticmethod
+    def forward(ctx, h_edge, LF, RF, time, plan_l, plan_r, *params):
+        import ctypes
+        al = lambda t: t if (t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0) else t.contiguous()
+        x, LFc, RFc = al(_rows(h_edge)), al(_rows(LF)), al(_rows(RF))
+        tc = _c(time).reshape(-1)
+        P = {}
+        for k, v in zip(_PosFfnFront.PARAMS, params):
+            P[k] = _wslice(v) if (v.dim() == 2 and k != 'Wg2') else _c(v).reshape(-1) if k in ('Wg2', 'bg2') else _c(v)
+        E, dev = x.shape[0], x.device
+        h = lambda *f: torch.empty(E, *f, dtype=torch.float16, device=dev)
+        bufs = {'a': h(64), 'prod': h(256), 'gpre': h(32), 'gpost': h(32), 'gate': h(1)}
+        a = _PosFfnFront._args(x, LFc, RFc, tc, plan_l, plan_r, P, bufs, E)
+        check(_L().mdx_op_posffn_fwd(ctypes.byref(a), stream()))
+        ctx.x, ctx.LF, ctx.RF, ctx.tc, ctx.P, ctx.bufs = x, LFc, RFc, tc, P, bufs
+        ctx.plan_l, ctx.plan_r, ctx.prec, ctx.x_dtype = plan_l, plan_r, _AMP, h_edge.dtype
+        ctx.refs = {k: v.detach() for k, v in zip(_PosFfnFront.PARAMS, params)}
+        ctx.time2d = time.detach().reshape(-1, 1)
+        return bufs['prod'], bufs['gate']
+
+    @staticmethod
+    def backward(ctx, g_prod, g_gate):
+        import ctypes
+        x, P, bufs, E, dev = ctx.x, ctx.P, ctx.bufs, ctx.x.shape[0], ctx.x.device
+        f16 = lambda t, f: (torch.zeros(E, f, dtype=torch.float16, device=dev) if t is None else
+                            (t if t.dtype == torch.float16 else t.to(torch.float16)).contiguous())
+        g_prod, g_gate = f16(g_prod, 256), f16(g_gate, 1)
+        h = lambda f: torch.empty(E, f, dtype=torch.float16, device=dev)
+        g = {'g_bf': h(256), 'g_nf': h(256), 'g_gpre': h(32), 'g_x': h(64), 'g_lf': h(64), 'g_rf': h(64)}
+        nwg, lnf = int(_L().mdx_op_bondffn_workgroups()), int(_L().mdx_op_posffn_lnp_floats())
+        lnp = torch.empty(nwg, lnf, dtype=torch.float32, device=dev)
+        b = _lib.MdxPosFfnBwdArgs()
+        b.f = _PosFfnFront._args(x, ctx.LF, ctx.RF, ctx.tc, ctx.plan_l, ctx.plan_r, P, bufs, E)
+        b.g_prod, b.ldgp, b.g_gate, b.lnp = g_prod.data_ptr(), g_prod.stride(0), g_gate.data_ptr(), lnp.data_ptr()
+        for nm, t in g.items():
+            setattr(b, nm, t.data_ptr())
+        check(_L().mdx_op_posffn_bwd(ctypes.byref(b), stream()))
+        need = dict(zip(_PosFfnFront.PARAMS, ctx.needs_input_grad[6:]))
+        grads = {k: None for k in _PosFfnFront.PARAMS}
+        with precision(ctx.prec):
+            wg = lambda gy, xin, wname, bname: _wgrad_into(grads, need, ctx.refs, E, gy, xin, wname, bname)
+            wg(g['g_bf'], x, 'Wb', None)
+            wg(g['g_nf'], bufs['a'], 'Wn', None)
+            wg(g['g_gpre'], x, 'Wg1x', 'bg1')
+            wg(g['g_gpre'], bufs['a'], 'Wg1a', None)
+            wg(g['g_gpre'], ctx.time2d, 'Wt', None)
+            wg(g_gate, bufs['gpost'], 'Wg2', 'bg2')
+        for nm, off in (('gg', 0), ('gbe', 32)):
+            if not need[nm]:
+                continue
+            dst = _sink_dst(ctx.refs[nm])
+            if dst is not None:
+                _sink_record(lnp.data_ptr() + 4 * off, dst, nwg, 1, 32, 32, lnf, 0, lnp)
+            else:
+                grads[nm] = lnp[:, off:off + 32].sum(0)
+        ni = ctx.needs_input_grad
+        g_x = g['g_x'] if ni[0] else None
+        if g_x is not None and g_x.dtype != ctx.x_dtype:
+            g_x = g_x.to(ctx.x_dtype)
+        g_LF = _segsum_raw(g['g_lf'], ctx.plan_l, torch.float16) if ni[1] else None
+        g_RF = _segsum_raw(g['g_rf'], ctx.plan_r, torch.float16) if ni[2] else None
+        ctx.bufs = ctx.P = None
+        return (g_x, g_LF, g_RF, None, None, None) + tuple(grads[k] for k in _PosFfnFront.PARAMS)
+
+
+def posffn_front(h_edge, lf, rf, time, plan_l, plan_r, params):
+    return _PosFfnFront.apply(h_edge, lf, rf, time, plan_l, plan_r, *[params[k] for k in _PosFfnFront.PARAMS])
