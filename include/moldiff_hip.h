@@ -478,6 +478,41 @@ typedef struct {
   void *g_bf, *g_nf, *g_gpre, *g_x, *g_lf, *g_rf;
   float* lnp;
 } mdx_posffn_bwd_args;
+/* NodeBlock message path in one forward and one backward launch (replaces, for training, reference models/graph.py:40-48: edge_net,
+ * the product with node_net(x)[col], msg_net, the gate MLP and the sigmoid product; the scatter_sum of :50 stays the caller's).
+ * Weights arrive as float16 A-operand packs written by mdx_op_pack_a (one launch for up to 10 matrices): job = {W (fp32, row stride ld),
+ * n_out, n_in, perm (1: the layer's input is the previous layer's accumulators), trans (1: pack W^T), out (n_out * n_in halves)}.
+ * Forward packs: W1e (256 x 64, perm 0), W2e, Wm (256 x 256, perm 1), Wg1 (the gate's edge columns, 256 x 64, perm 0), Wg2 (256 x 256,
+ * perm 1); backward packs (trans 1, perm 1): Wg2^T, Wm^T, W2e^T (256 x 256), Wg1^T, W1e^T (64 x 256).
+ * HN = node_net(x) (N,256) float16, PN = the gate's node + time columns applied per node (N,256) fp32, col (E) = right end point.
+ * Forward outputs, (E,256) float16 each: he_pre / he_post (edge_net's LayerNorm input / relu(output)), he, p = he * HN[col], m0 =
+ * msg_net(p), g_pre / g_post (gate LayerNorm), gt, msg = m0 * sigmoid(gt).  Backward: gA (N,256 fp32) = dL/d scatter_sum(msg, row);
+ * writes g_m0, g_gt, g_gpre, g_he, g_pre (weight-gradient operands), g_hne = per-edge dL/dHN[col], g_x (E,64) and
+ * mdx_op_bondffn_workgroups() partial rows of 1024 floats [d gamma_e | d beta_e | d gamma_g | d beta_g]. */
+typedef struct { const float* W; int64_t ld; int32_t n_out, n_in, perm, trans; void* out; } mdx_pack_job;
+typedef struct { mdx_pack_job job[10]; int32_t n; } mdx_pack_jobs;
+typedef struct {
+  const void* X; int64_t ldx;
+  const void* HN; int64_t ldhn;
+  const float* PN; int64_t ldpn;
+  const int64_t* col;
+  const void *pk_w1e, *pk_w2e, *pk_wm, *pk_wg1, *pk_wg2;
+  const float *b1e, *lng_e, *lnb_e, *b2e, *bm, *bg1, *lng_g, *lnb_g, *bg2;
+  void *he_pre, *he_post, *he, *p, *m0, *g_pre, *g_post, *gt, *msg;
+  int64_t E;
+} mdx_nodemsg_args;
+typedef struct {
+  mdx_nodemsg_args f;
+  const float* gA; int64_t ldga;
+  const int64_t* row;
+  const void *pk_wg2t, *pk_wg1t, *pk_wmt, *pk_w2et, *pk_w1et;
+  void *g_m0, *g_gt, *g_gpre, *g_hne, *g_he, *g_pre, *g_x;
+  float* lnp;
+} mdx_nodemsg_bwd_args;
+int mdx_op_pack_a(const mdx_pack_jobs* jobs, void* stream);
+int mdx_op_nodemsg_fwd(const mdx_nodemsg_args* a, void* stream);
+int mdx_op_nodemsg_bwd(const mdx_nodemsg_bwd_args* a, void* stream);
+int mdx_op_nodemsg_lnp_floats(void);
 int mdx_op_posffn_fwd(const mdx_posffn_args* a, void* stream);
 int mdx_op_posffn_bwd(const mdx_posffn_bwd_args* a, void* stream);
 int mdx_op_posffn_lnp_floats(void);

@@ -38,7 +38,7 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
 #ifndef MDX_BF_FWD_THREADS
-#define MDX_BF_FWD_THREADS 768   // forward: 12 waves per CU (135 VGPRs: three waves per SIMD fit); backward: 8 (256 VGPRs)
+#define MDX_BF_FWD_THREADS 512   // forward: 8 waves per CU (12 measured 100 us against 88 us: the third wave per SIMD thrashes the LDS weight reads)
 #endif
 constexpr int BF_THREADS = 512, BF_WAVES = 8;
 constexpr int BF_FWD_THREADS = MDX_BF_FWD_THREADS, BF_FWD_WAVES = BF_FWD_THREADS / 64;
@@ -1063,4 +1063,415 @@ extern "C" int mdx_op_posffn_bwd(const mdx_posffn_bwd_args* a, void* stream) {
   }
   hipLaunchKernelGGL(posffn_bwd_kernel, dim3(ncus()), dim3(PF_THREADS), PbLds::BYTES, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "posffn_bwd: launch failed");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// NodeBlock message path (reference models/graph.py:40-50: edge_net, the product with node_net(x)[col], msg_net, the gate MLP on
+// [edge | x[col] | t[col]] and the sigmoid product) as ONE forward and ONE backward launch.  Its three 256 x 256 weights (128 KiB each as
+// float16) do not fit LDS, so here -- unlike the kernels above -- the weights STREAM: a per-call pack kernel writes every weight of the
+// chain as float16 MFMA A-operand fragments ([k-step][feature tile][lane][8 halves], the k permutation of the accumulator-fed layers
+// baked in, transposes for the backward), and a wave fetches the 1-KiB fragment of each v_mfma_f32_16x16x32_f16 straight from L2 with
+// one 16-byte load per lane, eight fragments in flight ahead of the MFMAs that consume them.  The chain itself is the design of the
+// kernels above: a wave owns 16 rows, every later layer's B operand is the previous layer's accumulators, LayerNorm is wave-local.
+// LDS is free, so the backward's 256-wide LayerNorm-parameter gradients (they would cost 2 x 128 accumulator registers per lane) are
+// formed by transposing each tile through a wave-private 16.25-KiB LDS area: a lane then owns four FEATURES and adds the 16 rows in
+// order.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int NM_THREADS = 512, NM_WAVES = 8, NM_LNP = 1024;   // partial row: d gamma_e | d beta_e | d gamma_g | d beta_g (256 each)
+
+__global__ void pack_a_kernel(const mdx_pack_jobs a) {
+  const mdx_pack_job& jb = a.job[blockIdx.y];
+  const int FT = jb.n_out / 16;
+  const size_t total = (size_t)jb.n_out * jb.n_in;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+    const int j8 = (int)(o & 7), lane = (int)((o >> 3) & 63);
+    const size_t rest = o >> 9;
+    const int ft = (int)(rest % FT), ks = (int)(rest / FT);
+    const int c = lane & 15, q = lane >> 4;
+    const int n = 16 * ft + c;
+    const int k = jb.perm ? 16 * (2 * ks + (j8 >> 2)) + 4 * q + (j8 & 3) : 32 * ks + 8 * q + j8;
+    const float v = jb.trans ? jb.W[(size_t)k * jb.ld + n] : jb.W[(size_t)n * jb.ld + k];
+    reinterpret_cast<_Float16*>(jb.out)[o] = (_Float16)v;
+  }
+}
+
+// y[ft] += W x over KS k-steps, A fragments from a global pack ([ks][ft][lane][8]); fragments of the next half-step are requested
+// before the MFMAs of the current one (8 x 16 bytes per lane in flight)
+template <int FT, int KS>
+__device__ __forceinline__ void mmg(f32x4 (&y)[FT], const _Float16* __restrict__ pack, int lane, const f16x8_t (&x)[KS]) {
+  constexpr int G = FT >= 8 ? 8 : FT;        // fragments per half-step
+  constexpr int NG = KS * (FT / G);
+  const f16x8_t* p = reinterpret_cast<const f16x8_t*>(pack) + lane;
+  f16x8_t a[2][G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) a[0][i] = p[(size_t)i * 64];
+  static_for<0, NG>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int ks = g / (FT / G), f0 = (g % (FT / G)) * G;
+    if constexpr (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = p[(size_t)((g + 1) * G + i) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) y[f0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g & 1][i], x[ks], y[f0 + i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+template <int N>
+__device__ __forceinline__ void pairs(f16x8_t (&b)[N / 2], const uint2 (&pk)[N]) {
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) b[i] = pair8(pk[2 * i], pk[2 * i + 1]);
+}
+
+__global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodemsg_args a) {
+  __shared__ __attribute__((aligned(16))) float C[9 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  {
+    const float* src[9] = {a.b1e, a.lng_e, a.lnb_e, a.b2e, a.bm, a.bg1, a.lng_g, a.lnb_g, a.bg2};
+    for (int i = tid; i < 9 * 256; i += NM_THREADS) C[i] = src[i >> 8][i & 255];
+  }
+  __syncthreads();
+  const float *c_b1e = C, *c_ge = C + 256, *c_be = C + 512, *c_b2e = C + 768, *c_bm = C + 1024, *c_bg1 = C + 1280, *c_gg = C + 1536,
+              *c_gb = C + 1792, *c_bg2 = C + 2048;
+  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * NM_WAVES;
+  const _Float16* X = reinterpret_cast<const _Float16*>(a.X);
+  const _Float16* HN = reinterpret_cast<const _Float16*>(a.HN);
+  const _Float16 *w1e = reinterpret_cast<const _Float16*>(a.pk_w1e), *w2e = reinterpret_cast<const _Float16*>(a.pk_w2e),
+                 *wm = reinterpret_cast<const _Float16*>(a.pk_wm), *wg1 = reinterpret_cast<const _Float16*>(a.pk_wg1),
+                 *wg2 = reinterpret_cast<const _Float16*>(a.pk_wg2);
+  _Float16 *o_hepre = reinterpret_cast<_Float16*>(a.he_pre), *o_hepost = reinterpret_cast<_Float16*>(a.he_post),
+           *o_he = reinterpret_cast<_Float16*>(a.he), *o_p = reinterpret_cast<_Float16*>(a.p), *o_m0 = reinterpret_cast<_Float16*>(a.m0),
+           *o_gpre = reinterpret_cast<_Float16*>(a.g_pre), *o_gpost = reinterpret_cast<_Float16*>(a.g_post),
+           *o_gt = reinterpret_cast<_Float16*>(a.gt), *o_msg = reinterpret_cast<_Float16*>(a.msg);
+#pragma unroll 1
+  for (int tile = blockIdx.x * NM_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
+    const int64_t nc = a.col[r];
+    const _Float16* px = X + r * a.ldx + 8 * q;
+    const f16x8_t xb[2] = {*reinterpret_cast<const f16x8_t*>(px), *reinterpret_cast<const f16x8_t*>(px + 32)};
+    f32x4 y[16];
+    uint2 pk[16], pm[16];
+    f16x8_t b8[8];
+    // ---- edge_net: Linear -> LayerNorm -> ReLU -> Linear, then the product with node_net(x)[col]
+    zero<16>(y);
+    mmg<16, 2>(y, w1e, lane, xb);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      y[ft] = rh4(y[ft] + lds4(c_b1e + 16 * ft + 4 * q));
+      if (ok) sth4(o_hepre + ro + 16 * ft, pack4(y[ft]));
+    }
+    {
+      float mean, rstd;
+      ln_stats<16>(y, mean, rstd);
+#pragma unroll
+      for (int ft = 0; ft < 16; ++ft) {
+        pk[ft] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_ge + 16 * ft + 4 * q) + lds4(c_be + 16 * ft + 4 * q)));
+        if (ok) sth4(o_hepost + ro + 16 * ft, pk[ft]);
+      }
+    }
+    pairs<16>(b8, pk);
+    zero<16>(y);
+    mmg<16, 8>(y, w2e, lane, b8);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      y[ft] = rh4(y[ft] + lds4(c_b2e + 16 * ft + 4 * q));
+      pk[ft] = pack4(y[ft] * ldh4(HN + (size_t)nc * a.ldhn + 16 * ft + 4 * q));
+      if (ok) {
+        sth4(o_he + ro + 16 * ft, pack4(y[ft]));
+        sth4(o_p + ro + 16 * ft, pk[ft]);
+      }
+    }
+    // ---- msg_net
+    pairs<16>(b8, pk);
+    zero<16>(y);
+    mmg<16, 8>(y, wm, lane, b8);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      pm[ft] = pack4(y[ft] + lds4(c_bm + 16 * ft + 4 * q));
+      if (ok) sth4(o_m0 + ro + 16 * ft, pm[ft]);
+    }
+    // ---- gate: Linear([edge | x[col] | t[col]]) with the node / time columns as the hoisted fp32 addend PN[col]
+    zero<16>(y);
+    mmg<16, 2>(y, wg1, lane, xb);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      y[ft] = rh4((y[ft] + lds4(c_bg1 + 16 * ft + 4 * q)) + ldg4(a.PN + (size_t)nc * a.ldpn + 16 * ft + 4 * q));
+      if (ok) sth4(o_gpre + ro + 16 * ft, pack4(y[ft]));
+    }
+    {
+      float mean, rstd;
+      ln_stats<16>(y, mean, rstd);
+#pragma unroll
+      for (int ft = 0; ft < 16; ++ft) {
+        pk[ft] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_gg + 16 * ft + 4 * q) + lds4(c_gb + 16 * ft + 4 * q)));
+        if (ok) sth4(o_gpost + ro + 16 * ft, pk[ft]);
+      }
+    }
+    pairs<16>(b8, pk);
+    zero<16>(y);
+    mmg<16, 8>(y, wg2, lane, b8);
+    if (ok) {
+#pragma unroll
+      for (int ft = 0; ft < 16; ++ft) {
+        const f32x4 g = rh4(y[ft] + lds4(c_bg2 + 16 * ft + 4 * q));
+        sth4(o_gt + ro + 16 * ft, pack4(g));
+        sth4(o_msg + ro + 16 * ft, pack4(unpack4(pm[ft]) * rh4(sigmoid4(g))));
+      }
+    }
+  }
+}
+
+// tile (fp32, accumulator layout: lane (q, c) holds features 16 ft + 4 q .. of row c) -> column sums over the 16 rows, added to acc
+// (lane L owns features 4 L .. 4 L + 3): through the wave's LDS area T [16][NM_TLD]; rows in order 0..15
+constexpr int NM_TLD = 260;
+__device__ __forceinline__ void colsum_add(f32x4& acc, const f32x4 (&t)[16], float* T, int lane) {
+  const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ft = 0; ft < 16; ++ft) *reinterpret_cast<f32x4*>(T + c * NM_TLD + 16 * ft + 4 * q) = t[ft];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) acc = acc + *reinterpret_cast<const f32x4*>(T + rr * NM_TLD + 4 * lane);
+  __builtin_amdgcn_wave_barrier();   // the area is rewritten only after every lane has read it
+}
+
+// 256-wide LayerNorm + ReLU backward in place (g: dL/d output -> dL/d pre-activation), x = the pre-activation rows (packed float16);
+// the rows' contributions to d gamma / d beta go through colsum_add
+__device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const uint2 (&xp)[16], const float* gam, const float* bet, int q, bool ok,
+                                               f32x4& dgam, f32x4& dbet, float* T, int lane) {
+  constexpr float inv_n = 1.0f / 256;
+  float mean, rstd;
+  {
+    float sm = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      const f32x4 v = unpack4(xp[ft]);
+      sm += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    mean = sumq(sm) * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      const f32x4 v = unpack4(xp[ft]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float d = v[s] - mean;
+        d2 = fmaf(d, d, d2);
+      }
+    }
+    rstd = 1.0f / sqrtf(sumq(d2) * inv_n + MDX_LN_EPS);
+  }
+  // go = g masked by the ReLU (zero for rows past the end): d beta += go, d gamma += go * x_hat
+#pragma unroll
+  for (int ft = 0; ft < 16; ++ft) {
+    const f32x4 gm = lds4(gam + 16 * ft + 4 * q), bt = lds4(bet + 16 * ft + 4 * q);
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    const f32x4 yv = xh * gm + bt;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) g[ft][s] = (ok && yv[s] > 0.f) ? g[ft][s] : 0.f;
+  }
+  colsum_add(dbet, g, T, lane);
+  {
+    f32x4 t[16];
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) t[ft] = g[ft] * ((unpack4(xp[ft]) - splat4(mean)) * splat4(rstd));
+    colsum_add(dgam, t, T, lane);
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < 16; ++ft) {
+    const f32x4 gm = lds4(gam + 16 * ft + 4 * q);
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    g[ft] = g[ft] * gm;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      s1 += g[ft][s];
+      s2 = fmaf(g[ft][s], xh[s], s2);
+    }
+  }
+  const float m1 = sumq(s1) * inv_n, m2 = sumq(s2) * inv_n;
+#pragma unroll
+  for (int ft = 0; ft < 16; ++ft) {
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    g[ft] = (g[ft] - splat4(m1) - xh * splat4(m2)) * splat4(rstd);
+  }
+}
+
+__global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodemsg_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
+  float* C = reinterpret_cast<float*>(bf_smem);            // 4 x 256 LayerNorm parameters
+  float* Tall = C + 1024;                                   // NM_WAVES areas of 16 x NM_TLD floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  {
+    const float* src[4] = {a.f.lng_e, a.f.lnb_e, a.f.lng_g, a.f.lnb_g};
+    for (int i = tid; i < 1024; i += NM_THREADS) C[i] = src[i >> 8][i & 255];
+  }
+  __syncthreads();
+  float* T = Tall + (size_t)wave * 16 * NM_TLD;
+  const int E = (int)a.f.E, ntiles = (E + 15) >> 4, nw = gridDim.x * NM_WAVES;
+  const _Float16* X = reinterpret_cast<const _Float16*>(a.f.X);
+  const _Float16* HN = reinterpret_cast<const _Float16*>(a.f.HN);
+  const _Float16 *s_hepre = reinterpret_cast<const _Float16*>(a.f.he_pre), *s_he = reinterpret_cast<const _Float16*>(a.f.he),
+                 *s_m0 = reinterpret_cast<const _Float16*>(a.f.m0), *s_gpre = reinterpret_cast<const _Float16*>(a.f.g_pre),
+                 *s_gt = reinterpret_cast<const _Float16*>(a.f.gt);
+  const _Float16 *wg2t = reinterpret_cast<const _Float16*>(a.pk_wg2t), *wg1t = reinterpret_cast<const _Float16*>(a.pk_wg1t),
+                 *wmt = reinterpret_cast<const _Float16*>(a.pk_wmt), *w2et = reinterpret_cast<const _Float16*>(a.pk_w2et),
+                 *w1et = reinterpret_cast<const _Float16*>(a.pk_w1et);
+  _Float16 *o_gm0 = reinterpret_cast<_Float16*>(a.g_m0), *o_ggt = reinterpret_cast<_Float16*>(a.g_gt),
+           *o_ggpre = reinterpret_cast<_Float16*>(a.g_gpre), *o_ghne = reinterpret_cast<_Float16*>(a.g_hne),
+           *o_ghe = reinterpret_cast<_Float16*>(a.g_he), *o_gpre = reinterpret_cast<_Float16*>(a.g_pre), *o_gx = reinterpret_cast<_Float16*>(a.g_x);
+  f32x4 dge = splat4(0.f), dbe = splat4(0.f), dgg = splat4(0.f), dbg = splat4(0.f);
+#pragma unroll 1
+  for (int tile = blockIdx.x * NM_WAVES + wave; tile < ntiles; tile += nw) {
+    const int row = 16 * tile + c;
+    const bool ok = row < E;
+    const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
+    const int64_t nc = a.f.col[r], nr = a.row[r];
+    f32x4 y[16];
+    uint2 pk[16], xp[16];
+    f16x8_t b8[8];
+    f32x4 gx1[4];
+    // ---- msg = m0 * sigmoid(gt); the incoming gradient is dL/d(sum over the left node's rows), a float16 row per edge
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      const f32x4 g = rh4(ldg4(a.gA + (size_t)nr * a.ldga + 16 * ft + 4 * q));
+      const f32x4 m0 = ldh4(s_m0 + ro + 16 * ft), sg = sigmoid4(ldh4(s_gt + ro + 16 * ft));
+      pk[ft] = pack4(g * m0 * sg * (splat4(1.f) - sg));      // d gt
+      if (ok) {
+        sth4(o_gm0 + ro + 16 * ft, pack4(g * sg));          // d m0 (read back below: the registers are needed for the gate chain first)
+        sth4(o_ggt + ro + 16 * ft, pk[ft]);
+      }
+    }
+    // ---- gate backward
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(s_gpre + ro + 16 * ft);
+    pairs<16>(b8, pk);
+    zero<16>(y);
+    mmg<16, 8>(y, wg2t, lane, b8);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
+    ln256_relu_bwd(y, xp, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      pk[ft] = pack4(y[ft]);
+      if (ok) sth4(o_ggpre + ro + 16 * ft, pk[ft]);
+    }
+    pairs<16>(b8, pk);
+    zero<4>(gx1);
+    mmg<4, 8>(gx1, wg1t, lane, b8);
+    // ---- msg_net and the product p = he * hn[col]
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      const f32x4 g = rh4(ldg4(a.gA + (size_t)nr * a.ldga + 16 * ft + 4 * q));
+      pk[ft] = pack4(g * sigmoid4(ldh4(s_gt + ro + 16 * ft)));     // d m0 again (the same expression as above: same bits)
+    }
+    pairs<16>(b8, pk);
+    zero<16>(y);
+    mmg<16, 8>(y, wmt, lane, b8);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      const f32x4 gp = rh4(y[ft]);
+      pk[ft] = pack4(gp * ldh4(HN + (size_t)nc * a.f.ldhn + 16 * ft + 4 * q));       // d he
+      if (ok) {
+        sth4(o_ghne + ro + 16 * ft, pack4(gp * ldh4(s_he + ro + 16 * ft)));          // per-edge d hn[col]
+        sth4(o_ghe + ro + 16 * ft, pk[ft]);
+      }
+    }
+    // ---- edge_net backward
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(s_hepre + ro + 16 * ft);
+    pairs<16>(b8, pk);
+    zero<16>(y);
+    mmg<16, 8>(y, w2et, lane, b8);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
+    ln256_relu_bwd(y, xp, C + 0, C + 256, q, ok, dge, dbe, T, lane);
+#pragma unroll
+    for (int ft = 0; ft < 16; ++ft) {
+      pk[ft] = pack4(y[ft]);
+      if (ok) sth4(o_gpre + ro + 16 * ft, pk[ft]);
+    }
+    pairs<16>(b8, pk);
+    f32x4 gx2[4];
+    zero<4>(gx2);
+    mmg<4, 8>(gx2, w1et, lane, b8);
+    if (ok) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx2[ft]) + rh4(gx1[ft])));
+    }
+  }
+  // ---- LayerNorm-parameter gradients: lane L of every wave holds features 4 L .. 4 L + 3 of the four vectors; waves in fixed order
+  __syncthreads();
+  float* R = Tall;   // [NM_WAVES][NM_LNP]
+  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 4 * lane) = dge;
+  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 256 + 4 * lane) = dbe;
+  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 512 + 4 * lane) = dgg;
+  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 768 + 4 * lane) = dbg;
+  __syncthreads();
+  for (int i = tid; i < NM_LNP; i += NM_THREADS) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NM_WAVES; ++w) s += R[w * NM_LNP + i];
+    a.lnp[(size_t)blockIdx.x * NM_LNP + i] = s;
+  }
+}
+
+constexpr int NM_BWD_LDS = (1024 + NM_WAVES * 16 * NM_TLD) * 4;
+static bool g_attr_nb = false;
+
+extern "C" int mdx_op_nodemsg_lnp_floats(void) { return NM_LNP; }
+
+extern "C" int mdx_op_pack_a(const mdx_pack_jobs* jobs, void* stream) {
+  if (!jobs || jobs->n < 0 || jobs->n > 10) return mdx_set_error(MDX_ERR_ARG, "pack_a: bad job table");
+  if (jobs->n == 0) return MDX_OK;
+  for (int i = 0; i < jobs->n; ++i) {
+    const mdx_pack_job& j = jobs->job[i];
+    if (!j.W || !j.out || j.n_out % 16 || j.n_in % 32 || j.n_out <= 0 || j.n_in <= 0) return mdx_set_error(MDX_ERR_ARG, "pack_a: widths must be multiples of 16 / 32");
+  }
+  hipLaunchKernelGGL(pack_a_kernel, dim3(64, jobs->n), dim3(256), 0, (hipStream_t)stream, *jobs);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "pack_a: launch failed");
+}
+
+static int check_nodemsg(const mdx_nodemsg_args& a) {
+  if (a.E < 0) return mdx_set_error(MDX_ERR_ARG, "nodemsg: negative row count");
+  if (!a.X || !a.HN || !a.PN || !a.col || !a.pk_w1e || !a.pk_w2e || !a.pk_wm || !a.pk_wg1 || !a.pk_wg2 || !a.b1e || !a.lng_e || !a.lnb_e || !a.b2e ||
+      !a.bm || !a.bg1 || !a.lng_g || !a.lnb_g || !a.bg2)
+    return mdx_set_error(MDX_ERR_ARG, "nodemsg: null operand");
+  if ((a.ldx & 7) || (reinterpret_cast<uintptr_t>(a.X) & 15)) return mdx_set_error(MDX_ERR_ARG, "nodemsg: X rows must be 16-byte aligned");
+  if ((a.ldhn & 3) || (reinterpret_cast<uintptr_t>(a.HN) & 7) || (a.ldpn & 3) || (reinterpret_cast<uintptr_t>(a.PN) & 15))
+    return mdx_set_error(MDX_ERR_ARG, "nodemsg: node rows must be vector-aligned");
+  return MDX_OK;
+}
+
+extern "C" int mdx_op_nodemsg_fwd(const mdx_nodemsg_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "nodemsg_fwd: null argument block");
+  if (a->E == 0) return MDX_OK;
+  if (int rc = check_nodemsg(*a)) return rc;
+  if (!a->he_pre || !a->he_post || !a->he || !a->p || !a->m0 || !a->g_pre || !a->g_post || !a->gt || !a->msg) return mdx_set_error(MDX_ERR_ARG, "nodemsg_fwd: null output");
+  const int ntiles = (int)((a->E + 15) / 16);
+  const int grid = std::max(1, std::min(2 * ncus(), (ntiles + NM_WAVES - 1) / NM_WAVES));
+  hipLaunchKernelGGL(nodemsg_fwd_kernel, dim3(grid), dim3(NM_THREADS), 0, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "nodemsg_fwd: launch failed");
+}
+
+extern "C" int mdx_op_nodemsg_bwd(const mdx_nodemsg_bwd_args* a, void* stream) {
+  if (!a) return mdx_set_error(MDX_ERR_ARG, "nodemsg_bwd: null argument block");
+  if (int rc = check_nodemsg(a->f)) return rc;
+  if (!a->f.he_pre || !a->f.he || !a->f.m0 || !a->f.g_pre || !a->f.gt || !a->gA || !a->row || !a->pk_wg2t || !a->pk_wg1t || !a->pk_wmt || !a->pk_w2et ||
+      !a->pk_w1et || !a->g_m0 || !a->g_gt || !a->g_gpre || !a->g_hne || !a->g_he || !a->g_pre || !a->g_x || !a->lnp)
+    return mdx_set_error(MDX_ERR_ARG, "nodemsg_bwd: null operand");
+  if ((a->ldga & 3) || (reinterpret_cast<uintptr_t>(a->gA) & 15)) return mdx_set_error(MDX_ERR_ARG, "nodemsg_bwd: gA rows must be 16-byte aligned");
+  if (!g_attr_nb) {
+    if (hipFuncSetAttribute((const void*)nodemsg_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NM_BWD_LDS) != hipSuccess)
+      return mdx_set_error(MDX_ERR_HIP, "nodemsg_bwd: cannot reserve LDS");
+    g_attr_nb = true;
+  }
+  hipLaunchKernelGGL(nodemsg_bwd_kernel, dim3(ncus()), dim3(NM_THREADS), NM_BWD_LDS, (hipStream_t)stream, *a);
+  return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "nodemsg_bwd: launch failed");
 }
