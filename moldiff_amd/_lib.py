@@ -33,6 +33,7 @@ EXPORTS = [
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
     'mdx_op_edge_tail_fwd', 'mdx_op_edge_tail_bwd', 'mdx_op_edge_tail_lnp_floats',
     'mdx_op_posffn_fwd', 'mdx_op_posffn_bwd', 'mdx_op_posffn_lnp_floats',
+    'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
 ]
 
 
@@ -93,6 +94,26 @@ class MdxPosFfnArgs(ctypes.Structure):   # == mdx_posffn_args
 class MdxPosFfnBwdArgs(ctypes.Structure):   # == mdx_posffn_bwd_args
     _fields_ = [('f', MdxPosFfnArgs), ('g_prod', c_void_p), ('ldgp', c_int64), ('g_gate', c_void_p), ('g_bf', c_void_p), ('g_nf', c_void_p),
                 ('g_gpre', c_void_p), ('g_x', c_void_p), ('g_lf', c_void_p), ('g_rf', c_void_p), ('lnp', c_void_p)]
+
+
+class MdxPackJob(ctypes.Structure):   # == mdx_pack_job
+    _fields_ = [('W', c_void_p), ('ld', c_int64), ('n_out', c_int32), ('n_in', c_int32), ('perm', c_int32), ('trans', c_int32), ('out', c_void_p)]
+
+
+class MdxPackJobs(ctypes.Structure):   # == mdx_pack_jobs
+    _fields_ = [('job', MdxPackJob * 10), ('n', c_int32)]
+
+
+class MdxNodeMsgArgs(ctypes.Structure):   # == mdx_nodemsg_args
+    _fields_ = ([('X', c_void_p), ('ldx', c_int64), ('HN', c_void_p), ('ldhn', c_int64), ('PN', c_void_p), ('ldpn', c_int64), ('col', c_void_p)] +
+                [(n, c_void_p) for n in ('pk_w1e', 'pk_w2e', 'pk_wm', 'pk_wg1', 'pk_wg2', 'b1e', 'lng_e', 'lnb_e', 'b2e', 'bm', 'bg1', 'lng_g',
+                                         'lnb_g', 'bg2', 'he_pre', 'he_post', 'he', 'p', 'm0', 'g_pre', 'g_post', 'gt', 'msg')] + [('E', c_int64)])
+
+
+class MdxNodeMsgBwdArgs(ctypes.Structure):   # == mdx_nodemsg_bwd_args
+    _fields_ = ([('f', MdxNodeMsgArgs), ('gA', c_void_p), ('ldga', c_int64), ('row', c_void_p)] +
+                [(n, c_void_p) for n in ('pk_wg2t', 'pk_wg1t', 'pk_wmt', 'pk_w2et', 'pk_w1et', 'g_m0', 'g_gt', 'g_gpre', 'g_hne', 'g_he', 'g_pre',
+                                         'g_x', 'lnp')])
 
 
 class MdxConfig(ctypes.Structure):
@@ -215,6 +236,9 @@ def lib():
         L.mdx_op_edge_tail_bwd.argtypes = [POINTER(MdxEdgeTailBwdArgs), c_void_p]
         L.mdx_op_posffn_fwd.argtypes = [POINTER(MdxPosFfnArgs), c_void_p]
         L.mdx_op_posffn_bwd.argtypes = [POINTER(MdxPosFfnBwdArgs), c_void_p]
+        L.mdx_op_pack_a.argtypes = [POINTER(MdxPackJobs), c_void_p]
+        L.mdx_op_nodemsg_fwd.argtypes = [POINTER(MdxNodeMsgArgs), c_void_p]
+        L.mdx_op_nodemsg_bwd.argtypes = [POINTER(MdxNodeMsgBwdArgs), c_void_p]
         _lib = L
     return _lib
 

@@ -1099,18 +1099,23 @@ __global__ void pack_a_kernel(const mdx_pack_jobs a) {
 // before the MFMAs of the current one (8 x 16 bytes per lane in flight)
 template <int FT, int KS>
 __device__ __forceinline__ void mmg(f32x4 (&y)[FT], const _Float16* __restrict__ pack, int lane, const f16x8_t (&x)[KS]) {
-  constexpr int G = FT >= 8 ? 8 : FT;        // fragments per half-step
+  constexpr int G = 4;                       // fragments per group (two groups = 8 x 16 bytes per lane in flight)
   constexpr int NG = KS * (FT / G);
-  const f16x8_t* p = reinterpret_cast<const f16x8_t*>(pack) + lane;
+  // buffer loads: scalar base + the lane's byte offset + an immediate fragment offset -- no per-fragment vector address arithmetic
+  // (with flat loads the 128 hoisted 64-bit lane addresses of a 256 x 256 layer were what spilled)
+  asm volatile("" : "+s"(pack));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pack), 0, -1, 0x00020000);
+  const unsigned lo = 16u * (unsigned)lane;
+  auto frag = [&](int i) { return __builtin_bit_cast(f16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, i * 1024, 0)); };
   f16x8_t a[2][G];
 #pragma unroll
-  for (int i = 0; i < G; ++i) a[0][i] = p[(size_t)i * 64];
+  for (int i = 0; i < G; ++i) a[0][i] = frag(i);
   static_for<0, NG>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
     constexpr int ks = g / (FT / G), f0 = (g % (FT / G)) * G;
     if constexpr (g + 1 < NG) {
 #pragma unroll
-      for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = p[(size_t)((g + 1) * G + i) * 64];
+      for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = frag((g + 1) * G + i);
     }
 #pragma unroll
     for (int i = 0; i < G; ++i) y[f0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g & 1][i], x[ks], y[f0 + i], 0, 0, 0);
@@ -1154,8 +1159,10 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
     const _Float16* px = X + r * a.ldx + 8 * q;
     const f16x8_t xb[2] = {*reinterpret_cast<const f16x8_t*>(px), *reinterpret_cast<const f16x8_t*>(px + 32)};
     f32x4 y[16];
-    uint2 pk[16], pm[16];
     f16x8_t b8[8];
+    // B operand of the next layer from the tiles as they are produced (two tiles = one k-step); SB: keep the per-tile loads next to
+    // their use (hoisted together, 16 x 4 registers of LayerNorm parameters / gathered rows spill)
+#define NM_SB(ft) if ((ft) % 4 == 3) __builtin_amdgcn_sched_barrier(0)
     // ---- edge_net: Linear -> LayerNorm -> ReLU -> Linear, then the product with node_net(x)[col]
     zero<16>(y);
     mmg<16, 2>(y, w1e, lane, xb);
@@ -1163,36 +1170,51 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
     for (int ft = 0; ft < 16; ++ft) {
       y[ft] = rh4(y[ft] + lds4(c_b1e + 16 * ft + 4 * q));
       if (ok) sth4(o_hepre + ro + 16 * ft, pack4(y[ft]));
+      NM_SB(ft);
     }
     {
       float mean, rstd;
       ln_stats<16>(y, mean, rstd);
 #pragma unroll
-      for (int ft = 0; ft < 16; ++ft) {
-        pk[ft] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_ge + 16 * ft + 4 * q) + lds4(c_be + 16 * ft + 4 * q)));
-        if (ok) sth4(o_hepost + ro + 16 * ft, pk[ft]);
+      for (int g2 = 0; g2 < 8; ++g2) {
+        uint2 h[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ft = 2 * g2 + j;
+          h[j] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_ge + 16 * ft + 4 * q) + lds4(c_be + 16 * ft + 4 * q)));
+          if (ok) sth4(o_hepost + ro + 16 * ft, h[j]);
+        }
+        b8[g2] = pair8(h[0], h[1]);
+        NM_SB(2 * g2 + 1);
       }
     }
-    pairs<16>(b8, pk);
     zero<16>(y);
     mmg<16, 8>(y, w2e, lane, b8);
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      y[ft] = rh4(y[ft] + lds4(c_b2e + 16 * ft + 4 * q));
-      pk[ft] = pack4(y[ft] * ldh4(HN + (size_t)nc * a.ldhn + 16 * ft + 4 * q));
-      if (ok) {
-        sth4(o_he + ro + 16 * ft, pack4(y[ft]));
-        sth4(o_p + ro + 16 * ft, pk[ft]);
+    for (int g2 = 0; g2 < 8; ++g2) {
+      uint2 h[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ft = 2 * g2 + j;
+        const f32x4 he = rh4(y[ft] + lds4(c_b2e + 16 * ft + 4 * q));
+        h[j] = pack4(he * ldh4(HN + (size_t)nc * a.ldhn + 16 * ft + 4 * q));
+        if (ok) {
+          sth4(o_he + ro + 16 * ft, pack4(he));
+          sth4(o_p + ro + 16 * ft, h[j]);
+        }
       }
+      b8[g2] = pair8(h[0], h[1]);
+      NM_SB(2 * g2 + 1);
     }
-    // ---- msg_net
-    pairs<16>(b8, pk);
+    // ---- msg_net (m0 is read back at the end: L2-hot, and 32 registers cheaper than holding it across the gate chain)
     zero<16>(y);
     mmg<16, 8>(y, wm, lane, b8);
+    if (ok) {
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      pm[ft] = pack4(y[ft] + lds4(c_bm + 16 * ft + 4 * q));
-      if (ok) sth4(o_m0 + ro + 16 * ft, pm[ft]);
+      for (int ft = 0; ft < 16; ++ft) {
+        sth4(o_m0 + ro + 16 * ft, pack4(y[ft] + lds4(c_bm + 16 * ft + 4 * q)));
+        NM_SB(ft);
+      }
     }
     // ---- gate: Linear([edge | x[col] | t[col]]) with the node / time columns as the hoisted fp32 addend PN[col]
     zero<16>(y);
@@ -1201,17 +1223,24 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
     for (int ft = 0; ft < 16; ++ft) {
       y[ft] = rh4((y[ft] + lds4(c_bg1 + 16 * ft + 4 * q)) + ldg4(a.PN + (size_t)nc * a.ldpn + 16 * ft + 4 * q));
       if (ok) sth4(o_gpre + ro + 16 * ft, pack4(y[ft]));
+      NM_SB(ft);
     }
     {
       float mean, rstd;
       ln_stats<16>(y, mean, rstd);
 #pragma unroll
-      for (int ft = 0; ft < 16; ++ft) {
-        pk[ft] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_gg + 16 * ft + 4 * q) + lds4(c_gb + 16 * ft + 4 * q)));
-        if (ok) sth4(o_gpost + ro + 16 * ft, pk[ft]);
+      for (int g2 = 0; g2 < 8; ++g2) {
+        uint2 h[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ft = 2 * g2 + j;
+          h[j] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_gg + 16 * ft + 4 * q) + lds4(c_gb + 16 * ft + 4 * q)));
+          if (ok) sth4(o_gpost + ro + 16 * ft, h[j]);
+        }
+        b8[g2] = pair8(h[0], h[1]);
+        NM_SB(2 * g2 + 1);
       }
     }
-    pairs<16>(b8, pk);
     zero<16>(y);
     mmg<16, 8>(y, wg2, lane, b8);
     if (ok) {
@@ -1219,32 +1248,39 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
       for (int ft = 0; ft < 16; ++ft) {
         const f32x4 g = rh4(y[ft] + lds4(c_bg2 + 16 * ft + 4 * q));
         sth4(o_gt + ro + 16 * ft, pack4(g));
-        sth4(o_msg + ro + 16 * ft, pack4(unpack4(pm[ft]) * rh4(sigmoid4(g))));
+        sth4(o_msg + ro + 16 * ft, pack4(ldh4(o_m0 + ro + 16 * ft) * rh4(sigmoid4(g))));
+        NM_SB(ft);
       }
     }
   }
 }
 
-// tile (fp32, accumulator layout: lane (q, c) holds features 16 ft + 4 q .. of row c) -> column sums over the 16 rows, added to acc
-// (lane L owns features 4 L .. 4 L + 3): through the wave's LDS area T [16][NM_TLD]; rows in order 0..15
+// Column sums over the 16 rows of a tile (fp32, accumulator layout: lane (q, c) holds features 16 ft + 4 q .. of row c), added to acc
+// (lane L owns features 4 L .. 4 L + 3): the tile goes through the wave's LDS area T [16][NM_TLD] one feature tile at a time (cs_put),
+// then every lane adds its four features of rows 0..15 in order (cs_sum).
 constexpr int NM_TLD = 260;
-__device__ __forceinline__ void colsum_add(f32x4& acc, const f32x4 (&t)[16], float* T, int lane) {
-  const int c = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int ft = 0; ft < 16; ++ft) *reinterpret_cast<f32x4*>(T + c * NM_TLD + 16 * ft + 4 * q) = t[ft];
+__device__ __forceinline__ void cs_put(float* T, int ft, f32x4 v, int c, int q) { *reinterpret_cast<f32x4*>(T + c * NM_TLD + 16 * ft + 4 * q) = v; }
+__device__ __forceinline__ void cs_sum(f32x4& acc, const float* T, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) acc = acc + *reinterpret_cast<const f32x4*>(T + rr * NM_TLD + 4 * lane);
+  for (int rr = 0; rr < 16; ++rr) {   // four rows in flight (all 16 at once cost 64 registers where the kernel has none to spare):
+    acc = acc + *reinterpret_cast<const volatile f32x4*>(T + rr * NM_TLD + 4 * lane);
+    if (rr % 4 == 3) asm volatile("" : "+v"(acc));   // the sum is pinned every four rows, so the reads cannot all be hoisted above the adds
+  }
   __builtin_amdgcn_wave_barrier();   // the area is rewritten only after every lane has read it
 }
 
-// 256-wide LayerNorm + ReLU backward in place (g: dL/d output -> dL/d pre-activation), x = the pre-activation rows (packed float16);
-// the rows' contributions to d gamma / d beta go through colsum_add
-__device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const uint2 (&xp)[16], const float* gam, const float* bet, int q, bool ok,
+// 256-wide LayerNorm + ReLU backward in place (g: dL/d output -> dL/d pre-activation); xrow = this lane's row of the stored
+// pre-activation (float16, + 4 q); the rows' contributions to d gamma / d beta go through the LDS column sums
+__device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* xrow, const float* gam, const float* bet, int q, bool ok,
                                                f32x4& dgam, f32x4& dbet, float* T, int lane) {
   constexpr float inv_n = 1.0f / 256;
+  const int c = lane & 15;
+  uint2 xp[16];
+#pragma unroll
+  for (int ft = 0; ft < 16; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(xrow + 16 * ft);
   float mean, rstd;
   {
     float sm = 0.f;
@@ -1274,14 +1310,16 @@ __device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const uint2 (&xp)
     const f32x4 yv = xh * gm + bt;
 #pragma unroll
     for (int s = 0; s < 4; ++s) g[ft][s] = (ok && yv[s] > 0.f) ? g[ft][s] : 0.f;
+    cs_put(T, ft, g[ft], c, q);
+    if (ft % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
-  colsum_add(dbet, g, T, lane);
-  {
-    f32x4 t[16];
+  cs_sum(dbet, T, lane);
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) t[ft] = g[ft] * ((unpack4(xp[ft]) - splat4(mean)) * splat4(rstd));
-    colsum_add(dgam, t, T, lane);
+  for (int ft = 0; ft < 16; ++ft) {
+    cs_put(T, ft, g[ft] * ((unpack4(xp[ft]) - splat4(mean)) * splat4(rstd)), c, q);
+    if (ft % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
+  cs_sum(dgam, T, lane);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int ft = 0; ft < 16; ++ft) {
@@ -1293,6 +1331,7 @@ __device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const uint2 (&xp)
       s1 += g[ft][s];
       s2 = fmaf(g[ft][s], xh[s], s2);
     }
+    if (ft % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
   const float m1 = sumq(s1) * inv_n, m2 = sumq(s2) * inv_n;
 #pragma unroll
@@ -1315,7 +1354,6 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
   __syncthreads();
   float* T = Tall + (size_t)wave * 16 * NM_TLD;
   const int E = (int)a.f.E, ntiles = (E + 15) >> 4, nw = gridDim.x * NM_WAVES;
-  const _Float16* X = reinterpret_cast<const _Float16*>(a.f.X);
   const _Float16* HN = reinterpret_cast<const _Float16*>(a.f.HN);
   const _Float16 *s_hepre = reinterpret_cast<const _Float16*>(a.f.he_pre), *s_he = reinterpret_cast<const _Float16*>(a.f.he),
                  *s_m0 = reinterpret_cast<const _Float16*>(a.f.m0), *s_gpre = reinterpret_cast<const _Float16*>(a.f.g_pre),
@@ -1334,70 +1372,89 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
     const int64_t nc = a.f.col[r], nr = a.row[r];
     f32x4 y[16];
-    uint2 pk[16], xp[16];
     f16x8_t b8[8];
     f32x4 gx1[4];
+#define NM_SB(ft) if ((ft) % 4 == 3) __builtin_amdgcn_sched_barrier(0)
     // ---- msg = m0 * sigmoid(gt); the incoming gradient is dL/d(sum over the left node's rows), a float16 row per edge
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      const f32x4 g = rh4(ldg4(a.gA + (size_t)nr * a.ldga + 16 * ft + 4 * q));
-      const f32x4 m0 = ldh4(s_m0 + ro + 16 * ft), sg = sigmoid4(ldh4(s_gt + ro + 16 * ft));
-      pk[ft] = pack4(g * m0 * sg * (splat4(1.f) - sg));      // d gt
-      if (ok) {
-        sth4(o_gm0 + ro + 16 * ft, pack4(g * sg));          // d m0 (read back below: the registers are needed for the gate chain first)
-        sth4(o_ggt + ro + 16 * ft, pk[ft]);
+    for (int g2 = 0; g2 < 8; ++g2) {
+      uint2 h[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ft = 2 * g2 + j;
+        const f32x4 g = rh4(ldg4(a.gA + (size_t)nr * a.ldga + 16 * ft + 4 * q));
+        const f32x4 m0 = ldh4(s_m0 + ro + 16 * ft), sg = sigmoid4(ldh4(s_gt + ro + 16 * ft));
+        h[j] = pack4(g * m0 * sg * (splat4(1.f) - sg));      // d gt
+        if (ok) {
+          sth4(o_gm0 + ro + 16 * ft, pack4(g * sg));        // d m0 (formed again below: the registers go to the gate chain first)
+          sth4(o_ggt + ro + 16 * ft, h[j]);
+        }
       }
+      b8[g2] = pair8(h[0], h[1]);
+      NM_SB(2 * g2 + 1);
     }
     // ---- gate backward
-#pragma unroll
-    for (int ft = 0; ft < 16; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(s_gpre + ro + 16 * ft);
-    pairs<16>(b8, pk);
     zero<16>(y);
     mmg<16, 8>(y, wg2t, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
-    ln256_relu_bwd(y, xp, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
+    ln256_relu_bwd(y, s_gpre + ro, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      pk[ft] = pack4(y[ft]);
-      if (ok) sth4(o_ggpre + ro + 16 * ft, pk[ft]);
+    for (int g2 = 0; g2 < 8; ++g2) {
+      const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
+      if (ok) {
+        sth4(o_ggpre + ro + 16 * (2 * g2), h0);
+        sth4(o_ggpre + ro + 16 * (2 * g2 + 1), h1);
+      }
+      b8[g2] = pair8(h0, h1);
     }
-    pairs<16>(b8, pk);
     zero<4>(gx1);
     mmg<4, 8>(gx1, wg1t, lane, b8);
     // ---- msg_net and the product p = he * hn[col]
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      const f32x4 g = rh4(ldg4(a.gA + (size_t)nr * a.ldga + 16 * ft + 4 * q));
-      pk[ft] = pack4(g * sigmoid4(ldh4(s_gt + ro + 16 * ft)));     // d m0 again (the same expression as above: same bits)
+    for (int g2 = 0; g2 < 8; ++g2) {
+      uint2 h[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ft = 2 * g2 + j;
+        h[j] = *reinterpret_cast<const uint2*>(o_gm0 + ro + 16 * ft);     // d m0, written above by this lane (rows past the end: unused)
+      }
+      b8[g2] = pair8(h[0], h[1]);
+      NM_SB(2 * g2 + 1);
     }
-    pairs<16>(b8, pk);
     zero<16>(y);
     mmg<16, 8>(y, wmt, lane, b8);
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      const f32x4 gp = rh4(y[ft]);
-      pk[ft] = pack4(gp * ldh4(HN + (size_t)nc * a.f.ldhn + 16 * ft + 4 * q));       // d he
-      if (ok) {
-        sth4(o_ghne + ro + 16 * ft, pack4(gp * ldh4(s_he + ro + 16 * ft)));          // per-edge d hn[col]
-        sth4(o_ghe + ro + 16 * ft, pk[ft]);
+    for (int g2 = 0; g2 < 8; ++g2) {
+      uint2 h[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ft = 2 * g2 + j;
+        const f32x4 gp = rh4(y[ft]);
+        h[j] = pack4(gp * ldh4(HN + (size_t)nc * a.f.ldhn + 16 * ft + 4 * q));       // d he
+        if (ok) {
+          sth4(o_ghne + ro + 16 * ft, pack4(gp * ldh4(s_he + ro + 16 * ft)));        // per-edge d hn[col]
+          sth4(o_ghe + ro + 16 * ft, h[j]);
+        }
       }
+      b8[g2] = pair8(h[0], h[1]);
+      NM_SB(2 * g2 + 1);
     }
     // ---- edge_net backward
-#pragma unroll
-    for (int ft = 0; ft < 16; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(s_hepre + ro + 16 * ft);
-    pairs<16>(b8, pk);
     zero<16>(y);
     mmg<16, 8>(y, w2et, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
-    ln256_relu_bwd(y, xp, C + 0, C + 256, q, ok, dge, dbe, T, lane);
+    ln256_relu_bwd(y, s_hepre + ro, C + 0, C + 256, q, ok, dge, dbe, T, lane);
 #pragma unroll
-    for (int ft = 0; ft < 16; ++ft) {
-      pk[ft] = pack4(y[ft]);
-      if (ok) sth4(o_gpre + ro + 16 * ft, pk[ft]);
+    for (int g2 = 0; g2 < 8; ++g2) {
+      const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
+      if (ok) {
+        sth4(o_gpre + ro + 16 * (2 * g2), h0);
+        sth4(o_gpre + ro + 16 * (2 * g2 + 1), h1);
+      }
+      b8[g2] = pair8(h0, h1);
     }
-    pairs<16>(b8, pk);
     f32x4 gx2[4];
     zero<4>(gx2);
     mmg<4, 8>(gx2, w1et, lane, b8);

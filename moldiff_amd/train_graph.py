@@ -106,15 +106,28 @@ def smear(gs, d):
 
 def node_block(m, x, g, edge_attr, node_time):
     h_node = mlp(m.node_net, x)
-    h_edge = mlp(m.edge_net, edge_attr)
-    msg = T.linear(T.mul_gather(h_edge, h_node, g.right), m.msg_net.weight, m.msg_net.bias)
+    agg = per_node = None
     if m.use_gate:   # models/graph.py:46-48
         g0, ed = m.gate.net[0], edge_attr.shape[1]
         per_node = T.linear(cat(x, node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
-        gt = mlp_first(m.gate, edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right))
-        msg = T.gate(msg, gt)
-    out = T.linear_ln_relu(x, m.centroid_lin.weight, m.centroid_lin.bias, m.layer_norm.weight, m.layer_norm.bias,
-                           addend=T.scatter_sum(msg, g.left))
+        if len(m.edge_net.net) == 4 and len(m.gate.net) == 4:
+            en, gt_ = m.edge_net.net, m.gate.net
+            shapes = (tuple(en[0].weight.shape), tuple(en[3].weight.shape), tuple(m.msg_net.weight.shape), (g0.weight.shape[0], ed),
+                      tuple(gt_[3].weight.shape))
+            if T.nodemsg_fused_ok(edge_attr, h_node, per_node, shapes):
+                # round 6: the whole message path (edge_net, product, msg_net, gate MLP, sigmoid product) in one launch each way
+                agg = T.nodemsg(edge_attr, h_node, per_node, g.right, g.left, dict(
+                    W1e=en[0].weight, b1e=en[0].bias, lng_e=en[1].weight, lnb_e=en[1].bias, W2e=en[3].weight, b2e=en[3].bias,
+                    Wm=m.msg_net.weight, bm=m.msg_net.bias, Wg1=g0.weight[:, :ed], bg1=g0.bias, lng_g=gt_[1].weight, lnb_g=gt_[1].bias,
+                    Wg2=gt_[3].weight, bg2=gt_[3].bias))
+    if agg is None:
+        h_edge = mlp(m.edge_net, edge_attr)
+        msg = T.linear(T.mul_gather(h_edge, h_node, g.right), m.msg_net.weight, m.msg_net.bias)
+        if m.use_gate:
+            gt = mlp_first(m.gate, edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right))
+            msg = T.gate(msg, gt)
+        agg = T.scatter_sum(msg, g.left)
+    out = T.linear_ln_relu(x, m.centroid_lin.weight, m.centroid_lin.bias, m.layer_norm.weight, m.layer_norm.bias, addend=agg)
     return T.linear(out, m.out_transform.weight, m.out_transform.bias)
 
 

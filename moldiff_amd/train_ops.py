@@ -1121,3 +1121,118 @@ class _PosFfnFront(torch.autograd.Function):
 
 def posffn_front(h_edge, lf, rf, time, plan_l, plan_r, params):
     return _PosFfnFront.apply(h_edge, lf, rf, time, plan_l, plan_r, *[params[k] for k in _PosFfnFront.PARAMS])
+
+
+_FUSED_NODE = __import__('os').environ.get('MDX_TRAIN_FUSED_NODE', '1') != '0'
+
+
+def nodemsg_fused_ok(edge_attr, hn, pn, shapes):
+    """shapes = (edge_net.0, edge_net.3, msg_net, gate.0 edge columns, gate.3 weight shapes): built for 64 -> 256 -> 256"""
+    return (_FUSED and _FUSED_NODE and _AMP is not None and _AMP[0] == 2 and _AMP[1] and _AMP[2] and edge_attr.dtype == torch.float16
+            and edge_attr.dim() == 2 and edge_attr.shape[1] == 64 and edge_attr.shape[0] >= FUSED_MIN_ROWS and hn.dtype == torch.float16
+            and hn.shape[1] == 256 and pn.dtype == torch.float32 and pn.shape[1] == 256
+            and shapes == ((256, 64), (256, 256), (256, 256), (256, 64), (256, 256)))
+
+
+class _NodeMsg(torch.autograd.Function):
+    """scatter_sum(msg, left) of the NodeBlock message path (models/graph.py:40-50) as one node:
+    args = edge_attr (E,64) f16, HN = node_net(x) (N,256) f16, PN = gate.net.0[:, node + time columns](cat(x, t)) (N,256) fp32,
+    plan_col (right), plan_row (left), then PARAMS."""
+    PARAMS = ('W1e', 'b1e', 'lng_e', 'lnb_e', 'W2e', 'b2e', 'Wm', 'bm', 'Wg1', 'bg1', 'lng_g', 'lnb_g', 'Wg2', 'bg2')
+    # (name, weight, n_out, n_in, perm, trans) of the ten A-operand packs: five forward, five backward (transposes)
+    PACKS = (('pk_w1e', 'W1e', 256, 64, 0, 0), ('pk_w2e', 'W2e', 256, 256, 1, 0), ('pk_wm', 'Wm', 256, 256, 1, 0), ('pk_wg1', 'Wg1', 256, 64, 0, 0),
+             ('pk_wg2', 'Wg2', 256, 256, 1, 0), ('pk_wg2t', 'Wg2', 256, 256, 1, 1), ('pk_wg1t', 'Wg1', 64, 256, 1, 1), ('pk_wmt', 'Wm', 256, 256, 1, 1),
+             ('pk_w2et', 'W2e', 256, 256, 1, 1), ('pk_w1et', 'W1e', 64, 256, 1, 1))
+
+    @staticmethod
+    def _args(x, HN, PN, plan_col, P, packs, bufs, E):
+        a = _lib.MdxNodeMsgArgs()
+        a.X, a.ldx, a.HN, a.ldhn, a.PN, a.ldpn, a.col = x.data_ptr(), x.stride(0), HN.data_ptr(), HN.stride(0), PN.data_ptr(), PN.stride(0), plan_col.index.data_ptr()
+        for nm in ('pk_w1e', 'pk_w2e', 'pk_wm', 'pk_wg1', 'pk_wg2'):
+            setattr(a, nm, packs[nm])
+        for nm in ('b1e', 'lng_e', 'lnb_e', 'b2e', 'bm', 'bg1', 'lng_g', 'lnb_g', 'bg2'):
+            setattr(a, nm, P[nm].data_ptr())
+        for nm, t in bufs.items():
+            setattr(a, nm, t.data_ptr())
+        a.E = E
+        return a
+
+    @staticmethod
+    def forward(ctx, edge_attr, HN, PN, plan_col, plan_row, *params):
+        import ctypes
+        x = _rows(edge_attr)
+        if x.stride(0) % 8 or x.data_ptr() % 16:
+            x = x.contiguous()
+        HNc, PNc = _rows(HN), _rows(PN)
+        P = {k: _wslice(v) if v.dim() == 2 else _c(v) for k, v in zip(_NodeMsg.PARAMS, params)}
+        E, dev = x.shape[0], x.device
+        # the ten weight packs of this call: one buffer, one launch
+        sizes = [no * ni for _, _, no, ni, _, _ in _NodeMsg.PACKS]
+        buf = torch.empty(sum(sizes), dtype=torch.float16, device=dev)
+        jobs, packs, off = _lib.MdxPackJobs(), {}, 0
+        for i, (nm, wn, no, ni, perm, trans) in enumerate(_NodeMsg.PACKS):
+            j = jobs.job[i]
+            j.W, j.ld, j.n_out, j.n_in, j.perm, j.trans = P[wn].data_ptr(), P[wn].stride(0), no, ni, perm, trans
+            j.out = packs[nm] = buf.data_ptr() + 2 * off
+            off += sizes[i]
+        jobs.n = len(_NodeMsg.PACKS)
+        check(_L().mdx_op_pack_a(ctypes.byref(jobs), stream()))
+        h = lambda: torch.empty(E, 256, dtype=torch.float16, device=dev)
+        bufs = {k: h() for k in ('he_pre', 'he_post', 'he', 'p', 'm0', 'g_pre', 'g_post', 'gt', 'msg')}
+        a = _NodeMsg._args(x, HNc, PNc, plan_col, P, packs, bufs, E)
+        check(_L().mdx_op_nodemsg_fwd(ctypes.byref(a), stream()))
+        out = _segsum_raw(bufs['msg'], plan_row)
+        del bufs['msg']
+        ctx.x, ctx.HN, ctx.PN, ctx.P, ctx.bufs, ctx.packs, ctx.packbuf = x, HNc, PNc, P, bufs, packs, buf
+        ctx.plan_col, ctx.plan_row, ctx.prec, ctx.x_dtype = plan_col, plan_row, _AMP, edge_attr.dtype
+        ctx.refs = {k: v.detach() for k, v in zip(_NodeMsg.PARAMS, params)}
+        return out
+
+    @staticmethod
+    def backward(ctx, gA):
+        import ctypes
+        x, P, bufs, E, dev = ctx.x, ctx.P, ctx.bufs, ctx.x.shape[0], ctx.x.device
+        gA = _c(gA)
+        h = lambda f=256: torch.empty(E, f, dtype=torch.float16, device=dev)
+        g = {'g_m0': h(), 'g_gt': h(), 'g_gpre': h(), 'g_hne': h(), 'g_he': h(), 'g_pre': h(), 'g_x': h(64)}
+        nwg, lnf = int(_L().mdx_op_bondffn_workgroups()), int(_L().mdx_op_nodemsg_lnp_floats())
+        lnp = torch.empty(nwg, lnf, dtype=torch.float32, device=dev)
+        b = _lib.MdxNodeMsgBwdArgs()
+        fb = dict(bufs, msg=bufs['m0'])      # (the forward's msg buffer is gone; the backward does not read it)
+        b.f = _NodeMsg._args(x, ctx.HN, ctx.PN, ctx.plan_col, P, ctx.packs, fb, E)
+        b.gA, b.ldga, b.row = gA.data_ptr(), gA.stride(0), ctx.plan_row.index.data_ptr()
+        for nm in ('pk_wg2t', 'pk_wg1t', 'pk_wmt', 'pk_w2et', 'pk_w1et'):
+            setattr(b, nm, ctx.packs[nm])
+        for nm, t in g.items():
+            setattr(b, nm, t.data_ptr())
+        b.lnp = lnp.data_ptr()
+        check(_L().mdx_op_nodemsg_bwd(ctypes.byref(b), stream()))
+        need = dict(zip(_NodeMsg.PARAMS, ctx.needs_input_grad[5:]))
+        grads = {k: None for k in _NodeMsg.PARAMS}
+        with precision(ctx.prec):
+            wg = lambda gy, xin, wname, bname: _wgrad_into(grads, need, ctx.refs, E, gy, xin, wname, bname)
+            wg(g['g_m0'], bufs['p'], 'Wm', 'bm')
+            wg(g['g_gt'], bufs['g_post'], 'Wg2', 'bg2')
+            wg(g['g_gpre'], x, 'Wg1', 'bg1')
+            wg(g['g_he'], bufs['he_post'], 'W2e', 'b2e')
+            wg(g['g_pre'], x, 'W1e', 'b1e')
+        for nm, off in (('lng_e', 0), ('lnb_e', 256), ('lng_g', 512), ('lnb_g', 768)):
+            if not need[nm]:
+                continue
+            dst = _sink_dst(ctx.refs[nm])
+            if dst is not None:
+                _sink_record(lnp.data_ptr() + 4 * off, dst, nwg, 1, 256, 256, lnf, 0, lnp)
+            else:
+                grads[nm] = lnp[:, off:off + 256].sum(0)
+        ni = ctx.needs_input_grad
+        g_x = g['g_x'] if ni[0] else None
+        if g_x is not None and g_x.dtype != ctx.x_dtype:
+            g_x = g_x.to(ctx.x_dtype)
+        g_HN = _segsum_raw(g['g_hne'], ctx.plan_col, torch.float16) if ni[1] else None
+        g_PN = _segsum_raw(g['g_gpre'], ctx.plan_col, torch.float32) if ni[2] else None
+        ctx.bufs = ctx.P = ctx.packbuf = None
+        return (g_x, g_HN, g_PN, None, None) + tuple(grads[k] for k in _NodeMsg.PARAMS)
+
+
+def nodemsg(edge_attr, hn, pn, plan_col, plan_row, params):
+    return _NodeMsg.apply(edge_attr, hn, pn, plan_col, plan_row, *[params[k] for k in _NodeMsg.PARAMS])

@@ -240,3 +240,54 @@ def test_fused_pos_update_equals_the_per_operator_composition(sizes):
     for k in gr0:
         assert torch.isfinite(gr1[k]).all(), k
         assert _rel2(gr1[k], gr0[k]) < 1e-2, (k, _rel2(gr1[k], gr0[k]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# NodeBlock with the fused message path (streamed weights) against the per-operator composition
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('sizes', [[5, 7, 4], [24, 31, 18, 27, 22, 25, 30, 19, 26, 23]])
+def test_fused_node_block_equals_the_per_operator_composition(sizes):
+    """NodeBlock.forward (models/graph.py:29-55) with edge_net, the product with node_net(x)[col], msg_net, the gate MLP and the sigmoid
+    product in one launch each way (weights streamed as float16 A-operand packs): output and every gradient against the per-operator
+    path in the same float16 arithmetic."""
+    g = U.rng(31)
+    bn, hei, bh, ei, be = U.graph_from_sizes(sizes)
+    N, E = len(bn), ei.shape[1]
+    m = G.NodeBlock(256, 64, 256, True).to(DEV)
+    with torch.no_grad():
+        for k, p in sorted(m.named_parameters()):
+            if p.dim() == 2:
+                p.copy_(torch.from_numpy((g.standard_normal(tuple(p.shape)) * (1.0 / np.sqrt(p.shape[1]))).astype(np.float32)))
+            elif ('net.1.' in k or 'layer_norm' in k) and k.endswith('weight'):
+                p.copy_(torch.from_numpy((1.0 + 0.3 * g.standard_normal(tuple(p.shape))).astype(np.float32)))
+            else:
+                p.copy_(torch.from_numpy((0.2 * g.standard_normal(tuple(p.shape))).astype(np.float32)))
+    he = torch.from_numpy(g.standard_normal((E, 64)).astype(np.float32)).to(DEV).half()
+    hn = torch.from_numpy(g.standard_normal((N, 256)).astype(np.float32)).to(DEV).half()
+    tn = torch.from_numpy(g.random((N, 1)).astype(np.float32)).to(DEV)
+    g_out = torch.from_numpy(g.standard_normal((N, 256)).astype(np.float32)).to(DEV).half()
+    tg = TG.TrainGraph(ei.to(DEV), N)
+
+    def run(fused):
+        m.zero_grad(set_to_none=True)
+        x, h = he.clone().requires_grad_(True), hn.clone().requires_grad_(True)
+        old, old_rows = T._FUSED, T.FUSED_MIN_ROWS
+        T._FUSED, T.FUSED_MIN_ROWS = fused, 1
+        try:
+            with T.precision('fp16'):
+                out = TG.node_block(m, h, tg, x, tn)
+                out.backward(g_out)
+        finally:
+            T._FUSED, T.FUSED_MIN_ROWS = old, old_rows
+        return out.detach(), x.grad.detach(), h.grad.detach(), {k: q.grad.detach().clone() for k, q in m.named_parameters()}
+
+    o1, gx1, gh1, gr1 = run(True)
+    o0, gx0, gh0, gr0 = run(False)
+    print(f'\n[fused NodeBlock vs per-operator] out max {_rel(o1, o0):.2e}  dX L2 {_rel2(gx1, gx0):.2e}  dh L2 {_rel2(gh1, gh0):.2e}')
+    for k in gr0:
+        print(f'    {k:40s} L2 {_rel2(gr1[k], gr0[k]):.2e}')
+    assert _rel(o1, o0) < 3e-3, _rel(o1, o0)
+    assert _rel2(gx1, gx0) < 1e-2 and _rel2(gh1, gh0) < 1e-2
+    for k in gr0:
+        assert torch.isfinite(gr1[k]).all(), k
+        assert _rel2(gr1[k], gr0[k]) < 1e-2, (k, _rel2(gr1[k], gr0[k]))
