@@ -1077,7 +1077,11 @@ extern "C" int mdx_op_posffn_bwd(const mdx_posffn_bwd_args* a, void* stream) {
 // formed by transposing each tile through a wave-private 16.25-KiB LDS area: a lane then owns four FEATURES and adds the 16 rows in
 // order.
 // ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int NM_THREADS = 512, NM_WAVES = 8, NM_LNP = 1024;   // partial row: d gamma_e | d beta_e | d gamma_g | d beta_g (256 each)
+#ifndef MDX_NM_FWD_THREADS
+#define MDX_NM_FWD_THREADS 512   // (768 = three waves per SIMD measured 369 us against 362 us: the LDS pipe, not occupancy, is what the tile loop waits on)
+#endif
+constexpr int NM_THREADS = 512, NM_WAVES = 8, NM_LNP = 1024;
+constexpr int NMF_THREADS = MDX_NM_FWD_THREADS, NMF_WAVES = NMF_THREADS / 64;   // forward: 156 VGPRs, three waves per SIMD fit   // partial row: d gamma_e | d beta_e | d gamma_g | d beta_g (256 each)
 
 __global__ void pack_a_kernel(const mdx_pack_jobs a) {
   const mdx_pack_job& jb = a.job[blockIdx.y];
@@ -1123,24 +1127,73 @@ __device__ __forceinline__ void mmg(f32x4 (&y)[FT], const _Float16* __restrict__
   });
 }
 
+// The same product with the weight fragments shared by the workgroup (round 6, second cut): the 8 waves of a workgroup run the same layer
+// at the same time, so a k-step's FT fragments (FT KiB) are fetched from L2 ONCE per workgroup -- every thread copies 16 or 32 bytes
+// into one of two LDS buffers -- and each wave reads its A operands from LDS.  With private streams (mmg) every wave pulled the whole
+// 448 KiB of a tile's weights through L2 by itself: 4.3 GB per launch, ~10 TB/s, and the kernels ran at that rate (428 / 540 us).
+// One barrier per k-step: the buffer a step writes was last read two steps earlier, and no wave can be more than one barrier ahead.
+// `par` (the buffer parity) runs through consecutive calls.  Every wave of the workgroup must make the same calls.
+template <int FT, int KS, int NT = NM_THREADS>
+__device__ __forceinline__ void mmw(f32x4 (&y)[FT], const _Float16* __restrict__ pack, uint16_t* wbuf, int& par, int tid, int lane,
+                                    const f16x8_t (&x)[KS]) {
+  constexpr int CH = FT * 1024;                                      // bytes per k-step
+  constexpr int NL = (CH + NT * 16 - 1) / (NT * 16);                  // 16-byte copies per thread and k-step
+  asm volatile("" : "+s"(pack));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pack), 0, -1, 0x00020000);
+  uint4 st[NL];
+  auto fetch = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const unsigned o = (unsigned)(tid + i * NT) * 16u;
+      if (CH % (NT * 16) == 0 || o < (unsigned)CH) st[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, ks * CH, 0));
+    }
+  };
+  fetch(0);
+  static_for<0, KS>([&](auto kc) {
+    constexpr int ks = decltype(kc)::value;
+    char* buf = reinterpret_cast<char*>(wbuf) + ((par + ks) & 1) * 16384;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const unsigned o = (unsigned)(tid + i * NT) * 16u;
+      if (CH % (NT * 16) == 0 || o < (unsigned)CH) *reinterpret_cast<uint4*>(buf + o) = st[i];
+    }
+    if constexpr (ks + 1 < KS) fetch(ks + 1);
+    // raw barrier: __syncthreads() would also wait for vmcnt(0), i.e. for the fetch just issued and for every global store of the
+    // previous epilogue (gfx9 counts stores on vmcnt) -- only the LDS writes have to be complete here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* ab = buf + lane * 16;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      y[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8_t*>(ab + ft * 1024), x[ks], y[ft], 0, 0, 0);
+      if (ft % 8 == 7) __builtin_amdgcn_sched_barrier(0);   // at most eight fragments' reads ahead of their MFMAs (32 registers)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  par = (par + KS) & 1;
+}
+
 template <int N>
 __device__ __forceinline__ void pairs(f16x8_t (&b)[N / 2], const uint2 (&pk)[N]) {
 #pragma unroll
   for (int i = 0; i < N / 2; ++i) b[i] = pair8(pk[2 * i], pk[2 * i + 1]);
 }
 
-__global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodemsg_args a) {
+__global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_nodemsg_args a) {
   __shared__ __attribute__((aligned(16))) float C[9 * 256];
+  __shared__ __attribute__((aligned(16))) uint16_t wbuf[2 * 8192];     // two k-steps of weight fragments (mmw)
+  int par = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   {
     const float* src[9] = {a.b1e, a.lng_e, a.lnb_e, a.b2e, a.bm, a.bg1, a.lng_g, a.lnb_g, a.bg2};
-    for (int i = tid; i < 9 * 256; i += NM_THREADS) C[i] = src[i >> 8][i & 255];
+    for (int i = tid; i < 9 * 256; i += NMF_THREADS) C[i] = src[i >> 8][i & 255];
   }
   __syncthreads();
   const float *c_b1e = C, *c_ge = C + 256, *c_be = C + 512, *c_b2e = C + 768, *c_bm = C + 1024, *c_bg1 = C + 1280, *c_gg = C + 1536,
               *c_gb = C + 1792, *c_bg2 = C + 2048;
-  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * NM_WAVES;
+  const int E = (int)a.E, ntiles = (E + 15) >> 4, nw = gridDim.x * NMF_WAVES;
+  const int iters = (ntiles + nw - 1) / nw;     // the same for every wave of the grid: the weight copies are workgroup-cooperative
   const _Float16* X = reinterpret_cast<const _Float16*>(a.X);
   const _Float16* HN = reinterpret_cast<const _Float16*>(a.HN);
   const _Float16 *w1e = reinterpret_cast<const _Float16*>(a.pk_w1e), *w2e = reinterpret_cast<const _Float16*>(a.pk_w2e),
@@ -1151,9 +1204,10 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
            *o_gpre = reinterpret_cast<_Float16*>(a.g_pre), *o_gpost = reinterpret_cast<_Float16*>(a.g_post),
            *o_gt = reinterpret_cast<_Float16*>(a.gt), *o_msg = reinterpret_cast<_Float16*>(a.msg);
 #pragma unroll 1
-  for (int tile = blockIdx.x * NM_WAVES + wave; tile < ntiles; tile += nw) {
+  for (int it = 0; it < iters; ++it) {
+    const int tile = it * nw + blockIdx.x * NMF_WAVES + wave;
     const int row = 16 * tile + c;
-    const bool ok = row < E;
+    const bool ok = row < E;      // (a wave past the last tile computes on the clamped last row and stores nothing)
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
     const int64_t nc = a.col[r];
     const _Float16* px = X + r * a.ldx + 8 * q;
@@ -1165,7 +1219,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
 #define NM_SB(ft) if ((ft) % 4 == 3) __builtin_amdgcn_sched_barrier(0)
     // ---- edge_net: Linear -> LayerNorm -> ReLU -> Linear, then the product with node_net(x)[col]
     zero<16>(y);
-    mmg<16, 2>(y, w1e, lane, xb);
+    mmw<16, 2, NMF_THREADS>(y, w1e, wbuf, par, tid, lane, xb);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) {
       y[ft] = rh4(y[ft] + lds4(c_b1e + 16 * ft + 4 * q));
@@ -1189,7 +1243,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
       }
     }
     zero<16>(y);
-    mmg<16, 8>(y, w2e, lane, b8);
+    mmw<16, 8, NMF_THREADS>(y, w2e, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       uint2 h[2];
@@ -1208,7 +1262,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
     }
     // ---- msg_net (m0 is read back at the end: L2-hot, and 32 registers cheaper than holding it across the gate chain)
     zero<16>(y);
-    mmg<16, 8>(y, wm, lane, b8);
+    mmw<16, 8, NMF_THREADS>(y, wm, wbuf, par, tid, lane, b8);
     if (ok) {
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft) {
@@ -1218,7 +1272,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
     }
     // ---- gate: Linear([edge | x[col] | t[col]]) with the node / time columns as the hoisted fp32 addend PN[col]
     zero<16>(y);
-    mmg<16, 2>(y, wg1, lane, xb);
+    mmw<16, 2, NMF_THREADS>(y, wg1, wbuf, par, tid, lane, xb);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) {
       y[ft] = rh4((y[ft] + lds4(c_bg1 + 16 * ft + 4 * q)) + ldg4(a.PN + (size_t)nc * a.ldpn + 16 * ft + 4 * q));
@@ -1242,7 +1296,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
       }
     }
     zero<16>(y);
-    mmg<16, 8>(y, wg2, lane, b8);
+    mmw<16, 8, NMF_THREADS>(y, wg2, wbuf, par, tid, lane, b8);
     if (ok) {
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft) {
@@ -1258,16 +1312,23 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_fwd_kernel(const mdx_nodem
 // Column sums over the 16 rows of a tile (fp32, accumulator layout: lane (q, c) holds features 16 ft + 4 q .. of row c), added to acc
 // (lane L owns features 4 L .. 4 L + 3): the tile goes through the wave's LDS area T [16][NM_TLD] one feature tile at a time (cs_put),
 // then every lane adds its four features of rows 0..15 in order (cs_sum).
-constexpr int NM_TLD = 260;
-__device__ __forceinline__ void cs_put(float* T, int ft, f32x4 v, int c, int q) { *reinterpret_cast<f32x4*>(T + c * NM_TLD + 16 * ft + 4 * q) = v; }
-__device__ __forceinline__ void cs_sum(f32x4& acc, const float* T, int lane) {
+constexpr int NM_TLD = 132;   // half a row (128 features) + 4: the 256 columns go through in two halves (LDS: 8.25 KiB per wave)
+__device__ __forceinline__ void cs_put(float* T, int ft8, f32x4 v, int c, int q) { *reinterpret_cast<f32x4*>(T + c * NM_TLD + 16 * ft8 + 4 * q) = v; }
+// lanes 32 hf .. 32 hf + 31 own the features of half hf: lane L adds features 4 L .. 4 L + 3 of rows 0..15 in order
+__device__ __forceinline__ void cs_sum(f32x4& acc, const float* T, int lane, int hf) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {
+    // every lane reads (lanes of the other half read the same words and add zero: no divergent branch around the sums)
+    const float keep = ((lane >> 5) == hf) ? 1.0f : 0.0f;
+    f32x4 part = splat4(0.f);
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {   // four rows in flight (all 16 at once cost 64 registers where the kernel has none to spare):
-    acc = acc + *reinterpret_cast<const volatile f32x4*>(T + rr * NM_TLD + 4 * lane);
-    if (rr % 4 == 3) asm volatile("" : "+v"(acc));   // the sum is pinned every four rows, so the reads cannot all be hoisted above the adds
+    for (int rr = 0; rr < 16; ++rr) {   // four rows in flight (all 16 at once cost 64 registers where the kernel has none to spare):
+      part = part + *reinterpret_cast<const volatile f32x4*>(T + rr * NM_TLD + 4 * (lane & 31));
+      if (rr % 4 == 3) asm volatile("" : "+v"(part));   // pinned every four rows, so the reads cannot all be hoisted above the adds
+    }
+    acc = acc + part * splat4(keep);
   }
   __builtin_amdgcn_wave_barrier();   // the area is rewritten only after every lane has read it
 }
@@ -1310,16 +1371,17 @@ __device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* x
     const f32x4 yv = xh * gm + bt;
 #pragma unroll
     for (int s = 0; s < 4; ++s) g[ft][s] = (ok && yv[s] > 0.f) ? g[ft][s] : 0.f;
-    cs_put(T, ft, g[ft], c, q);
     if (ft % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
-  cs_sum(dbet, T, lane);
 #pragma unroll
-  for (int ft = 0; ft < 16; ++ft) {
-    cs_put(T, ft, g[ft] * ((unpack4(xp[ft]) - splat4(mean)) * splat4(rstd)), c, q);
-    if (ft % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+  for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+    for (int f8 = 0; f8 < 8; ++f8) cs_put(T, f8, g[8 * hf + f8], c, q);
+    cs_sum(dbet, T, lane, hf);
+#pragma unroll
+    for (int f8 = 0; f8 < 8; ++f8) cs_put(T, f8, g[8 * hf + f8] * ((unpack4(xp[8 * hf + f8]) - splat4(mean)) * splat4(rstd)), c, q);
+    cs_sum(dgam, T, lane, hf);
   }
-  cs_sum(dgam, T, lane);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int ft = 0; ft < 16; ++ft) {
@@ -1343,8 +1405,10 @@ __device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* x
 
 __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodemsg_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
-  float* C = reinterpret_cast<float*>(bf_smem);            // 4 x 256 LayerNorm parameters
-  float* Tall = C + 1024;                                   // NM_WAVES areas of 16 x NM_TLD floats
+  uint16_t* wbuf = bf_smem;                                  // two k-steps of weight fragments (mmw), 32 KiB
+  float* C = reinterpret_cast<float*>(bf_smem + 2 * 8192);    // 4 x 256 LayerNorm parameters
+  float* Tall = C + 1024;                                     // NM_WAVES areas of 16 x NM_TLD floats (>= NM_WAVES x NM_LNP floats for the end)
+  int par = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   {
@@ -1354,6 +1418,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
   __syncthreads();
   float* T = Tall + (size_t)wave * 16 * NM_TLD;
   const int E = (int)a.f.E, ntiles = (E + 15) >> 4, nw = gridDim.x * NM_WAVES;
+  const int iters = (ntiles + nw - 1) / nw;
   const _Float16* HN = reinterpret_cast<const _Float16*>(a.f.HN);
   const _Float16 *s_hepre = reinterpret_cast<const _Float16*>(a.f.he_pre), *s_he = reinterpret_cast<const _Float16*>(a.f.he),
                  *s_m0 = reinterpret_cast<const _Float16*>(a.f.m0), *s_gpre = reinterpret_cast<const _Float16*>(a.f.g_pre),
@@ -1366,7 +1431,8 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
            *o_ghe = reinterpret_cast<_Float16*>(a.g_he), *o_gpre = reinterpret_cast<_Float16*>(a.g_pre), *o_gx = reinterpret_cast<_Float16*>(a.g_x);
   f32x4 dge = splat4(0.f), dbe = splat4(0.f), dgg = splat4(0.f), dbg = splat4(0.f);
 #pragma unroll 1
-  for (int tile = blockIdx.x * NM_WAVES + wave; tile < ntiles; tile += nw) {
+  for (int it = 0; it < iters; ++it) {
+    const int tile = it * nw + blockIdx.x * NM_WAVES + wave;
     const int row = 16 * tile + c;
     const bool ok = row < E;
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
@@ -1395,7 +1461,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     }
     // ---- gate backward
     zero<16>(y);
-    mmg<16, 8>(y, wg2t, lane, b8);
+    mmw<16, 8>(y, wg2t, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
     ln256_relu_bwd(y, s_gpre + ro, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
@@ -1409,7 +1475,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
       b8[g2] = pair8(h0, h1);
     }
     zero<4>(gx1);
-    mmg<4, 8>(gx1, wg1t, lane, b8);
+    mmw<4, 8>(gx1, wg1t, wbuf, par, tid, lane, b8);
     // ---- msg_net and the product p = he * hn[col]
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
@@ -1423,7 +1489,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
       NM_SB(2 * g2 + 1);
     }
     zero<16>(y);
-    mmg<16, 8>(y, wmt, lane, b8);
+    mmw<16, 8>(y, wmt, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       uint2 h[2];
@@ -1442,7 +1508,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     }
     // ---- edge_net backward
     zero<16>(y);
-    mmg<16, 8>(y, w2et, lane, b8);
+    mmw<16, 8>(y, w2et, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
     ln256_relu_bwd(y, s_hepre + ro, C + 0, C + 256, q, ok, dge, dbe, T, lane);
@@ -1457,7 +1523,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     }
     f32x4 gx2[4];
     zero<4>(gx2);
-    mmg<4, 8>(gx2, w1et, lane, b8);
+    mmw<4, 8>(gx2, w1et, wbuf, par, tid, lane, b8);
     if (ok) {
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx2[ft]) + rh4(gx1[ft])));
@@ -1479,7 +1545,8 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
   }
 }
 
-constexpr int NM_BWD_LDS = (1024 + NM_WAVES * 16 * NM_TLD) * 4;
+constexpr int NM_BWD_LDS = 2 * 16384 + (1024 + NM_WAVES * 16 * NM_TLD) * 4;
+static_assert(NM_WAVES * 16 * NM_TLD >= NM_WAVES * NM_LNP, "the end-of-kernel reduction reuses the column-sum areas");
 static bool g_attr_nb = false;
 
 extern "C" int mdx_op_nodemsg_lnp_floats(void) { return NM_LNP; }
@@ -1512,8 +1579,8 @@ extern "C" int mdx_op_nodemsg_fwd(const mdx_nodemsg_args* a, void* stream) {
   if (int rc = check_nodemsg(*a)) return rc;
   if (!a->he_pre || !a->he_post || !a->he || !a->p || !a->m0 || !a->g_pre || !a->g_post || !a->gt || !a->msg) return mdx_set_error(MDX_ERR_ARG, "nodemsg_fwd: null output");
   const int ntiles = (int)((a->E + 15) / 16);
-  const int grid = std::max(1, std::min(2 * ncus(), (ntiles + NM_WAVES - 1) / NM_WAVES));
-  hipLaunchKernelGGL(nodemsg_fwd_kernel, dim3(grid), dim3(NM_THREADS), 0, (hipStream_t)stream, *a);
+  const int grid = std::max(1, std::min(ncus(), (ntiles + NMF_WAVES - 1) / NMF_WAVES));
+  hipLaunchKernelGGL(nodemsg_fwd_kernel, dim3(grid), dim3(NMF_THREADS), 0, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "nodemsg_fwd: launch failed");
 }
 
