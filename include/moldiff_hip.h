@@ -393,6 +393,19 @@ int mdx_op_wgrad_layout(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t
 int64_t mdx_op_ln_relu_bwd_rows(int64_t M);
 int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks, void* stream);
 
+/* Queued (grouped) weight gradients, float16 autocast mode.  A step's weight-gradient contractions dW = dY^T X (the backward of every
+ * nn.Linear of reference models/common.py:181-201 and models/graph.py, i.e. torch.autograd's mm_backward for the weight) feed nothing
+ * before the optimizer, so the host may queue them and run a whole table per launch.  mdx_op_wgrad_plan: tile class and layout of one
+ * contraction -- out[0..7] = kind (0..3 transpose-read kernel with tiles 128x128 / 128x64 / 64x128 / 64x64 (n x k), 4 converting kernel),
+ * gx, gy (tiles along K, N), S (row ranges), mper (rows per range), float offset of the [S][N] bias partials, floats of the whole partial
+ * area (the layout of mdx_op_xgemm_tn_t / mdx_op_wgrad_layout), blocks.  dt bit 0 / 1: dY / X stored as float16; `aligned`: both start on
+ * 16 bytes.  mdx_op_wgrad_grouped: one launch over a DEVICE table of n records of one kind -- 16 x int64 {dY, X, P, Pb (0 = no bias
+ * partials), ldg, ldx, M, N, K, mper, gx, gy, S, dt, first_block, 0}, first_block = running sum of the records' blocks,
+ * total_blocks = their sum; every record's partials are bit-identical to mdx_op_xgemm_tn_t(dW = NULL) with the same row ranges and are
+ * summed by mdx_op_reduce_deferred. */
+int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t dt, int64_t ldg, int64_t ldx, int32_t aligned, int64_t* out);
+int mdx_op_wgrad_grouped(const int64_t* desc, int32_t n, int64_t total_blocks, int32_t kind, void* stream);
+
 /* ---- fused row-owner training operators (round 6; csrc/mdx_train_fused.hip) ---------------------------------------------------------
  * One forward and one backward launch for a whole BondFFN of the EdgeBlock in the float16 autocast arithmetic
  * (replaces, for training, reference models/graph.py:133-141 -- bond_linear, the product with node_linear(h)[idx], the inter MLP

@@ -27,7 +27,7 @@ EXPORTS = [
     'mdx_op_sgemm_nt', 'mdx_op_sgemm_tn', 'mdx_op_hgemm_nt', 'mdx_op_hgemm_tn', 'mdx_op_xgemm_nt', 'mdx_op_xgemm_tn', 'mdx_op_amp_adamw',
     'mdx_op_xgemm_nt_t', 'mdx_op_xgemm_nt_ln_t', 'mdx_op_xgemm_nt_ln_supported', 'mdx_op_xgemm_tn_t', 'mdx_op_ln_relu_fwd_t', 'mdx_op_ln_relu_bwd_t', 'mdx_op_ew_fwd_t', 'mdx_op_ew_bwd_t',
     'mdx_op_gather_rows_t', 'mdx_op_segsum_rows_t', 'mdx_op_mul_gather_fwd_t', 'mdx_op_mul_gather_bwd_t',
-    'mdx_op_wgrad_layout', 'mdx_op_ln_relu_bwd_rows', 'mdx_op_reduce_deferred', 'mdx_op_transpose', 'mdx_op_transpose_batch', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
+    'mdx_op_wgrad_layout', 'mdx_op_wgrad_plan', 'mdx_op_wgrad_grouped', 'mdx_op_ln_relu_bwd_rows', 'mdx_op_reduce_deferred', 'mdx_op_transpose', 'mdx_op_transpose_batch', 'mdx_op_linear_rows', 'mdx_op_linear_rows_ws', 'mdx_op_linear_rows_supported', 'mdx_op_colreduce', 'mdx_op_ln_relu_fwd', 'mdx_op_ln_relu_bwd', 'mdx_op_ln_relu_bwd_ws',
     'mdx_op_ew_fwd', 'mdx_op_ew_bwd', 'mdx_op_gather_rows', 'mdx_op_segsum_rows', 'mdx_op_mul_gather_fwd', 'mdx_op_mul_gather_bwd', 'mdx_op_edge_geom_fwd', 'mdx_op_edge_geom_bwd',
     'mdx_op_smear_fwd', 'mdx_op_smear_bwd', 'mdx_op_force_fwd', 'mdx_op_force_bwd', 'mdx_op_sumsq', 'mdx_op_adamw',
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
@@ -210,6 +210,8 @@ def lib():
         L.mdx_op_mul_gather_fwd.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]
         L.mdx_op_mul_gather_bwd.argtypes = [c_void_p] * 6 + [c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]
         L.mdx_op_wgrad_layout.argtypes = [c_int64, c_int64, c_int64, c_int32, c_int32, POINTER(c_int64), POINTER(c_int64)]
+        L.mdx_op_wgrad_plan.argtypes = [c_int64, c_int64, c_int64, c_int32, c_int32, c_int64, c_int64, c_int32, POINTER(c_int64)]
+        L.mdx_op_wgrad_grouped.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_void_p]
         L.mdx_op_ln_relu_bwd_rows.argtypes = [c_int64]
         L.mdx_op_ln_relu_bwd_rows.restype = c_int64
         L.mdx_op_reduce_deferred.argtypes = [c_void_p, c_int32, c_int64, c_void_p]

@@ -626,23 +626,23 @@ constexpr int HW_MC = 64;
 // Workgroup tile TNW (columns of G) x TKW (columns of X), 64 or 128 each (round 3: 128 where the layer is that wide -- four times the
 // MFMAs per staged byte and per barrier of the 64 x 64 tile, half the passes over G and X).  Wave w owns the (TNW/2) x (TKW/2) quadrant.
 template <int HT, int TNW, int TKW>
-__global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg, const TP X, int ldx,
-                                                              int M, int N, int K, int mper, float* __restrict__ P,
-                                                              float* __restrict__ Pb) {
+__device__ __forceinline__ void hgemm_tn_split_body(const TP G, int ldg, const TP X, int ldx, int M, int N, int K, int mper,
+                                                    float* __restrict__ P, float* __restrict__ Pb, const int bx, const int by,
+                                                    const int bz) {
   __shared__ __attribute__((aligned(16))) uint16_t Gt[TNW * H_LD];
   __shared__ __attribute__((aligned(16))) uint16_t Xt[TKW * H_LD];
   constexpr int IN = TNW / 32, IK = TKW / 32;      // 16 x 16 tiles per wave along n / k
   constexpr int NBG = TNW / 64, NBX = TKW / 64;    // 4 x 4 staging blocks per thread and step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.y * TNW, k0 = blockIdx.x * TKW;
-  const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
+  const int n0 = by * TNW, k0 = bx * TKW;
+  const int mbeg = bz * mper, mend = min(M, mbeg + mper);
   const int wn = (wave >> 1) * (TNW / 2), wk = (wave & 1) * (TKW / 2);
   const bool vecg = tp_vec_ok(G.p, G.h, ldg) && ((n0 & 3) == 0);
   const bool vecx = tp_vec_ok(X.p, X.h, ldx) && ((k0 & 3) == 0);
   f32x4 acc[IN][IK];
   acc_zero<IN, IK>(acc);
-  const bool do_bias = Pb && blockIdx.x == 0 && tid < TNW;
+  const bool do_bias = Pb && bx == 0 && tid < TNW;
   float bsum = 0.f;
   // 4 x 4 blocks: block b of a W-wide tile = rows 4 (b / (W/4)) ..+3, columns 4 (b % (W/4)) ..+3; transposed in registers, they leave
   // as four 8-byte LDS stores ([column][4 consecutive rows]) -- round 2 wrote sixteen 2-byte stores per block, which (with the
@@ -704,8 +704,8 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg
     }
     __syncthreads();
   }
-  if (do_bias && n0 + tid < N) Pb[(size_t)blockIdx.z * N + n0 + tid] = bsum;
-  float* out = P + (size_t)blockIdx.z * N * K;
+  if (do_bias && n0 + tid < N) Pb[(size_t)bz * N + n0 + tid] = bsum;
+  float* out = P + (size_t)bz * N * K;
 #pragma unroll
   for (int i = 0; i < IN; ++i)
 #pragma unroll
@@ -715,6 +715,13 @@ __global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg
         const int n = n0 + wn + 16 * i + 4 * q + r, k = k0 + wk + 16 * j + c;
         if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
       }
+}
+
+template <int HT, int TNW, int TKW>
+__global__ __launch_bounds__(256) void hgemm_tn_split_kernel(const TP G, int ldg, const TP X, int ldx,
+                                                              int M, int N, int K, int mper, float* __restrict__ P,
+                                                              float* __restrict__ Pb) {
+  hgemm_tn_split_body<HT, TNW, TKW>(G, ldg, X, ldx, M, N, K, mper, P, Pb, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // float16 weight gradient on float16 CONTAINERS (half storage, round 3): P[z][n][k] = sum_{m in split z} G[m][n] * X[m][k].
@@ -738,21 +745,21 @@ __device__ __forceinline__ f16x8_t lds_tr8(const _Float16* p) {
   return __builtin_shufflevector(__builtin_bit_cast(f16x4v_t, lo), __builtin_bit_cast(f16x4v_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 template <int TNW, int TKW>
-__global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __restrict__ G, int ldg, const _Float16* __restrict__ X, int ldx,
-                                                           int M, int N, int K, int mper, float* __restrict__ P,
-                                                           float* __restrict__ Pb) {
+__device__ __forceinline__ void hgemm_tn_tr_body(const _Float16* __restrict__ G, int ldg, const _Float16* __restrict__ X, int ldx, int M,
+                                                 int N, int K, int mper, float* __restrict__ P, float* __restrict__ Pb, const int bx,
+                                                 const int by, const int bz) {
   constexpr int SUB = HW_MC * 16;                  // halves per 16-column subtile
   __shared__ __attribute__((aligned(16))) _Float16 Gt[(TNW / 16) * SUB];
   __shared__ __attribute__((aligned(16))) _Float16 Xt[(TKW / 16) * SUB];
   constexpr int IN = TNW / 32, IK = TKW / 32;      // 16 x 16 tiles per wave along n / k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.y * TNW, k0 = blockIdx.x * TKW;
-  const int mbeg = blockIdx.z * mper, mend = min(M, mbeg + mper);
+  const int n0 = by * TNW, k0 = bx * TKW;
+  const int mbeg = bz * mper, mend = min(M, mbeg + mper);
   const int wn = (wave >> 1) * (TNW / 2), wk = (wave & 1) * (TKW / 2);
   f32x4 acc[IN][IK];
   acc_zero<IN, IK>(acc);
-  const bool do_bias = Pb && blockIdx.x == 0 && tid < TNW;
+  const bool do_bias = Pb && bx == 0 && tid < TNW;
   float bsum = 0.f;
   // staging: W / 32 16-byte pieces per thread and tile; lanes 8 s .. 8 s + 7 of a wave fill 4 rows of subtile s
   uint4 rg[TNW / 32], rx[TKW / 32];
@@ -813,8 +820,8 @@ __global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __rest
     }
     __syncthreads();
   }
-  if (do_bias && n0 + tid < N) Pb[(size_t)blockIdx.z * N + n0 + tid] = bsum;
-  float* out = P + (size_t)blockIdx.z * N * K;
+  if (do_bias && n0 + tid < N) Pb[(size_t)bz * N + n0 + tid] = bsum;
+  float* out = P + (size_t)bz * N * K;
 #pragma unroll
   for (int i = 0; i < IN; ++i)
 #pragma unroll
@@ -824,6 +831,46 @@ __global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __rest
         const int n = n0 + wn + 16 * i + 4 * q + r, k = k0 + wk + 16 * j + c;
         if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
       }
+}
+
+template <int TNW, int TKW>
+__global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __restrict__ G, int ldg, const _Float16* __restrict__ X, int ldx,
+                                                           int M, int N, int K, int mper, float* __restrict__ P,
+                                                           float* __restrict__ Pb) {
+  hgemm_tn_tr_body<TNW, TKW>(G, ldg, X, ldx, M, N, K, mper, P, Pb, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped weight gradients (round 6): the ~260 weight-gradient contractions of a training step do not feed anything before the
+// optimizer, so the host queues them (train_ops.sgemm_tn with an active gradient sink) and ONE launch per tile class runs a whole
+// table of them.  Record (16 x int64): G, X, P, Pb, ldg, ldx, M, N, K, mper, gx (tiles along K), gy (tiles along N), S (row ranges),
+// dt (bit 0 G float16, bit 1 X float16), first_block, unused.  A job's blocks are numbered like its own grid would be (k tile
+// fastest, then n tile, then row range: the blocks that share rows of G and X are neighbours, L2 serves the re-reads); the bodies are
+// the stand-alone kernels', so a job's partials are bit-identical to a stand-alone launch with the same `mper`.
+// KIND 0..3: transpose-read kernel with tiles 128x128, 128x64, 64x128, 64x64; 4: converting kernel, 64x64 tiles, float16 products.
+template <int KIND>
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const long long* __restrict__ desc, int n) {
+  const long long blk = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[16 * mid + 14] <= blk) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + 16 * lo;
+  const int rel = (int)(blk - d[14]);
+  const int gx = (int)d[10], gy = (int)d[11];
+  const int bx = rel % gx, by = (rel / gx) % gy, bz = rel / (gx * gy);
+  float* P = reinterpret_cast<float*>(d[2]);
+  float* Pb = reinterpret_cast<float*>(d[3]);
+  const int ldg = (int)d[4], ldx = (int)d[5], M = (int)d[6], N = (int)d[7], K = (int)d[8], mper = (int)d[9];
+  if constexpr (KIND < 4) {
+    const _Float16* G = reinterpret_cast<const _Float16*>(d[0]);
+    const _Float16* X = reinterpret_cast<const _Float16*>(d[1]);
+    hgemm_tn_tr_body<(KIND < 2 ? 128 : 64), ((KIND & 1) ? 64 : 128)>(G, ldg, X, ldx, M, N, K, mper, P, Pb, bx, by, bz);
+  } else {
+    const int dt = (int)d[13];
+    const TP G{reinterpret_cast<const void*>(d[0]), dt & 1}, X{reinterpret_cast<const void*>(d[1]), (dt >> 1) & 1};
+    hgemm_tn_split_body<1, 64, 64>(G, ldg, X, ldx, M, N, K, mper, P, Pb, bx, by, bz);
+  }
 }
 
 // Weight gradient without transposes: P[z][n][k] = sum_{m in split z} G[m][n] * X[m][k]   (G = dY (M,N), X (M,K) row-major).
@@ -2234,6 +2281,49 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
   } else {
     launch_reduce_partials(partial, S, (int)N, (int)K, nullptr, dW, (int)ldw, scratch, s, rkind);
     if (db) launch_reduce_partials(pb, S, 1, (int)N, nullptr, db, (int)N, pb + (size_t)S * N, s, rkind);
+  }
+  return launched();
+}
+// Queued weight gradients (float16 autocast mode; see wgrad_grouped_kernel).  mdx_op_wgrad_plan: which tile class a contraction takes
+// and its block / partial layout -- out[0..7] = kind, gx, gy, S, mper, offset of the bias partials (floats from P), floats of the whole
+// partial area (products, first reduction stage, bias partials and theirs: the layout of mdx_op_xgemm_tn_t), blocks.  `aligned` = both
+// operands start on 16 bytes.  mdx_op_wgrad_grouped: one launch over a device table of `n` records of one kind (16 x int64 each, layout
+// at the kernel), `total_blocks` = sum of their blocks; the partials are left for mdx_op_reduce_deferred.
+extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t dt, int64_t ldg, int64_t ldx, int32_t aligned,
+                                 int64_t* out) {
+  if (!out || N <= 0 || K <= 0) return bad("wgrad_plan: bad arguments");
+  if (splits < 1) splits = 1;
+  int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
+  mper = (mper + HW_MC - 1) / HW_MC * HW_MC;
+  const int64_t S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
+  const int64_t nc = (S + RED_CHUNK - 1) / RED_CHUNK;
+  int kind = 4, tn = 64, tk = 64;
+  if ((dt & 3) == 3 && N % 64 == 0 && K % 64 == 0 && ldg % 8 == 0 && ldx % 8 == 0 && aligned) {
+    tn = N % 128 == 0 ? 128 : 64;
+    tk = K % 128 == 0 ? 128 : 64;
+    kind = (tn == 128 ? 0 : 2) + (tk == 128 ? 0 : 1);
+  }
+  const int64_t gx = (K + tk - 1) / tk, gy = (N + tn - 1) / tn;
+  out[0] = kind, out[1] = gx, out[2] = gy, out[3] = S, out[4] = mper;
+  out[5] = (S + nc) * N * K;
+  out[6] = (S + nc) * (N * K + N);
+  out[7] = gx * gy * S;
+  return MDX_OK;
+}
+extern "C" int mdx_op_wgrad_grouped(const int64_t* desc, int32_t n, int64_t total_blocks, int32_t kind, void* stream) {
+  if (n <= 0 || total_blocks <= 0) return MDX_OK;
+  if (!desc) return bad("wgrad_grouped: null record table");
+  if (total_blocks > 0x7fffffffll) return bad("wgrad_grouped: too many blocks");
+  hipStream_t s = (hipStream_t)stream;
+  const long long* d = reinterpret_cast<const long long*>(desc);
+  const dim3 grid((unsigned)total_blocks);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(wgrad_grouped_kernel<0>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 1: hipLaunchKernelGGL(wgrad_grouped_kernel<1>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 2: hipLaunchKernelGGL(wgrad_grouped_kernel<2>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 3: hipLaunchKernelGGL(wgrad_grouped_kernel<3>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 4: hipLaunchKernelGGL(wgrad_grouped_kernel<4>, grid, dim3(256), 0, s, d, (int)n); break;
+    default: return bad("wgrad_grouped: kind must be 0..4");
   }
   return launched();
 }

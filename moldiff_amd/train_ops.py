@@ -120,12 +120,12 @@ class grad_sink:
         f = self.flat
         self.prev = _SINK
         _SINK = {'data': f.data.data_ptr(), 'grad': f.grad.data_ptr(), 'nbytes': f.data.numel() * 4, 'recs': [], 'recs2': [], 'keep': [], 'blocks': 0, 'blocks2': 0,
-                 'device': f.data.device, 'seen': set()}
+                 'device': f.data.device, 'seen': set(), 'wq': [], 'wq_bytes': 0}
         return self
 
     def __exit__(self, *exc):
         global _SINK
-        if _SINK is not None and _SINK['recs']:
+        if _SINK is not None and (_SINK['recs'] or _SINK['wq']):
             flush_grad_sink()
         _SINK = self.prev
 
@@ -172,7 +172,10 @@ def flush_grad_sink():
     """every recorded gradient summed into its slot of the flat gradient buffer: one launch, plus one over the chunk sums of the
     records that had more than 256 partials"""
     sk = _SINK
-    if sk is None or not sk['recs']:
+    if sk is None:
+        return
+    _flush_wgrads()
+    if not sk['recs']:
         return
     for recs, counter in ((sk['recs'], 'blocks'), (sk['recs2'], 'blocks2')):
         if recs:
@@ -247,6 +250,70 @@ def _wgrad_layout(M, N, K, splits, half):
     return r
 
 
+# ---- queued weight gradients (round 6) -----------------------------------------------------------------------------------------
+# Inside a gradient sink, in the float16 autocast mode, a deferred weight gradient is not launched where autograd reaches it: the
+# contraction is QUEUED (operands kept alive) and `_flush_wgrads` -- at the end of backward, or when the queue holds WGRAD_QUEUE_BYTES
+# of operands -- runs the whole queue as one launch per tile class (csrc wgrad_grouped_kernel) with the partials in ONE buffer; the
+# sink records are made then.  ~260 launches (and as many partial-buffer allocations) per step become <= 5; the row ranges are chosen
+# for the queue as a whole (WGRAD_ROWS rows per block; a stand-alone launch needs ~512 blocks of its own to fill the chip, i.e. up to
+# 128 row ranges = 33 MB of partials for one 256 x 256 weight).  MDX_WGRAD_GROUPED=0 keeps the per-call launches.
+_WG_ON = __import__('os').environ.get('MDX_WGRAD_GROUPED', '1') != '0'
+WGRAD_ROWS = int(__import__('os').environ.get('MDX_WGRAD_ROWS', '2048'))
+WGRAD_QUEUE_BYTES = int(float(__import__('os').environ.get('MDX_WGRAD_QUEUE_GB', '24')) * 2 ** 30)
+_PLANS = {}
+
+
+def _wgrad_plan(M, N, K, dt, ldg, ldx, aligned):
+    """(kind, gx, gy, S, mper, bias offset, partial floats, blocks) of a queued weight gradient (csrc mdx_op_wgrad_plan), cached per shape"""
+    key = (M, N, K, dt, ldg, ldx, aligned, WGRAD_ROWS)
+    r = _PLANS.get(key)
+    if r is None:
+        import ctypes
+        out = (ctypes.c_int64 * 8)()
+        check(_L().mdx_op_wgrad_plan(M, N, K, max(1, (M + WGRAD_ROWS - 1) // WGRAD_ROWS), dt, ldg, ldx, aligned, out))
+        r = _PLANS[key] = tuple(out)
+    return r
+
+
+def _flush_wgrads():
+    """run the queued weight gradients (one launch per tile class) and hand their partials to the gradient sink"""
+    sk = _SINK
+    if sk is None or not sk['wq']:
+        return
+    jobs, sk['wq'], sk['wq_bytes'] = sk['wq'], [], 0
+    total = sum((j[2][6] + 3) // 4 * 4 for j in jobs)
+    part = torch.empty(total, dtype=torch.float32, device=sk['device'])
+    base, off = part.data_ptr(), 0
+    by_kind, placed = {}, []
+    for g, x, plan, dims, dst_w, ldw, dst_b, rk in jobs:
+        kind, gx, gy, S, mper, boff, psize, blocks = plan
+        M, N, K, dt = dims
+        P = base + 4 * off
+        by_kind.setdefault(kind, []).append([g.data_ptr(), x.data_ptr(), P, (P + 4 * boff) if dst_b is not None else 0, g.stride(0), x.stride(0),
+                                             M, N, K, mper, gx, gy, S, dt, 0, blocks])
+        placed.append((P, S, N, K, boff, dst_w, ldw, dst_b, rk))
+        off += (psize + 3) // 4 * 4
+    rows, launches = [], []
+    for kind in sorted(by_kind):
+        recs = by_kind[kind]
+        recs.sort(key=lambda r: -r[9])       # the long blocks first (no tail of E-row blocks behind the N-row jobs)
+        fb = 0
+        for r in recs:
+            r[14], fb = fb, fb + r[15]
+        launches.append((kind, len(rows), len(recs), fb))
+        rows += recs
+    desc = torch.tensor(rows, dtype=torch.int64).to(sk['device'], non_blocking=True)
+    st = stream()
+    for kind, start, n, tb in launches:
+        check(_L().mdx_op_wgrad_grouped(desc.data_ptr() + 128 * start, n, tb, kind, st))
+    sk['keep'] += [part, desc]
+    for P, S, N, K, boff, dst_w, ldw, dst_b, rk in placed:
+        _sink_record(P, dst_w, S, N, K, ldw, N * K, rk, None)
+        if dst_b is not None:
+            _sink_record(P + 4 * boff, dst_b, S, 1, N, N, N, rk, None)
+    sk['keep'] += [part, desc]       # (again: a repeated destination above flushes the sink, which drops its references)
+
+
 def sgemm_tn(g, x, splits, want_bias=False, defer=None):
     """g (M,N)^T @ x (M,K) -> (N,K): the weight gradient, straight from the row-major tensors; with want_bias also the
     column sums of g (the bias gradient) from the same pass -> (dW, db).
@@ -254,6 +321,16 @@ def sgemm_tn(g, x, splits, want_bias=False, defer=None):
     M, N = g.shape
     K = x.shape[1]
     splits = max(1, int(splits))
+    if defer is not None and _WG_ON and _SINK is not None and _AMP is not None and _AMP[0] == 2 and g.stride(1) == 1 and x.stride(1) == 1:
+        dst_w, ldw, dst_b = defer
+        dt = _h(g) | (_h(x) << 1)
+        plan = _wgrad_plan(M, N, K, dt, g.stride(0), x.stride(0), int(g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0))
+        sk = _SINK
+        sk['wq'].append((g, x, plan, (M, N, K, dt), dst_w, ldw, dst_b if want_bias else None, _AMP[0] if _AMP[1] else 0))
+        sk['wq_bytes'] += g.numel() * g.element_size() + x.numel() * x.element_size()
+        if sk['wq_bytes'] > WGRAD_QUEUE_BYTES:
+            _flush_wgrads()
+        return None
     part = torch.empty((splits + (splits + 255) // 256) * (N * K + N), dtype=torch.float32, device=g.device)
     if defer is not None:
         dst_w, ldw, dst_b = defer

@@ -400,3 +400,42 @@ def test_class_range_assert_is_postponed_not_dropped():
     verify = chk.finish()
     with pytest.raises(AssertionError, match='8 >= 8'):
         verify()
+
+
+@pytest.mark.parametrize('rows', [64, 2048])
+def test_queued_weight_gradients_equal_the_per_call_launches(rows):
+    """Round 6: inside a gradient sink the float16 mode queues every weight-gradient contraction and runs the queue as one launch per
+    tile class (train_ops._flush_wgrads, csrc wgrad_grouped_kernel).  The flat gradient buffer must be what the per-call launches
+    produce: same contraction bodies, fp32 partials; only the row ranges differ (rows per block instead of ~512 blocks per call), so
+    the two agree to fp32 summation-order rounding before the final float16 rounding of each sum (<= 1 float16 ulp on an element)."""
+    import copy
+    from moldiff_amd import train_ops
+    base = U.moldiff('MolDiff_simple', DEV)
+    batch = _tiny_batch(11, sizes=(9, 14, 7, 12, 10))
+    t = torch.tensor([100, 300, 500, 700, 900], device=DEV)
+    g = U.rng(12)
+    N, Eh = batch[1].shape[0], batch[3].shape[0]
+    noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))).to(DEV), u_node=U.t32(g.random((N, 8))).to(DEV),
+                 u_halfedge=U.t32(g.random((Eh, 6))).to(DEV))
+    grads = {}
+    old = (train_ops._WG_ON, train_ops.WGRAD_ROWS, train_ops.FUSED_MIN_ROWS)
+    try:
+        train_ops.FUSED_MIN_ROWS = 1
+        for on in (False, True):
+            train_ops._WG_ON, train_ops.WGRAD_ROWS = on, rows
+            m = copy.deepcopy(base)
+            for mod in m.modules():
+                if hasattr(mod, '_eng'):
+                    mod._eng, mod._eng_sig = None, None
+            tr = Trainer(m, lr=0.0, max_grad_norm=None, precision='fp16', init_scale=256.0)
+            tr.step(*batch, time_step=t, noise=noise)
+            grads[on] = tr.flat.grad.clone()
+    finally:
+        train_ops._WG_ON, train_ops.WGRAD_ROWS, train_ops.FUSED_MIN_ROWS = old
+    a, b = grads[False], grads[True]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and float(a.abs().max()) > 0
+    # float16 rounding of each sum: one ulp = 2^-10 relative; elements near zero compare absolutely against the buffer's scale
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 2.0 ** -9 * scale
+    assert float((a - b).norm()) <= 2e-4 * float(a.norm())
+    assert float((a != b).float().mean()) < 0.05       # almost every element is bit-identical
