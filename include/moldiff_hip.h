@@ -160,6 +160,13 @@ int mdx_gauss_posterior(const float* coef_x0, const float* coef_xt, const float*
 int mdx_cat_posterior(const float* q_mats, const float* qT_onestep, int32_t K, int32_t T, const float* in0,
                       int32_t is_logits, const float* log_vt, const int64_t* t, const int64_t* batch, int64_t n,
                       float* out, void* stream);
+/* Training: the categorical loss rows of models/model.py:170-189 and their gradient w.r.t. the decoder logits in one launch --
+ * log_softmax, q_v_posterior (transition.py:285-315) of the true and the predicted classes, compute_v_Lt (transition.py:317-327:
+ * KL for t > 0, decoder NLL at t == 0) and the backward torch.autograd would run through them.  logits / log_vt / log_v0 (n,K), K <= 8;
+ * row_loss (n); dlogits (n,K) = d row_loss[i] / d logits[i][:] (the caller scales by 100 / n x the upstream gradient). */
+int mdx_op_cat_loss(const float* q_mats, const float* qT_onestep, int32_t K, int32_t T, const float* logits, const float* log_vt,
+                    const float* log_v0, const int64_t* t, const int64_t* batch, int64_t n, float* row_loss, float* dlogits,
+                    void* stream);
 /* log_sample_categorical, diffusion.py:79-85 (u passed in) + onehot_encode, transition.py:255. */
 int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n, int64_t* cls, float* onehot,
                       void* stream);

@@ -33,7 +33,7 @@ EXPORTS = [
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
     'mdx_op_edge_tail_fwd', 'mdx_op_edge_tail_bwd', 'mdx_op_edge_tail_lnp_floats',
     'mdx_op_posffn_fwd', 'mdx_op_posffn_bwd', 'mdx_op_posffn_lnp_floats',
-    'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
+    'mdx_op_cat_loss', 'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
 ]
 
 
@@ -168,6 +168,8 @@ def lib():
         L.mdx_cat_posterior.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_cat_loss.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p]
         L.mdx_prior_draw.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]
         L.mdx_noise.argtypes = [c_void_p, c_uint64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]
         L.mdx_guidance_uncertainty_grad.argtypes = [c_void_p, c_int32, c_int64, c_void_p, c_void_p]

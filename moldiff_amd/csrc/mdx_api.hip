@@ -1670,6 +1670,17 @@ extern "C" int mdx_cat_posterior(const float* q_mats, const float* qT, int32_t K
   return MDX_OK;
 }
 
+extern "C" int mdx_op_cat_loss(const float* q_mats, const float* qT, int32_t K, int32_t T, const float* logits, const float* log_vt,
+                               const float* log_v0, const int64_t* t, const int64_t* batch, int64_t n, float* row_loss, float* dlogits,
+                               void* stream) {
+  if (K < 2 || K > 8) return fail(MDX_ERR_UNSUPPORTED, "K must be in 2..8");
+  if (n < 0 || T < 1 || (n > 0 && (!q_mats || !qT || !logits || !log_vt || !log_v0 || !t || !batch || !row_loss || !dlogits)))
+    return fail(MDX_ERR_ARG, "bad argument");
+  launch_cat_loss(q_mats, qT, K, logits, log_vt, log_v0, t, batch, (int)n, row_loss, dlogits, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
 extern "C" int mdx_gumbel_argmax(const float* logits, const float* u, int32_t K, int64_t n, int64_t* cls, float* onehot,
                                  void* stream) {
   if (K < 1 || n < 0 || (n > 0 && (!logits || !u))) return fail(MDX_ERR_ARG, "bad argument");

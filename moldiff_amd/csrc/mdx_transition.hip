@@ -287,6 +287,141 @@ void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, co
 #undef MDX_CP
 }
 
+// ---- training: the categorical loss rows and their gradient in one launch (round 6) ---------------------------------------------------
+// Reference models/model.py:170-189: log_recon = log_softmax(logits); post_true = q_v_posterior(log_v0, log_vt); post_pred =
+// q_v_posterior(log_recon, log_vt) (models/transition.py:285-315); row term = KL(post_true || post_pred) for t > 0, -sum exp(log_v0)
+// post_pred at t == 0 (compute_v_Lt :317-327 with models/diffusion.py categorical_kl / log_categorical).  The layer-by-layer torch
+// evaluation of that tail and of its autograd costs ~190 launches of (rows x K <= 8) element-wise kernels per training step; here a
+// thread owns a row, evaluates both posteriors with the arithmetic of cat_posterior_row, and back-propagates by hand:
+//   g_pp = d row / d post_pred = -(mask exp(log_v0) + (1 - mask) exp(post_true))
+//   t > 0: post_pred = o - logsumexp(o), o = A + B, B = max(log(f2 + eps), -32), f2 = exp(log_recon) Q[t-1]   (A: no logits inside)
+//          g_o = g_pp - exp(post_pred) sum(g_pp); g_f2 = g_o [log(f2 + eps) >= -32] / (f2 + eps); g_lr = exp(log_recon) (Q[t-1] g_f2)
+//   t = 0: post_pred = log_recon (torch.where routes the whole gradient there): g_lr = g_pp
+//   log_recon = x - logsumexp(x): g_x = g_lr - softmax(x) sum(g_lr)
+// (what torch.autograd computes through transition.q_v_posterior_autograd, clamp_min passing the gradient where its input >= the bound).
+template <int K>
+__global__ void cat_loss_kernel(const float* __restrict__ qmats, const float* __restrict__ qT1, const float* __restrict__ logits,
+                                const float* __restrict__ log_vt, const float* __restrict__ log_v0, const int64_t* __restrict__ t,
+                                const int64_t* __restrict__ batch, int n, float* __restrict__ row_loss, float* __restrict__ dlogits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t tv = t[batch[i]];
+  const int64_t tm1 = tv > 0 ? tv - 1 : 0;
+  const float* Q1 = qT1 + (size_t)tv * K * K;
+  const float* Q0 = qmats + (size_t)tm1 * K * K;
+  float x[K], lt[K], l0[K], lr[K], er[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    x[k] = logits[(size_t)i * K + k];
+    lt[k] = log_vt[(size_t)i * K + k];
+    l0[k] = log_v0[(size_t)i * K + k];
+  }
+  {  // log_softmax
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) m = fmaxf(m, x[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s += expf(x[k] - m);
+    const float ls = logf(s);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      lr[k] = (x[k] - m) - ls;
+      er[k] = expf(lr[k]);
+    }
+  }
+  float et[K], e0[K], A[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    et[k] = expf(lt[k]);
+    e0[k] = expf(l0[k]);
+  }
+  // the two posteriors share A = max(log(exp(log_vt) Q1 + eps), -32)
+  float pt[K], pp[K], f2p[K];
+  {
+    float ot[K], op[K], mt = -INFINITY, mp = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float f1 = 0.f, f2t = 0.f, f2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        f1 += et[j] * Q1[j * K + k];
+        f2t += e0[j] * Q0[j * K + k];
+        f2 += er[j] * Q0[j * K + k];
+      }
+      A[k] = fmaxf(logf(f1 + 1e-30f), -32.f);
+      ot[k] = A[k] + fmaxf(logf(f2t + 1e-30f), -32.f);
+      op[k] = A[k] + fmaxf(logf(f2 + 1e-30f), -32.f);
+      f2p[k] = f2;
+      mt = fmaxf(mt, ot[k]);
+      mp = fmaxf(mp, op[k]);
+    }
+    float st = 0.f, sp = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      st += expf(ot[k] - mt);
+      sp += expf(op[k] - mp);
+    }
+    const float lset = mt + logf(st), lsep = mp + logf(sp);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pt[k] = (tv == 0) ? l0[k] : (ot[k] - lset);
+      pp[k] = (tv == 0) ? lr[k] : (op[k] - lsep);
+    }
+  }
+  const float mask = (tv == 0) ? 1.f : 0.f;
+  float kl = 0.f, nll = 0.f, gpp[K], gsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float ept = expf(pt[k]);
+    kl += ept * (pt[k] - pp[k]);
+    nll += e0[k] * pp[k];
+    gpp[k] = -(mask * e0[k] + (1.f - mask) * ept);
+    gsum += gpp[k];
+  }
+  row_loss[i] = mask * (-nll) + (1.f - mask) * kl;
+  float glr[K];
+  if (tv == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) glr[k] = gpp[k];
+  } else {
+    float gf2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float go = gpp[k] - expf(pp[k]) * gsum;
+      const float u = f2p[k] + 1e-30f;
+      gf2[k] = (logf(u) >= -32.f) ? go / u : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc += gf2[k] * Q0[j * K + k];
+      glr[j] = er[j] * acc;
+    }
+  }
+  float gl = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) gl += glr[k];
+#pragma unroll
+  for (int k = 0; k < K; ++k) dlogits[(size_t)i * K + k] = glr[k] - er[k] * gl;
+}
+
+void launch_cat_loss(const float* qmats, const float* qT1, int K, const float* logits, const float* log_vt, const float* log_v0,
+                     const int64_t* t, const int64_t* batch, int n, float* row_loss, float* dlogits, hipStream_t s) {
+  if (n <= 0) return;
+  dim3 g((n + 127) / 128), b(128);
+#define MDX_CL(KK)                                                                                                                  \
+  case KK:                                                                                                                          \
+    hipLaunchKernelGGL(cat_loss_kernel<KK>, g, b, 0, s, qmats, qT1, logits, log_vt, log_v0, t, batch, n, row_loss, dlogits);         \
+    break;
+  switch (K) {
+    MDX_CL(2) MDX_CL(3) MDX_CL(4) MDX_CL(5) MDX_CL(6) MDX_CL(7) MDX_CL(8)
+    default: break;
+  }
+#undef MDX_CL
+}
+
 void launch_step_transition(const StepTransArgs& a, hipStream_t s) {
   const int n = std::max(3 * a.N, a.Eh);
   if (n > 0) hipLaunchKernelGGL(step_transition_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);

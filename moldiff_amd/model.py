@@ -30,6 +30,8 @@ from .diffusion import get_beta_schedule
 from .graph import NodeEdgeNet, _sig, synth_gates
 from .transition import ContigousTransition, GeneralCategoricalTransition
 
+_FUSED_LOSS = os.environ.get('MDX_TRAIN_FUSED_LOSS', '1') != '0'   # training: categorical loss tail as one launch (train_ops.cat_loss)
+
 
 class MolDiff(Module):
     def __getstate__(self):
@@ -192,6 +194,10 @@ class MolDiff(Module):
         for name, tr, logits, log_t, log_0, batch in (
                 ('loss_node', self.node_transition, preds['pred_node'], log_node_t, log_node_0, batch_node),
                 ('loss_edge', self.edge_transition, preds['pred_halfedge'], log_half_t, log_half_0, batch_halfedge)):
+            if train and _FUSED_LOSS and logits.is_cuda and 2 <= logits.shape[-1] <= 8 and logits.shape[0] > 0:
+                from . import train_ops      # round 6: the whole tail and its backward as one launch (csrc cat_loss_kernel)
+                out[name] = train_ops.cat_loss(tr, logits, log_t, log_0, t, batch)
+                continue
             log_recon = F.log_softmax(logits, dim=-1)
             post_true = tr.q_v_posterior(log_0, log_t, t, batch, v0_prob=True)
             post_pred = (tr.q_v_posterior_autograd(log_recon, log_t, t, batch) if train

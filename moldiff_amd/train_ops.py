@@ -1313,3 +1313,35 @@ class _NodeMsg(torch.autograd.Function):
 
 def nodemsg(edge_attr, hn, pn, plan_col, plan_row, params):
     return _NodeMsg.apply(edge_attr, hn, pn, plan_col, plan_row, *[params[k] for k in _NodeMsg.PARAMS])
+
+
+# ---- the categorical loss tail as one node (round 6; csrc/mdx_transition.hip cat_loss_kernel) -----------------------------------------
+class _CatLoss(torch.autograd.Function):
+    """100 x mean over rows of {KL(q(v_{t-1} | v_t, v_0) || p_theta) for t > 0 | decoder NLL at t == 0} (models/model.py:170-189) as ONE
+    launch that also leaves d row / d logits; the backward is a scaling.  Replaces ~45 torch launches forward and ~50 backward per loss
+    term (log_softmax, the posterior algebra of transition.q_v_posterior_autograd, compute_v_Lt)."""
+
+    @staticmethod
+    def forward(ctx, logits, q_mats, qT, log_vt, log_v0, t, batch):
+        lg, lvt, lv0 = _c(logits), _c(log_vt), _c(log_v0)
+        n, K = lg.shape
+        tt = t.detach().to(torch.int64).contiguous()
+        bb = batch.detach().to(torch.int64).contiguous()
+        row = torch.empty(n, dtype=torch.float32, device=lg.device)
+        dl = torch.empty(n, K, dtype=torch.float32, device=lg.device)
+        check(_L().mdx_op_cat_loss(ptr(q_mats), ptr(qT), K, q_mats.shape[0], ptr(lg), ptr(lvt), ptr(lv0), ptr(tt), ptr(bb), n, ptr(row), ptr(dl),
+                                   stream()))
+        ctx.save_for_backward(dl)
+        ctx.scale, ctx.dtype = 100.0 / max(n, 1), logits.dtype
+        return torch.mean(row) * 100
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        gl = dl * (g * ctx.scale)
+        return (gl if gl.dtype == ctx.dtype else gl.to(ctx.dtype)), None, None, None, None, None, None
+
+
+def cat_loss(transition, logits, log_vt, log_v0, t, batch):
+    """torch.mean(transition.compute_v_Lt(q_v_posterior(log_v0, log_vt), q_v_posterior(log_softmax(logits), log_vt), log_v0)) * 100"""
+    return _CatLoss.apply(logits, transition.q_mats, transition.transpopse_q_onestep_mats, log_vt, log_v0, t, batch)

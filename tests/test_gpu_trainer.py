@@ -328,8 +328,15 @@ def test_deferred_gradient_sink_equals_autograd_accumulation(precision, sizes):
     N, Eh = batch[1].shape[0], batch[3].shape[0]
     noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))).to(DEV), u_node=U.t32(g.random((N, 8))).to(DEV),
                  u_halfedge=U.t32(g.random((Eh, 6))).to(DEV))
-    tr.step(*batch, time_step=t, noise=noise)
-    sunk = tr.flat.grad.clone()
+    sunk = {}
+    old = train_ops._WG_ON
+    try:
+        for queued in (False, True):                  # round 6: with and without the weight-gradient queue (float16 mode only)
+            train_ops._WG_ON = queued
+            tr.step(*batch, time_step=t, noise=noise)
+            sunk[queued] = tr.flat.grad.clone()
+    finally:
+        train_ops._WG_ON = old
     tr.zero_grad()
     with train_ops.precision(precision):
         loss = m.get_loss(*batch, time_step=t, noise=noise)['loss']
@@ -337,9 +344,14 @@ def test_deferred_gradient_sink_equals_autograd_accumulation(precision, sizes):
     plain = tr.flat.grad.clone()
     assert float(plain.abs().max()) > 0
     if precision == 'f32':
-        assert torch.equal(sunk, plain)
+        assert torch.equal(sunk[False], plain) and torch.equal(sunk[True], plain)
     else:
-        assert float((sunk - plain).abs().max()) <= 1e-6 * float(plain.abs().max())
+        assert float((sunk[False] - plain).abs().max()) <= 1e-6 * float(plain.abs().max())
+        # the queue cuts the rows into its own ranges: fp32 partial sums in another order, then the SAME float16 rounding of each
+        # element's sum -- at most one float16 ulp (2^-10 relative; absolute 2^-24 x scale for elements near zero) apart
+        d = (sunk[True] - plain).abs()
+        assert bool((d <= 2.0 ** -10 * plain.abs() + 2.0 ** -20 * float(plain.abs().max())).all())
+        assert float((d > 0).float().mean()) < 0.05
 
 
 def test_batched_weight_transposes_are_exact_views():
@@ -439,3 +451,40 @@ def test_queued_weight_gradients_equal_the_per_call_launches(rows):
     assert float((a - b).abs().max()) <= 2.0 ** -9 * scale
     assert float((a - b).norm()) <= 2e-4 * float(a.norm())
     assert float((a != b).float().mean()) < 0.05       # almost every element is bit-identical
+
+
+def test_fused_categorical_loss_equals_the_torch_tail():
+    """Round 6: train_ops.cat_loss (csrc cat_loss_kernel: log_softmax, both posteriors, KL / NLL rows and the hand-written backward in
+    one launch) against the layer-by-layer torch evaluation it replaces (models/model.py:170-189 through
+    transition.q_v_posterior_autograd + compute_v_Lt and torch.autograd): value and d/d logits, with rows at t == 0, at t == 1 and
+    with confident logits (the clamp at -32 / eps = 1e-30 branches)."""
+    import torch.nn.functional as F
+    from moldiff_amd import train_ops
+    from moldiff_amd.diffusion import index_to_log_onehot
+    m = U.moldiff('MolDiff_simple', DEV)
+    g = U.rng(5)
+    B = 40
+    t = torch.from_numpy(g.integers(0, 1000, B)).to(DEV)
+    t[:6] = torch.tensor([0, 0, 1, 1, 999, 2], device=DEV)
+    for tr, n in ((m.node_transition, 1500), (m.edge_transition, 4000)):
+        K = tr.num_classes
+        batch = torch.from_numpy(np.sort(g.integers(0, B, n))).to(DEV)
+        v = torch.from_numpy(g.integers(0, K, n)).to(DEV)
+        scale = torch.from_numpy(g.choice([0.3, 3.0, 40.0], n)).float().to(DEV).unsqueeze(-1)
+        logits = (U.t32(g.standard_normal((n, K))).to(DEV) * scale).requires_grad_(True)
+        with torch.no_grad():
+            log_v0 = index_to_log_onehot(v, K, checked=False)
+            _, log_vt = tr.q_vt_sample(log_v0, t, batch, U.t32(g.random((n, K))).to(DEV))
+        log_recon = F.log_softmax(logits, dim=-1)
+        post_true = tr.q_v_posterior(log_v0, log_vt, t, batch, v0_prob=True)
+        post_pred = tr.q_v_posterior_autograd(log_recon, log_vt, t, batch)
+        ref = torch.mean(tr.compute_v_Lt(post_true, post_pred, log_v0, t=t, batch=batch)) * 100
+        (g_ref,) = torch.autograd.grad(ref * 3.0, logits)
+        logits2 = logits.detach().clone().requires_grad_(True)
+        got = train_ops.cat_loss(tr, logits2, log_vt, log_v0, t, batch)
+        (g_got,) = torch.autograd.grad(got * 3.0, logits2)
+        assert torch.isfinite(got) and torch.isfinite(g_got).all()
+        assert abs(float(got) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (float(got), float(ref))
+        gs = float(g_ref.abs().max())
+        assert gs > 0 and float((g_got - g_ref).abs().max()) <= 2e-5 * gs, (float((g_got - g_ref).abs().max()), gs)
+        assert float((g_got - g_ref).norm()) <= 2e-6 * float(g_ref.norm())

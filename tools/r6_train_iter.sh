@@ -11,12 +11,15 @@ cd $ROOT
 timeout 1500 python -m pytest tests/test_gpu_trainer.py tests/test_gpu_fused_train.py tests/test_gpu_train_ops.py tests/test_loss.py -x -q -m gpu > $OUT/r6t_${TAG}_tests.txt 2>&1
 tail -3 $OUT/r6t_${TAG}_tests.txt
 cd /tmp && export TMPDIR=/tmp
-for rows in ${SWEEP:-0 1024 2048 4096 8192}; do
+# the box's host cores are shared: every setting is measured REPS times, the summary prints each and the minimum counts
+for rep in $(seq 1 ${REPS:-3}); do
+for rows in ${SWEEP:-0 2048}; do
   if [ $rows = 0 ]; then
-    MDX_WGRAD_GROUPED=0 python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 20 --warmup 6 > $OUT/r6t_${TAG}_train_off.json 2> /dev/null
+    MDX_WGRAD_GROUPED=0 python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 20 --warmup 6 > $OUT/r6t_${TAG}_train_off_$rep.json 2> /dev/null
   else
-    MDX_WGRAD_ROWS=$rows python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 20 --warmup 6 > $OUT/r6t_${TAG}_train_rows$rows.json 2> /dev/null
+    MDX_WGRAD_ROWS=$rows python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 20 --warmup 6 > $OUT/r6t_${TAG}_train_rows${rows}_$rep.json 2> /dev/null
   fi
+done
 done
 rm -rf /tmp/prof_tr
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tr -o p -- python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 10 > $OUT/r6t_${TAG}_train_under_rocprof.json 2> /dev/null
