@@ -491,3 +491,44 @@ def test_fused_categorical_loss_equals_the_torch_tail():
         gs = float(g_ref.abs().max())
         assert gs > 0 and float((g_got - g_ref).abs().max()) <= 2e-5 * gs, (float((g_got - g_ref).abs().max()), gs)
         assert float((g_got - g_ref).norm()) <= 2e-6 * float(g_ref.norm())
+
+
+@pytest.mark.parametrize('fused_rows', [1024, 1])
+def test_cpp_fast_path_is_bit_identical_to_the_python_bodies(fused_rows):
+    """Round 6: csrc/mdx_fast.cpp (moldiff_amd/_mdx_fast.so) holds the training operators' host logic in C++ -- gradient sink, weight-
+    gradient queue, Linear / Linear+LayerNorm / element-wise autograd nodes, the fused operators' bodies.  Same kernels, same buffers,
+    same row ranges: the loss, the flat gradient buffer and the updated weights of two optimisation steps must be BIT-identical with
+    MDX_TRAIN_FAST on and off (fused_rows = 1: with the fused row-owner kernels forced on at this size, so their C++ bodies run)."""
+    import copy
+    from moldiff_amd import train_ops
+    base = U.moldiff('MolDiff', DEV)
+    batch = _tiny_batch(41, sizes=(9, 14, 7, 12, 10, 6))
+    t = torch.tensor([0, 100, 300, 500, 700, 999], device=DEV)
+    g = U.rng(42)
+    N, Eh = batch[1].shape[0], batch[3].shape[0]
+    noise = dict(eps_pos=U.t32(g.standard_normal((N, 3))).to(DEV), u_node=U.t32(g.random((N, 8))).to(DEV),
+                 u_halfedge=U.t32(g.random((Eh, 6))).to(DEV))
+    res = {}
+    old = (train_ops._FAST_ON, train_ops.FUSED_MIN_ROWS)
+    try:
+        train_ops.FUSED_MIN_ROWS = fused_rows
+        for fast in (False, True):
+            train_ops._FAST_ON = fast
+            m = copy.deepcopy(base)
+            for mod in m.modules():
+                if hasattr(mod, '_eng'):
+                    mod._eng, mod._eng_sig = None, None
+            tr = Trainer(m, lr=1e-4, max_grad_norm=50.0, precision='fp16', init_scale=256.0)
+            n0 = train_ops._fast().launches() if fast else 0
+            o1 = tr.step(*batch, time_step=t, noise=noise)
+            g1 = tr.flat.grad.clone()
+            o2 = tr.step(*batch, time_step=t, noise=noise)
+            res[fast] = (float(o1['loss']), float(o2['loss']), g1, tr.flat.grad.clone(), tr.flat.data.clone(), float(o2['grad_norm']))
+            if fast:
+                assert train_ops._fast().launches() - n0 > 100        # the C++ bodies did run
+    finally:
+        train_ops._FAST_ON, train_ops.FUSED_MIN_ROWS = old
+    a, b = res[False], res[True]
+    assert a[0] == b[0] and a[1] == b[1] and a[5] == b[5], (a[0], b[0], a[1], b[1])
+    assert float(a[2].abs().max()) > 0
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
