@@ -93,6 +93,16 @@ struct State {
   int64_t n_launch = 0;
 } S;
 
+// a node's backward runs in the precision of its forward (train_ops: `with precision(ctx.prec)`), whatever the mode is by then
+inline int64_t amp_pack() { return S.amp0 | (S.amp_auto << 4) | (S.amp_store << 5); }
+struct AmpGuard {
+  int a0, a1, a2;
+  explicit AmpGuard(int64_t packed) : a0(S.amp0), a1(S.amp_auto), a2(S.amp_store) {
+    S.amp0 = (int)(packed & 15), S.amp_auto = (int)((packed >> 4) & 1), S.amp_store = (int)((packed >> 5) & 1);
+  }
+  ~AmpGuard() { S.amp0 = a0, S.amp_auto = a1, S.amp_store = a2; }
+};
+
 bool fast_mode() { return S.sink && S.amp0 == 2 && S.amp_auto && S.amp_store; }
 
 int64_t sink_dst(const Tensor& t) {
@@ -325,17 +335,21 @@ class LinearFn : public torch::autograd::Function<LinearFn> {
     ctx->save_for_backward({xc, wc, (b && b->defined()) ? *b : Tensor()});
     ctx->saved_data["f"] = (int64_t)((b && b->defined()) | ((addend && addend->defined()) << 1));
     ctx->saved_data["xd"] = (int64_t)x.scalar_type();
+    ctx->saved_data["amp"] = amp_pack();
     ctx->saved_data["ad"] = (int64_t)((addend && addend->defined()) ? addend->scalar_type() : at::kFloat);
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    AmpGuard guard(ctx->saved_data["amp"].toInt());
     auto sv = ctx->get_saved_variables();
     LinCtx c;
     c.x = sv[0], c.w = sv[1], c.b = sv[2];
     const int64_t f = ctx->saved_data["f"].toInt();
     c.has_bias = f & 1, c.has_addend = f & 2;
-    c.need_x = ctx->needs_input_grad(0), c.need_w = ctx->needs_input_grad(1), c.need_b = ctx->needs_input_grad(2);
-    c.need_add = ctx->needs_input_grad(3);
+    // (needs_input_grad counts the TENSOR arguments that were present: x, w, [b], [addend], ...)
+    c.need_x = ctx->needs_input_grad(0), c.need_w = ctx->needs_input_grad(1);
+    c.need_b = c.has_bias && ctx->needs_input_grad(2);
+    c.need_add = c.has_addend && ctx->needs_input_grad(2 + (c.has_bias ? 1 : 0));
     c.x_dtype = (at::ScalarType)ctx->saved_data["xd"].toInt();
     c.add_dtype = (at::ScalarType)ctx->saved_data["ad"].toInt();
     Tensor gx, ga;
@@ -381,10 +395,12 @@ class LinearLnReluFn : public torch::autograd::Function<LinearLnReluFn> {
     ctx->save_for_backward({xc, wc, (b && b->defined()) ? *b : Tensor(), pre, g, bt, stats, gamma, beta});
     ctx->saved_data["f"] = (int64_t)((b && b->defined()) | ((addend && addend->defined()) << 1));
     ctx->saved_data["xd"] = (int64_t)x.scalar_type();
+    ctx->saved_data["amp"] = amp_pack();
     ctx->saved_data["ad"] = (int64_t)((addend && addend->defined()) ? addend->scalar_type() : at::kFloat);
     return post;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    AmpGuard guard(ctx->saved_data["amp"].toInt());
     auto sv = ctx->get_saved_variables();
     Tensor gpre;
     ln_backward(grads[0], sv[3], sv[6], sv[4], sv[5], sv[7], sv[8], 1, gpre);
@@ -392,8 +408,10 @@ class LinearLnReluFn : public torch::autograd::Function<LinearLnReluFn> {
     c.x = sv[0], c.w = sv[1], c.b = sv[2];
     const int64_t f = ctx->saved_data["f"].toInt();
     c.has_bias = f & 1, c.has_addend = f & 2;
-    c.need_x = ctx->needs_input_grad(0), c.need_w = ctx->needs_input_grad(1), c.need_b = ctx->needs_input_grad(2);
-    c.need_add = ctx->needs_input_grad(3);
+    // (needs_input_grad counts the TENSOR arguments that were present: x, w, [b], [addend], ...)
+    c.need_x = ctx->needs_input_grad(0), c.need_w = ctx->needs_input_grad(1);
+    c.need_b = c.has_bias && ctx->needs_input_grad(2);
+    c.need_add = c.has_addend && ctx->needs_input_grad(2 + (c.has_bias ? 1 : 0));
     c.x_dtype = (at::ScalarType)ctx->saved_data["xd"].toInt();
     c.add_dtype = (at::ScalarType)ctx->saved_data["ad"].toInt();
     Tensor gx, ga;
@@ -418,16 +436,18 @@ class EwFn : public torch::autograd::Function<EwFn> {
     ++S.n_launch;
     ctx->save_for_backward({ac, bc});
     ctx->saved_data["op"] = op;
+    ctx->saved_data["amp"] = amp_pack();
     ctx->saved_data["da"] = (int64_t)a.scalar_type();
     ctx->saved_data["db"] = (int64_t)b.scalar_type();
     return out;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    AmpGuard guard(ctx->saved_data["amp"].toInt());
     auto sv = ctx->get_saved_variables();
     const Tensor &a = sv[0], &b = sv[1];
     Tensor g = tc(grads[0]);
-    Tensor da = ctx->needs_input_grad(1) ? at::empty_like(a) : Tensor();
-    Tensor db = ctx->needs_input_grad(2) ? at::empty_like(b) : Tensor();
+    Tensor da = ctx->needs_input_grad(0) ? at::empty_like(a) : Tensor();     // (indices over the tensor arguments: a, b)
+    Tensor db = ctx->needs_input_grad(1) ? at::empty_like(b) : Tensor();
     chk(mdx_op_ew_bwd_t((int32_t)ctx->saved_data["op"].toInt(), a.data_ptr(), b.data_ptr(), g.data_ptr(), P(da), P(db), a.numel(),
                         H(a) | (H(b) << 1) | (H(g) << 2) | (H(da) << 3) | (H(db) << 4), cur_stream()));
     ++S.n_launch;

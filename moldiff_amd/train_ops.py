@@ -1458,6 +1458,7 @@ class _BondFfnScatterF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, bond_in, NL, GN, time, plan_in, plan_out, *params):
         ps = list(params)
+        ctx.prec = _AMP
         r = F.bondffn_fwd(bond_in, NL, GN, time, plan_in.index, plan_out.order, plan_out.ptr, plan_out.n, ps)
         ctx.F, ctx.saved, ctx.ps, ctx.plan_in, ctx.plan_out = F, r[1:], ps, plan_in, plan_out
         t2 = time.detach()
@@ -1468,7 +1469,8 @@ class _BondFfnScatterF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gS):
         ni, pi = ctx.needs_input_grad, ctx.plan_in
-        g = ctx.F.bondffn_bwd(gS, ctx.saved, pi.index, pi.order, pi.ptr, pi.n, ctx.plan_out.index, ctx.time2d, ctx.ps, ni[1], ni[2], ni[3])
+        with precision(ctx.prec):
+            g = ctx.F.bondffn_bwd(gS, ctx.saved, pi.index, pi.order, pi.ptr, pi.n, ctx.plan_out.index, ctx.time2d, ctx.ps, ni[1], ni[2], ni[3])
         gx = g[0]
         if gx is not None and gx.dtype != ctx.x_dtype:
             gx = gx.to(ctx.x_dtype)
@@ -1480,6 +1482,7 @@ class _EdgeTailF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, h, BL, BR, plan_l, plan_r, *params):
         ps = list(params)
+        ctx.prec = _AMP
         r = F.edge_tail_fwd(h, BL, BR, plan_l.index, plan_r.index, ps)
         ctx.F, ctx.saved, ctx.ps, ctx.plan_l, ctx.plan_r, ctx.x_dtype = F, r[1:], ps, plan_l, plan_r, h.dtype
         return r[0]
@@ -1487,7 +1490,8 @@ class _EdgeTailF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         ni, pl, pr = ctx.needs_input_grad, ctx.plan_l, ctx.plan_r
-        g = ctx.F.edge_tail_bwd(g_out, ctx.saved, pl.index, pr.index, pl.order, pl.ptr, pr.order, pr.ptr, pl.n, ctx.ps, ni[1], ni[2], ni[3])
+        with precision(ctx.prec):
+            g = ctx.F.edge_tail_bwd(g_out, ctx.saved, pl.index, pr.index, pl.order, pl.ptr, pr.order, pr.ptr, pl.n, ctx.ps, ni[1], ni[2], ni[3])
         gh = g[0]
         if gh is not None and gh.dtype != ctx.x_dtype:
             gh = gh.to(ctx.x_dtype)
@@ -1499,6 +1503,7 @@ class _PosFfnFrontF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, h_edge, LF, RF, time, plan_l, plan_r, *params):
         ps = list(params)
+        ctx.prec = _AMP
         r = F.posffn_fwd(h_edge, LF, RF, time, plan_l.index, plan_r.index, ps)
         # saved for the backward: [x, LF, RF, te, a, gpre, gpost, prod, gate]
         ctx.F, ctx.saved, ctx.ps, ctx.plan_l, ctx.plan_r, ctx.x_dtype = F, r[2:] + [r[0], r[1]], ps, plan_l, plan_r, h_edge.dtype
@@ -1508,8 +1513,9 @@ class _PosFfnFrontF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_prod, g_gate):
         ni, pl, pr = ctx.needs_input_grad, ctx.plan_l, ctx.plan_r
-        g = ctx.F.posffn_bwd(g_prod, g_gate, ctx.saved, pl.index, pr.index, pl.order, pl.ptr, pr.order, pr.ptr, pl.n, ctx.time2d, ctx.ps,
-                             ni[1], ni[2], ni[3])
+        with precision(ctx.prec):
+            g = ctx.F.posffn_bwd(g_prod, g_gate, ctx.saved, pl.index, pr.index, pl.order, pl.ptr, pr.order, pr.ptr, pl.n, ctx.time2d, ctx.ps,
+                                 ni[1], ni[2], ni[3])
         gx = g[0]
         if gx is not None and gx.dtype != ctx.x_dtype:
             gx = gx.to(ctx.x_dtype)
@@ -1521,6 +1527,7 @@ class _NodeMsgF(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, edge_attr, HN, PN, plan_col, plan_row, *params):
         ps = list(params)
+        ctx.prec = _AMP
         r = F.nodemsg_fwd(edge_attr, HN, PN, plan_col.index, plan_row.order, plan_row.ptr, plan_row.n, ps)
         ctx.F, ctx.saved, ctx.ps, ctx.plan_col, ctx.plan_row, ctx.x_dtype = F, r[1:], ps, plan_col, plan_row, edge_attr.dtype
         return r[0]
@@ -1528,7 +1535,8 @@ class _NodeMsgF(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gA):
         ni, pc = ctx.needs_input_grad, ctx.plan_col
-        g = ctx.F.nodemsg_bwd(gA, ctx.saved, pc.index, pc.order, pc.ptr, pc.n, ctx.plan_row.index, ctx.ps, ni[1], ni[2], ni[3])
+        with precision(ctx.prec):
+            g = ctx.F.nodemsg_bwd(gA, ctx.saved, pc.index, pc.order, pc.ptr, pc.n, ctx.plan_row.index, ctx.ps, ni[1], ni[2], ni[3])
         gx = g[0]
         if gx is not None and gx.dtype != ctx.x_dtype:
             gx = gx.to(ctx.x_dtype)

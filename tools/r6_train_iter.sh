@@ -20,6 +20,7 @@ for rows in ${SWEEP:-0 2048}; do
     MDX_WGRAD_ROWS=$rows python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 20 --warmup 6 > $OUT/r6t_${TAG}_train_rows${rows}_$rep.json 2> /dev/null
   fi
 done
+MDX_TRAIN_FAST=0 python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 20 --warmup 6 > $OUT/r6t_${TAG}_train_pybodies_$rep.json 2> /dev/null
 done
 rm -rf /tmp/prof_tr
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tr -o p -- python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 10 > $OUT/r6t_${TAG}_train_under_rocprof.json 2> /dev/null
