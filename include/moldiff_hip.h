@@ -403,7 +403,8 @@ int mdx_op_reduce_deferred(const int64_t* desc, int32_t n, int64_t total_blocks,
 /* Queued (grouped) weight gradients, float16 autocast mode.  A step's weight-gradient contractions dW = dY^T X (the backward of every
  * nn.Linear of reference models/common.py:181-201 and models/graph.py, i.e. torch.autograd's mm_backward for the weight) feed nothing
  * before the optimizer, so the host may queue them and run a whole table per launch.  mdx_op_wgrad_plan: tile class and layout of one
- * contraction -- out[0..7] = kind (0..3 transpose-read kernel with tiles 128x128 / 128x64 / 64x128 / 64x64 (n x k), 4 converting kernel),
+ * contraction -- out[0..7] = kind (0..3 transpose-read kernel with tiles 128x128 / 128x64 / 64x128 / 64x64 (n x k), 4 converting kernel,
+ * 5 / 6 the transpose-read kernel with 32x64 / 64x32 tiles, 7 a scaled column sum for N == 1 or K == 1),
  * gx, gy (tiles along K, N), S (row ranges), mper (rows per range), float offset of the [S][N] bias partials, floats of the whole partial
  * area (the layout of mdx_op_xgemm_tn_t / mdx_op_wgrad_layout), blocks.  dt bit 0 / 1: dY / X stored as float16; `aligned`: both start on
  * 16 bytes.  mdx_op_wgrad_grouped: one launch over a DEVICE table of n records of one kind -- 16 x int64 {dY, X, P, Pb (0 = no bias

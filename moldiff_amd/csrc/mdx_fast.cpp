@@ -158,7 +158,7 @@ void flush_wgrads() {
   struct Placed { int64_t Pp, Sn, N, K, boff, dst_w, ldw, dst_b, rk; };
   std::vector<Placed> placed;
   placed.reserve(jobs.size());
-  std::vector<std::array<int64_t, 16>> by_kind[5];
+  std::vector<std::array<int64_t, 16>> by_kind[8];
   int64_t off = 0;
   for (auto& j : jobs) {
     const int64_t kind = j.plan[0], gx = j.plan[1], gy = j.plan[2], Sn = j.plan[3], mper = j.plan[4], boff = j.plan[5], psize = j.plan[6],
@@ -172,7 +172,7 @@ void flush_wgrads() {
   std::vector<int64_t> rows_;
   struct Launch { int kind; int64_t start, n, tb; };
   std::vector<Launch> launches;
-  for (int kind = 0; kind < 5; ++kind) {
+  for (int kind = 0; kind < 8; ++kind) {
     auto& recs = by_kind[kind];
     if (recs.empty()) continue;
     std::stable_sort(recs.begin(), recs.end(), [](const std::array<int64_t, 16>& a, const std::array<int64_t, 16>& b) { return a[9] > b[9]; });

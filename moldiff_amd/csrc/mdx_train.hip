@@ -413,12 +413,27 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const bool vecb = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-  for (int i = tid; i < N * (K / 4); i += blockDim.x) {
-    const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
-    const f32x4 v = load4_guard(B + (size_t)n * ldb, k4, K, true, vecb);
-    const uint2 h = {(uint32_t)HalfT<1>::cvt(v[0]) | ((uint32_t)HalfT<1>::cvt(v[1]) << 16),
-                     (uint32_t)HalfT<1>::cvt(v[2]) | ((uint32_t)HalfT<1>::cvt(v[3]) << 16)};
-    *reinterpret_cast<uint2*>(Ws + n * LD + k4) = h;
+  // weight -> LDS as float16.  Eight 16-byte loads in flight per thread (round 6): with one, a workgroup needed ~20 us for a 256 x 256
+  // weight -- the whole cost of a Linear over the N node rows (43 workgroups, one tile per wave): 25 us per launch, ~100 launches a step.
+  {
+    constexpr int NV = N * (K / 4), U = NV >= 8 * 512 ? 8 : (NV >= 4 * 512 ? 4 : 1);
+    for (int i0 = tid; i0 < NV; i0 += U * (int)blockDim.x) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i < NV) v[u] = load4_guard(B + (size_t)(i / (K / 4)) * ldb, (i % (K / 4)) * 4, K, true, vecb);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i < NV) {
+          const uint2 h = {(uint32_t)HalfT<1>::cvt(v[u][0]) | ((uint32_t)HalfT<1>::cvt(v[u][1]) << 16),
+                           (uint32_t)HalfT<1>::cvt(v[u][2]) | ((uint32_t)HalfT<1>::cvt(v[u][3]) << 16)};
+          *reinterpret_cast<uint2*>(Ws + (i / (K / 4)) * LD + (i % (K / 4)) * 4) = h;
+        }
+      }
+    }
   }
   for (int i = tid; i < N; i += blockDim.x) bs[i] = bias ? bias[i] : 0.f;
   __syncthreads();  // the only barrier
@@ -846,7 +861,66 @@ __global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __rest
 // dt (bit 0 G float16, bit 1 X float16), first_block, unused.  A job's blocks are numbered like its own grid would be (k tile
 // fastest, then n tile, then row range: the blocks that share rows of G and X are neighbours, L2 serves the re-reads); the bodies are
 // the stand-alone kernels', so a job's partials are bit-identical to a stand-alone launch with the same `mper`.
-// KIND 0..3: transpose-read kernel with tiles 128x128, 128x64, 64x128, 64x64; 4: converting kernel, 64x64 tiles, float16 products.
+// KIND 0..3: transpose-read kernel with tiles 128x128, 128x64, 64x128, 64x64; 4: converting kernel, 64x64 tiles, float16 products;
+// 5 / 6: transpose-read kernel with 32x64 / 64x32 tiles; 7: one output row or one input column (wgrad_colsum_body).
+// Weight gradient with ONE output row or ONE input column (a Linear to a scalar: PosUpdate's 256 -> 1 and its gate's 32 -> 1; the time
+// column of a gate's first Linear): dW[c] = sum_m s[m] A[m][c] with (s, A) = (dY (M,1), X (M,C)) or (X (M,1), dY (M,C)) -- a scaled column
+// sum, not a matrix product (the 64 x 64 MFMA tile of the converting kernel spent 20 us per call on 63/64 zero columns).  256 threads =
+// 256 / (C/4) rows x C/4 lanes of four columns; row groups are combined through LDS in a fixed order.  Bias partials: the plain column
+// sums of dY (A = dY) or sum_m s[m] (s = dY).  C % 4 == 0, C <= 256.
+__device__ __forceinline__ void wgrad_colsum_body(const TP s_, const TP A_, int lda, int C, bool bias_is_A, int M, int mper, float* __restrict__ P,
+                                                  float* __restrict__ Pb, const int bz) {
+  __shared__ f32x4 red[256];
+  __shared__ f32x4 redb[256];
+  const int tid = threadIdx.x, lpr = C >> 2, rows_it = 256 / lpr;
+  const int cl = tid % lpr, rl = tid / lpr;
+  const int mbeg = bz * mper, mend = min(M, mbeg + mper);
+  const bool vec = tp_vec_ok(A_.p, A_.h, lda);
+  f32x4 acc = splat4(0.f), accb = splat4(0.f);
+  if (rl < rows_it) {
+#pragma unroll 4
+    for (int m = mbeg + rl; m < mend; m += rows_it) {
+      float sv = ld1(s_, (size_t)m);
+      f32x4 a;
+      if (vec) {
+        a = ld4(A_, (size_t)m * lda + 4 * cl);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = ld1(A_, (size_t)m * lda + 4 * cl + r);
+      }
+      // autocast arithmetic: operands of a Linear's contraction are float16 VALUES (the converting kernel rounds fp32 containers the same way)
+      if (!s_.h) sv = round_half<1>(sv);
+      if (!A_.h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = round_half<1>(a[r]);
+      }
+      acc = acc + a * splat4(sv);
+      accb = accb + (bias_is_A ? a : splat4(sv));
+    }
+  }
+  red[tid] = acc;
+  redb[tid] = accb;
+  __syncthreads();
+  if (tid < lpr) {
+    f32x4 r = splat4(0.f), rb = splat4(0.f);
+    for (int g = 0; g < rows_it; ++g) {
+      r = r + red[g * lpr + tid];
+      rb = rb + redb[g * lpr + tid];
+    }
+    float* out = P + (size_t)bz * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[4 * tid + e] = r[e];
+    if (Pb) {
+      if (bias_is_A) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Pb[(size_t)bz * C + 4 * tid + e] = rb[e];
+      } else if (tid == 0) {
+        Pb[bz] = rb[0];   // (every lane of a row added s[m] once: lane 0's sum over the row groups is sum_m s[m])
+      }
+    }
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const long long* __restrict__ desc, int n) {
   const long long blk = blockIdx.x;
@@ -866,6 +940,15 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const long long* __r
     const _Float16* G = reinterpret_cast<const _Float16*>(d[0]);
     const _Float16* X = reinterpret_cast<const _Float16*>(d[1]);
     hgemm_tn_tr_body<(KIND < 2 ? 128 : 64), ((KIND & 1) ? 64 : 128)>(G, ldg, X, ldx, M, N, K, mper, P, Pb, bx, by, bz);
+  } else if constexpr (KIND == 5 || KIND == 6) {   // 32-wide layers (the gates' hidden width): 32 x 64 / 64 x 32 tiles of the same kernel
+    const _Float16* G = reinterpret_cast<const _Float16*>(d[0]);
+    const _Float16* X = reinterpret_cast<const _Float16*>(d[1]);
+    hgemm_tn_tr_body<(KIND == 5 ? 32 : 64), (KIND == 5 ? 64 : 32)>(G, ldg, X, ldx, M, N, K, mper, P, Pb, bx, by, bz);
+  } else if constexpr (KIND == 7) {                // N == 1 or K == 1: scaled column sums
+    const int dt = (int)d[13];
+    const TP G{reinterpret_cast<const void*>(d[0]), dt & 1}, X{reinterpret_cast<const void*>(d[1]), (dt >> 1) & 1};
+    if (N == 1) wgrad_colsum_body(G, X, ldx, K, false, M, mper, P, Pb, bz);
+    else wgrad_colsum_body(X, G, ldg, N, true, M, mper, P, Pb, bz);
   } else {
     const int dt = (int)d[13];
     const TP G{reinterpret_cast<const void*>(d[0]), dt & 1}, X{reinterpret_cast<const void*>(d[1]), (dt >> 1) & 1};
@@ -2302,6 +2385,12 @@ extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits
     tn = N % 128 == 0 ? 128 : 64;
     tk = K % 128 == 0 ? 128 : 64;
     kind = (tn == 128 ? 0 : 2) + (tk == 128 ? 0 : 1);
+  } else if ((dt & 3) == 3 && ldg % 8 == 0 && ldx % 8 == 0 && aligned && ((N == 32 && K == 64) || (N == 64 && K == 32))) {
+    tn = (int)N, tk = (int)K;
+    kind = N == 32 ? 5 : 6;
+  } else if ((N == 1 && K % 4 == 0 && K <= 256) || (K == 1 && N % 4 == 0 && N <= 256)) {
+    tn = (int)N, tk = (int)K;   // one block per row range
+    kind = 7;
   }
   const int64_t gx = (K + tk - 1) / tk, gy = (N + tn - 1) / tn;
   out[0] = kind, out[1] = gx, out[2] = gy, out[3] = S, out[4] = mper;
@@ -2323,7 +2412,10 @@ extern "C" int mdx_op_wgrad_grouped(const int64_t* desc, int32_t n, int64_t tota
     case 2: hipLaunchKernelGGL(wgrad_grouped_kernel<2>, grid, dim3(256), 0, s, d, (int)n); break;
     case 3: hipLaunchKernelGGL(wgrad_grouped_kernel<3>, grid, dim3(256), 0, s, d, (int)n); break;
     case 4: hipLaunchKernelGGL(wgrad_grouped_kernel<4>, grid, dim3(256), 0, s, d, (int)n); break;
-    default: return bad("wgrad_grouped: kind must be 0..4");
+    case 5: hipLaunchKernelGGL(wgrad_grouped_kernel<5>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 6: hipLaunchKernelGGL(wgrad_grouped_kernel<6>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 7: hipLaunchKernelGGL(wgrad_grouped_kernel<7>, grid, dim3(256), 0, s, d, (int)n); break;
+    default: return bad("wgrad_grouped: kind must be 0..7");
   }
   return launched();
 }
