@@ -13,6 +13,7 @@
 //   edge_geom, smear, force                              rel/dist of an edge, Gaussian smearing, w*rel/d/(d+1) + backwards
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -402,6 +403,12 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
                                                              const float* __restrict__ bias, const TP addend, int ldd, const TPW C,
                                                              int ldc, int M, const LnEpi ln = LnEpi{}) {
   constexpr int K = 32 * KT, N = 16 * FT, LD = K + 8;
+  // blockIdx.y = column group (round 6; not with the LayerNorm epilogue): a Linear over the ~5,500 NODE rows needs only ~43 workgroups
+  // for its rows, each of which used to stage the WHOLE weight; cut into groups of N output columns the same rows are served by
+  // gridDim.y times the workgroups, each staging 1 / gridDim.y of the weight (A is re-read from L2).
+  const int col0 = N * (int)blockIdx.y;
+  B += (size_t)col0 * ldb;
+  if (bias) bias += col0;
   extern __shared__ __attribute__((aligned(16))) uint16_t hr_smem[];
   uint16_t* Ws = hr_smem;                                   // [N][LD] float16
   float* bs = reinterpret_cast<float*>(hr_smem + N * LD);   // [N] (+ [N] gamma, [N] beta with the LayerNorm epilogue)
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
     for (int ks = 0; ks < KT; ++ks) d[ks] = *reinterpret_cast<const uint4*>(p + 32 * ks);
   };
   if (tile < ntiles) load(x, tile);
-  const bool veco = tp_vec_ok(C.p, C.h, ldc), vecd = addend.p && tp_vec_ok(addend.p, addend.h, ldd);
+  const bool veco = tp_vec_ok(C.p, C.h, ldc) && (col0 & 3) == 0, vecd = addend.p && tp_vec_ok(addend.p, addend.h, ldd) && (col0 & 3) == 0;
   const uint16_t* wl = Ws + c * LD + 8 * q;
 #pragma unroll 1
   for (; tile < ntiles; tile += nw) {
@@ -474,17 +481,17 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
         f32x4 v = acc[ft] + lds4(bs + col);
         if (addend.p) {
           if (vecd) {
-            v = v + ld4(addend, (size_t)row * ldd + col);
+            v = v + ld4(addend, (size_t)row * ldd + col0 + col);
           } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += ld1(addend, (size_t)row * ldd + col + r);
+            for (int r = 0; r < 4; ++r) v[r] += ld1(addend, (size_t)row * ldd + col0 + col + r);
           }
         }
         if (ROUND) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = round_half<1>(v[r]);
         }
-        const size_t o = (size_t)row * ldc + col;
+        const size_t o = (size_t)row * ldc + col0 + col;
         if (veco) {
           st4(C, o, v);
         } else {
@@ -530,7 +537,7 @@ int mdx_num_cus();  // mdx_edge2.hip
 namespace {
 template <int KT, int FT, bool ROUND, bool LN = false>
 static void launch_hgemm_nt_rows(const _Float16* A, int lda, const float* B, int ldb, const float* bias, const TP& addend, int ldd,
-                                 const TPW& C, int ldc, int M, hipStream_t s, const LnEpi& ln = LnEpi{}) {
+                                 const TPW& C, int ldc, int M, hipStream_t s, const LnEpi& ln = LnEpi{}, int groups = 1) {
   constexpr int lds = 16 * FT * (32 * KT + 8) * 2 + 16 * FT * 4 * (LN ? 3 : 1);
   static bool attr = false;
   if (!attr) {
@@ -545,7 +552,8 @@ static void launch_hgemm_nt_rows(const _Float16* A, int lda, const float* B, int
   }
   const int ntiles = (M + 15) / 16;
   const int grid = std::max(1, std::min(mdx_num_cus() * per_cu, (ntiles + 7) / 8));
-  hipLaunchKernelGGL((hgemm_nt_rows_kernel<KT, FT, ROUND, LN>), dim3(grid), dim3(512), lds, s, A, lda, B, ldb, bias, addend, ldd, C, ldc, M, ln);
+  hipLaunchKernelGGL((hgemm_nt_rows_kernel<KT, FT, ROUND, LN>), dim3(grid, groups), dim3(512), lds, s, A, lda, B, ldb, bias, addend, ldd, C, ldc, M,
+                     ln);
 }
 
 #ifdef MDX_EXPERIMENTAL
@@ -1492,6 +1500,43 @@ __global__ void segsum_rows4_kernel(const TP src, const int64_t* __restrict__ or
   for (; j < e; ++j) s = s + ld4(src, 4 * ((size_t)order[j] * F4 + f));
   st4(out, 4 * i, s);
 }
+// The same sum with a segment's rows dealt to FOUR threads (round 6): thread k of an output element takes rows k, k + 4, ... of the segment
+// (four in flight each: sixteen row gathers per element instead of four), the four partial sums are combined through LDS in the fixed
+// order ((p0 + p1) + p2) + p3.  A node has ~28 rows; with one thread per element the kernel ran seven dependent gather rounds at ten
+// waves per CU (25 us for 20-80 MB).  Deterministic; NOT the summation order of segsum_rows4_kernel (which short segments keep: R * F4
+// large enough to fill the chip anyway does not occur in the training path).
+__global__ __launch_bounds__(256) void segsum_rows4s_kernel(const TP src, const int64_t* __restrict__ order, const int64_t* __restrict__ ptr,
+                                                            int64_t R, int F4, const TPW out) {
+  __shared__ f32x4 part[3][64];
+  const int k = threadIdx.x >> 6, it = threadIdx.x & 63;
+  const size_t i = (size_t)blockIdx.x * 64 + it;
+  const bool live = i < (size_t)R * F4;
+  f32x4 s = splat4(0.f);
+  if (live) {
+    const int64_t r = i / F4;
+    const int f = (int)(i % F4);
+    int64_t j = ptr[r] + k;
+    const int64_t e = ptr[r + 1];
+    for (; j + 12 < e; j += 16) {
+      const int64_t o0 = order[j], o1 = order[j + 4], o2 = order[j + 8], o3 = order[j + 12];
+      const f32x4 v0 = ld4(src, 4 * ((size_t)o0 * F4 + f)), v1 = ld4(src, 4 * ((size_t)o1 * F4 + f));
+      const f32x4 v2 = ld4(src, 4 * ((size_t)o2 * F4 + f)), v3 = ld4(src, 4 * ((size_t)o3 * F4 + f));
+      s = s + v0;
+      s = s + v1;
+      s = s + v2;
+      s = s + v3;
+    }
+    for (; j < e; j += 4) s = s + ld4(src, 4 * ((size_t)order[j] * F4 + f));
+  }
+  if (k) part[k - 1][it] = s;
+  __syncthreads();
+  if (k == 0 && live) {
+    s = s + part[0][it];
+    s = s + part[1][it];
+    s = s + part[2][it];
+    st4(out, 4 * i, s);
+  }
+}
 // y[i] = a[i] * t[idx[i]] and its two gradients (da = g * t[idx];  dt[r] = sum_{j in seg r} g[order[j]] * a[order[j]]):
 // the product with a gathered per-node row without materialising the gathered (rows x F) tensor.  F % 4 == 0.
 __global__ void mulg_fwd_kernel(const TP a, const TP t, const int64_t* __restrict__ idx, int64_t M, int F4, const TPW y, int rk) {
@@ -1940,7 +1985,12 @@ extern "C" int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const
   const TP ts{src, dt & 1};
   const TPW to{out, (dt >> 1) & 1};
   if ((F & 3) == 0 && tp_vec_ok(src, ts.h, 4) && tp_vec_ok(out, to.h, 4)) {
-    hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk((size_t)R * (F / 4))), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
+    const size_t items = (size_t)R * (F / 4);
+    static const bool split_off = getenv("MDX_SEGSUM_SPLIT") && atoi(getenv("MDX_SEGSUM_SPLIT")) == 0;
+    if (!split_off && items < ((size_t)1 << 22))
+      hipLaunchKernelGGL(segsum_rows4s_kernel, dim3((unsigned)((items + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
+    else
+      hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk(items)), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
   } else {
     if (dt) return bad("segsum_rows: half storage needs F % 4 == 0 and aligned rows");
     hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, (const float*)src, order, ptr, R, F,
@@ -2210,18 +2260,27 @@ extern "C" int mdx_op_xgemm_nt_t(const void* Av, int64_t lda, const float* B, in
     if (round_out) launch_hgemm_nt_rows<KTv, FTv, true>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s); \
     else launch_hgemm_nt_rows<KTv, FTv, false>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s);   \
   } while (0)
-#define MDX_HR_F(KTv)                      \
-  do {                                     \
-    if (ftn == 2) MDX_HR(KTv, 2);          \
-    else if (ftn == 4) MDX_HR(KTv, 4);     \
-    else if (ftn == 8) MDX_HR(KTv, 8);     \
-    else MDX_HR(KTv, 16);                  \
+#define MDX_HRG(KTv, FTv, Gv)                                                                                                                 \
+  do {                                                                                                                                          \
+    if (round_out) launch_hgemm_nt_rows<KTv, FTv, true>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s, LnEpi{}, Gv); \
+    else launch_hgemm_nt_rows<KTv, FTv, false>(Ah, (int)lda, B, (int)ldb, bias, addend, (int)ldd, C, (int)ldc, (int)M, s, LnEpi{}, Gv);   \
+  } while (0)
+    // few rows (the per-node layers): column groups, see the kernel
+    static const bool no_groups = getenv("MDX_ROWS_GROUPS") && atoi(getenv("MDX_ROWS_GROUPS")) == 0;
+    const bool few = !no_groups && (M + 127) / 128 <= mdx_num_cus() / 2;
+#define MDX_HR_F(KTv)                                  \
+  do {                                                 \
+    if (ftn == 2) MDX_HR(KTv, 2);                      \
+    else if (ftn == 4) { if (few) MDX_HRG(KTv, 2, 2); else MDX_HR(KTv, 4); }   \
+    else if (ftn == 8) { if (few) MDX_HRG(KTv, 2, 4); else MDX_HR(KTv, 8); }   \
+    else { if (few) MDX_HRG(KTv, 4, 4); else MDX_HR(KTv, 16); }                \
   } while (0)
     if (kt == 1) MDX_HR_F(1);
     else if (kt == 2) MDX_HR_F(2);
     else if (kt == 4) MDX_HR_F(4);
     else MDX_HR_F(8);
 #undef MDX_HR_F
+#undef MDX_HRG
 #undef MDX_HR
     return launched();
   }
