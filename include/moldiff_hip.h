@@ -379,6 +379,13 @@ int mdx_op_ln_relu_fwd_t(const void* x, const float* gamma, const float* beta, i
 int mdx_op_ln_relu_bwd_t(const void* dy, const void* x, const float* stats, const float* gamma, const float* beta, int64_t M, int32_t F,
                          int32_t relu, void* dx, float* dgb, float* ws, int32_t dt, void* stream);
 int mdx_op_ew_fwd_t(int32_t op, const void* a, const void* b, void* out, int64_t n, int32_t dt, void* stream);
+/* out = srcs[0] + ... + srcs[k-1] (k <= 12 tensors of n elements, half[j] != 0: float16 container), summed in fp32 in argument order,
+ * stored once: the gradient of a tensor with several consumers in one launch (torch.autograd accumulates them pairwise). */
+/* Segment order of the right end points from that of the left ones for a directed edge list [half-edges ; flipped half-edges]
+ * (models/model.py:269): order_left = stable argsort of left (E = 2 Eh), ptr (R + 1) its segment starts (shared by both index vectors);
+ * order_right receives the stable argsort of right.  Replaces a second sort per training step. */
+int mdx_op_plan_flip(const int64_t* order_left, const int64_t* ptr, int64_t R, int64_t Eh, int64_t* order_right, void* stream);
+int mdx_op_sum_n(const void* const* srcs, const int32_t* half, int32_t k, int64_t n, void* out, int32_t out_half, void* stream);
 int mdx_op_ew_bwd_t(int32_t op, const void* a, const void* b, const void* g, void* da, void* db, int64_t n, int32_t dt, void* stream);
 int mdx_op_gather_rows_t(const void* x, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt, void* stream);
 int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, void* out, int32_t dt,

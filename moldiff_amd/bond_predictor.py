@@ -153,7 +153,7 @@ class BondPredictor(Module):
         with torch.enable_grad() if train else torch.no_grad():
             if train:
                 from . import train_graph
-                pred_halfedge = train_graph.bondpred_forward(self, h_node, pos, batch_node, edge_index, batch_edge, t)
+                pred_halfedge = train_graph.bondpred_forward(self, h_node, pos, batch_node, edge_index, batch_edge, t, flipped_halves=True)
             else:
                 pred_halfedge = self(h_node, pos, batch_node, edge_index, batch_edge, t,
                                      _graph=_lib.graph_for_halfedges(halfedge_index, batch_node, int(t.numel())))

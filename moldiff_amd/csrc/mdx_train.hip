@@ -1423,6 +1423,28 @@ __global__ void ew_fwd4_kernel(int opr, const TP a, const TP b, const TPW o, siz
   }
   st4(o, 4 * i, r);
 }
+// out = sum of up to 12 tensors of one shape (round 6): the gradient of a tensor with several consumers.  autograd would add the
+// consumers' gradients pairwise (k - 1 launches of an element-wise add, each rounding to the container); here they are summed in
+// fp32 in argument order and rounded ONCE.  Operands fp32 or float16 containers, 4 elements per thread.
+struct SumN {
+  const void* p[12];
+  int h[12];
+  int n;
+};
+__global__ void sum_n4_kernel(const SumN a, const TPW o, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 s = ld4(TP{a.p[0], a.h[0]}, 4 * i);
+  for (int j = 1; j < a.n; ++j) s = s + ld4(TP{a.p[j], a.h[j]}, 4 * i);
+  st4(o, 4 * i, s);
+}
+__global__ void sum_n1_kernel(const SumN a, const TPW o, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = ld1(TP{a.p[0], a.h[0]}, i);
+  for (int j = 1; j < a.n; ++j) s += ld1(TP{a.p[j], a.h[j]}, i);
+  st1(o, i, s);
+}
 __global__ void ew_bwd4_kernel(int op, const TP a, const TP b, const TP g, const TPW da, const TPW db, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
@@ -1536,6 +1558,22 @@ __global__ __launch_bounds__(256) void segsum_rows4s_kernel(const TP src, const 
     s = s + part[2][it];
     st4(out, 4 * i, s);
   }
+}
+// CSR order of the RIGHT end points from that of the LEFT ones when the directed edge list is [half-edges ; flipped half-edges]
+// (reference models/model.py:269, :143: edge_index = cat([he, he.flip(0)], 1)): right[i] = left[(i + Eh) mod E], so both index vectors
+// hold the same multiset (same segment starts) and the stable order of `right` inside a node's segment is: the entries j >= Eh of
+// the left order (as j - Eh, ascending), then the entries j < Eh (as j + Eh).  One thread per node; replaces a second stable sort
+// (11 launches of torch.sort + searchsorted) per training step.
+__global__ void plan_flip_kernel(const int64_t* __restrict__ order_l, const int64_t* __restrict__ ptr, int64_t R, int64_t Eh,
+                                 int64_t* __restrict__ order_r) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int64_t b = ptr[r], e = ptr[r + 1];
+  int64_t c = b;                       // first position whose entry is >= Eh (entries ascend inside a segment)
+  while (c < e && order_l[c] < Eh) ++c;
+  int64_t w = b;
+  for (int64_t j = c; j < e; ++j) order_r[w++] = order_l[j] - Eh;
+  for (int64_t j = b; j < c; ++j) order_r[w++] = order_l[j] + Eh;
 }
 // y[i] = a[i] * t[idx[i]] and its two gradients (da = g * t[idx];  dt[r] = sum_{j in seg r} g[order[j]] * a[order[j]]):
 // the product with a gathered per-node row without materialising the gathered (rows x F) tensor.  F % 4 == 0.
@@ -1940,6 +1978,28 @@ extern "C" int mdx_op_ew_fwd_t(int32_t op, const void* a, const void* b, void* o
     hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, (const float*)a, (const float*)b,
                        (float*)out, (size_t)n);
   }
+  return launched();
+}
+extern "C" int mdx_op_plan_flip(const int64_t* order_left, const int64_t* ptr, int64_t R, int64_t Eh, int64_t* order_right, void* stream) {
+  if (R <= 0) return MDX_OK;
+  if (!order_left || !ptr || !order_right || Eh < 0) return bad("plan_flip: null argument");
+  hipLaunchKernelGGL(plan_flip_kernel, dim3(nblk((size_t)R)), dim3(256), 0, (hipStream_t)stream, order_left, ptr, R, Eh, order_right);
+  return launched();
+}
+extern "C" int mdx_op_sum_n(const void* const* srcs, const int32_t* half, int32_t k, int64_t n, void* out, int32_t out_half, void* stream) {
+  if (n <= 0) return MDX_OK;
+  if (k < 1 || k > 12 || !srcs || !half || !out) return bad("sum_n: 1..12 operands");
+  SumN a;
+  bool vec = (n & 3) == 0 && tp_vec_ok(out, out_half, 4);
+  for (int j = 0; j < k; ++j) {
+    if (!srcs[j]) return bad("sum_n: null operand");
+    a.p[j] = srcs[j], a.h[j] = half[j] ? 1 : 0;
+    vec = vec && tp_vec_ok(srcs[j], a.h[j], 4);
+  }
+  a.n = k;
+  const TPW to{out, out_half ? 1 : 0};
+  if (vec) hipLaunchKernelGGL(sum_n4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, a, to, (size_t)n / 4);
+  else hipLaunchKernelGGL(sum_n1_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, a, to, (size_t)n);
   return launched();
 }
 extern "C" int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream) {

@@ -1133,31 +1133,41 @@ __device__ __forceinline__ void mmg(f32x4 (&y)[FT], const _Float16* __restrict__
 // 448 KiB of a tile's weights through L2 by itself: 4.3 GB per launch, ~10 TB/s, and the kernels ran at that rate (428 / 540 us).
 // One barrier per k-step: the buffer a step writes was last read two steps earlier, and no wave can be more than one barrier ahead.
 // `par` (the buffer parity) runs through consecutive calls.  Every wave of the workgroup must make the same calls.
-template <int FT, int KS, int NT = NM_THREADS>
+// D = k-steps of fragments in flight per thread (round 6, third cut): with one, every k-step waited for its own L2 round trip -- 28
+// k-steps of ~2.5 us per 16-row tile WAS the kernel's time (pipes 26 % busy, profiles/HISTORY.md); the LDS double buffer stays (a buffer
+// is rewritten two barriers after its last read), only the registers between L2 and LDS get deeper.
+#ifndef MDX_NM_DEPTH_F
+#define MDX_NM_DEPTH_F 4
+#endif
+#ifndef MDX_NM_DEPTH_B
+#define MDX_NM_DEPTH_B 2
+#endif
+template <int FT, int KS, int NT = NM_THREADS, int D = MDX_NM_DEPTH_B>
 __device__ __forceinline__ void mmw(f32x4 (&y)[FT], const _Float16* __restrict__ pack, uint16_t* wbuf, int& par, int tid, int lane,
                                     const f16x8_t (&x)[KS]) {
   constexpr int CH = FT * 1024;                                      // bytes per k-step
   constexpr int NL = (CH + NT * 16 - 1) / (NT * 16);                  // 16-byte copies per thread and k-step
   asm volatile("" : "+s"(pack));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pack), 0, -1, 0x00020000);
-  uint4 st[NL];
-  auto fetch = [&](int ks) {
+  uint4 st[D][NL];
+  auto fetch = [&](auto slot, int ks) {
+    constexpr int sl = decltype(slot)::value;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const unsigned o = (unsigned)(tid + i * NT) * 16u;
-      if (CH % (NT * 16) == 0 || o < (unsigned)CH) st[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, ks * CH, 0));
+      if (CH % (NT * 16) == 0 || o < (unsigned)CH) st[sl][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, ks * CH, 0));
     }
   };
-  fetch(0);
+  static_for<0, (D < KS ? D : KS)>([&](auto dc) { fetch(dc, decltype(dc)::value); });
   static_for<0, KS>([&](auto kc) {
     constexpr int ks = decltype(kc)::value;
     char* buf = reinterpret_cast<char*>(wbuf) + ((par + ks) & 1) * 16384;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const unsigned o = (unsigned)(tid + i * NT) * 16u;
-      if (CH % (NT * 16) == 0 || o < (unsigned)CH) *reinterpret_cast<uint4*>(buf + o) = st[i];
+      if (CH % (NT * 16) == 0 || o < (unsigned)CH) *reinterpret_cast<uint4*>(buf + o) = st[ks % D][i];
     }
-    if constexpr (ks + 1 < KS) fetch(ks + 1);
+    if constexpr (ks + D < KS) fetch(std::integral_constant<int, ks % D>{}, ks + D);
     // raw barrier: __syncthreads() would also wait for vmcnt(0), i.e. for the fetch just issued and for every global store of the
     // previous epilogue (gfx9 counts stores on vmcnt) -- only the LDS writes have to be complete here
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1219,7 +1229,7 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
 #define NM_SB(ft) if ((ft) % 4 == 3) __builtin_amdgcn_sched_barrier(0)
     // ---- edge_net: Linear -> LayerNorm -> ReLU -> Linear, then the product with node_net(x)[col]
     zero<16>(y);
-    mmw<16, 2, NMF_THREADS>(y, w1e, wbuf, par, tid, lane, xb);
+    mmw<16, 2, NMF_THREADS, MDX_NM_DEPTH_F>(y, w1e, wbuf, par, tid, lane, xb);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) {
       y[ft] = rh4(y[ft] + lds4(c_b1e + 16 * ft + 4 * q));
@@ -1243,7 +1253,7 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
       }
     }
     zero<16>(y);
-    mmw<16, 8, NMF_THREADS>(y, w2e, wbuf, par, tid, lane, b8);
+    mmw<16, 8, NMF_THREADS, MDX_NM_DEPTH_F>(y, w2e, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       uint2 h[2];
@@ -1262,7 +1272,7 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
     }
     // ---- msg_net (m0 is read back at the end: L2-hot, and 32 registers cheaper than holding it across the gate chain)
     zero<16>(y);
-    mmw<16, 8, NMF_THREADS>(y, wm, wbuf, par, tid, lane, b8);
+    mmw<16, 8, NMF_THREADS, MDX_NM_DEPTH_F>(y, wm, wbuf, par, tid, lane, b8);
     if (ok) {
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft) {
@@ -1272,7 +1282,7 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
     }
     // ---- gate: Linear([edge | x[col] | t[col]]) with the node / time columns as the hoisted fp32 addend PN[col]
     zero<16>(y);
-    mmw<16, 2, NMF_THREADS>(y, wg1, wbuf, par, tid, lane, xb);
+    mmw<16, 2, NMF_THREADS, MDX_NM_DEPTH_F>(y, wg1, wbuf, par, tid, lane, xb);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) {
       y[ft] = rh4((y[ft] + lds4(c_bg1 + 16 * ft + 4 * q)) + ldg4(a.PN + (size_t)nc * a.ldpn + 16 * ft + 4 * q));
@@ -1296,7 +1306,7 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
       }
     }
     zero<16>(y);
-    mmw<16, 8, NMF_THREADS>(y, wg2, wbuf, par, tid, lane, b8);
+    mmw<16, 8, NMF_THREADS, MDX_NM_DEPTH_F>(y, wg2, wbuf, par, tid, lane, b8);
     if (ok) {
 #pragma unroll
       for (int ft = 0; ft < 16; ++ft) {

@@ -151,7 +151,7 @@ class MolDiff(Module):
             h_edge = torch.cat([h_half, h_half], dim=0)
         if train:
             from . import train_graph
-            preds = train_graph.moldiff_forward(self, h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t)
+            preds = train_graph.moldiff_forward(self, h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t, flipped_halves=True)
         else:
             preds = self.forward(h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t,
                                  _graph=_lib.graph_for_halfedges(halfedge_index, batch_node, int(t.numel())))
@@ -183,7 +183,7 @@ class MolDiff(Module):
             h_edge = torch.cat([h_half, h_half], dim=0)
         if train:
             from . import train_graph
-            preds = train_graph.moldiff_forward(self, h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t)
+            preds = train_graph.moldiff_forward(self, h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t, flipped_halves=True)
         else:
             # (plan keyed on the half-edge tensor: `edge_index` is a fresh torch.cat on every call)
             preds = self.forward(h_node, pos_pert, batch_node, h_edge, edge_index, batch_edge, t,

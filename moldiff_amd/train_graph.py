@@ -18,11 +18,16 @@ from . import train_ops as T
 class TrainGraph:
     """Index plans of one packed batch in the reference's edge order [half-edges, flipped half-edges]."""
 
-    def __init__(self, edge_index, n_nodes):
+    def __init__(self, edge_index, n_nodes, flipped_halves=False):
+        """flipped_halves: the caller built edge_index as cat([he, he.flip(0)], 1) (get_loss does, models/model.py:143): the right end
+        points' plan is then derived from the left one's instead of sorted a second time."""
         self.edge_index = edge_index
         self.N, self.E = int(n_nodes), int(edge_index.shape[1])
         self.left = T.IndexPlan(edge_index[0], n_nodes)
-        self.right = T.IndexPlan(edge_index[1], n_nodes)
+        if flipped_halves and self.E % 2 == 0 and edge_index.is_cuda and self.E > 0:
+            self.right = T.FlippedPlan(self.left, edge_index[1], self.E // 2)
+        else:
+            self.right = T.IndexPlan(edge_index[1], n_nodes)
 
 
 def cat(*xs):
@@ -60,6 +65,22 @@ def res_add(x, delta):
     if not _RESID32:
         return T.add(x, delta)
     return T.add(x if x.dtype == torch.float32 else x.float(), delta)
+
+
+class _Uses:
+    """A tensor with k consumers inside a block, handed out as k aliases of ONE fan-out node (train_ops.fanout): the gradients of
+    the consumers are then summed by one launch instead of k - 1 element-wise adds of torch.autograd.  `u()` = the next alias (the
+    tensor itself once the aliases are used up: still correct, autograd adds the rest)."""
+
+    def __init__(self, x, k):
+        self.x, self.it = x, iter(T.fanout(x, k))
+
+    def __call__(self):
+        return next(self.it, self.x)
+
+
+def _u(x):
+    return x() if isinstance(x, _Uses) else x
 
 
 def mlp_from_pre(m, pre):
@@ -105,11 +126,12 @@ def smear(gs, d):
 # weight-slice gradients back into the full matrix), ~35 % fewer FLOPs and no unaligned 321-wide operand.
 
 def node_block(m, x, g, edge_attr, node_time):
-    h_node = mlp(m.node_net, x)
+    edge_attr = _u(edge_attr)
+    h_node = mlp(m.node_net, _u(x))
     agg = per_node = None
     if m.use_gate:   # models/graph.py:46-48
         g0, ed = m.gate.net[0], edge_attr.shape[1]
-        per_node = T.linear(cat(x, node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
+        per_node = T.linear(cat(_u(x), node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
         if len(m.edge_net.net) == 4 and len(m.gate.net) == 4:
             en, gt_ = m.edge_net.net, m.gate.net
             shapes = (tuple(en[0].weight.shape), tuple(en[3].weight.shape), tuple(m.msg_net.weight.shape), (g0.weight.shape[0], ed),
@@ -127,7 +149,7 @@ def node_block(m, x, g, edge_attr, node_time):
             gt = mlp_first(m.gate, edge_attr, g0.weight[:, :ed], g0.bias, addend=T.gather(per_node, g.right))
             msg = T.gate(msg, gt)
         agg = T.scatter_sum(msg, g.left)
-    out = T.linear_ln_relu(x, m.centroid_lin.weight, m.centroid_lin.bias, m.layer_norm.weight, m.layer_norm.bias, addend=agg)
+    out = T.linear_ln_relu(_u(x), m.centroid_lin.weight, m.centroid_lin.bias, m.layer_norm.weight, m.layer_norm.bias, addend=agg)
     return T.linear(out, m.out_transform.weight, m.out_transform.bias)
 
 
@@ -136,13 +158,13 @@ def bond_ffn(m, bond_in, time, node_rows=None, plan=None, node_edges=None):
     bond_feat = T.linear(bond_in, m.bond_linear.weight)
     if not m.use_gate:   # models/graph.py:138-140: no gate, the inter module's output is the result
         if node_edges is None:
-            return mlp(m.inter_module, T.mul_gather(bond_feat, T.linear(node_rows, m.node_linear.weight), plan))
+            return mlp(m.inter_module, T.mul_gather(bond_feat, T.linear(_u(node_rows), m.node_linear.weight), plan))
         return mlp(m.inter_module, T.mul(bond_feat, T.linear(node_edges, m.node_linear.weight)))
     g0, bd = m.gate.net[0], bond_in.shape[1]
     nd = g0.weight.shape[1] - bd - 1
     if node_edges is None:
-        prod = T.mul_gather(bond_feat, T.linear(node_rows, m.node_linear.weight), plan)
-        gate_node = T.gather(T.linear(node_rows, g0.weight[:, bd:bd + nd], keep32=True), plan)
+        prod = T.mul_gather(bond_feat, T.linear(_u(node_rows), m.node_linear.weight), plan)
+        gate_node = T.gather(T.linear(_u(node_rows), g0.weight[:, bd:bd + nd], keep32=True), plan)
     else:
         prod = T.mul(bond_feat, T.linear(node_edges, m.node_linear.weight))
         gate_node = T.linear(node_edges, g0.weight[:, bd:bd + nd], keep32=True)
@@ -162,8 +184,8 @@ def bond_ffn_scatter(m, bond_in, time, node_rows, plan, plan_out):
         dims = (bd, m.bond_linear.weight.shape[0], m.inter_module.net[3].weight.shape[0], g0.weight.shape[0], nd)
         if (len(m.inter_module.net) == 4 and len(m.gate.net) == 4 and m.gate.net[3].weight.shape[0] == dims[2]
                 and m.inter_module.net[0].weight.shape == (dims[1], dims[1])):
-            node_lin = T.linear(node_rows, m.node_linear.weight)
-            gate_node = T.linear(node_rows, g0.weight[:, bd:bd + nd], keep32=True)
+            node_lin = T.linear(_u(node_rows), m.node_linear.weight)
+            gate_node = T.linear(_u(node_rows), g0.weight[:, bd:bd + nd], keep32=True)
             if T.bondffn_fused_ok(bond_in, node_lin, gate_node, dims):
                 im, gt = m.inter_module.net, m.gate.net
                 return T.bondffn_scatter(bond_in, node_lin, gate_node, time, plan, plan_out, dict(
@@ -177,10 +199,11 @@ def edge_block(m, h_bond, g, h_node, bond_time, residual=False):
     """EdgeBlock.forward; residual=True returns h_bond + EdgeBlock(h_bond) (the caller's `h_edge = h_edge + ...`, models/graph.py:360),
     which the fused tail kernel forms in the same launch."""
     # per-node sums first (N rows), then ONE gather per endpoint: (S_L + node_ffn_left(h))[left] + (S_R + node_ffn_right(h))[right]
-    sl = bond_ffn_scatter(m.bond_ffn_left, h_bond, bond_time, h_node, g.left, g.right)
-    sr = bond_ffn_scatter(m.bond_ffn_right, h_bond, bond_time, h_node, g.right, g.left)
-    by_left = T.linear(h_node, m.node_ffn_left.weight, m.node_ffn_left.bias, addend=sl)
-    by_right = T.linear(h_node, m.node_ffn_right.weight, m.node_ffn_right.bias, addend=sr)
+    sl = bond_ffn_scatter(m.bond_ffn_left, _u(h_bond), bond_time, h_node, g.left, g.right)
+    sr = bond_ffn_scatter(m.bond_ffn_right, _u(h_bond), bond_time, h_node, g.right, g.left)
+    by_left = T.linear(_u(h_node), m.node_ffn_left.weight, m.node_ffn_left.bias, addend=sl)
+    by_right = T.linear(_u(h_node), m.node_ffn_right.weight, m.node_ffn_right.bias, addend=sr)
+    h_bond = _u(h_bond)
     if residual and T.edge_tail_fused_ok(h_bond, by_left, by_right) and m.self_ffn.weight.shape == (64, 64):
         return T.edge_tail(h_bond, by_left, by_right, g.left, g.right, dict(
             Ws=m.self_ffn.weight, bs=m.self_ffn.bias, lng=m.layer_norm.weight, lnb=m.layer_norm.bias, Wo=m.out_transform.weight,
@@ -220,11 +243,15 @@ def node_edge_net(net, h_node, pos, h_edge, g, node_time, edge_time):
             h_dist = smear(net.distance_expansion, dist)
         emb = net.edge_embs[i]
         h_edge = T.linear(cat(h_edge, h_dist) if net.update_edge else h_dist, emb.weight, emb.bias)
-        upd = node_block(net.node_blocks_with_edge[i], h_node, g, h_edge, node_time)
+        # round 6: the block's consumers of h_node (3 in the NodeBlock, 6 in the EdgeBlock, the residual) and of h_edge (1 + 3) take
+        # aliases of one fan-out node each (_Uses): one gradient-sum launch per stream and block instead of 9 + 3 autograd adds
+        hn = _Uses(h_node, 10 if net.update_edge else 4)
+        he = _Uses(h_edge, 4) if net.update_edge else h_edge
+        upd = node_block(net.node_blocks_with_edge[i], hn, g, he, node_time)
         if net.update_edge:
             # (the edge stream is re-embedded by a Linear in every block, graph.py:357: it IS a float16 tensor under autocast)
-            h_edge = edge_block(net.edge_blocks[i], h_edge, g, h_node, edge_time, residual=True)
-        h_node = res_add(h_node, upd)
+            h_edge = edge_block(net.edge_blocks[i], he, g, hn, edge_time, residual=True)
+        h_node = res_add(hn(), upd)
         if net.update_pos:
             pos = T.add(pos, pos_update(net.pos_blocks[i], h_node, h_edge, g, rel, dist, edge_time))
     return h_node, pos, h_edge
@@ -236,8 +263,8 @@ def time_embedding(gs, t_rows):
         return smear(gs, t_rows.float())
 
 
-def moldiff_forward(model, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_index, batch_edge, t):
-    g = TrainGraph(edge_index, h_node_pert.shape[0])
+def moldiff_forward(model, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_index, batch_edge, t, flipped_halves=False):
+    g = TrainGraph(edge_index, h_node_pert.shape[0], flipped_halves)
     ts = model.time_emb[0]
     tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
     h_node = cat32(T.linear(h_node_pert, model.node_embedder.weight), time_embedding(ts, tn))
@@ -252,8 +279,8 @@ def moldiff_forward(model, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_
     return {'pred_node': pred_node.float(), 'pred_pos': pos, 'pred_halfedge': pred_half.float()}
 
 
-def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge, t):
-    g = TrainGraph(edge_index, h_node.shape[0])
+def bondpred_forward(model, h_node, pos_node, batch_node, edge_index, batch_edge, t, flipped_halves=False):
+    g = TrainGraph(edge_index, h_node.shape[0], flipped_halves)
     tn, te = t.index_select(0, batch_node), t.index_select(0, batch_edge)
     h_edge = cat(h_node[edge_index[0]], h_node[edge_index[1]])            # one-hot pairs: pure indexing
     if model.num_timesteps != 0:

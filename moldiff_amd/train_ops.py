@@ -779,6 +779,43 @@ def gate(a, b):
     return _ew(GATE, a, b)
 
 
+_FANOUT = __import__('os').environ.get('MDX_TRAIN_FANOUT', '1') != '0'
+
+
+class _Fanout(torch.autograd.Function):
+    """k aliases of x for its k consumers; the backward sums their gradients in ONE launch (csrc sum_n4_kernel: fp32 sum in consumer
+    order, one rounding to x's container) where autograd would run k - 1 element-wise adds."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.dtype, ctx.shape = x.dtype, x.shape
+        return tuple(x.view_as(x) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        import ctypes
+        gs = [_t(g) for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            g = gs[0]
+            return (g if g.dtype == ctx.dtype else g.to(ctx.dtype)), None
+        odt = ctx.dtype if ctx.dtype in (torch.float16, torch.float32) else torch.float32
+        out = torch.empty(ctx.shape, dtype=odt, device=gs[0].device)
+        k = len(gs)
+        ptrs = (ctypes.c_void_p * k)(*[g.data_ptr() for g in gs])
+        halfs = (ctypes.c_int32 * k)(*[_h(g) for g in gs])
+        check(_L().mdx_op_sum_n(ptrs, halfs, k, out.numel(), ptr(out), _h(out), stream()))
+        return (out if odt == ctx.dtype else out.to(ctx.dtype)), None
+
+
+def fanout(x, k):
+    """k aliases of x, one per consumer (see _Fanout); plain repetition when there is nothing to gain"""
+    if k < 3 or k > 12 or not _FANOUT or not x.is_cuda or not x.requires_grad or not torch.is_grad_enabled():
+        return (x,) * k
+    return _Fanout.apply(x, k)
+
+
 class IndexPlan:
     """An index vector (rows -> targets in [0, n)) with the CSR needed to sum rows per target without atomics:
     `order` = stable argsort, `ptr` = segment starts.  Built once per batch (index bookkeeping, not arithmetic)."""
@@ -791,6 +828,17 @@ class IndexPlan:
         self.order = srt.indices.contiguous()
         # segment starts from the sorted values (torch.bincount would read the maximum back to the host: a device sync per plan)
         self.ptr = torch.searchsorted(srt.values, torch.arange(self.n + 1, dtype=torch.int64, device=index.device))
+
+
+class FlippedPlan:
+    """IndexPlan of the RIGHT end points of a directed edge list [half-edges ; flipped half-edges] derived from the plan of the left ones
+    (csrc plan_flip_kernel): same segment starts, the order by one launch instead of a second stable sort."""
+
+    def __init__(self, left_plan, index, n_half):
+        self.index = index.detach().to(torch.int64).contiguous()
+        self.n, self.ptr = left_plan.n, left_plan.ptr
+        self.order = torch.empty_like(left_plan.order)
+        check(_L().mdx_op_plan_flip(ptr(left_plan.order), ptr(left_plan.ptr), self.n, int(n_half), ptr(self.order), stream()))
 
 
 def _gather_raw(x, plan, out_dtype=None):

@@ -367,3 +367,38 @@ def test_linear_with_layernorm_epilogue_falls_back_where_the_fused_kernel_is_not
         assert not T.linear_ln_ok(xs, w, None)           # 300 rows, K = 80
         y16 = T.linear_ln_relu(xs, w, b, gm, be)
     assert _rel(y16, ref) < 2e-2
+
+
+def test_flipped_plan_equals_a_second_stable_sort():
+    """Round 6: for the directed edge list [half-edges ; flipped half-edges] the right end points' CSR plan is derived from the left
+    one's by one launch (csrc plan_flip_kernel) -- order and segment starts must equal what the stable sort of the right index gives,
+    on a ragged list with isolated nodes and repeated pairs."""
+    g = U.rng(77)
+    n, Eh = 211, 3001
+    hl = torch.from_numpy(g.integers(0, n - 7, Eh))      # (nodes n-7.. have no edge at all)
+    hr = torch.from_numpy(g.integers(0, n - 7, Eh))
+    left, right = torch.cat([hl, hr]).to(DEV), torch.cat([hr, hl]).to(DEV)
+    pl = T.IndexPlan(left, n)
+    ref = T.IndexPlan(right, n)
+    got = T.FlippedPlan(pl, right, Eh)
+    assert torch.equal(got.ptr, ref.ptr) and torch.equal(got.order, ref.order) and torch.equal(got.index, ref.index) and got.n == ref.n
+
+
+@pytest.mark.parametrize('half', [False, True])
+def test_fanout_sums_the_consumers_gradients_in_one_launch(half):
+    """Round 6: T.fanout hands a tensor to k consumers as aliases of one node whose backward is a single k-input sum (csrc
+    sum_n4_kernel: fp32 accumulation, one rounding) -- equal to autograd's pairwise accumulation up to the rounding of the container."""
+    g = U.rng(5)
+    x = _leaf(g, 515, 64)
+    ws = [U.t32(g.standard_normal((515, 64))).to(DEV) for _ in range(7)]
+    xin = x.half() if half else x
+    if half:
+        xin.retain_grad()
+    parts = T.fanout(xin, 7)
+    assert len(parts) == 7 and all(p.data_ptr() == xin.data_ptr() for p in parts)
+    loss = sum((p.float() * w).sum() for p, w in zip(parts[:6], ws))      # the 7th alias is never used: its gradient is skipped
+    loss.backward()
+    ref = sum(ws[:6])
+    tol = 2e-3 if half else 2e-6
+    assert _rel(x.grad, ref) < tol
+    assert T.fanout(x, 2) == (x, x)                                       # nothing to gain below three consumers
