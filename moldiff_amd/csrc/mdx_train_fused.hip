@@ -1202,11 +1202,53 @@ __device__ __forceinline__ void sth8_pair(_Float16* row_base, int g2, uint2 ha, 
   if (ok) *reinterpret_cast<uint4*>(row_base + col) = v;
 }
 
+// Whole 16 x 256 float16 tiles through a wave-private LDS area (round 6): chunks go in in accumulator layout (lane (c, q): row c, columns
+// 16 ft + 4 q .. + 3), full rows come out -- lanes 0..31 read row 2 i, lanes 32..63 row 2 i + 1, 16 bytes each, so a store instruction writes
+// two complete 512-byte rows (1 KiB contiguous) instead of 16 rows x 32 or 64 bytes.  Row stride 528 bytes (132 dwords): the 8-byte writes
+// of a half wave and the 16-byte reads of a quarter wave each cover the 64 banks once.  Only the owning wave touches its area (LDS
+// operations of a wave execute in order: no barrier).
+constexpr int TS_LD = 264;                       // halves per row of the area
+constexpr int TS_BYTES = 16 * TS_LD * 2;         // 8,448 bytes per wave
+__device__ __forceinline__ void ts_put(uint16_t* T, int ft, uint2 h, int c, int q) { *reinterpret_cast<uint2*>(T + c * TS_LD + 16 * ft + 4 * q) = h; }
+__device__ __forceinline__ void ts_put2(uint16_t* T, int g2, f16x8_t b, int c, int q) {   // the two tiles of a B operand (pair8)
+  const uint4 u = __builtin_bit_cast(uint4, b);
+  ts_put(T, 2 * g2, uint2{u.x, u.y}, c, q);
+  ts_put(T, 2 * g2 + 1, uint2{u.z, u.w}, c, q);
+}
+// The rows leave through BUFFER stores: a resource per output (scalar base, size = the matrix: rows past the end are dropped by the
+// bounds check, no predicate), the tile's byte offset as the scalar offset, one lane offset for all eight stores, the row pair as the
+// immediate.  (With flat stores the compiler kept eight 64-bit addresses per output alive: 274 spilled registers in the backward.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ts_rsrc(_Float16* out, int E) {
+  return __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)E * (unsigned)(KW * 2)), 0x00020000);
+}
+template <int B>
+__device__ __forceinline__ void ts_flush_b(const uint16_t* T, __amdgpu_buffer_rsrc_t rs, int tile, int lane) {
+  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(tile) * (unsigned)(16 * KW * 2);
+  const unsigned vo = (unsigned)(lane >> 5) * (unsigned)(KW * 2) + 16u * (unsigned)(lane & 31);
+  const uint16_t* src = T + (lane >> 5) * TS_LD + 8 * (lane & 31);
+#pragma unroll
+  for (int i0 = 0; i0 < 8; i0 += B) {
+    uint4 v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) v[i] = *reinterpret_cast<const uint4*>(src + 2 * (i0 + i) * TS_LD);
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int ii = i0 + i;
+      typedef unsigned int u32x4_t __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[i]), rs, vo, so + (unsigned)ii * 1024u, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+__device__ __forceinline__ void ts_flush(const uint16_t* T, __amdgpu_buffer_rsrc_t rs, int tile, int lane) { ts_flush_b<8>(T, rs, tile, lane); }
+
 __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_nodemsg_args a) {
   __shared__ __attribute__((aligned(16))) float C[9 * 256];
   __shared__ __attribute__((aligned(16))) uint16_t wbuf[2 * 8192];     // two k-steps of weight fragments (mmw)
+  extern __shared__ __attribute__((aligned(16))) uint16_t nm_ts[];     // NMF_WAVES transposition areas (ts_put / ts_flush)
   int par = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint16_t* T = nm_ts + (size_t)wave * (TS_BYTES / 2);
   const int c = lane & 15, q = lane >> 4;
   {
     const float* src[9] = {a.b1e, a.lng_e, a.lnb_e, a.b2e, a.bm, a.bg1, a.lng_g, a.lnb_g, a.bg2};
@@ -1247,9 +1289,11 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
     for (int g2 = 0; g2 < 8; ++g2) {
       y[2 * g2] = rh4(y[2 * g2] + lds4(c_b1e + 32 * g2 + 4 * q));
       y[2 * g2 + 1] = rh4(y[2 * g2 + 1] + lds4(c_b1e + 32 * g2 + 16 + 4 * q));
-      sth8_pair(o_hepre + rb, g2, pack4(y[2 * g2]), pack4(y[2 * g2 + 1]), q, ok);
+      ts_put(T, 2 * g2, pack4(y[2 * g2]), c, q);
+      ts_put(T, 2 * g2 + 1, pack4(y[2 * g2 + 1]), c, q);
       NM_SB(2 * g2 + 1);
     }
+    ts_flush(T, ts_rsrc(o_hepre, E), tile, lane);
     {
       float mean, rstd;
       ln_stats<16>(y, mean, rstd);
@@ -1261,11 +1305,12 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
           const int ft = 2 * g2 + j;
           h[j] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_ge + 16 * ft + 4 * q) + lds4(c_be + 16 * ft + 4 * q)));
         }
-        sth8_pair(o_hepost + rb, g2, h[0], h[1], q, ok);
         b8[g2] = pair8(h[0], h[1]);
+        ts_put2(T, g2, b8[g2], c, q);
         NM_SB(2 * g2 + 1);
       }
     }
+    ts_flush(T, ts_rsrc(o_hepost, E), tile, lane);
     zero<16>(y);
     mmw<16, 8, NMF_THREADS, MDX_NM_DEPTH_F>(y, w2e, wbuf, par, tid, lane, b8);
 #pragma unroll
@@ -1278,11 +1323,15 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
         hh[j] = pack4(he);
         h[j] = pack4(he * ldh4(HN + (size_t)nc * a.ldhn + 16 * ft + 4 * q));
       }
-      sth8_pair(o_he + rb, g2, hh[0], hh[1], q, ok);
-      sth8_pair(o_p + rb, g2, h[0], h[1], q, ok);
+      ts_put(T, 2 * g2, hh[0], c, q);
+      ts_put(T, 2 * g2 + 1, hh[1], c, q);
       b8[g2] = pair8(h[0], h[1]);
       NM_SB(2 * g2 + 1);
     }
+    ts_flush(T, ts_rsrc(o_he, E), tile, lane);
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) ts_put2(T, g2, b8[g2], c, q);
+    ts_flush(T, ts_rsrc(o_p, E), tile, lane);
     // ---- msg_net (m0 is read back at the end: L2-hot, and 32 registers cheaper than holding it across the gate chain)
     zero<16>(y);
     mmw<16, 8, NMF_THREADS, MDX_NM_DEPTH_F>(y, wm, wbuf, par, tid, lane, b8);
@@ -1303,9 +1352,11 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
         const int ft = 2 * g2 + j;
         y[ft] = rh4((y[ft] + lds4(c_bg1 + 16 * ft + 4 * q)) + ldg4(a.PN + (size_t)nc * a.ldpn + 16 * ft + 4 * q));
       }
-      sth8_pair(o_gpre + rb, g2, pack4(y[2 * g2]), pack4(y[2 * g2 + 1]), q, ok);
+      ts_put(T, 2 * g2, pack4(y[2 * g2]), c, q);
+      ts_put(T, 2 * g2 + 1, pack4(y[2 * g2 + 1]), c, q);
       NM_SB(2 * g2 + 1);
     }
+    ts_flush(T, ts_rsrc(o_gpre, E), tile, lane);
     {
       float mean, rstd;
       ln_stats<16>(y, mean, rstd);
@@ -1317,11 +1368,12 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
           const int ft = 2 * g2 + j;
           h[j] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(c_gg + 16 * ft + 4 * q) + lds4(c_gb + 16 * ft + 4 * q)));
         }
-        sth8_pair(o_gpost + rb, g2, h[0], h[1], q, ok);
         b8[g2] = pair8(h[0], h[1]);
+        ts_put2(T, g2, b8[g2], c, q);
         NM_SB(2 * g2 + 1);
       }
     }
+    ts_flush(T, ts_rsrc(o_gpost, E), tile, lane);
     zero<16>(y);
     mmw<16, 8, NMF_THREADS, MDX_NM_DEPTH_F>(y, wg2, wbuf, par, tid, lane, b8);
     // (m0 keeps the per-lane 8-byte pattern above: every lane reads back the bytes it wrote itself)
@@ -1335,10 +1387,12 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
         hg[j] = pack4(g);
         hm[j] = pack4(ldh4(o_m0 + ro + 16 * ft) * rh4(sigmoid4(g)));
       }
-      sth8_pair(o_gt + rb, g2, hg[0], hg[1], q, ok);
+      ts_put(T, 2 * g2, hg[0], c, q);
+      ts_put(T, 2 * g2 + 1, hg[1], c, q);
       sth8_pair(o_msg + rb, g2, hm[0], hm[1], q, ok);
       NM_SB(2 * g2 + 1);
     }
+    ts_flush(T, ts_rsrc(o_gt, E), tile, lane);
   }
 }
 
@@ -1469,6 +1523,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     const int row = 16 * tile + c;
     const bool ok = row < E;
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
+    const size_t rb = r * KW;
     const int64_t nc = a.f.col[r], nr = a.row[r];
     f32x4 y[16];
     f16x8_t b8[8];
@@ -1486,9 +1541,9 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
         h[j] = pack4(g * m0 * sg * (splat4(1.f) - sg));      // d gt
         if (ok) {
           sth4(o_gm0 + ro + 16 * ft, pack4(g * sg));        // d m0 (formed again below: the registers go to the gate chain first)
-          sth4(o_ggt + ro + 16 * ft, h[j]);
         }
       }
+      sth8_pair(o_ggt + rb, g2, h[0], h[1], q, ok);         // (the backward has no registers for the LDS transposition of the forward)
       b8[g2] = pair8(h[0], h[1]);
       NM_SB(2 * g2 + 1);
     }
@@ -1501,10 +1556,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
-      if (ok) {
-        sth4(o_ggpre + ro + 16 * (2 * g2), h0);
-        sth4(o_ggpre + ro + 16 * (2 * g2 + 1), h1);
-      }
+      sth8_pair(o_ggpre + rb, g2, h0, h1, q, ok);
       b8[g2] = pair8(h0, h1);
     }
     zero<4>(gx1);
@@ -1525,17 +1577,16 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     mmw<16, 8>(y, wmt, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
-      uint2 h[2];
+      uint2 h[2], hn[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int ft = 2 * g2 + j;
         const f32x4 gp = rh4(y[ft]);
         h[j] = pack4(gp * ldh4(HN + (size_t)nc * a.f.ldhn + 16 * ft + 4 * q));       // d he
-        if (ok) {
-          sth4(o_ghne + ro + 16 * ft, pack4(gp * ldh4(s_he + ro + 16 * ft)));        // per-edge d hn[col]
-          sth4(o_ghe + ro + 16 * ft, h[j]);
-        }
+        hn[j] = pack4(gp * ldh4(s_he + ro + 16 * ft));                               // per-edge d hn[col]
       }
+      sth8_pair(o_ghne + rb, g2, hn[0], hn[1], q, ok);
+      sth8_pair(o_ghe + rb, g2, h[0], h[1], q, ok);
       b8[g2] = pair8(h[0], h[1]);
       NM_SB(2 * g2 + 1);
     }
@@ -1548,10 +1599,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
-      if (ok) {
-        sth4(o_gpre + ro + 16 * (2 * g2), h0);
-        sth4(o_gpre + ro + 16 * (2 * g2 + 1), h1);
-      }
+      sth8_pair(o_gpre + rb, g2, h0, h1, q, ok);
       b8[g2] = pair8(h0, h1);
     }
     f32x4 gx2[4];
@@ -1597,6 +1645,7 @@ extern "C" int mdx_op_pack_a(const mdx_pack_jobs* jobs, void* stream) {
 
 static int check_nodemsg(const mdx_nodemsg_args& a) {
   if (a.E < 0) return mdx_set_error(MDX_ERR_ARG, "nodemsg: negative row count");
+  if (a.E >= ((int64_t)1 << 23)) return mdx_set_error(MDX_ERR_UNSUPPORTED, "nodemsg: more than 2^23 rows in one launch (32-bit buffer offsets)");
   if (!a.X || !a.HN || !a.PN || !a.col || !a.pk_w1e || !a.pk_w2e || !a.pk_wm || !a.pk_wg1 || !a.pk_wg2 || !a.b1e || !a.lng_e || !a.lnb_e || !a.b2e ||
       !a.bm || !a.bg1 || !a.lng_g || !a.lnb_g || !a.bg2)
     return mdx_set_error(MDX_ERR_ARG, "nodemsg: null operand");
@@ -1613,7 +1662,13 @@ extern "C" int mdx_op_nodemsg_fwd(const mdx_nodemsg_args* a, void* stream) {
   if (!a->he_pre || !a->he_post || !a->he || !a->p || !a->m0 || !a->g_pre || !a->g_post || !a->gt || !a->msg) return mdx_set_error(MDX_ERR_ARG, "nodemsg_fwd: null output");
   const int ntiles = (int)((a->E + 15) / 16);
   const int grid = std::max(1, std::min(ncus(), (ntiles + NMF_WAVES - 1) / NMF_WAVES));
-  hipLaunchKernelGGL(nodemsg_fwd_kernel, dim3(grid), dim3(NMF_THREADS), 0, (hipStream_t)stream, *a);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)nodemsg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMF_WAVES * TS_BYTES) != hipSuccess)
+      return mdx_set_error(MDX_ERR_HIP, "nodemsg_fwd: cannot reserve LDS");
+    attr = true;
+  }
+  hipLaunchKernelGGL(nodemsg_fwd_kernel, dim3(grid), dim3(NMF_THREADS), NMF_WAVES * TS_BYTES, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? MDX_OK : mdx_set_error(MDX_ERR_HIP, "nodemsg_fwd: launch failed");
 }
 
