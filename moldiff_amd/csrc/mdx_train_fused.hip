@@ -79,6 +79,26 @@ __device__ __forceinline__ int kperm(int k) {
   return 32 * (t >> 1) + 8 * q + 4 * (t & 1) + s;
 }
 // W (N outputs x K inputs, fp32, row stride ld) -> dst [N][K + 8] float16.  PERM: accumulator-fed layer (see kperm).
+// Two adjacent feature tiles of a 16-row tile as ONE 16-byte store per lane (round 6).  A lane (row c, q) holds columns 16 ft + 4 q .. + 3
+// of every tile: 8 bytes in float16, so a tile's store instruction wrote 16 rows x 32 bytes -- and with them the forward of this
+// kernel took 355 us against 148 us without its stores (0.7 GB: 2.3 x the time HBM needs for them).  v_permlane16_swap exchanges the
+// chunks of lane rows q and q ^ 1: even rows end up with columns 4 q .. 4 q + 7 of tile `a`, odd rows with columns 4 (q - 1) .. + 7 of tile
+// `b` -- one instruction then writes 16 rows x 64 contiguous bytes.  Every lane of the wave must call it (the store itself is predicated).
+__device__ __forceinline__ void sth8_pair(_Float16* row_base, int g2, uint2 ha, uint2 hb, int q, bool ok) {
+  const auto sx = __builtin_amdgcn_permlane16_swap(ha.x, hb.x, false, false);
+  const auto sy = __builtin_amdgcn_permlane16_swap(ha.y, hb.y, false, false);
+  const uint4 v = {sx[0], sy[0], sx[1], sy[1]};
+  const int col = (q & 1) ? 32 * g2 + 16 + 4 * (q - 1) : 32 * g2 + 4 * q;
+  if (ok) *reinterpret_cast<uint4*>(row_base + col) = v;
+}
+
+// FT (even) packed tiles of one row block: FT / 2 paired stores
+template <int FT>
+__device__ __forceinline__ void st_tiles(_Float16* row_base, const uint2 (&pk)[FT], int q, bool ok) {
+#pragma unroll
+  for (int g2 = 0; g2 < FT / 2; ++g2) sth8_pair(row_base, g2, pk[2 * g2], pk[2 * g2 + 1], q, ok);
+}
+
 template <int N, int K, bool PERM>
 __device__ __forceinline__ void stage_w(uint16_t* dst, const float* __restrict__ W, int ld, int tid, int nt = BF_THREADS) {
   for (int i = tid; i < N * K; i += nt) {
@@ -209,8 +229,8 @@ __global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_b
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) {
         pk[ft] = pack4(rh4(y[ft]) * nl[ft]);
-        if (ok) sth4(o_prod + r * KI + 16 * ft + 4 * q, pk[ft]);
       }
+      st_tiles<8>(o_prod + r * KI, pk, q, ok);
     }
     // ---- inter module: Linear -> LayerNorm -> ReLU -> Linear
     f32x4 inter[4];
@@ -222,8 +242,9 @@ __global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_b
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) {
         y[ft] = rh4(y[ft] + lds4(C + FwdLds::C_BI1 + 16 * ft + 4 * q));
-        if (ok) sth4(o_pre1 + r * KI + 16 * ft + 4 * q, pack4(y[ft]));
+        pk[ft] = pack4(y[ft]);
       }
+      st_tiles<8>(o_pre1 + r * KI, pk, q, ok);
       float mean, rstd;
       ln_stats<8>(y, mean, rstd);
 #pragma unroll
@@ -231,15 +252,18 @@ __global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_b
         const f32x4 v = relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(C + FwdLds::C_G1 + 16 * ft + 4 * q) +
                               lds4(C + FwdLds::C_BE1 + 16 * ft + 4 * q));
         pk[ft] = pack4(v);
-        if (ok) sth4(o_post1 + r * KI + 16 * ft + 4 * q, pk[ft]);
       }
+      st_tiles<8>(o_post1 + r * KI, pk, q, ok);
       const f16x8_t hb[4] = {pair8(pk[0], pk[1]), pair8(pk[2], pk[3]), pair8(pk[4], pk[5]), pair8(pk[6], pk[7])};
       zero<4>(inter);
       mm<4, 4, LDI>(inter, wi2, hb);
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) {
         inter[ft] = rh4(inter[ft] + lds4(C + FwdLds::C_BI2 + 16 * ft + 4 * q));
-        if (ok) sth4(o_inter + r * KO + 16 * ft + 4 * q, pack4(inter[ft]));
+      }
+      {
+        const uint2 pi[4] = {pack4(inter[0]), pack4(inter[1]), pack4(inter[2]), pack4(inter[3])};
+        st_tiles<4>(o_inter + r * KO, pi, q, ok);
       }
     }
     // ---- gate: Linear([X | node | t]) -> LayerNorm -> ReLU -> Linear; the node part arrives hoisted (GN rows), the time column is w_t t
@@ -253,8 +277,9 @@ __global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_b
       for (int ft = 0; ft < 2; ++ft) {
         const f32x4 ad = ldg4(a.GN + (size_t)ni * a.ldgn + 16 * ft + 4 * q) + splat4(th) * lds4(C + FwdLds::C_WT + 16 * ft + 4 * q);
         y[ft] = rh4((y[ft] + lds4(C + FwdLds::C_BG1 + 16 * ft + 4 * q)) + ad);
-        if (ok) sth4(o_gpre + r * KG + 16 * ft + 4 * q, pack4(y[ft]));
+        pg[ft] = pack4(y[ft]);
       }
+      st_tiles<2>(o_gpre + r * KG, pg, q, ok);
       float mean, rstd;
       ln_stats<2>(y, mean, rstd);
 #pragma unroll
@@ -262,8 +287,8 @@ __global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_b
         const f32x4 v = relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(C + FwdLds::C_GG + 16 * ft + 4 * q) +
                               lds4(C + FwdLds::C_GBE + 16 * ft + 4 * q));
         pg[ft] = pack4(v);
-        if (ok) sth4(o_gpost + r * KG + 16 * ft + 4 * q, pg[ft]);
       }
+      st_tiles<2>(o_gpost + r * KG, pg, q, ok);
       const f16x8_t gb[1] = {pair8(pg[0], pg[1])};
       f32x4 g2[4];
       zero<4>(g2);
@@ -271,10 +296,13 @@ __global__ __launch_bounds__(BF_FWD_THREADS) void bondffn_fwd_kernel(const mdx_b
 #pragma unroll
       for (int ft = 0; ft < 4; ++ft) {
         g2[ft] = rh4(g2[ft] + lds4(C + FwdLds::C_BG2 + 16 * ft + 4 * q));
-        if (ok) {
-          sth4(o_gate + r * KO + 16 * ft + 4 * q, pack4(g2[ft]));
-          sth4(o_out + r * KO + 16 * ft + 4 * q, pack4(inter[ft] * rh4(sigmoid4(g2[ft]))));
-        }
+      }
+      {
+        const uint2 pgt[4] = {pack4(g2[0]), pack4(g2[1]), pack4(g2[2]), pack4(g2[3])};
+        st_tiles<4>(o_gate + r * KO, pgt, q, ok);
+        const uint2 po[4] = {pack4(inter[0] * rh4(sigmoid4(g2[0]))), pack4(inter[1] * rh4(sigmoid4(g2[1]))),
+                             pack4(inter[2] * rh4(sigmoid4(g2[2]))), pack4(inter[3] * rh4(sigmoid4(g2[3])))};
+        st_tiles<4>(o_out + r * KO, po, q, ok);
       }
     }
     xr[0] = xn[0]; xr[1] = xn[1]; ni = nin; te = ten;
@@ -413,11 +441,9 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
       const f32x4 it = ldh4(s_inter + r * KO + 16 * ft + 4 * q), sg = sigmoid4(ldh4(s_gate + r * KO + 16 * ft + 4 * q));
       pgi[ft] = pack4(g * sg);
       pgg[ft] = pack4(g * it * sg * (splat4(1.f) - sg));
-      if (ok) {
-        sth4(o_ginter + r * KO + 16 * ft + 4 * q, pgi[ft]);
-        sth4(o_ggate + r * KO + 16 * ft + 4 * q, pgg[ft]);
-      }
     }
+    st_tiles<4>(o_ginter + r * KO, pgi, q, ok);
+    st_tiles<4>(o_ggate + r * KO, pgg, q, ok);
     __builtin_amdgcn_sched_barrier(0);
     // ---- inter module backward
     uint2 pgb[8];
@@ -436,8 +462,8 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) {
         pg[ft] = pack4(g[ft]);
-        if (ok) sth4(o_gpre1 + r * KI + 16 * ft + 4 * q, pg[ft]);
       }
+      st_tiles<8>(o_gpre1 + r * KI, pg, q, ok);
       const f16x8_t b1[4] = {pair8(pg[0], pg[1]), pair8(pg[2], pg[3]), pair8(pg[4], pg[5]), pair8(pg[6], pg[7])};
       zero<8>(g);
       mm<8, 4, LDI>(g, wi1t, b1);     // dL/d prod
@@ -448,13 +474,17 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
       zero<8>(x);
       mm<8, 2, LDB>(x, wb, xb);
 #pragma unroll
-      for (int ft = 0; ft < 8; ++ft) {
-        const f32x4 gp = rh4(g[ft]), nl = ldh4(NL + (size_t)ni * a.f.ldnl + 16 * ft + 4 * q);
-        pgb[ft] = pack4(gp * nl);
-        if (ok) {
-          sth4(o_gbf + r * KI + 16 * ft + 4 * q, pgb[ft]);
-          sth4(o_gnl + r * KI + 16 * ft + 4 * q, pack4(gp * rh4(x[ft])));
+      for (int g2 = 0; g2 < 4; ++g2) {
+        uint2 pn[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ft = 2 * g2 + j;
+          const f32x4 gp = rh4(g[ft]), nl = ldh4(NL + (size_t)ni * a.f.ldnl + 16 * ft + 4 * q);
+          pgb[ft] = pack4(gp * nl);
+          pn[j] = pack4(gp * rh4(x[ft]));
         }
+        sth8_pair(o_gbf + r * KI, g2, pgb[2 * g2], pgb[2 * g2 + 1], q, ok);
+        sth8_pair(o_gnl + r * KI, g2, pn[0], pn[1], q, ok);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -474,8 +504,8 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
         pgp[ft] = pack4(g[ft]);
-        if (ok) sth4(o_ggpre + r * KG + 16 * ft + 4 * q, pgp[ft]);
       }
+      st_tiles<2>(o_ggpre + r * KG, pgp, q, ok);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- dL/dX = bond_linear^T d bf + W_g1e^T d gate_pre  (two Linear data gradients, each a float16 tensor, summed in float16)
@@ -487,9 +517,10 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
       const f16x8_t bg[1] = {pair8(pgp[0], pgp[1])};
       zero<4>(g2);
       mm<4, 1, LDG>(g2, wg1t, bg);
-      if (ok) {
-#pragma unroll
-        for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(g1[ft]) + rh4(g2[ft])));
+      {
+        const uint2 px[4] = {pack4(rh4(g1[0]) + rh4(g2[0])), pack4(rh4(g1[1]) + rh4(g2[1])), pack4(rh4(g1[2]) + rh4(g2[2])),
+                             pack4(rh4(g1[3]) + rh4(g2[3]))};
+        st_tiles<4>(o_gx + r * KB, px, q, ok);
       }
     }
   }
@@ -756,10 +787,9 @@ __global__ __launch_bounds__(PF_THREADS) void posffn_fwd_kernel(const mdx_posffn
       zero<8>(yb); zero<8>(yn);
       mm<8, 2, LDB>(yb, wb + 128 * h * LDB, xb);
       mm<8, 2, LDB>(yn, wn + 128 * h * LDB, ab);
-      if (ok) {
 #pragma unroll
-        for (int ft = 0; ft < 8; ++ft) sth4(o_prod + r * KW + 128 * h + 16 * ft + 4 * q, pack4(rh4(yb[ft]) * rh4(yn[ft])));
-      }
+      for (int g2 = 0; g2 < 4; ++g2)
+        sth8_pair(o_prod + r * KW + 128 * h, g2, pack4(rh4(yb[2 * g2]) * rh4(yn[2 * g2])), pack4(rh4(yb[2 * g2 + 1]) * rh4(yn[2 * g2 + 1])), q, ok);
     }
     // ---- gate: the node (a) and time columns of its first Linear are an fp32 addend of the bond columns' product, like the per-operator path
     {
@@ -772,8 +802,8 @@ __global__ __launch_bounds__(PF_THREADS) void posffn_fwd_kernel(const mdx_posffn
       for (int ft = 0; ft < 2; ++ft) {
         const f32x4 ad = splat4(th) * lds4(C + PfLds::C_WT + 16 * ft + 4 * q) + ga[ft];
         gx[ft] = rh4((gx[ft] + lds4(C + PfLds::C_BG1 + 16 * ft + 4 * q)) + ad);
-        if (ok) sth4(o_gpre + r * KG + 16 * ft + 4 * q, pack4(gx[ft]));
       }
+      sth8_pair(o_gpre + r * KG, 0, pack4(gx[0]), pack4(gx[1]), q, ok);
       float mean, rstd;
       ln_stats<2>(gx, mean, rstd);
       float dot = 0.f;
@@ -781,11 +811,11 @@ __global__ __launch_bounds__(PF_THREADS) void posffn_fwd_kernel(const mdx_posffn
       for (int ft = 0; ft < 2; ++ft) {
         const f32x4 v = rh4(relu4((gx[ft] - splat4(mean)) * splat4(rstd) * lds4(C + PfLds::C_GG + 16 * ft + 4 * q) + lds4(C + PfLds::C_GBE + 16 * ft + 4 * q)));
         pg[ft] = pack4(v);
-        if (ok) sth4(o_gpost + r * KG + 16 * ft + 4 * q, pg[ft]);
         const f32x4 w2 = lds4(C + PfLds::C_WG2 + 16 * ft + 4 * q);
 #pragma unroll
         for (int s = 0; s < 4; ++s) dot = fmaf(v[s], w2[s], dot);
       }
+      sth8_pair(o_gpost + r * KG, 0, pg[0], pg[1], q, ok);
       dot = sumq(dot);
       if (ok && q == 0) o_gate[r] = (_Float16)(dot + bg2);
     }
@@ -852,10 +882,11 @@ __global__ __launch_bounds__(PF_THREADS) void posffn_bwd_kernel(const mdx_posffn
         const f32x4 g = ldh4(GP + r * a.ldgp + 128 * h + 16 * ft + 4 * q);
         pgb[8 * h + ft] = pack4(g * rh4(yn[ft]));
         pgn[8 * h + ft] = pack4(g * rh4(yb[ft]));
-        if (ok) {
-          sth4(o_gbf + r * KW + 128 * h + 16 * ft + 4 * q, pgb[8 * h + ft]);
-          sth4(o_gnf + r * KW + 128 * h + 16 * ft + 4 * q, pgn[8 * h + ft]);
-        }
+      }
+#pragma unroll
+      for (int g2 = 0; g2 < 4; ++g2) {
+        sth8_pair(o_gbf + r * KW + 128 * h, g2, pgb[8 * h + 2 * g2], pgb[8 * h + 2 * g2 + 1], q, ok);
+        sth8_pair(o_gnf + r * KW + 128 * h, g2, pgn[8 * h + 2 * g2], pgn[8 * h + 2 * g2 + 1], q, ok);
       }
     }
     f32x4 gx1[4], ga1[4];
@@ -885,8 +916,8 @@ __global__ __launch_bounds__(PF_THREADS) void posffn_bwd_kernel(const mdx_posffn
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft) {
         pgp[ft] = pack4(g[ft]);
-        if (ok) sth4(o_ggpre + r * KG + 16 * ft + 4 * q, pgp[ft]);
       }
+      sth8_pair(o_ggpre + r * KG, 0, pgp[0], pgp[1], q, ok);
     }
     {
       const f16x8_t bg[1] = {pair8(pgp[0], pgp[1])};
@@ -894,14 +925,20 @@ __global__ __launch_bounds__(PF_THREADS) void posffn_bwd_kernel(const mdx_posffn
       zero<4>(gx2); zero<4>(ga2);
       mm<4, 1, LDG>(gx2, wgxt, bg);
       mm<4, 1, LDG>(ga2, wgat, bg);
-      if (ok) {
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-          sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx1[ft]) + rh4(gx2[ft])));
+      for (int g2 = 0; g2 < 2; ++g2) {
+        uint2 px[2], pl[2], pr[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int ft = 2 * g2 + j;
+          px[j] = pack4(rh4(gx1[ft]) + rh4(gx2[ft]));
           const f32x4 ga = rh4(rh4(ga1[ft]) + rh4(ga2[ft]));
-          sth4(o_glf + r * KB + 16 * ft + 4 * q, pack4(ga * ldh4(RF + orr + 16 * ft + 4 * q)));
-          sth4(o_grf + r * KB + 16 * ft + 4 * q, pack4(ga * ldh4(LF + ol + 16 * ft + 4 * q)));
+          pl[j] = pack4(ga * ldh4(RF + orr + 16 * ft + 4 * q));
+          pr[j] = pack4(ga * ldh4(LF + ol + 16 * ft + 4 * q));
         }
+        sth8_pair(o_gx + r * KB, g2, px[0], px[1], q, ok);
+        sth8_pair(o_glf + r * KB, g2, pl[0], pl[1], q, ok);
+        sth8_pair(o_grf + r * KB, g2, pr[0], pr[1], q, ok);
       }
     }
   }
@@ -1187,19 +1224,6 @@ template <int N>
 __device__ __forceinline__ void pairs(f16x8_t (&b)[N / 2], const uint2 (&pk)[N]) {
 #pragma unroll
   for (int i = 0; i < N / 2; ++i) b[i] = pair8(pk[2 * i], pk[2 * i + 1]);
-}
-
-// Two adjacent feature tiles of a 16-row tile as ONE 16-byte store per lane (round 6).  A lane (row c, q) holds columns 16 ft + 4 q .. + 3
-// of every tile: 8 bytes in float16, so a tile's store instruction wrote 16 rows x 32 bytes -- and with them the forward of this
-// kernel took 355 us against 148 us without its stores (0.7 GB: 2.3 x the time HBM needs for them).  v_permlane16_swap exchanges the
-// chunks of lane rows q and q ^ 1: even rows end up with columns 4 q .. 4 q + 7 of tile `a`, odd rows with columns 4 (q - 1) .. + 7 of tile
-// `b` -- one instruction then writes 16 rows x 64 contiguous bytes.  Every lane of the wave must call it (the store itself is predicated).
-__device__ __forceinline__ void sth8_pair(_Float16* row_base, int g2, uint2 ha, uint2 hb, int q, bool ok) {
-  const auto sx = __builtin_amdgcn_permlane16_swap(ha.x, hb.x, false, false);
-  const auto sy = __builtin_amdgcn_permlane16_swap(ha.y, hb.y, false, false);
-  const uint4 v = {sx[0], sy[0], sx[1], sy[1]};
-  const int col = (q & 1) ? 32 * g2 + 16 + 4 * (q - 1) : 32 * g2 + 4 * q;
-  if (ok) *reinterpret_cast<uint4*>(row_base + col) = v;
 }
 
 // Whole 16 x 256 float16 tiles through a wave-private LDS area (round 6): chunks go in in accumulator layout (lane (c, q): row c, columns
