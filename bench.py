@@ -153,7 +153,7 @@ def compact_line(full, full_path='bench_full.json'):
             if 'error' in c:
                 summ[name] = {'error': _short(c['error'], 80)}
                 continue
-            e = _pick(c, ('ms_per_step', 'value', 'host_issue_ms_per_step', 'launches_per_step'))
+            e = _pick(c, ('ms_per_step', 'value', 'host_issue_ms_per_step', 'host_only_ms_per_step', 'launches_per_step'))
             r = c.get('roofline') or {}
             if r.get('frac') is not None:
                 e['frac'] = _num(r['frac'])
@@ -512,6 +512,26 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms = elapsed / steps * 1e3
+    # host-only time of a step: three more steps, each issued with the device idle (a synchronize before it).  `issued` above cannot be
+    # shorter than the GPU's time by more than one step: Trainer.step waits for the PREVIOUS step's class-range check at its top
+    host_only = 0.0
+    for _ in range(3):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        tr.step(*batch)
+        host_only += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    launches = None
+    try:
+        from moldiff_amd import train_ops as _T
+        F = _T._fast()
+        if F is not None:
+            n0 = F.launches()
+            tr.step(*batch)
+            torch.cuda.synchronize()
+            launches = int(F.launches() - n0)
+    except Exception:
+        launches = None
     N, Eh = int(batch[1].shape[0]), int(batch[3].shape[0])
     E = 2 * Eh
     nb = 8 if model_kind == 'bondpred' else 6
@@ -524,6 +544,9 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
     out = {'metric': 'molecules/sec (training step: forward + backward + all-reduce + clip + AdamW)', 'value': batch_size * world / (ms / 1e3),
            'unit': 'molecules/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms,
            'host_issue_ms_per_step': issued / steps * 1e3,
+           'host_only_ms_per_step': host_only / 3 * 1e3,
+           'host_path': ('C++ operator bodies (moldiff_amd/_mdx_fast.so)' if launches is not None else 'Python operator bodies (MDX_TRAIN_FAST=0)'),
+           'library_launches_from_cpp_bodies_per_step': launches,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': TRAIN_DTYPE[precision], 'data': 'synthetic',
            'config': {'workload': f'train_{model_kind}.yml: batch_size={batch_size} molecules/GPU (rank 0: N={N} atoms, E={E} directed '
@@ -535,8 +558,8 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
                         'frac_of_fp32_mfma_peak': ach / PEAK_FP32_MFMA, 'flops_per_step': flop,
                         'flops_what': '3 x the hoisted forward count (forward, data gradient, weight gradient of every Linear)',
                         'traffic': None,
-                        'note': 'whole-step fraction: the step is a chain of ~2,000 launches, half of its time HBM-bound row-wise passes '
-                                'between the GEMMs (DESIGN.md section 3.3, profiles/HISTORY.md section 10)'},
+                        'note': 'whole-step fraction: the step is a chain of ~790 launches (rocprofv3: profiles/r6_train_fp16_kernel_stats.csv), '
+                                'most of its time in latency- / store-bound fused row-owner kernels (DESIGN.md section 3.3)'},
            'peak_hbm_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
            'loss_first_last': [float(losses[0]), float(losses[-1])]}
     return out, model, sizes
