@@ -878,52 +878,67 @@ __global__ __launch_bounds__(256) void hgemm_tn_tr_kernel(const _Float16* __rest
 // sums of dY (A = dY) or sum_m s[m] (s = dY).  C % 4 == 0, C <= 256.
 __device__ __forceinline__ void wgrad_colsum_body(const TP s_, const TP A_, int lda, int C, bool bias_is_A, int M, int mper, float* __restrict__ P,
                                                   float* __restrict__ Pb, const int bz) {
-  __shared__ f32x4 red[256];
-  __shared__ f32x4 redb[256];
-  const int tid = threadIdx.x, lpr = C >> 2, rows_it = 256 / lpr;
+  // a thread owns 8 columns of float16 rows (one 16-byte load) or 4 of fp32 rows, and every (256 / lanes-per-row)-th row of the range
+  __shared__ f32x4 red[2][256];
+  __shared__ f32x4 redb[2][256];
+  const int tid = threadIdx.x;
+  const bool wide = A_.h && (C & 7) == 0 && (lda & 7) == 0 && ((reinterpret_cast<uintptr_t>(A_.p) & 15) == 0);
+  const int cpt = wide ? 8 : 4, lpr = C / cpt, rows_it = 256 / lpr;
   const int cl = tid % lpr, rl = tid / lpr;
   const int mbeg = bz * mper, mend = min(M, mbeg + mper);
   const bool vec = tp_vec_ok(A_.p, A_.h, lda);
-  f32x4 acc = splat4(0.f), accb = splat4(0.f);
+  f32x4 acc[2] = {splat4(0.f), splat4(0.f)}, accb[2] = {splat4(0.f), splat4(0.f)};
   if (rl < rows_it) {
 #pragma unroll 4
     for (int m = mbeg + rl; m < mend; m += rows_it) {
       float sv = ld1(s_, (size_t)m);
-      f32x4 a;
-      if (vec) {
-        a = ld4(A_, (size_t)m * lda + 4 * cl);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = ld1(A_, (size_t)m * lda + 4 * cl + r);
-      }
       // autocast arithmetic: operands of a Linear's contraction are float16 VALUES (the converting kernel rounds fp32 containers the same way)
       if (!s_.h) sv = round_half<1>(sv);
-      if (!A_.h) {
+      f32x4 a0, a1 = splat4(0.f);
+      if (wide) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(A_.p) + (size_t)m * lda + 8 * cl);
+        const f16x4_t lo = __builtin_bit_cast(f16x4_t, uint2{u.x, u.y}), hi = __builtin_bit_cast(f16x4_t, uint2{u.z, u.w});
+        a0 = f32x4{(float)lo[0], (float)lo[1], (float)lo[2], (float)lo[3]};
+        a1 = f32x4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]};
+      } else {
+        if (vec) {
+          a0 = ld4(A_, (size_t)m * lda + 4 * cl);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = round_half<1>(a[r]);
+          for (int r = 0; r < 4; ++r) a0[r] = ld1(A_, (size_t)m * lda + 4 * cl + r);
+        }
+        if (!A_.h) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a0[r] = round_half<1>(a0[r]);
+        }
       }
-      acc = acc + a * splat4(sv);
-      accb = accb + (bias_is_A ? a : splat4(sv));
+      acc[0] = acc[0] + a0 * splat4(sv);
+      acc[1] = acc[1] + a1 * splat4(sv);
+      accb[0] = accb[0] + (bias_is_A ? a0 : splat4(sv));
+      accb[1] = accb[1] + (bias_is_A ? a1 : splat4(sv));
     }
   }
-  red[tid] = acc;
-  redb[tid] = accb;
+  red[0][tid] = acc[0], red[1][tid] = acc[1];
+  redb[0][tid] = accb[0], redb[1][tid] = accb[1];
   __syncthreads();
   if (tid < lpr) {
-    f32x4 r = splat4(0.f), rb = splat4(0.f);
+    f32x4 r[2] = {splat4(0.f), splat4(0.f)}, rb[2] = {splat4(0.f), splat4(0.f)};
     for (int g = 0; g < rows_it; ++g) {
-      r = r + red[g * lpr + tid];
-      rb = rb + redb[g * lpr + tid];
+      r[0] = r[0] + red[0][g * lpr + tid], r[1] = r[1] + red[1][g * lpr + tid];
+      rb[0] = rb[0] + redb[0][g * lpr + tid], rb[1] = rb[1] + redb[1][g * lpr + tid];
     }
     float* out = P + (size_t)bz * C;
+    const int nh = cpt / 4;
+    for (int h = 0; h < nh; ++h)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) out[4 * tid + e] = r[e];
+      for (int e = 0; e < 4; ++e) out[cpt * tid + 4 * h + e] = r[h][e];
     if (Pb) {
       if (bias_is_A) {
+        for (int h = 0; h < nh; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Pb[(size_t)bz * C + 4 * tid + e] = rb[e];
+          for (int e = 0; e < 4; ++e) Pb[(size_t)bz * C + cpt * tid + 4 * h + e] = rb[h][e];
       } else if (tid == 0) {
-        Pb[bz] = rb[0];   // (every lane of a row added s[m] once: lane 0's sum over the row groups is sum_m s[m])
+        Pb[bz] = rb[0][0];   // (every lane of a row added s[m] once: lane 0's sum over the row groups is sum_m s[m])
       }
     }
   }

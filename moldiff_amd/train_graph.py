@@ -131,7 +131,11 @@ def node_block(m, x, g, edge_attr, node_time):
     agg = per_node = None
     if m.use_gate:   # models/graph.py:46-48
         g0, ed = m.gate.net[0], edge_attr.shape[1]
-        per_node = T.linear(cat(_u(x), node_time), g0.weight[:, ed:], keep32=True)         # x[col] and node_time[col] columns
+        # x[col] and node_time[col] columns of the gate's first Linear, per node.  The time column is its own rank-1 partial sum (round 6):
+        # cat(x, t) was a 257-wide operand -- a concatenation, a cast and the slow odd-K GEMM forward, data gradient and weight gradient
+        nx = x.x.shape[1] if isinstance(x, _Uses) else x.shape[1]
+        per_node = T.linear(_u(x), g0.weight[:, ed:ed + nx], keep32=True,
+                            addend=T.linear(node_time, g0.weight[:, ed + nx:], keep32=True))
         if len(m.edge_net.net) == 4 and len(m.gate.net) == 4:
             en, gt_ = m.edge_net.net, m.gate.net
             shapes = (tuple(en[0].weight.shape), tuple(en[3].weight.shape), tuple(m.msg_net.weight.shape), (g0.weight.shape[0], ed),
