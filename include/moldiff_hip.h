@@ -309,6 +309,13 @@ int mdx_op_ln_relu_fwd(const float* x, const float* gamma, const float* beta, in
 int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,
                        int32_t F, int32_t relu, float* dx, float* dgb, float* ws, void* stream);
 size_t mdx_op_ln_relu_bwd_ws(int64_t M, int32_t F);
+/* The same backward when the layer after the LayerNorm is a Linear to ONE output (PosUpdate's inter MLP, 256 -> 1, reference
+ * models/graph.py:388-392 through models/common.py:191-198): the upstream gradient dy[row][c] = f16(g1[row] * f16(w1[c])) is formed
+ * in the kernel from g1 (M values; dt bit 0: float16) and the Linear's weight row w1 (F, fp32) -- autograd's `grad_input` GEMM with
+ * K = 1, its weight transpose and the (M,F) gradient tensor are not materialised.  Leaves the [dgamma | dbeta] partial rows in ws
+ * (mdx_op_ln_relu_bwd_rows(M) rows of 2F floats) for mdx_op_reduce_deferred.  F in {32, 64, 128, 256}; dt bit 1: x, bit 2: dx float16. */
+int mdx_op_ln_relu_bwd_r1_t(const void* g1, const float* w1, const void* x, const float* stats, const float* gamma, const float* beta,
+                            int64_t M, int32_t F, int32_t relu, void* dx, float* ws, int32_t dt, void* stream);
 /* element-wise pairs, op: 0 a+b, 1 a-b, 2 a*b, 3 a*sigmoid(b).  Backward writes da / db (either may be NULL). */
 int mdx_op_ew_fwd(int32_t op, const float* a, const float* b, float* out, int64_t n, void* stream);
 int mdx_op_ew_bwd(int32_t op, const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream);

@@ -33,7 +33,7 @@ EXPORTS = [
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
     'mdx_op_edge_tail_fwd', 'mdx_op_edge_tail_bwd', 'mdx_op_edge_tail_lnp_floats',
     'mdx_op_posffn_fwd', 'mdx_op_posffn_bwd', 'mdx_op_posffn_lnp_floats',
-    'mdx_op_cat_loss', 'mdx_op_sum_n', 'mdx_op_plan_flip', 'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
+    'mdx_op_cat_loss', 'mdx_op_ln_relu_bwd_r1_t', 'mdx_op_sum_n', 'mdx_op_plan_flip', 'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
 ]
 
 
@@ -216,6 +216,7 @@ def lib():
         L.mdx_op_wgrad_grouped.argtypes = [c_void_p, c_int32, c_int64, c_int32, c_void_p]
         L.mdx_op_sum_n.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int32, c_void_p]
         L.mdx_op_plan_flip.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+        L.mdx_op_ln_relu_bwd_r1_t.argtypes = [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]
         L.mdx_op_ln_relu_bwd_rows.argtypes = [c_int64]
         L.mdx_op_ln_relu_bwd_rows.restype = c_int64
         L.mdx_op_reduce_deferred.argtypes = [c_void_p, c_int32, c_int64, c_void_p]

@@ -420,6 +420,74 @@ class LinearLnReluFn : public torch::autograd::Function<LinearLnReluFn> {
   }
 };
 
+// ---- Linear + LayerNorm + ReLU + Linear to ONE output (common.MLP of PosUpdate's inter module: 256 -> 256 -> 1) -----------------------------
+// forward: the fused Linear+LayerNorm launch, then the row dot as a GEMM with N = 1.  backward: the second Linear's weight gradient is
+// queued, its data gradient is the rank-1 product g1[row] * w2[c], formed INSIDE the LayerNorm backward (mdx_op_ln_relu_bwd_r1_t): the
+// (E,256) gradient tensor, the K = 1 GEMM and the weight transpose of the per-operator path are gone.
+class LinearLnReluDotFn : public torch::autograd::Function<LinearLnReluDotFn> {
+ public:
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& w, const Tensor& b, const Tensor& gamma, const Tensor& beta,
+                        const Tensor& w2, const Tensor& b2) {
+    Tensor xc = rows(x), wc = rows(w), bc = fc(b), g = fc(gamma), bt = fc(beta), w2c = rows(w2), b2c = fc(b2);
+    const int64_t M = xc.size(0), K = xc.size(1), N = wc.size(0);
+    TORCH_CHECK(w2c.size(0) == 1 && w2c.size(1) == N, "linear_ln_relu_dot: second weight must be (1, N)");
+    Tensor pre = half_empty(M, N, xc), post = half_empty(M, N, xc);
+    Tensor stats = at::empty({M, 2}, xc.options().dtype(at::kFloat));
+    chk(mdx_op_xgemm_nt_ln_t(xc.data_ptr(), xc.stride(0), reinterpret_cast<const float*>(wc.data_ptr()), wc.stride(0),
+                             reinterpret_cast<const float*>(bc.data_ptr()), nullptr, 0, pre.data_ptr(), N,
+                             reinterpret_cast<const float*>(g.data_ptr()), reinterpret_cast<const float*>(bt.data_ptr()), post.data_ptr(), N,
+                             reinterpret_cast<float*>(stats.data_ptr()), 1, M, N, K, S.amp0, 1, 1 | 4 | 8, cur_stream()));
+    ++S.n_launch;
+    Tensor y = xgemm_nt(post, w2c.data_ptr(), w2c.stride(0), 1, N, b2c, Tensor(), false, c10::nullopt);
+    ctx->save_for_backward({xc, wc, b, pre, g, bt, stats, gamma, beta, post, w2c, b2, w2});
+    ctx->saved_data["xd"] = (int64_t)x.scalar_type();
+    ctx->saved_data["amp"] = amp_pack();
+    return y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    AmpGuard guard(ctx->saved_data["amp"].toInt());
+    auto sv = ctx->get_saved_variables();
+    const Tensor &pre = sv[3], &g = sv[4], &bt = sv[5], &stats = sv[6], &post = sv[9], &w2c = sv[10];
+    Tensor gy = tc(grads[0]);                                  // (M,1)
+    const int64_t M = pre.size(0), F = pre.size(1);
+    // second Linear: weight (+ bias) gradient queued
+    const int64_t dst_w2 = sink_dst(sv[12]), dst_b2 = sink_dst(sv[11]);
+    TORCH_CHECK(dst_w2 && dst_b2, "linear_ln_relu_dot: parameters left the gradient sink");
+    wq_append(gy, post, dst_w2, sv[12].stride(0), dst_b2, rk_now());
+    // LayerNorm backward with the rank-1 upstream gradient
+    Tensor gpre = at::empty_like(pre);
+    Tensor ws = at::empty({(int64_t)(mdx_op_ln_relu_bwd_ws(M, (int32_t)F) / 4 + 1)}, pre.options().dtype(at::kFloat));
+    const int64_t dst_g = sink_dst(sv[7]), dst_bt = sink_dst(sv[8]);
+    TORCH_CHECK(dst_g && dst_bt && ((uintptr_t)ws.data_ptr()) % 16 == 0, "linear_ln_relu_dot: LayerNorm parameters not in the gradient sink");
+    chk(mdx_op_ln_relu_bwd_r1_t(gy.data_ptr(), reinterpret_cast<const float*>(w2c.data_ptr()), pre.data_ptr(),
+                                reinterpret_cast<const float*>(stats.data_ptr()), reinterpret_cast<const float*>(g.data_ptr()),
+                                reinterpret_cast<const float*>(bt.data_ptr()), M, (int32_t)F, 1, gpre.data_ptr(),
+                                reinterpret_cast<float*>(ws.data_ptr()), H(gy) | (H(pre) << 1) | (H(gpre) << 2), cur_stream()));
+    ++S.n_launch;
+    const int64_t nrows = mdx_op_ln_relu_bwd_rows(M);
+    sink_record(A(ws), dst_g, nrows, 1, F, F, 2 * F, 0, ws);
+    sink_record(A(ws) + 4 * F, dst_bt, nrows, 1, F, F, 2 * F, 0, ws);
+    // first Linear
+    LinCtx c;
+    c.x = sv[0], c.w = sv[1], c.b = sv[2];
+    c.has_bias = true, c.has_addend = false;
+    c.need_x = ctx->needs_input_grad(0), c.need_w = ctx->needs_input_grad(1), c.need_b = ctx->needs_input_grad(2);
+    c.x_dtype = (at::ScalarType)ctx->saved_data["xd"].toInt();
+    Tensor gx, ga;
+    linear_backward(c, gpre, gx, ga);
+    return {gx, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+bool linear_ln_dot_fast_ok(const Tensor& x, const Tensor& w, const Tensor& b, const Tensor& gamma, const Tensor& beta, const Tensor& w2,
+                           const Tensor& b2) {
+  if (!linear_fast_ok(x, w, b)) return false;
+  for (const Tensor* p : {&gamma, &beta, &w2, &b2})
+    if (!sink_dst(*p) || !p->requires_grad()) return false;
+  const int64_t F = w.size(0);
+  return w2.dim() == 2 && w2.size(0) == 1 && w2.size(1) == F && w2.stride(1) == 1 && (F == 32 || F == 64 || F == 128 || F == 256) &&
+         x.scalar_type() == at::kHalf;
+}
+
 // ---- element-wise (train_ops._Ew): add 0, sub 1, mul 2, gate 3 ------------------------------------------------------------------------
 class EwFn : public torch::autograd::Function<EwFn> {
  public:
@@ -798,6 +866,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("linear_ln_relu", [](const Tensor& x, const Tensor& w, const c10::optional<Tensor>& b, const c10::optional<Tensor>& addend,
                              const Tensor& gamma, const Tensor& beta) { return LinearLnReluFn::apply(x, w, b, addend, gamma, beta); });
   m.def("ew", [](int64_t op, const Tensor& a, const Tensor& b) { return EwFn::apply(op, a, b); });
+  m.def("linear_ln_dot_fast_ok", &linear_ln_dot_fast_ok);
+  m.def("linear_ln_relu_dot", [](const Tensor& x, const Tensor& w, const Tensor& b, const Tensor& gamma, const Tensor& beta, const Tensor& w2,
+                                 const Tensor& b2) { return LinearLnReluDotFn::apply(x, w, b, gamma, beta, w2, b2); });
   m.def("all_in_sink", &all_in_sink);
   m.def("bondffn_fwd", &bondffn_fwd);
   m.def("bondffn_bwd", &bondffn_bwd);

@@ -1328,17 +1328,22 @@ __global__ __launch_bounds__(256) void ln_relu_fwd4_kernel(const TP x, const flo
 }
 
 // backward: a wave walks `steps` consecutive row groups; dx per row; the workgroup's partial of dgamma / dbeta -> part[blockIdx.x][2F]
+// r1w != NULL (round 6): the upstream gradient is the rank-1 product dy[row][c] = f16(g1[row] * f16(r1w[c])) -- the data gradient of a
+// Linear to ONE output (PosUpdate's 256 -> 1) that follows this LayerNorm; dy.p then holds g1 (M values), and the (M,F) gradient
+// tensor, the K = 1 GEMM that formed it and the transpose of its weight never exist.
 template <int LPR>
 __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const TP dy, const TP x,
                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int M, int relu, int rows_per,
-                                                            const TPW dx, float* __restrict__ part) {
+                                                            const TPW dx, float* __restrict__ part, const float* __restrict__ r1w = nullptr) {
   constexpr int F = 4 * LPR, RPS = 64 / LPR;
   const int lane = threadIdx.x & 63, wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int sub = lane / LPR, c4 = lane % LPR;
   const int r0 = wg * rows_per, r1 = min(M, r0 + rows_per);
   const f32x4 gm = {gamma[4 * c4], gamma[4 * c4 + 1], gamma[4 * c4 + 2], gamma[4 * c4 + 3]};  // (parameters: any 4-byte offset)
   const f32x4 bt = {beta[4 * c4], beta[4 * c4 + 1], beta[4 * c4 + 2], beta[4 * c4 + 3]};
+  f32x4 w1 = splat4(0.f);
+  if (r1w) w1 = f32x4{round_half<1>(r1w[4 * c4]), round_half<1>(r1w[4 * c4 + 1]), round_half<1>(r1w[4 * c4 + 2]), round_half<1>(r1w[4 * c4 + 3])};
   f32x4 dg = splat4(0.f), db = splat4(0.f);
   for (int rb = r0; rb < r1; rb += RPS) {
     const int row = rb + sub;
@@ -1346,7 +1351,16 @@ __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const TP dy, const TP
     const size_t o = (size_t)(ok ? row : r0) * F + 4 * c4;
     const float mean = stats[2 * (size_t)(ok ? row : r0)], rstd = stats[2 * (size_t)(ok ? row : r0) + 1];
     const f32x4 xh = (ld4(x, o) - splat4(mean)) * splat4(rstd);
-    f32x4 g = ok ? ld4(dy, o) : splat4(0.f);
+    f32x4 g = splat4(0.f);
+    if (r1w) {
+      if (ok) {
+        const float gv = round_half<1>(ld1(dy, (size_t)row));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = round_half<1>(gv * w1[k]);
+      }
+    } else if (ok) {
+      g = ld4(dy, o);
+    }
     if (relu) {
       const f32x4 yv = xh * gm + bt;
 #pragma unroll
@@ -1970,6 +1984,26 @@ extern "C" int mdx_op_ln_relu_bwd_t(const void* dyv, const void* xv, const float
   // [dgamma | dbeta] = sum over the nwp / 4 per-workgroup partial rows, fixed-order parallel reduction (dgb == NULL: deferred, the
   // partial rows stay in ws for mdx_op_reduce_deferred)
   if (dgb) launch_reduce_partials(ws, nwp / 4, 1, 2 * F, nullptr, dgb, 2 * F, ws + (size_t)(nwp / 4) * 2 * F, s);
+  return launched();
+}
+extern "C" int mdx_op_ln_relu_bwd_r1_t(const void* g1, const float* w1, const void* xv, const float* stats, const float* gamma, const float* beta,
+                                       int64_t M, int32_t F, int32_t relu, void* dxv, float* ws, int32_t dt, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0) return MDX_OK;
+  if (!g1 || !w1 || !xv || !stats || !gamma || !beta || !dxv || !ws) return bad("ln_relu_bwd_r1: null operand");
+  const TP dy{g1, dt & 1}, x{xv, (dt >> 1) & 1};
+  const TPW dx{dxv, (dt >> 2) & 1};
+  const int RPW = MDX_LN_RPW;
+  const int nw = (int)((M + RPW - 1) / RPW), nwp = (nw + 3) / 4 * 4;
+  if (!(tp_vec_ok(xv, x.h, 4) && tp_vec_ok(dxv, dx.h, 4) && ((reinterpret_cast<uintptr_t>(ws) & 15) == 0)))
+    return mdx_set_error(MDX_ERR_UNSUPPORTED, "ln_relu_bwd_r1: aligned rows required");
+#define MDX_LNB1(LPR)                                                                                                             \
+  case 4 * LPR:                                                                                                                   \
+    hipLaunchKernelGGL(ln_relu_bwd4_kernel<LPR>, dim3((unsigned)(nwp / 4)), dim3(256), 32 * F, s, dy, x, stats, gamma, beta, (int)M, relu, \
+                       RPW, dx, ws, w1);                                                                                          \
+    break;
+  switch (F) { MDX_LNB1(8) MDX_LNB1(16) MDX_LNB1(32) MDX_LNB1(64) default: return mdx_set_error(MDX_ERR_UNSUPPORTED, "ln_relu_bwd_r1: F must be 32, 64, 128 or 256"); }
+#undef MDX_LNB1
   return launched();
 }
 extern "C" int mdx_op_ln_relu_bwd(const float* dy, const float* x, const float* stats, const float* gamma, const float* beta, int64_t M,

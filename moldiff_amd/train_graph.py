@@ -232,7 +232,12 @@ def pos_update(m, h_node, h_edge, g, rel, dist, edge_time):
             prod, gate = T.posffn_front(h_edge, lf_n, rf_n, edge_time, g.left, g.right, dict(
                 Wb=ff.bond_linear.weight, Wn=ff.node_linear.weight, Wg1x=g0.weight[:, :bd], Wg1a=g0.weight[:, bd:bd + nd],
                 Wt=g0.weight[:, bd + nd:], bg1=g0.bias, gg=gt[1].weight, gbe=gt[1].bias, Wg2=gt[3].weight, bg2=gt[3].bias))
-            w = T.gate(mlp(ff.inter_module, prod), gate)
+            im = ff.inter_module.net
+            if len(im) == 4 and im[3].weight.shape[0] == 1 and im[3].bias is not None and im[0].bias is not None:
+                inter = T.linear_ln_relu_dot(prod, im[0].weight, im[0].bias, im[1].weight, im[1].bias, im[3].weight, im[3].bias)
+            else:
+                inter = mlp(ff.inter_module, prod)
+            w = T.gate(inter, gate)
             return T.scatter_sum(T.force(w, rel, dist), g.left)
     lf = T.gather(lf_n, g.left)
     w = bond_ffn(ff, h_edge, edge_time, node_edges=T.mul_gather(lf, rf_n, g.right))

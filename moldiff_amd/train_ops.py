@@ -727,6 +727,17 @@ def linear_ln_relu(x, w, b, gamma, beta, addend=None):
     return ln_relu(linear(x, w, b, addend=addend), gamma, beta, True)
 
 
+def linear_ln_relu_dot(x, w, b, gamma, beta, w2, b2):
+    """linear(relu(LayerNorm(x @ w.T + b)), w2, b2) with w2 of ONE row -- common.MLP(…, 1) as PosUpdate's inter module uses it.  On the
+    C++ fast path (float16 mode inside a sink) one node whose backward forms the second Linear's rank-1 data gradient inside the LayerNorm
+    backward (csrc mdx_op_ln_relu_bwd_r1_t); otherwise the two operators."""
+    sk = _SINK
+    if (sk is not None and sk['fast'] is not None and b is not None and b2 is not None and linear_ln_ok(x, w, None)
+            and sk['fast'].linear_ln_dot_fast_ok(x, w, b, gamma, beta, w2, b2)):
+        return sk['fast'].linear_ln_relu_dot(x, w, b, gamma, beta, w2, b2)
+    return linear(linear_ln_relu(x, w, b, gamma, beta), w2, b2)
+
+
 class _Ew(torch.autograd.Function):
     @staticmethod
     def forward(ctx, op, a, b):
