@@ -160,6 +160,12 @@ int mdx_gauss_posterior(const float* coef_x0, const float* coef_xt, const float*
 int mdx_cat_posterior(const float* q_mats, const float* qT_onestep, int32_t K, int32_t T, const float* in0,
                       int32_t is_logits, const float* log_vt, const int64_t* t, const int64_t* batch, int64_t n,
                       float* out, void* stream);
+/* Training / add_noise: GeneralCategoricalTransition.add_noise (models/transition.py:266-283: index_to_log_onehot, q_vt_pred, the
+ * Gumbel-max draw of q_vt_sample with the uniforms u (n,K) passed in, onehot_encode) in one launch: v (n) class ids of the clean batch
+ * -> onehot (n,K) of the drawn classes, log_vt = log(clamp(onehot, 1e-30)), log_v0 = log(clamp(onehot(v), 1e-30)).  log_off = log(1e-30)
+ * as the caller's torch evaluates it in fp32.  Ids outside [0, K) are clamped (the caller reports them, models/diffusion.py:54). */
+int mdx_op_cat_add_noise(const float* q_mats, int32_t K, int32_t T, const int64_t* v, const int64_t* t, const int64_t* batch, const float* u,
+                         int64_t n, float log_off, float* onehot, float* log_vt, float* log_v0, void* stream);
 /* Training: the categorical loss rows of models/model.py:170-189 and their gradient w.r.t. the decoder logits in one launch --
  * log_softmax, q_v_posterior (transition.py:285-315) of the true and the predicted classes, compute_v_Lt (transition.py:317-327:
  * KL for t > 0, decoder NLL at t == 0) and the backward torch.autograd would run through them.  logits / log_vt / log_v0 (n,K), K <= 8;

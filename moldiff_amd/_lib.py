@@ -33,7 +33,7 @@ EXPORTS = [
     'mdx_op_bondffn_fwd', 'mdx_op_bondffn_bwd', 'mdx_op_bondffn_workgroups', 'mdx_op_bondffn_lnp_floats',
     'mdx_op_edge_tail_fwd', 'mdx_op_edge_tail_bwd', 'mdx_op_edge_tail_lnp_floats',
     'mdx_op_posffn_fwd', 'mdx_op_posffn_bwd', 'mdx_op_posffn_lnp_floats',
-    'mdx_op_cat_loss', 'mdx_op_ln_relu_bwd_r1_t', 'mdx_op_sum_n', 'mdx_op_plan_flip', 'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
+    'mdx_op_cat_loss', 'mdx_op_cat_add_noise', 'mdx_op_ln_relu_bwd_r1_t', 'mdx_op_sum_n', 'mdx_op_plan_flip', 'mdx_op_pack_a', 'mdx_op_nodemsg_fwd', 'mdx_op_nodemsg_bwd', 'mdx_op_nodemsg_lnp_floats',
 ]
 
 
@@ -168,6 +168,8 @@ def lib():
         L.mdx_cat_posterior.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_void_p]
         L.mdx_gumbel_argmax.argtypes = [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
+        L.mdx_op_cat_add_noise.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p,
+                                           c_void_p, c_void_p]
         L.mdx_op_cat_loss.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_void_p]
         L.mdx_prior_draw.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]
@@ -511,6 +513,20 @@ def cat_posterior(q_mats, qT, in0, log_vt, t, batch, is_logits=False):
 
 
 _LOG_EPS32 = None
+
+
+def cat_add_noise(q_mats, v, t, batch, u, K):
+    """GeneralCategoricalTransition.add_noise's arithmetic in one launch (csrc cat_add_noise_kernel) -> (onehot, log_vt, log_v0)"""
+    global _LOG_EPS32
+    _need_gpu(v, t, batch, u, q_mats)
+    if _LOG_EPS32 is None:
+        _LOG_EPS32 = float(torch.log(torch.tensor([1e-30], dtype=torch.float32))[0])
+    v, t, batch, u = i64c(v), i64c(t), i64c(batch), f32c(u)
+    n = v.shape[0]
+    oh, lvt, lv0 = (torch.empty(n, K, dtype=torch.float32, device=v.device) for _ in range(3))
+    check(lib().mdx_op_cat_add_noise(ptr(q_mats), K, q_mats.shape[0], ptr(v), ptr(t), ptr(batch), ptr(u), n, _LOG_EPS32, ptr(oh), ptr(lvt), ptr(lv0),
+                                     stream()))
+    return oh, lvt, lv0
 
 
 def prior_draw(init_prob, u, n, cls=None, onehot=None, log_onehot=None, cls8=None):

@@ -1670,6 +1670,15 @@ extern "C" int mdx_cat_posterior(const float* q_mats, const float* qT, int32_t K
   return MDX_OK;
 }
 
+extern "C" int mdx_op_cat_add_noise(const float* q_mats, int32_t K, int32_t T, const int64_t* v, const int64_t* t, const int64_t* batch,
+                                    const float* u, int64_t n, float log_off, float* onehot, float* log_vt, float* log_v0, void* stream) {
+  if (K < 2 || K > 8) return fail(MDX_ERR_UNSUPPORTED, "K must be in 2..8");
+  if (n < 0 || T < 1 || (n > 0 && (!q_mats || !v || !t || !batch || !u || !onehot || !log_vt || !log_v0))) return fail(MDX_ERR_ARG, "bad argument");
+  launch_cat_add_noise(q_mats, K, v, t, batch, u, (int)n, log_off, onehot, log_vt, log_v0, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return MDX_OK;
+}
+
 extern "C" int mdx_op_cat_loss(const float* q_mats, const float* qT, int32_t K, int32_t T, const float* logits, const float* log_vt,
                                const float* log_v0, const int64_t* t, const int64_t* batch, int64_t n, float* row_loss, float* dlogits,
                                void* stream) {

@@ -89,7 +89,7 @@ struct State {
   // transposed parameters (train_ops.TransposedParams)
   int64_t wt_base = 0, wt_nbytes = 0, wt_buf = 0;
   std::vector<int64_t> wt_off;                       // sorted byte offsets
-  std::vector<std::array<int64_t, 3>> wt_ent;        // (element offset, R, C) per entry
+  std::vector<std::array<int64_t, 4>> wt_ent;        // (element offset in the parameter buffer, R, C, element offset of W^T) per entry
   int64_t n_launch = 0;
 } S;
 
@@ -260,10 +260,10 @@ bool wt_view(const Tensor& w, int64_t& ptr, int64_t& ld) {
   auto it = std::upper_bound(S.wt_off.begin(), S.wt_off.end(), rel);
   if (it == S.wt_off.begin()) return false;
   const auto& e = S.wt_ent[(it - S.wt_off.begin()) - 1];
-  const int64_t off = e[0], R = e[1], C = e[2];
+  const int64_t off = e[0], R = e[1], C = e[2], doff = e[3];
   const int64_t col = rel / 4 - off;
   if (col < 0 || col >= C || w.stride(0) != C || w.size(0) != R || col + w.size(1) > C) return false;
-  const int64_t p = S.wt_buf + 4 * (off + col * R);
+  const int64_t p = S.wt_buf + 4 * (doff + col * R);
   if (p % 16) return false;
   ptr = p, ld = R;
   return true;
@@ -493,9 +493,7 @@ class EwFn : public torch::autograd::Function<EwFn> {
  public:
   static Tensor forward(AutogradContext* ctx, int64_t op, const Tensor& a, const Tensor& b) {
     Tensor ac = tc(a), bc = tc(b);
-    if (ac.scalar_type() != bc.scalar_type() || (ac.scalar_type() == at::kHalf && (ac.numel() % 4 || ac.size(-1) % 4))) {
-      ac = ac.to(at::kFloat), bc = bc.to(at::kFloat);
-    }
+    if (ac.scalar_type() != bc.scalar_type()) ac = ac.to(at::kFloat), bc = bc.to(at::kFloat);
     TORCH_CHECK(ac.sizes() == bc.sizes(), "element-wise operands differ in shape");
     Tensor out = at::empty_like(ac);
     const int64_t rk = (op == 2 || op == 3) ? rk_now() : 0;
@@ -852,7 +850,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   });
   m.def("wq_append", &wq_append);
   m.def("flush", &flush_sink);
-  m.def("set_wt", [](int64_t base, int64_t nbytes, int64_t buf, std::vector<int64_t> offs, std::vector<std::array<int64_t, 3>> ents) {
+  m.def("set_wt", [](int64_t base, int64_t nbytes, int64_t buf, std::vector<int64_t> offs, std::vector<std::array<int64_t, 4>> ents) {
     S.wt_base = base, S.wt_nbytes = nbytes, S.wt_buf = buf, S.wt_off = std::move(offs), S.wt_ent = std::move(ents);
   });
   m.def("launches", []() { return S.n_launch; });

@@ -381,6 +381,8 @@ void launch_pos_posterior(const float* c0, const float* ct, const float* sd, con
 void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, const float* logits_or_log_v0, int is_logits,
                           const float* log_vt, const int64_t* t, const int64_t* batch, int n, float* out, hipStream_t s);
 void launch_uncertainty_grad(const float* logits, int K, int n, float* glogits, hipStream_t s);
+void launch_cat_add_noise(const float* qmats, int K, const int64_t* v, const int64_t* t, const int64_t* batch, const float* u, int n,
+                          float log_off, float* onehot, float* log_vt, float* log_v0, hipStream_t s);
 void launch_cat_loss(const float* qmats, const float* qT1, int K, const float* logits, const float* log_vt, const float* log_v0,
                      const int64_t* t, const int64_t* batch, int n, float* row_loss, float* dlogits, hipStream_t s);
 void launch_add_inplace(float* dst, const float* src, int n, hipStream_t s);

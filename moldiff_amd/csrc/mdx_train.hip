@@ -1474,6 +1474,28 @@ __global__ void sum_n1_kernel(const SumN a, const TPW o, size_t n) {
   for (int j = 1; j < a.n; ++j) s += ld1(TP{a.p[j], a.h[j]}, i);
   st1(o, i, s);
 }
+// any length / alignment, fp32 or float16 containers (round 6: an (E,1) gate product has E % 4 != 0 and used to go through two casts to
+// fp32 and back)
+__global__ void ew_fwd1_kernel(int opr, const TP a, const TP b, const TPW o, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int op = opr & 255, rk = opr >> 8;
+  const float x = ld1(a, i), y = ld1(b, i);
+  const float v = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : x * round_kind(sigmoidf_(y), rk);
+  st1(o, i, round_kind(v, rk));
+}
+__global__ void ew_bwd1_kernel(int op, const TP a, const TP b, const TP g, const TPW da, const TPW db, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gv = ld1(g, i);
+  float ga, gb;
+  if (op == 0) { ga = gv; gb = gv; }
+  else if (op == 1) { ga = gv; gb = -gv; }
+  else if (op == 2) { ga = gv * ld1(b, i); gb = gv * ld1(a, i); }
+  else { const float sg = sigmoidf_(ld1(b, i)); ga = gv * sg; gb = gv * ld1(a, i) * sg * (1.0f - sg); }
+  if (da.p) st1(da, i, ga);
+  if (db.p) st1(db, i, gb);
+}
 __global__ void ew_bwd4_kernel(int op, const TP a, const TP b, const TP g, const TPW da, const TPW db, size_t n4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
@@ -2022,8 +2044,9 @@ extern "C" int mdx_op_ew_fwd_t(int32_t op, const void* a, const void* b, void* o
   const TPW to{out, (dt >> 2) & 1};
   if ((n & 3) == 0 && tp_vec_ok(a, ta.h, 4) && tp_vec_ok(b, tb.h, 4) && tp_vec_ok(out, to.h, 4)) {
     hipLaunchKernelGGL(ew_fwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, ta, tb, to, (size_t)n / 4);
+  } else if (dt) {
+    hipLaunchKernelGGL(ew_fwd1_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, ta, tb, to, (size_t)n);
   } else {
-    if (dt) return bad("ew: half storage needs n % 4 == 0 and aligned operands");
     hipLaunchKernelGGL(ew_fwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, (const float*)a, (const float*)b,
                        (float*)out, (size_t)n);
   }
@@ -2063,8 +2086,9 @@ extern "C" int mdx_op_ew_bwd_t(int32_t op, const void* a, const void* b, const v
   if ((n & 3) == 0 && tp_vec_ok(a, ta.h, 4) && tp_vec_ok(b, tb.h, 4) && tp_vec_ok(g, tg.h, 4) && tp_vec_ok(da, tda.h, 4) &&
       tp_vec_ok(db, tdb.h, 4)) {
     hipLaunchKernelGGL(ew_bwd4_kernel, dim3(nblk((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, op, ta, tb, tg, tda, tdb, (size_t)n / 4);
+  } else if (dt) {
+    hipLaunchKernelGGL(ew_bwd1_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, ta, tb, tg, tda, tdb, (size_t)n);
   } else {
-    if (dt) return bad("ew: half storage needs n % 4 == 0 and aligned operands");
     hipLaunchKernelGGL(ew_bwd_kernel, dim3(nblk((size_t)n)), dim3(256), 0, (hipStream_t)stream, op, (const float*)a, (const float*)b,
                        (const float*)g, (float*)da, (float*)db, (size_t)n);
   }

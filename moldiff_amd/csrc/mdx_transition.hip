@@ -287,6 +287,64 @@ void launch_cat_posterior(const float* qmats, const float* qT1, int K, int T, co
 #undef MDX_CP
 }
 
+// ---- training: q(v_t | v_0) draw of a clean batch in one launch (round 6) -------------------------------------------------------------
+// Reference models/transition.py:266-283 (add_noise -> q_vt_sample -> q_vt_pred, index_to_log_onehot models/diffusion.py:53-57,
+// log_sample_categorical :79-85): log_v0 = log(clamp(onehot(v), 1e-30)); logits = log(exp(log_v0) Q[t] + 1e-30).clamp_min(-32);
+// cls = argmax(logits + Gumbel(u)); outputs onehot(cls), log(clamp(onehot(cls), 1e-30)), log_v0.  One thread per row, the sum over the K
+// source classes in index order; log_off = log(1e-30) as torch computes it in fp32 (the caller passes torch's value).  Class ids >= K are
+// clamped to K - 1 (the caller's range check reports them: diffusion.deferred_class_checks).
+template <int K>
+__global__ void cat_add_noise_kernel(const float* __restrict__ qmats, const int64_t* __restrict__ v, const int64_t* __restrict__ t,
+                                     const int64_t* __restrict__ batch, const float* __restrict__ u, int n, float log_off,
+                                     float* __restrict__ onehot, float* __restrict__ log_vt, float* __restrict__ log_v0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t cv = v[i];
+  cv = cv < 0 ? 0 : (cv >= K ? K - 1 : cv);
+  const float* Q = qmats + (size_t)t[batch[i]] * K * K;
+  float l0[K], e0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    l0[k] = (k == (int)cv) ? 0.f : log_off;
+    e0[k] = expf(l0[k]);
+    log_v0[(size_t)i * K + k] = l0[k];
+  }
+  int best = 0;
+  float bv = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float f = 0.f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) f += e0[j] * Q[j * K + k];
+    const float lg = fmaxf(logf(f + 1e-30f), -32.f);
+    const float g = -logf(-logf(u[(size_t)i * K + k] + 1e-30f) + 1e-30f);
+    const float z = g + lg;
+    if (k == 0 || z > bv) {  // first maximum wins, like torch.argmax
+      bv = z;
+      best = k;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    onehot[(size_t)i * K + k] = (k == best) ? 1.f : 0.f;
+    log_vt[(size_t)i * K + k] = (k == best) ? 0.f : log_off;
+  }
+}
+void launch_cat_add_noise(const float* qmats, int K, const int64_t* v, const int64_t* t, const int64_t* batch, const float* u, int n,
+                          float log_off, float* onehot, float* log_vt, float* log_v0, hipStream_t s) {
+  if (n <= 0) return;
+  dim3 g((n + 127) / 128), b(128);
+#define MDX_CAN(KK)                                                                                                                       \
+  case KK:                                                                                                                                \
+    hipLaunchKernelGGL(cat_add_noise_kernel<KK>, g, b, 0, s, qmats, v, t, batch, u, n, log_off, onehot, log_vt, log_v0);                   \
+    break;
+  switch (K) {
+    MDX_CAN(2) MDX_CAN(3) MDX_CAN(4) MDX_CAN(5) MDX_CAN(6) MDX_CAN(7) MDX_CAN(8)
+    default: break;
+  }
+#undef MDX_CAN
+}
+
 // ---- training: the categorical loss rows and their gradient in one launch (round 6) ---------------------------------------------------
 // Reference models/model.py:170-189: log_recon = log_softmax(logits); post_true = q_v_posterior(log_v0, log_vt); post_pred =
 // q_v_posterior(log_recon, log_vt) (models/transition.py:285-315); row term = KL(post_true || post_pred) for t > 0, -sum exp(log_v0)

@@ -150,6 +150,15 @@ class deferred_class_checks:
         return verify
 
 
+def check_class_range(x, num_classes):
+    """the reference's class-range assert (models/diffusion.py:54) on its own: immediately, or recorded inside `deferred_class_checks`"""
+    if x.numel():
+        if deferred_class_checks._active is not None and x.is_cuda:
+            deferred_class_checks._active.items.append((x.max(), num_classes))
+        else:
+            assert x.max().item() < num_classes, f'Error: {x.max().item()} >= {num_classes}'
+
+
 def index_to_log_onehot(x, num_classes, checked=True):
     """log of the one-hot encoding, clamped at log(1e-30).  checked: the reference's assert on the class range (models/diffusion.py:54),
     a host-device synchronisation; callers whose ids come out of an argmax over `num_classes` logits pass False (in range by

@@ -124,9 +124,10 @@ def _h(t):
 
 
 def _same(a, b):
-    """two operands of an element-wise operator in one container type (mixed -> fp32)"""
+    """two operands of an element-wise operator in one container type (mixed -> fp32; any length: the library falls back to its scalar
+    kernels when the 4-wide float16 ones do not apply)"""
     a, b = _t(a), _t(b)
-    if a.dtype != b.dtype or (a.dtype == torch.float16 and (a.numel() % 4 or a.shape[-1] % 4)):   # half kernels are 4-wide
+    if a.dtype != b.dtype:
         a, b = a.float(), b.float()
     return a, b
 
@@ -423,15 +424,19 @@ _WT = None
 class TransposedParams:
     def __init__(self, flat):
         self.base, self.nbytes = flat.data.data_ptr(), 4 * flat.numel
-        self.buf = torch.empty_like(flat.data)
-        self.entries, desc, off, tiles = {}, [], 0, 1
+        # every W^T starts on 16 bytes in its own buffer (round 6: with the parameter buffer's offsets a third of the weights' transposes
+        # were unaligned and fell back to a transpose launch per data gradient)
+        self.buf = torch.empty(flat.numel + 4 * len(flat.params) + 4, dtype=torch.float32, device=flat.data.device)
+        pad = (-self.buf.data_ptr() // 4) % 4
+        self.entries, desc, off, doff, tiles = {}, [], 0, pad, 1
         for p in flat.params:
             n = p.numel()
             if p.dim() == 2 and p.shape[0] % 4 == 0:     # W^T rows are R = shape[0] floats: 16-byte aligned rows for the GEMM loads
                 R, C = p.shape
-                self.entries[4 * off] = (off, R, C)
-                desc += [self.base + 4 * off, self.buf.data_ptr() + 4 * off, R, C]
+                self.entries[4 * off] = (off, R, C, doff)
+                desc += [self.base + 4 * off, self.buf.data_ptr() + 4 * doff, R, C]
                 tiles = max(tiles, ((R + 31) // 32) * ((C + 31) // 32))
+                doff += (n + 3) // 4 * 4
             off += n
         self.offsets = sorted(self.entries)
         self.n, self.tiles = len(desc) // 4, tiles
@@ -449,13 +454,13 @@ class TransposedParams:
         i = bisect.bisect_right(self.offsets, rel) - 1
         if i < 0:
             return None
-        off, R, C = self.entries[self.offsets[i]]
+        off, R, C, doff = self.entries[self.offsets[i]]
         col = rel // 4 - off
         if col < 0 or col >= C or w.stride(0) != C or w.shape[0] != R or col + w.shape[1] > C:
             return None
-        if (self.buf.data_ptr() + 4 * (off + col * R)) % 16:
+        if (self.buf.data_ptr() + 4 * (doff + col * R)) % 16:
             return None                                 # the GEMM's 16-byte operand loads want aligned rows
-        return self.buf[off:off + R * C].view(C, R)[col:col + w.shape[1]]
+        return self.buf[doff:doff + R * C].view(C, R)[col:col + w.shape[1]]
 
 
 class transposed_params:
@@ -482,7 +487,7 @@ def _fast_sync_wt():
         if tp is None:
             F.set_wt(0, 0, 0, [], [])
         else:
-            F.set_wt(tp.base, tp.nbytes, tp.buf.data_ptr(), tp.offsets, [list(tp.entries[o]) for o in tp.offsets])
+            F.set_wt(tp.base, tp.nbytes, tp.buf.data_ptr(), tp.offsets, [list(tp.entries[o]) for o in tp.offsets])   # (off, R, C, dst off)
 
 
 def transpose(x, pad=4):

@@ -11,8 +11,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .diffusion import to_torch_const, index_to_log_onehot, categorical_kl, log_categorical
+from .diffusion import to_torch_const, index_to_log_onehot, categorical_kl, log_categorical, check_class_range
 from . import _lib
+
+_FUSED_NOISE = __import__('os').environ.get('MDX_FUSED_ADD_NOISE', '1') != '0'
 
 
 class ContigousTransition(nn.Module):
@@ -123,6 +125,13 @@ class GeneralCategoricalTransition(nn.Module):
         return cls, index_to_log_onehot(cls, self.num_classes, checked=False)   # ids from an argmax over num_classes logits
 
     def add_noise(self, v, time_step, batch, u=None):
+        if _FUSED_NOISE and v.is_cuda and v.dim() == 1 and v.numel() and 2 <= self.num_classes <= 8:
+            # round 6: index_to_log_onehot, q_vt_pred, the Gumbel-max draw and the two one-hot encodings in one launch (csrc
+            # cat_add_noise_kernel) instead of ~28 (rows x K) torch launches; the class-range assert keeps its (deferred) form
+            check_class_range(v, self.num_classes)
+            if u is None:
+                u = torch.rand(v.shape[0], self.num_classes, dtype=torch.float32, device=v.device)
+            return _lib.cat_add_noise(self.q_mats, v, time_step, batch, u, self.num_classes)
         log_v0 = index_to_log_onehot(v, self.num_classes)
         cls, log_vt = self.q_vt_sample(log_v0, time_step, batch, u)
         return F.one_hot(cls, self.num_classes).float(), log_vt, log_v0

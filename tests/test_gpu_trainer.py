@@ -532,3 +532,34 @@ def test_cpp_fast_path_is_bit_identical_to_the_python_bodies(fused_rows):
     assert a[0] == b[0] and a[1] == b[1] and a[5] == b[5], (a[0], b[0], a[1], b[1])
     assert float(a[2].abs().max()) > 0
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
+def test_fused_categorical_add_noise_equals_the_torch_composition():
+    """Round 6: GeneralCategoricalTransition.add_noise as one launch (csrc cat_add_noise_kernel) against the operator-by-operator
+    evaluation it replaces (index_to_log_onehot, q_vt_pred, Gumbel-max, one-hot; models/transition.py:266-283): the drawn classes are
+    identical for injected uniforms (apart from draws whose two best Gumbel scores are closer than 1e-5: none expected), and
+    log_vt / log_v0 / the one-hot tensors are bit-identical given the classes."""
+    from moldiff_amd import transition as TR
+    m = U.moldiff('MolDiff_simple', DEV)
+    g = U.rng(9)
+    B = 37
+    t = torch.from_numpy(g.integers(0, 1000, B)).to(DEV)
+    t[:4] = torch.tensor([0, 1, 999, 500], device=DEV)
+    for tr, n in ((m.node_transition, 3000), (m.edge_transition, 9000)):
+        K = tr.num_classes
+        batch = torch.from_numpy(np.sort(g.integers(0, B, n))).to(DEV)
+        v = torch.from_numpy(g.integers(0, K, n)).to(DEV)
+        u = U.t32(g.random((n, K))).to(DEV)
+        old = TR._FUSED_NOISE
+        try:
+            TR._FUSED_NOISE = False
+            oh0, lvt0, lv00 = tr.add_noise(v, t, batch, u)
+            TR._FUSED_NOISE = True
+            oh1, lvt1, lv01 = tr.add_noise(v, t, batch, u)
+        finally:
+            TR._FUSED_NOISE = old
+        assert torch.equal(lv00, lv01)
+        same = (oh0.argmax(-1) == oh1.argmax(-1))
+        assert float((~same).float().mean()) <= 1e-3, float((~same).float().mean())
+        assert torch.equal(oh0[same], oh1[same]) and torch.equal(lvt0[same], lvt1[same])
+        assert bool((oh1.sum(-1) == 1).all())

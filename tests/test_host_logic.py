@@ -349,17 +349,18 @@ def test_transposed_parameter_views_cover_weights_and_their_column_slices():
     flat = FlatParams(net)
     tp = T.TransposedParams(flat)
     assert tp.n == 2                                              # the (5, 256) weight has rows of 5 floats: not 16-byte aligned
-    for off, (o, R, C) in tp.entries.items():
-        tp.buf[o:o + R * C] = flat.data[o:o + R * C].view(R, C).t().contiguous().view(-1)
+    for off, (o, R, C, do) in tp.entries.items():              # (round 6: every W^T starts on 16 bytes at its own offset `do`)
+        tp.buf[do:do + R * C] = flat.data[o:o + R * C].view(R, C).t().contiguous().view(-1)
+        assert (tp.buf.data_ptr() + 4 * do) % 16 == 0
     w = net[0].weight
     assert torch.equal(tp.view(w), w.t()) and tp.view(w).stride() == (64, 1)
     v = tp.view(w[:, 16:48])
     assert v is not None and torch.equal(v, w[:, 16:48].t()) and v.data_ptr() == tp.view(w).data_ptr() + 4 * 16 * 64
     assert tp.view(w[8:16]) is None                               # row slices are not views of the transpose
     assert tp.view(net[3].weight) is None and tp.view(net[1].weight) is None and tp.view(torch.zeros(64, 80)) is None
-    w2 = net[2].weight                                            # its offset inside the flat buffer decides the alignment
+    w2 = net[2].weight
     v2 = tp.view(w2)
-    assert v2 is None or torch.equal(v2, w2.t())
+    assert v2 is not None and torch.equal(v2, w2.t())             # (aligned whatever its offset in the parameter buffer)
 
 
 def test_class_range_assert_is_synchronous_on_the_api_and_recorded_inside_the_deferred_context():
