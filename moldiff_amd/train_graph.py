@@ -251,7 +251,14 @@ def node_edge_net(net, h_node, pos, h_edge, g, node_time, edge_time):
             rel, dist = T.edge_geom(pos, g.left, g.right)
             h_dist = smear(net.distance_expansion, dist)
         emb = net.edge_embs[i]
-        h_edge = T.linear(cat(h_edge, h_dist) if net.update_edge else h_dist, emb.weight, emb.bias)
+        if net.update_edge and h_edge.dtype == torch.float16:
+            # Linear([h_edge | h_dist]) as two partial sums (round 6): the 84-wide concatenation cost a cast, a copy and the odd-K GEMM
+            # forward, data gradient and weight gradient on the E edge rows; the distance columns' product rides in as the fp32 addend
+            # and the layer's result is rounded once, like every hoisted layer here
+            ne = h_edge.shape[1]
+            h_edge = T.linear(h_edge, emb.weight[:, :ne], emb.bias, addend=T.linear(h_dist, emb.weight[:, ne:], keep32=True))
+        else:
+            h_edge = T.linear(cat(h_edge, h_dist) if net.update_edge else h_dist, emb.weight, emb.bias)
         # round 6: the block's consumers of h_node (3 in the NodeBlock, 6 in the EdgeBlock, the residual) and of h_edge (1 + 3) take
         # aliases of one fan-out node each (_Uses): one gradient-sum launch per stream and block instead of 9 + 3 autograd adds
         hn = _Uses(h_node, 10 if net.update_edge else 4)
