@@ -2577,8 +2577,11 @@ extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits
   const int64_t nc = (S + RED_CHUNK - 1) / RED_CHUNK;
   int kind = 4, tn = 64, tk = 64;
   if ((dt & 3) == 3 && N % 64 == 0 && K % 64 == 0 && ldg % 8 == 0 && ldx % 8 == 0 && aligned) {
-    tn = N % 128 == 0 ? 128 : 64;
-    tk = K % 128 == 0 ? 128 : 64;
+    // MDX_WGRAD_TILE: 0 (default) 128-wide tiles where the layer allows; 1: n x k = 128 x 64; 2: 64 x 64 (A/B knob: the 128 x 128 class runs
+    // at two waves per SIMD, 172 registers)
+    static const int tile_knob = getenv("MDX_WGRAD_TILE") ? atoi(getenv("MDX_WGRAD_TILE")) : 0;
+    tn = (N % 128 == 0 && tile_knob < 2) ? 128 : 64;
+    tk = (K % 128 == 0 && tile_knob < 1) ? 128 : 64;
     kind = (tn == 128 ? 0 : 2) + (tk == 128 ? 0 : 1);
   } else if ((dt & 3) == 3 && ldg % 8 == 0 && ldx % 8 == 0 && aligned && ((N == 32 && K == 64) || (N == 64 && K == 32))) {
     tn = (int)N, tk = (int)K;

@@ -1585,6 +1585,12 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     }
     zero<4>(gx1);
     mmw<4, 8>(gx1, wg1t, wbuf, par, tid, lane, b8);
+    // park the gate chain's dL/dX in its output rows (float16 values: lossless) until the edge chain's half arrives: 16 registers less
+    // across the msg_net / edge_net backward, which spills
+    if (ok) {
+#pragma unroll
+      for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx1[ft])));
+    }
     // ---- msg_net and the product p = he * hn[col]
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
@@ -1631,7 +1637,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     mmw<4, 8>(gx2, w1et, wbuf, par, tid, lane, b8);
     if (ok) {
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx2[ft]) + rh4(gx1[ft])));
+      for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx2[ft]) + ldh4(o_gx + r * KB + 16 * ft + 4 * q)));
     }
   }
   // ---- LayerNorm-parameter gradients: lane L of every wave holds features 4 L .. 4 L + 3 of the four vectors; waves in fixed order
