@@ -89,7 +89,12 @@ __device__ __forceinline__ void sth8_pair(_Float16* row_base, int g2, uint2 ha, 
   const auto sy = __builtin_amdgcn_permlane16_swap(ha.y, hb.y, false, false);
   const uint4 v = {sx[0], sy[0], sx[1], sy[1]};
   const int col = (q & 1) ? 32 * g2 + 16 + 4 * (q - 1) : 32 * g2 + 4 * q;
+#ifdef MDX_TRAIN_NT
+  typedef unsigned int nt_u32x4_t __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+  if (ok) __builtin_nontemporal_store(__builtin_bit_cast(nt_u32x4_t, v), reinterpret_cast<nt_u32x4_t*>(row_base + col));
+#else
   if (ok) *reinterpret_cast<uint4*>(row_base + col) = v;
+#endif
 }
 
 // FT (even) packed tiles of one row block: FT / 2 paired stores
@@ -1259,7 +1264,11 @@ __device__ __forceinline__ void ts_flush_b(const uint16_t* T, __amdgpu_buffer_rs
     for (int i = 0; i < B; ++i) {
       const int ii = i0 + i;
       typedef unsigned int u32x4_t __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+#ifdef MDX_TRAIN_NT
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[i]), rs, vo, so + (unsigned)ii * 1024u, 2);   // nt
+#else
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[i]), rs, vo, so + (unsigned)ii * 1024u, 0);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
   }
