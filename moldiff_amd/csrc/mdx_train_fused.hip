@@ -1305,7 +1305,11 @@ __global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_node
   for (int it = 0; it < iters; ++it) {
     const int tile = it * nw + blockIdx.x * NMF_WAVES + wave;
     const int row = 16 * tile + c;
+#ifdef MDX_NM_NOSTORE            // ablation (timing only, results are garbage): no epilogue stores -- profiles/r6_ab_nodemsg_stores.txt
+    const bool ok = row < E && a.E < 0;
+#else
     const bool ok = row < E;      // (a wave past the last tile computes on the clamped last row and stores nothing)
+#endif
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q, rb = r * KW;
     const int64_t nc = a.col[r];
     const _Float16* px = X + r * a.ldx + 8 * q;

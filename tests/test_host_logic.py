@@ -385,3 +385,34 @@ def test_weight_gradient_row_ranges():
     assert T._splits_for(154666, 64, 80, True) == T._splits_for(154666, 64, 80, False)   # 80 is not tile-aligned: converting kernel
     assert T._splits_for(300, 256, 256, True) == 2                # never fewer than 128 rows per range
     assert T._splits_for(100, 64, 64) == 1
+
+
+def test_cpp_fast_path_extension_loads_and_keeps_its_state_machine_on_the_cpu():
+    """csrc/mdx_fast.cpp (moldiff_amd/_mdx_fast.so): the extension imports without a GPU, exposes every entry point train_ops calls, and
+    its sink bookkeeping (destination lookup, nesting guard, precision state) works on plain CPU tensors -- no launch is made here."""
+    import torch
+    from moldiff_amd import train_ops as T
+    F = T._fast()
+    assert F is not None
+    for name in ('set_precision', 'set_options', 'sink_begin', 'sink_end', 'sink_active', 'fast_mode', 'sink_dst', 'sink_record', 'wq_append', 'flush',
+                 'set_wt', 'launches', 'linear_fast_ok', 'linear', 'linear_ln_fast_ok', 'linear_ln_relu', 'linear_ln_dot_fast_ok',
+                 'linear_ln_relu_dot', 'ew', 'all_in_sink', 'bondffn_fwd', 'bondffn_bwd', 'edge_tail_fwd', 'edge_tail_bwd', 'posffn_fwd',
+                 'posffn_bwd', 'nodemsg_fwd', 'nodemsg_bwd'):
+        assert hasattr(F, name), name
+    data, grad = torch.zeros(64), torch.zeros(64)
+    assert not F.sink_active() and F.sink_dst(data[8:16]) == 0
+    F.sink_begin(data, grad)
+    try:
+        assert F.sink_active() and not F.fast_mode()                   # no float16 mode set: the fast nodes stay off
+        assert F.sink_dst(data[8:16]) == grad.data_ptr() + 32 and F.sink_dst(torch.zeros(4)) == 0
+        F.set_precision(2, 1, 1)
+        assert F.fast_mode()
+        import pytest
+        with pytest.raises(RuntimeError, match='do not nest'):
+            F.sink_begin(data, grad)
+        w = torch.nn.Parameter(torch.zeros(4, 4))
+        assert not F.linear_fast_ok(torch.zeros(3, 4), w, None)       # CPU tensors / parameters outside the sink never take the fast node
+    finally:
+        F.set_precision(0, 0, 0)
+        F.sink_end()
+    assert not F.sink_active()
