@@ -1558,7 +1558,11 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
   for (int it = 0; it < iters; ++it) {
     const int tile = it * nw + blockIdx.x * NM_WAVES + wave;
     const int row = 16 * tile + c;
+#ifdef MDX_NM_NOSTORE_B
+    const bool ok = row < E && a.f.E < 0;
+#else
     const bool ok = row < E;
+#endif
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
     const size_t rb = r * KW;
     const int64_t nc = a.f.col[r], nr = a.row[r];
