@@ -1626,6 +1626,54 @@ __global__ void plan_flip_kernel(const int64_t* __restrict__ order_l, const int6
   for (int64_t j = c; j < e; ++j) order_r[w++] = order_l[j] - Eh;
   for (int64_t j = b; j < c; ++j) order_r[w++] = order_l[j] + Eh;
 }
+// The same with EIGHT float16 features per thread (one 16-byte load per row; F % 8 == 0, float16 rows, 16-byte aligned): the sums per
+// feature and their order are those of segsum_rows4s_kernel (bit-identical), half the threads and load instructions.
+__global__ __launch_bounds__(256) void segsum_rows8s_kernel(const _Float16* __restrict__ src, const int64_t* __restrict__ order,
+                                                            const int64_t* __restrict__ ptr, int64_t R, int F8, const TPW out) {
+  __shared__ f32x4 part[3][2][64];
+  const int k = threadIdx.x >> 6, it = threadIdx.x & 63;
+  const size_t i = (size_t)blockIdx.x * 64 + it;
+  const bool live = i < (size_t)R * F8;
+  f32x4 s0 = splat4(0.f), s1 = splat4(0.f);
+  auto ld8 = [&](int64_t o, int f, f32x4& a, f32x4& b) {
+    const uint4 u = *reinterpret_cast<const uint4*>(src + 8 * ((size_t)o * F8 + f));
+    const f16x4_t lo = __builtin_bit_cast(f16x4_t, uint2{u.x, u.y}), hi = __builtin_bit_cast(f16x4_t, uint2{u.z, u.w});
+    a = f32x4{(float)lo[0], (float)lo[1], (float)lo[2], (float)lo[3]};
+    b = f32x4{(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]};
+  };
+  if (live) {
+    const int64_t r = i / F8;
+    const int f = (int)(i % F8);
+    int64_t j = ptr[r] + k;
+    const int64_t e = ptr[r + 1];
+    for (; j + 12 < e; j += 16) {
+      const int64_t o0 = order[j], o1 = order[j + 4], o2 = order[j + 8], o3 = order[j + 12];
+      f32x4 a0, b0, a1, b1, a2, b2, a3, b3;
+      ld8(o0, f, a0, b0);
+      ld8(o1, f, a1, b1);
+      ld8(o2, f, a2, b2);
+      ld8(o3, f, a3, b3);
+      s0 = s0 + a0; s1 = s1 + b0;
+      s0 = s0 + a1; s1 = s1 + b1;
+      s0 = s0 + a2; s1 = s1 + b2;
+      s0 = s0 + a3; s1 = s1 + b3;
+    }
+    for (; j < e; j += 4) {
+      f32x4 a, b;
+      ld8(order[j], f, a, b);
+      s0 = s0 + a; s1 = s1 + b;
+    }
+  }
+  if (k) part[k - 1][0][it] = s0, part[k - 1][1][it] = s1;
+  __syncthreads();
+  if (k == 0 && live) {
+    s0 = s0 + part[0][0][it]; s1 = s1 + part[0][1][it];
+    s0 = s0 + part[1][0][it]; s1 = s1 + part[1][1][it];
+    s0 = s0 + part[2][0][it]; s1 = s1 + part[2][1][it];
+    st4(out, 8 * i, s0);
+    st4(out, 8 * i + 4, s1);
+  }
+}
 // y[i] = a[i] * t[idx[i]] and its two gradients (da = g * t[idx];  dt[r] = sum_{j in seg r} g[order[j]] * a[order[j]]):
 // the product with a gathered per-node row without materialising the gathered (rows x F) tensor.  F % 4 == 0.
 __global__ void mulg_fwd_kernel(const TP a, const TP t, const int64_t* __restrict__ idx, int64_t M, int F4, const TPW y, int rk) {
@@ -2123,7 +2171,11 @@ extern "C" int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const
     // float16 rows only: the fp32 mode keeps the sequential CSR order -- the order of torch's index_add on the CPU, i.e. of the reference
     // and the oracle, which its parity tests rely on (a 32-wide LayerNorm gain's gradient moved from 4.8e-5 to 1.6e-4 of its norm at
     // 256 molecules with the dealt order; both are fp32 rounding, but the contract there is 1e-4)
-    if (!split_off && ts.h && items < ((size_t)1 << 22))
+    static const bool wide_off = getenv("MDX_SEGSUM_WIDE") && atoi(getenv("MDX_SEGSUM_WIDE")) == 0;
+    if (!split_off && !wide_off && ts.h && (F & 7) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && items < ((size_t)1 << 22))
+      hipLaunchKernelGGL(segsum_rows8s_kernel, dim3((unsigned)(((size_t)R * (F / 8) + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                         reinterpret_cast<const _Float16*>(src), order, ptr, R, F / 8, to);
+    else if (!split_off && ts.h && items < ((size_t)1 << 22))
       hipLaunchKernelGGL(segsum_rows4s_kernel, dim3((unsigned)((items + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
     else
       hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk(items)), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
