@@ -398,6 +398,20 @@ __device__ __forceinline__ float sum_q4(float v) {   // sum over the four lanes 
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Two adjacent feature tiles of a float16 output row as one 16-byte store per lane (round 6; see csrc/mdx_train_fused.hip sth8_pair): the
+// lane rows q / q ^ 1 exchange their 8-byte chunks with v_permlane16_swap, an instruction then writes 16 rows x 64 contiguous bytes
+// instead of 16 x 32.  Every lane of the wave's active rows must call it.
+__device__ __forceinline__ void st8h_pair(_Float16* row_base, int g2, f32x4 va, f32x4 vb, int q) {
+  const f16x4_t ha = {(_Float16)va[0], (_Float16)va[1], (_Float16)va[2], (_Float16)va[3]};
+  const f16x4_t hb = {(_Float16)vb[0], (_Float16)vb[1], (_Float16)vb[2], (_Float16)vb[3]};
+  const uint2 ua = __builtin_bit_cast(uint2, ha), ub = __builtin_bit_cast(uint2, hb);
+  const auto sx = __builtin_amdgcn_permlane16_swap(ua.x, ub.x, false, false);
+  const auto sy = __builtin_amdgcn_permlane16_swap(ua.y, ub.y, false, false);
+  const uint4 v = {sx[0], sy[0], sx[1], sy[1]};
+  const int col = (q & 1) ? 32 * g2 + 16 + 4 * (q - 1) : 32 * g2 + 4 * q;
+  *reinterpret_cast<uint4*>(row_base + col) = v;
+}
+
 template <int KT, int FT, bool ROUND, bool LN = false>
 __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                              const float* __restrict__ bias, const TP addend, int ldd, const TPW C,
@@ -456,6 +470,9 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
   };
   if (tile < ntiles) load(x, tile);
   const bool veco = tp_vec_ok(C.p, C.h, ldc) && (col0 & 3) == 0, vecd = addend.p && tp_vec_ok(addend.p, addend.h, ldd) && (col0 & 3) == 0;
+  // float16 rows on 16 bytes: pairs of feature tiles leave as 16-byte stores (st8h_pair)
+  const bool pairc = (FT % 2 == 0) && C.h && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C.p) & 15) == 0 && (col0 & 7) == 0;
+  const bool pairp = LN && (FT % 2 == 0) && ln.post.h && (ln.ldp & 7) == 0 && (reinterpret_cast<uintptr_t>(ln.post.p) & 15) == 0;
   const uint16_t* wl = Ws + c * LD + 8 * q;
 #pragma unroll 1
   for (; tile < ntiles; tile += nw) {
@@ -492,13 +509,15 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
           for (int r = 0; r < 4; ++r) v[r] = round_half<1>(v[r]);
         }
         const size_t o = (size_t)row * ldc + col0 + col;
-        if (veco) {
+        if (pairc) {
+          if (ft & 1) st8h_pair(reinterpret_cast<_Float16*>(C.p) + (size_t)row * ldc + col0, ft >> 1, acc[ft - 1], v, q);
+        } else if (veco) {
           st4(C, o, v);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) st1(C, o + r, v[r]);
         }
-        if (LN) acc[ft] = v;
+        if (LN || pairc) acc[ft] = v;     // (the finished values: the LayerNorm epilogue / the pair store of the next tile reads them)
       }
     }
     if (LN) {   // (every lane takes part in the cross-lane sums; rows past M hold clamped duplicates and store nothing)
@@ -519,7 +538,12 @@ __global__ __launch_bounds__(512) void hgemm_nt_rows_kernel(const _Float16* __re
           const int col = 16 * ft + 4 * q;
           f32x4 y = acc[ft] * splat4(rstd) * lds4(bs + N + col) + lds4(bs + 2 * N + col);
           if (ln.relu) y = relu4(y);
-          st4(ln.post, (size_t)row * ln.ldp + col, y);
+          if (pairp) {
+            if (ft & 1) st8h_pair(reinterpret_cast<_Float16*>(ln.post.p) + (size_t)row * ln.ldp, ft >> 1, acc[ft - 1], y, q);
+            acc[ft] = y;
+          } else {
+            st4(ln.post, (size_t)row * ln.ldp + col, y);
+          }
         }
         if (q == 0) {
           ln.stats[2 * (size_t)row] = mean;
@@ -1345,6 +1369,10 @@ __global__ __launch_bounds__(256) void ln_relu_bwd4_kernel(const TP dy, const TP
   f32x4 w1 = splat4(0.f);
   if (r1w) w1 = f32x4{round_half<1>(r1w[4 * c4]), round_half<1>(r1w[4 * c4 + 1]), round_half<1>(r1w[4 * c4 + 2]), round_half<1>(r1w[4 * c4 + 3])};
   f32x4 dg = splat4(0.f), db = splat4(0.f);
+#ifndef MDX_LNB_UNROLL
+#define MDX_LNB_UNROLL 2
+#endif
+#pragma unroll MDX_LNB_UNROLL
   for (int rb = r0; rb < r1; rb += RPS) {
     const int row = rb + sub;
     const bool ok = row < r1;
