@@ -401,6 +401,8 @@ int mdx_op_plan_flip(const int64_t* order_left, const int64_t* ptr, int64_t R, i
 int mdx_op_sum_n(const void* const* srcs, const int32_t* half, int32_t k, int64_t n, void* out, int32_t out_half, void* stream);
 int mdx_op_ew_bwd_t(int32_t op, const void* a, const void* b, const void* g, void* da, void* db, int64_t n, int32_t dt, void* stream);
 int mdx_op_gather_rows_t(const void* x, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt, void* stream);
+/* (segsum_rows_t: dt bit 0 / 1 = src / out float16; bit 2 = the caller accepts a summation order other than the sequential CSR order -- fp32
+ * rows are then dealt to four threads per element like float16 rows always are; without it fp32 sums keep the order of torch's index_add) */
 int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const int64_t* ptr, int64_t R, int32_t F, void* out, int32_t dt,
                          void* stream);
 int mdx_op_mul_gather_fwd_t(const void* a, const void* t, const int64_t* idx, int64_t M, int32_t F, void* y, int32_t dt, void* stream);

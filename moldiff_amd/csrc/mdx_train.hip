@@ -1749,6 +1749,37 @@ __global__ void segsum_rows_kernel(const float* __restrict__ src, const int64_t*
   out[i] = s;
 }
 
+// The scalar form dealt to four threads per element (round 6; any F, fp32): the (E,3) force / position-gradient sums of the float16
+// mode ran one thread per (node, xyz) -- 19k threads, 28 dependent gathers each, 20 us per launch, 16 launches a step.  Only when the
+// caller allows another summation order (dt bit 2 of mdx_op_segsum_rows_t: the autocast mode; fp32 training keeps the sequential
+// order of the reference's index_add).
+__global__ __launch_bounds__(256) void segsum_rows1s_kernel(const float* __restrict__ src, const int64_t* __restrict__ order,
+                                                            const int64_t* __restrict__ ptr, int64_t R, int F, float* __restrict__ out) {
+  __shared__ float part[3][64];
+  const int k = threadIdx.x >> 6, it = threadIdx.x & 63;
+  const size_t i = (size_t)blockIdx.x * 64 + it;
+  const bool live = i < (size_t)R * F;
+  float s = 0.f;
+  if (live) {
+    const int64_t r = i / F;
+    const int f = (int)(i % F);
+    int64_t j = ptr[r] + k;
+    const int64_t e = ptr[r + 1];
+    for (; j + 12 < e; j += 16) {
+      const int64_t o0 = order[j], o1 = order[j + 4], o2 = order[j + 8], o3 = order[j + 12];
+      const float v0 = src[(size_t)o0 * F + f], v1 = src[(size_t)o1 * F + f], v2 = src[(size_t)o2 * F + f], v3 = src[(size_t)o3 * F + f];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    for (; j < e; j += 4) s += src[(size_t)order[j] * F + f];
+  }
+  if (k) part[k - 1][it] = s;
+  __syncthreads();
+  if (k == 0 && live) out[i] = ((s + part[0][it]) + part[1][it]) + part[2][it];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // edge geometry / smearing / force (reference models/graph.py:349-352, common.py GaussianSmearing, graph.py:391-394)
 // ------------------------------------------------------------------------------------------------------------------
@@ -2203,14 +2234,18 @@ extern "C" int mdx_op_segsum_rows_t(const void* src, const int64_t* order, const
     if (!split_off && !wide_off && ts.h && (F & 7) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && items < ((size_t)1 << 22))
       hipLaunchKernelGGL(segsum_rows8s_kernel, dim3((unsigned)(((size_t)R * (F / 8) + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                          reinterpret_cast<const _Float16*>(src), order, ptr, R, F / 8, to);
-    else if (!split_off && ts.h && items < ((size_t)1 << 22))
+    else if (!split_off && (ts.h || (dt & 4)) && items < ((size_t)1 << 22))
       hipLaunchKernelGGL(segsum_rows4s_kernel, dim3((unsigned)((items + 63) / 64)), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
     else
       hipLaunchKernelGGL(segsum_rows4_kernel, dim3(nblk(items)), dim3(256), 0, (hipStream_t)stream, ts, order, ptr, R, F / 4, to);
   } else {
-    if (dt) return bad("segsum_rows: half storage needs F % 4 == 0 and aligned rows");
-    hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, (const float*)src, order, ptr, R, F,
-                       (float*)out);
+    if (dt & 3) return bad("segsum_rows: half storage needs F % 4 == 0 and aligned rows");
+    if (dt & 4)
+      hipLaunchKernelGGL(segsum_rows1s_kernel, dim3((unsigned)(((size_t)R * F + 63) / 64)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                         order, ptr, R, F, (float*)out);
+    else
+      hipLaunchKernelGGL(segsum_rows_kernel, dim3(nblk((size_t)R * F)), dim3(256), 0, (hipStream_t)stream, (const float*)src, order, ptr, R, F,
+                         (float*)out);
   }
   return launched();
 }

@@ -867,7 +867,9 @@ def _gather_raw(x, plan, out_dtype=None):
 def _segsum_raw(src, plan, out_dtype=torch.float32):
     F = src.shape[1]
     out = torch.empty(plan.n, F, dtype=out_dtype, device=src.device)
-    check(_L().mdx_op_segsum_rows_t(ptr(src), ptr(plan.order), ptr(plan.ptr), plan.n, F, ptr(out), _h(src) | (_h(out) << 1), stream()))
+    # bit 2: in an autocast mode fp32 rows may be summed in the dealt order too (the fp32 mode keeps the reference's sequential order)
+    check(_L().mdx_op_segsum_rows_t(ptr(src), ptr(plan.order), ptr(plan.ptr), plan.n, F, ptr(out),
+                                    _h(src) | (_h(out) << 1) | (4 if (_AMP is not None and _AMP[1]) else 0), stream()))
     return out
 
 
@@ -953,7 +955,7 @@ class _EdgeGeom(torch.autograd.Function):
         rel = torch.empty(E, 3, dtype=torch.float32, device=p.device)
         dist = torch.empty(E, dtype=torch.float32, device=p.device)
         check(_L().mdx_op_edge_geom_fwd(ptr(p), ptr(pl.index), ptr(pr.index), E, ptr(rel), ptr(dist), stream()))
-        ctx.pl, ctx.pr = pl, pr
+        ctx.pl, ctx.pr, ctx.prec = pl, pr, _AMP
         ctx.save_for_backward(rel, dist)
         return rel, dist
 
@@ -964,7 +966,8 @@ class _EdgeGeom(torch.autograd.Function):
         g = torch.empty_like(rel)
         check(_L().mdx_op_edge_geom_bwd(ptr(rel), ptr(dist), ptr(_c(grel) if grel is not None else None),
                                         ptr(_c(gdist) if gdist is not None else None), E, ptr(g), stream()))
-        gl, gr = _segsum_raw(g, ctx.pl), _segsum_raw(g, ctx.pr)
+        with precision(ctx.prec):
+            gl, gr = _segsum_raw(g, ctx.pl), _segsum_raw(g, ctx.pr)
         out = torch.empty_like(gl)
         check(_L().mdx_op_ew_fwd(SUB, ptr(gl), ptr(gr), ptr(out), gl.numel(), stream()))
         return out, None, None
