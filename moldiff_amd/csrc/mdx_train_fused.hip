@@ -616,7 +616,10 @@ __global__ __launch_bounds__(ET_THREADS) void edge_tail_fwd_kernel(const mdx_edg
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
       y[ft] = rh4((y[ft] + lds4(C + EtLds::C_BS + 16 * ft + 4 * q)) + ad[ft]);
-      if (ok) sth4(o_pre + r * KB + 16 * ft + 4 * q, pack4(y[ft]));
+    }
+    {
+      const uint2 pp[4] = {pack4(y[0]), pack4(y[1]), pack4(y[2]), pack4(y[3])};
+      st_tiles<4>(o_pre + r * KB, pp, q, ok);
     }
     float mean, rstd;
     ln_stats<4>(y, mean, rstd);
@@ -624,15 +627,16 @@ __global__ __launch_bounds__(ET_THREADS) void edge_tail_fwd_kernel(const mdx_edg
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
       pk[ft] = pack4(relu4((y[ft] - splat4(mean)) * splat4(rstd) * lds4(C + EtLds::C_G + 16 * ft + 4 * q) + lds4(C + EtLds::C_B + 16 * ft + 4 * q)));
-      if (ok) sth4(o_post + r * KB + 16 * ft + 4 * q, pk[ft]);
     }
+    st_tiles<4>(o_post + r * KB, pk, q, ok);
     const f16x8_t hb[2] = {pair8(pk[0], pk[1]), pair8(pk[2], pk[3])};
     zero<4>(y);
     mm<4, 2, LDB>(y, wo, hb);
-    if (ok) {
+    {
+      uint2 po[4];
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft)
-        sth4(o_out + r * KB + 16 * ft + 4 * q, pack4(hres[ft] + rh4(y[ft] + lds4(C + EtLds::C_BO + 16 * ft + 4 * q))));
+      for (int ft = 0; ft < 4; ++ft) po[ft] = pack4(hres[ft] + rh4(y[ft] + lds4(C + EtLds::C_BO + 16 * ft + 4 * q)));
+      st_tiles<4>(o_out + r * KB, po, q, ok);
     }
   }
 }
@@ -677,14 +681,16 @@ __global__ __launch_bounds__(ET_THREADS) void edge_tail_bwd_kernel(const mdx_edg
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
       pp[ft] = pack4(g[ft]);
-      if (ok) sth4(o_gpre + r * KB + 16 * ft + 4 * q, pp[ft]);
     }
+    st_tiles<4>(o_gpre + r * KB, pp, q, ok);
     const f16x8_t pb[2] = {pair8(pp[0], pp[1]), pair8(pp[2], pp[3])};
     zero<4>(g);
     mm<4, 2, LDB>(g, wst, pb);
-    if (ok) {
+    {
+      uint2 ph[4];
 #pragma unroll
-      for (int ft = 0; ft < 4; ++ft) sth4(o_gh + r * KB + 16 * ft + 4 * q, pack4(unpack4(pg[ft]) + rh4(g[ft])));   // residual + self_ffn^T
+      for (int ft = 0; ft < 4; ++ft) ph[ft] = pack4(unpack4(pg[ft]) + rh4(g[ft]));   // residual + self_ffn^T
+      st_tiles<4>(o_gh + r * KB, ph, q, ok);
     }
   }
   __syncthreads();
