@@ -969,7 +969,7 @@ __device__ __forceinline__ void wgrad_colsum_body(const TP s_, const TP A_, int 
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const long long* __restrict__ desc, int n) {
+__global__ __launch_bounds__(256) void wgrad_grouped_kernel(const long long* __restrict__ desc, int n, int xcd_deal) {
   const long long blk = blockIdx.x;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
@@ -979,7 +979,21 @@ __global__ __launch_bounds__(256) void wgrad_grouped_kernel(const long long* __r
   const long long* d = desc + 16 * lo;
   const int rel = (int)(blk - d[14]);
   const int gx = (int)d[10], gy = (int)d[11];
-  const int bx = rel % gx, by = (rel / gx) % gy, bz = rel / (gx * gy);
+  // XCD-aware numbering: workgroup ids go round-robin over the 8 XCDs (id % 8) and each XCD has its own L2, so the gx * gy tiles of
+  // one row range -- which read the same rows of G and X -- must sit on ids that are EQUAL mod 8, close in dispatch order.  Blocks are
+  // dealt in chunks of 8 row ranges: inside a chunk, id i works on row range i % 8 and tile i / 8 (the last, short chunk deals over
+  // what is left).  Which block computes a (tile, row range) does not change its result.  MDX_WGRAD_XCD=0 (xcd_deal = 0): the plain order.
+  int bz, t;
+  const int T = gx * gy;
+  if (xcd_deal && T > 1) {
+    const int S = (int)d[12];
+    const int chunk = rel / (8 * T), i = rel - chunk * 8 * T;
+    const int w = min(8, S - 8 * chunk);
+    bz = 8 * chunk + i % w, t = i / w;
+  } else {
+    bz = rel / T, t = rel - bz * T;
+  }
+  const int bx = t % gx, by = t / gx;
   float* P = reinterpret_cast<float*>(d[2]);
   float* Pb = reinterpret_cast<float*>(d[3]);
   const int ldg = (int)d[4], ldx = (int)d[5], M = (int)d[6], N = (int)d[7], K = (int)d[8], mper = (int)d[9];
@@ -2736,15 +2750,16 @@ extern "C" int mdx_op_wgrad_grouped(const int64_t* desc, int32_t n, int64_t tota
   hipStream_t s = (hipStream_t)stream;
   const long long* d = reinterpret_cast<const long long*>(desc);
   const dim3 grid((unsigned)total_blocks);
+  static const int xcd = getenv("MDX_WGRAD_XCD") ? atoi(getenv("MDX_WGRAD_XCD")) : 1;
   switch (kind) {
-    case 0: hipLaunchKernelGGL(wgrad_grouped_kernel<0>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 1: hipLaunchKernelGGL(wgrad_grouped_kernel<1>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 2: hipLaunchKernelGGL(wgrad_grouped_kernel<2>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 3: hipLaunchKernelGGL(wgrad_grouped_kernel<3>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 4: hipLaunchKernelGGL(wgrad_grouped_kernel<4>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 5: hipLaunchKernelGGL(wgrad_grouped_kernel<5>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 6: hipLaunchKernelGGL(wgrad_grouped_kernel<6>, grid, dim3(256), 0, s, d, (int)n); break;
-    case 7: hipLaunchKernelGGL(wgrad_grouped_kernel<7>, grid, dim3(256), 0, s, d, (int)n); break;
+    case 0: hipLaunchKernelGGL(wgrad_grouped_kernel<0>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 1: hipLaunchKernelGGL(wgrad_grouped_kernel<1>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 2: hipLaunchKernelGGL(wgrad_grouped_kernel<2>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 3: hipLaunchKernelGGL(wgrad_grouped_kernel<3>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 4: hipLaunchKernelGGL(wgrad_grouped_kernel<4>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 5: hipLaunchKernelGGL(wgrad_grouped_kernel<5>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 6: hipLaunchKernelGGL(wgrad_grouped_kernel<6>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
+    case 7: hipLaunchKernelGGL(wgrad_grouped_kernel<7>, grid, dim3(256), 0, s, d, (int)n, xcd); break;
     default: return bad("wgrad_grouped: kind must be 0..7");
   }
   return launched();
