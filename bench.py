@@ -165,6 +165,8 @@ def compact_line(full, full_path='bench_full.json'):
                 e['cpu_value'] = _num(c['cpu_baseline'].get('value'))
             if isinstance(c.get('f32'), dict):
                 e['f32_ms_per_step'] = _num(c['f32'].get('ms_per_step'))
+            if isinstance(c.get('loss_fixed_probe_before_after'), list):
+                e['loss_fixed_probe'] = [_num(x) if isinstance(x, float) else _short(str(x), 40) for x in c['loss_fixed_probe_before_after']]
             summ[name] = e
         optional.append(('configs', summ))
     for k in ('roofline_edge_b', 'segment_sum', 'aggregation_large'):
@@ -490,6 +492,24 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
     batch = clean_batch([int(s) for s in sizes], 100 + rank, dev)
     torch.manual_seed(2023 + rank)
     losses = []
+
+    # fixed probe (outside the timed region): the loss at FIXED time steps and FIXED noise, evaluated under no_grad by the fp32 sampling
+    # kernels before the first and after the last optimisation step.  `loss_first_last` compares two steps with different random t and
+    # noise (the per-step loss of a diffusion model swings by 2x with t alone); this pair shows whether the weights descended.
+    def fixed_probe_loss():
+        try:
+            g = torch.Generator(device='cpu').manual_seed(77)
+            nn_, ne_, nm_ = int(batch[1].shape[0]), int(batch[3].shape[0]), int(batch[6])
+            tfix = ((torch.arange(nm_, dtype=torch.int64) * 997) % 1000).to(dev)
+            noise = dict(eps_pos=torch.randn(nn_, 3, generator=g).to(dev), u_node=torch.rand(nn_, 8, generator=g).to(dev))
+            if model_kind != 'bondpred':
+                noise['u_halfedge'] = torch.rand(ne_, 6, generator=g).to(dev)
+            with torch.no_grad():
+                return float(model.get_loss(*batch, time_step=tfix, noise=noise)['loss'])
+        except Exception as e:   # never let the probe break the measurement
+            return repr(e)
+
+    probe_before = fixed_probe_loss()
     for _ in range(warmup):
         tr.step(*batch)
 
@@ -532,6 +552,7 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
             launches = int(F.launches() - n0)
     except Exception:
         launches = None
+    probe_after = fixed_probe_loss()
     N, Eh = int(batch[1].shape[0]), int(batch[3].shape[0])
     E = 2 * Eh
     nb = 8 if model_kind == 'bondpred' else 6
@@ -558,10 +579,13 @@ def train_measure(model_kind, precision, batch_size, steps, warmup, dev, rank=0,
                         'frac_of_fp32_mfma_peak': ach / PEAK_FP32_MFMA, 'flops_per_step': flop,
                         'flops_what': '3 x the hoisted forward count (forward, data gradient, weight gradient of every Linear)',
                         'traffic': None,
-                        'note': 'whole-step fraction: the step is a chain of ~790 launches (rocprofv3: profiles/r6_train_fp16_kernel_stats.csv), '
+                        'note': 'whole-step fraction: the step is a chain of ~690 launches (rocprofv3: profiles/r6_train_fp16_kernel_stats.csv), '
                                 'most of its time in latency- / store-bound fused row-owner kernels (DESIGN.md section 3.3)'},
            'peak_hbm_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
-           'loss_first_last': [float(losses[0]), float(losses[-1])]}
+           'loss_first_last': [float(losses[0]), float(losses[-1])],
+           'loss_fixed_probe_before_after': [probe_before, probe_after],
+           'loss_fixed_probe_what': f'get_loss at fixed time steps and fixed noise (fp32 kernels, no_grad) before the first and after the last of '
+                                    f'the {warmup + steps + 4} optimisation steps of this run; loss_first_last are two steps with different random t'}
     return out, model, sizes
 
 
