@@ -1129,7 +1129,13 @@ extern "C" int mdx_op_posffn_bwd(const mdx_posffn_bwd_args* a, void* stream) {
 #define MDX_NM_FWD_THREADS 512   // (768 = three waves per SIMD measured 369 us against 362 us: the LDS pipe, not occupancy, is what the tile loop waits on)
 #endif
 constexpr int NM_THREADS = 512, NM_WAVES = 8, NM_LNP = 1024;
-constexpr int NMF_THREADS = MDX_NM_FWD_THREADS, NMF_WAVES = NMF_THREADS / 64;   // forward: 156 VGPRs, three waves per SIMD fit   // partial row: d gamma_e | d beta_e | d gamma_g | d beta_g (256 each)
+constexpr int NMF_THREADS = MDX_NM_FWD_THREADS, NMF_WAVES = NMF_THREADS / 64;
+// workgroups per CU the forward is launched for: with 256 threads TWO independent workgroups share a CU (one wave per SIMD each, 76 KiB
+// of LDS each) -- a workgroup's waves run in barrier lockstep on the shared weight buffer, so whatever stalls one wave (its epilogue's
+// store burst: gfx9 counts stores on vmcnt, a wave's next weight fetch is usable only after them) stalls all of them; two groups stall
+// independently
+constexpr int NMF_WG_PER_CU = NMF_THREADS <= 256 ? 2 : 1;
+constexpr int NMF_WPS = NMF_THREADS <= 512 ? 2 : 3;   // waves per SIMD the forward is compiled for   // forward: 156 VGPRs, three waves per SIMD fit   // partial row: d gamma_e | d beta_e | d gamma_g | d beta_g (256 each)
 
 __global__ void pack_a_kernel(const mdx_pack_jobs a) {
   const mdx_pack_job& jb = a.job[blockIdx.y];
@@ -1281,7 +1287,7 @@ __device__ __forceinline__ void ts_flush_b(const uint16_t* T, __amdgpu_buffer_rs
 }
 __device__ __forceinline__ void ts_flush(const uint16_t* T, __amdgpu_buffer_rsrc_t rs, int tile, int lane) { ts_flush_b<8>(T, rs, tile, lane); }
 
-__global__ __launch_bounds__(NMF_THREADS) void nodemsg_fwd_kernel(const mdx_nodemsg_args a) {
+__global__ __launch_bounds__(NMF_THREADS, NMF_WPS) void nodemsg_fwd_kernel(const mdx_nodemsg_args a) {
   __shared__ __attribute__((aligned(16))) float C[9 * 256];
   __shared__ __attribute__((aligned(16))) uint16_t wbuf[2 * 8192];     // two k-steps of weight fragments (mmw)
   extern __shared__ __attribute__((aligned(16))) uint16_t nm_ts[];     // NMF_WAVES transposition areas (ts_put / ts_flush)
@@ -1714,7 +1720,7 @@ extern "C" int mdx_op_nodemsg_fwd(const mdx_nodemsg_args* a, void* stream) {
   if (int rc = check_nodemsg(*a)) return rc;
   if (!a->he_pre || !a->he_post || !a->he || !a->p || !a->m0 || !a->g_pre || !a->g_post || !a->gt || !a->msg) return mdx_set_error(MDX_ERR_ARG, "nodemsg_fwd: null output");
   const int ntiles = (int)((a->E + 15) / 16);
-  const int grid = std::max(1, std::min(ncus(), (ntiles + NMF_WAVES - 1) / NMF_WAVES));
+  const int grid = std::max(1, std::min(NMF_WG_PER_CU * ncus(), (ntiles + NMF_WAVES - 1) / NMF_WAVES));
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)nodemsg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMF_WAVES * TS_BYTES) != hipSuccess)
