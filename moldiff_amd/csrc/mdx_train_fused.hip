@@ -1577,7 +1577,12 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
 #endif
     const size_t r = (size_t)min(row, E - 1), ro = r * KW + 4 * q;
     const size_t rb = r * KW;
-    const int64_t nc = a.f.col[r], nr = a.row[r];
+#ifdef MDX_NM_ROW0_B             // ablation (timing only): every tile reads the tape rows of tile 0 (1: cache-hot, same pattern) or row 0 (2)
+    const size_t rl = MDX_NM_ROW0_B == 1 ? (size_t)c : 0, rol = rl * KW + 4 * q;
+#else
+    const size_t rl = r, rol = ro;
+#endif
+    const int64_t nc = a.f.col[rl], nr = a.row[rl];
     f32x4 y[16];
     f16x8_t b8[8];
     f32x4 gx1[4];
@@ -1590,7 +1595,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
       for (int j = 0; j < 2; ++j) {
         const int ft = 2 * g2 + j;
         const f32x4 g = rh4(ldg4(a.gA + (size_t)nr * a.ldga + 16 * ft + 4 * q));
-        const f32x4 m0 = ldh4(s_m0 + ro + 16 * ft), sg = sigmoid4(ldh4(s_gt + ro + 16 * ft));
+        const f32x4 m0 = ldh4(s_m0 + rol + 16 * ft), sg = sigmoid4(ldh4(s_gt + rol + 16 * ft));
         h[j] = pack4(g * m0 * sg * (splat4(1.f) - sg));      // d gt
         if (ok) {
           sth4(o_gm0 + ro + 16 * ft, pack4(g * sg));        // d m0 (formed again below: the registers go to the gate chain first)
@@ -1605,7 +1610,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     mmw<16, 8>(y, wg2t, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
-    ln256_relu_bwd(y, s_gpre + ro, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
+    ln256_relu_bwd(y, s_gpre + rol, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
@@ -1642,7 +1647,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
         const int ft = 2 * g2 + j;
         const f32x4 gp = rh4(y[ft]);
         h[j] = pack4(gp * ldh4(HN + (size_t)nc * a.f.ldhn + 16 * ft + 4 * q));       // d he
-        hn[j] = pack4(gp * ldh4(s_he + ro + 16 * ft));                               // per-edge d hn[col]
+        hn[j] = pack4(gp * ldh4(s_he + rol + 16 * ft));                               // per-edge d hn[col]
       }
       sth8_pair(o_ghne + rb, g2, hn[0], hn[1], q, ok);
       sth8_pair(o_ghe + rb, g2, h[0], h[1], q, ok);
@@ -1654,7 +1659,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     mmw<16, 8>(y, w2et, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
-    ln256_relu_bwd(y, s_hepre + ro, C + 0, C + 256, q, ok, dge, dbe, T, lane);
+    ln256_relu_bwd(y, s_hepre + rol, C + 0, C + 256, q, ok, dge, dbe, T, lane);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
