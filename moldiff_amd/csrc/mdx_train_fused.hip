@@ -1469,28 +1469,126 @@ __device__ __forceinline__ void cs_sum(f32x4& acc, const float* T, int lane, int
   __builtin_amdgcn_wave_barrier();   // the area is rewritten only after every lane has read it
 }
 
-// 256-wide LayerNorm + ReLU backward in place (g: dL/d output -> dL/d pre-activation); xrow = this lane's row of the stored
-// pre-activation (float16, + 4 q); the rows' contributions to d gamma / d beta go through the LDS column sums
-__device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* xrow, const float* gam, const float* bet, int q, bool ok,
-                                               f32x4& dgam, f32x4& dbet, float* T, int lane) {
+// Column sums over the 16 rows of a tile WITHOUT the LDS transposition (round 6, third session): a reduce-scatter butterfly over the 16
+// lanes c of a lane row (= one DPP row; q, the feature quad, is the same in all of them).  Step 1 pairs c with c ^ 8 (row_ror:8): a lane
+// keeps the eight tiles whose bit 3 equals its own and adds the partner's values of them; step 2 (row_half_mirror: c ^ 7, same bit 3,
+// other bit 2) halves again, steps 3 / 4 (quad_perm: c ^ 2, c ^ 1) end with ONE tile per lane: lane (c, q) holds the sum over the 16
+// rows of features 16 c + 4 q .. + 3.  60 DPP adds + 120 selects per call instead of 8 LDS writes, a wave barrier and 16 dependent LDS
+// reads per half (the LDS version cost the backward 71 us of 458 per launch and the registers that made it spill).  Deterministic; the
+// order of additions is the butterfly's (pairs of rows), not rows 0..15 in sequence.
+#ifndef MDX_NM_LNP_DPP
+#define MDX_NM_LNP_DPP 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+// one butterfly step on a pair of tiles: keep the tile of this lane's side, add the partner lane's value of it
+template <int CTRL>
+__device__ __forceinline__ f32x4 rs_comb(f32x4 lo, f32x4 hi, bool bit) {
+  f32x4 out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float send = bit ? lo[r] : hi[r], keep = bit ? hi[r] : lo[r];
+    out[r] = keep + dpp_row<CTRL>(send);
+  }
+  return out;
+}
+// depth first (a tile pair is folded as soon as both halves exist): at most ~6 tiles of temporaries alive instead of the 8 + 4 of a
+// step-by-step butterfly -- the kernel has no registers to spare
+template <class F>
+__device__ __forceinline__ f32x4 colsum16(F&& val, int c) {
+  constexpr int ROR8 = 0x128, HALF_MIRROR = 0x141, QP_X2 = 0x4E, QP_X1 = 0xB1;
+  const bool b3 = (c & 8) != 0, b2 = (c & 4) != 0, b1 = (c & 2) != 0, b0 = (c & 1) != 0;
+  auto k8 = [&](int j) { return rs_comb<ROR8>(val(j), val(j + 8), b3); };                 // tile j + 8 b3
+  auto k4 = [&](int j) {                                                                    // tile j + 4 b2 + 8 b3
+    const f32x4 a = k8(j);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 b = k8(j + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    return rs_comb<HALF_MIRROR>(a, b, b2);
+  };
+  auto k2 = [&](int j) {
+    const f32x4 a = k4(j);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 b = k4(j + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    return rs_comb<QP_X2>(a, b, b1);
+  };
+  const f32x4 a = k2(0);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 b = k2(1);
+  __builtin_amdgcn_sched_barrier(0);
+  return rs_comb<QP_X1>(a, b, b0);
+}
+
+// A 16 x 256 float16 tile of a stored tensor into the wave's LDS area, the inverse of ts_flush (round 6, third session): eight buffer loads
+// of two complete 512-byte rows each (lanes 0..31 row 2 i, lanes 32..63 row 2 i + 1, 16 bytes per lane; rows past the end read as zero
+// through the bounds check), written as they are; ts_get then returns the accumulator-layout chunk (row c, columns 16 ft + 4 q .. + 3)
+// the direct 8-byte loads fetched -- 16 rows x 32 bytes per instruction, which cost the backward 48 us per launch (profiles/HISTORY.md:
+// row-0 ablation).  The tile STAYS in LDS while the LayerNorm backward reads it six times: 32 registers less than holding it.
+typedef unsigned int tsu4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int tsu2_t __attribute__((ext_vector_type(2)));
+template <int B>
+__device__ __forceinline__ void ts_load(uint16_t* T, const _Float16* src, int E, int tile, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = ts_rsrc(const_cast<_Float16*>(src), E);
+  const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(tile) * (unsigned)(16 * KW * 2);
+  const unsigned vo = (unsigned)(lane >> 5) * (unsigned)(KW * 2) + 16u * (unsigned)(lane & 31);
+  uint16_t* dst = T + (lane >> 5) * TS_LD + 8 * (lane & 31);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // every lane has finished with the area's previous content
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i0 = 0; i0 < 8; i0 += B) {
+    uint4 v[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so + (unsigned)(i0 + i) * 1024u, 0));
+#pragma unroll
+    for (int i = 0; i < B; ++i) *reinterpret_cast<volatile tsu4_t*>(dst + 2 * (i0 + i) * TS_LD) = __builtin_bit_cast(tsu4_t, v[i]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint2 ts_get(const uint16_t* T, int ft, int c, int q) {
+  const tsu2_t v = *reinterpret_cast<const volatile tsu2_t*>(T + c * TS_LD + 16 * ft + 4 * q);
+  return uint2{v.x, v.y};
+}
+#ifndef MDX_NM_TSLOAD
+#define MDX_NM_TSLOAD 1
+#endif
+static_assert(!MDX_NM_TSLOAD || MDX_NM_LNP_DPP, "the staged tile lives in the area the LDS column sums would use");
+
+// 256-wide LayerNorm + ReLU backward in place (g: dL/d output -> dL/d pre-activation); xsrc = the stored pre-activation (E x 256
+// float16), read through the wave's LDS area (MDX_NM_TSLOAD) or directly (xrow = this lane's row + 4 q); the rows' contributions to
+// d gamma / d beta are summed over the tile by the DPP butterfly (or the LDS column sums)
+__device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* xsrc, const _Float16* xrow, int E, int tile, const float* gam,
+                                               const float* bet, int q, bool ok, float* pgam, float* pbet, float* T, int lane) {
   constexpr float inv_n = 1.0f / 256;
   const int c = lane & 15;
+#if MDX_NM_TSLOAD
+  const uint16_t* Th = reinterpret_cast<const uint16_t*>(T);
+  ts_load<4>(reinterpret_cast<uint16_t*>(T), xsrc, E, tile, lane);
+#define XP(ft) ts_get(Th, (ft), c, q)
+#else
   uint2 xp[16];
 #pragma unroll
   for (int ft = 0; ft < 16; ++ft) xp[ft] = *reinterpret_cast<const uint2*>(xrow + 16 * ft);
+#define XP(ft) xp[ft]
+#endif
   float mean, rstd;
   {
     float sm = 0.f;
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) {
-      const f32x4 v = unpack4(xp[ft]);
+      const f32x4 v = unpack4(XP(ft));
       sm += (v[0] + v[1]) + (v[2] + v[3]);
     }
     mean = sumq(sm) * inv_n;
     float d2 = 0.f;
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) {
-      const f32x4 v = unpack4(xp[ft]);
+      const f32x4 v = unpack4(XP(ft));
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const float d = v[s] - mean;
@@ -1503,26 +1601,41 @@ __device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* x
 #pragma unroll
   for (int ft = 0; ft < 16; ++ft) {
     const f32x4 gm = lds4(gam + 16 * ft + 4 * q), bt = lds4(bet + 16 * ft + 4 * q);
-    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    const f32x4 xh = (unpack4(XP(ft)) - splat4(mean)) * splat4(rstd);
     const f32x4 yv = xh * gm + bt;
 #pragma unroll
     for (int s = 0; s < 4; ++s) g[ft][s] = (ok && yv[s] > 0.f) ? g[ft][s] : 0.f;
     if (ft % 4 == 3) __builtin_amdgcn_sched_barrier(0);
   }
+#if defined(MDX_NM_NOLNP)         // (ablation, timing only: without the LayerNorm-parameter column sums)
+#elif MDX_NM_LNP_DPP              // lane (c, q) accumulates features 16 c + 4 q .. + 3
+  // the running sums live in LDS (this lane's own four floats per vector: no other lane touches them): as registers they were alive
+  // across the whole tile loop -- 16 of them were the difference between no spills and ~60
+  *reinterpret_cast<f32x4*>(pbet) = *reinterpret_cast<const f32x4*>(pbet) + colsum16([&](int ft) { return g[ft]; }, c);
+  __builtin_amdgcn_sched_barrier(0);
+  *reinterpret_cast<f32x4*>(pgam) = *reinterpret_cast<const f32x4*>(pgam) +
+                                    colsum16([&](int ft) { return g[ft] * ((unpack4(XP(ft)) - splat4(mean)) * splat4(rstd)); }, c);
+  __builtin_amdgcn_sched_barrier(0);
+#else                             // lane L accumulates features 4 L .. 4 L + 3 (LDS column sums)
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
     for (int f8 = 0; f8 < 8; ++f8) cs_put(T, f8, g[8 * hf + f8], c, q);
-    cs_sum(dbet, T, lane, hf);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(pbet);
+    cs_sum(acc, T, lane, hf);
+    *reinterpret_cast<f32x4*>(pbet) = acc;
 #pragma unroll
-    for (int f8 = 0; f8 < 8; ++f8) cs_put(T, f8, g[8 * hf + f8] * ((unpack4(xp[8 * hf + f8]) - splat4(mean)) * splat4(rstd)), c, q);
-    cs_sum(dgam, T, lane, hf);
+    for (int f8 = 0; f8 < 8; ++f8) cs_put(T, f8, g[8 * hf + f8] * ((unpack4(XP(8 * hf + f8)) - splat4(mean)) * splat4(rstd)), c, q);
+    acc = *reinterpret_cast<const f32x4*>(pgam);
+    cs_sum(acc, T, lane, hf);
+    *reinterpret_cast<f32x4*>(pgam) = acc;
   }
+#endif
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int ft = 0; ft < 16; ++ft) {
     const f32x4 gm = lds4(gam + 16 * ft + 4 * q);
-    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    const f32x4 xh = (unpack4(XP(ft)) - splat4(mean)) * splat4(rstd);
     g[ft] = g[ft] * gm;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1534,10 +1647,11 @@ __device__ __forceinline__ void ln256_relu_bwd(f32x4 (&g)[16], const _Float16* x
   const float m1 = sumq(s1) * inv_n, m2 = sumq(s2) * inv_n;
 #pragma unroll
   for (int ft = 0; ft < 16; ++ft) {
-    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    const f32x4 xh = (unpack4(XP(ft)) - splat4(mean)) * splat4(rstd);
     g[ft] = (g[ft] - splat4(m1) - xh * splat4(m2)) * splat4(rstd);
   }
 }
+#undef XP
 
 __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodemsg_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) uint16_t bf_smem[];
@@ -1565,7 +1679,11 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
   _Float16 *o_gm0 = reinterpret_cast<_Float16*>(a.g_m0), *o_ggt = reinterpret_cast<_Float16*>(a.g_gt),
            *o_ggpre = reinterpret_cast<_Float16*>(a.g_gpre), *o_ghne = reinterpret_cast<_Float16*>(a.g_hne),
            *o_ghe = reinterpret_cast<_Float16*>(a.g_he), *o_gpre = reinterpret_cast<_Float16*>(a.g_pre), *o_gx = reinterpret_cast<_Float16*>(a.g_x);
-  f32x4 dge = splat4(0.f), dbe = splat4(0.f), dgg = splat4(0.f), dbg = splat4(0.f);
+  // this lane's running LayerNorm-parameter sums: four floats in each of the wave's four vectors of R (d gamma_e | d beta_e | d gamma_g | d beta_g)
+  float* R = Tall + (size_t)NM_WAVES * 16 * NM_TLD;   // [NM_WAVES][NM_LNP], behind the waves' tile areas
+  float* racc = R + wave * NM_LNP + (MDX_NM_LNP_DPP ? 16 * c + 4 * q : 4 * lane);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(racc + 256 * k) = splat4(0.f);
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
     const int tile = it * nw + blockIdx.x * NM_WAVES + wave;
@@ -1610,7 +1728,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     mmw<16, 8>(y, wg2t, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
-    ln256_relu_bwd(y, s_gpre + rol, C + 512, C + 768, q, ok, dgg, dbg, T, lane);
+    ln256_relu_bwd(y, s_gpre, s_gpre + rol, E, tile, C + 512, C + 768, q, ok, racc + 512, racc + 768, T, lane);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
@@ -1659,7 +1777,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
     mmw<16, 8>(y, w2et, wbuf, par, tid, lane, b8);
 #pragma unroll
     for (int ft = 0; ft < 16; ++ft) y[ft] = rh4(y[ft]);
-    ln256_relu_bwd(y, s_hepre + rol, C + 0, C + 256, q, ok, dge, dbe, T, lane);
+    ln256_relu_bwd(y, s_hepre, s_hepre + rol, E, tile, C + 0, C + 256, q, ok, racc, racc + 256, T, lane);
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const uint2 h0 = pack4(y[2 * g2]), h1 = pack4(y[2 * g2 + 1]);
@@ -1674,13 +1792,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
       for (int ft = 0; ft < 4; ++ft) sth4(o_gx + r * KB + 16 * ft + 4 * q, pack4(rh4(gx2[ft]) + ldh4(o_gx + r * KB + 16 * ft + 4 * q)));
     }
   }
-  // ---- LayerNorm-parameter gradients: lane L of every wave holds features 4 L .. 4 L + 3 of the four vectors; waves in fixed order
-  __syncthreads();
-  float* R = Tall;   // [NM_WAVES][NM_LNP]
-  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 4 * lane) = dge;
-  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 256 + 4 * lane) = dbe;
-  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 512 + 4 * lane) = dgg;
-  *reinterpret_cast<f32x4*>(R + wave * NM_LNP + 768 + 4 * lane) = dbg;
+  // ---- LayerNorm-parameter gradients: every wave's row of R is complete; waves are added in fixed order
   __syncthreads();
   for (int i = tid; i < NM_LNP; i += NM_THREADS) {
     float s = 0.f;
@@ -1690,8 +1802,7 @@ __global__ __launch_bounds__(NM_THREADS) void nodemsg_bwd_kernel(const mdx_nodem
   }
 }
 
-constexpr int NM_BWD_LDS = 2 * 16384 + (1024 + NM_WAVES * 16 * NM_TLD) * 4;
-static_assert(NM_WAVES * 16 * NM_TLD >= NM_WAVES * NM_LNP, "the end-of-kernel reduction reuses the column-sum areas");
+constexpr int NM_BWD_LDS = 2 * 16384 + (1024 + NM_WAVES * 16 * NM_TLD + NM_WAVES * NM_LNP) * 4;   // weights, constants, tile areas, parameter sums: 135.6 KiB
 static bool g_attr_nb = false;
 
 extern "C" int mdx_op_nodemsg_lnp_floats(void) { return NM_LNP; }
