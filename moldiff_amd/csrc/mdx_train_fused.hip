@@ -377,6 +377,108 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&g)[FT], const uint2 (&xp)[FT
   }
 }
 
+// ---- column sums over the 16 rows of a tile by DPP (round 6, third session; the 256-wide version and the reasoning: colsum16 below)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+// one butterfly step on a pair of tiles: keep the tile of this lane's side, add the partner lane's value of it
+template <int CTRL>
+__device__ __forceinline__ f32x4 rs_comb(f32x4 lo, f32x4 hi, bool bit) {
+  f32x4 out;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float send = bit ? lo[r] : hi[r], keep = bit ? hi[r] : lo[r];
+    out[r] = keep + dpp_row<CTRL>(send);
+  }
+  return out;
+}
+// 8 tiles (128 features) -> TWO floats per lane: three tile-halving steps (c ^ 8, c ^ 7, c ^ 2) leave tile b1 + 2 b2 + 4 b3 of this lane's q,
+// the fourth (c ^ 1) splits its four values: lane (c, q) ends with the sums over the 16 rows of features
+// 16 (c >> 1) + 4 q + 2 (c & 1) + {0, 1}.  Two registers per LayerNorm vector instead of the 32 per-lane partials the kernel carried
+// through its tile loop (80 registers of accumulators = its 38 spilled ones).
+template <class F>
+__device__ __forceinline__ void colsum8x2(F&& val, int c, float& o0, float& o1) {
+  constexpr int ROR8 = 0x128, HALF_MIRROR = 0x141, QP_X2 = 0x4E, QP_X1 = 0xB1;
+  const bool b3 = (c & 8) != 0, b2 = (c & 4) != 0, b1 = (c & 2) != 0, b0 = (c & 1) != 0;
+  auto k4 = [&](int j) { return rs_comb<ROR8>(val(j), val(j + 4), b3); };                 // tile j + 4 b3
+  auto k2 = [&](int j) {                                                                    // tile j + 2 b2 + 4 b3
+    const f32x4 a = k4(j);
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 b = k4(j + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    return rs_comb<HALF_MIRROR>(a, b, b2);
+  };
+  const f32x4 a = k2(0);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 b = k2(1);
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 t = rs_comb<QP_X2>(a, b, b1);
+  o0 = (b0 ? t[2] : t[0]) + dpp_row<QP_X1>(b0 ? t[0] : t[2]);
+  o1 = (b0 ? t[3] : t[1]) + dpp_row<QP_X1>(b0 ? t[1] : t[3]);
+}
+// ln_relu_bwd<8> with the LayerNorm-parameter sums of the tile folded over its rows at once (acc: d gamma x 2, d beta x 2 of this lane's
+// two features, see colsum8x2)
+__device__ __forceinline__ void ln_relu_bwd8_rs(f32x4 (&g)[8], const uint2 (&xp)[8], const float* gam, const float* bet, int q, int c, bool ok,
+                                                float (&acc)[4]) {
+  constexpr float inv_n = 1.0f / 128;
+  float mean, rstd;
+  {
+    float sm = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+      const f32x4 v = unpack4(xp[ft]);
+      sm += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    mean = sumq(sm) * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int ft = 0; ft < 8; ++ft) {
+      const f32x4 v = unpack4(xp[ft]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[r] - mean;
+        d2 = fmaf(d, d, d2);
+      }
+    }
+    rstd = 1.0f / sqrtf(sumq(d2) * inv_n + MDX_LN_EPS);
+  }
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft) {   // go = g masked by the ReLU (zero for rows past the end)
+    const f32x4 gm = lds4(gam + 16 * ft + 4 * q), bt = lds4(bet + 16 * ft + 4 * q);
+    const f32x4 y = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd) * gm + bt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[ft][r] = (ok && y[r] > 0.f) ? g[ft][r] : 0.f;
+  }
+  {
+    float s0, s1_;
+    colsum8x2([&](int ft) { return g[ft]; }, c, s0, s1_);
+    acc[2] += s0, acc[3] += s1_;
+    __builtin_amdgcn_sched_barrier(0);
+    colsum8x2([&](int ft) { return g[ft] * ((unpack4(xp[ft]) - splat4(mean)) * splat4(rstd)); }, c, s0, s1_);
+    acc[0] += s0, acc[1] += s1_;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft) {
+    const f32x4 gm = lds4(gam + 16 * ft + 4 * q);
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    g[ft] = g[ft] * gm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1 += g[ft][r];
+      s2 = fmaf(g[ft][r], xh[r], s2);
+    }
+  }
+  const float m1 = sumq(s1) * inv_n, m2 = sumq(s2) * inv_n;
+#pragma unroll
+  for (int ft = 0; ft < 8; ++ft) {
+    const f32x4 xh = (unpack4(xp[ft]) - splat4(mean)) * splat4(rstd);
+    g[ft] = (g[ft] - splat4(m1) - xh * splat4(m2)) * splat4(rstd);
+  }
+}
+
 // sum over the 16 lanes of a DPP row (the wave's 16 rows c = 0..15 of one q); result in every lane of the row
 __device__ __forceinline__ float sum_c(float v) {
   v += __shfl_xor(v, 1);
@@ -423,8 +525,17 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
   const uint16_t* wg2t = S + BwdLds::WG2T + c * LDO + 8 * q;
   const uint16_t* wg1t = S + BwdLds::WG1T + c * LDG + 8 * q;
 
+#ifndef MDX_BF_LNP_DPP
+#define MDX_BF_LNP_DPP 1
+#endif
+#if MDX_BF_LNP_DPP
+  float acc1[4] = {0.f, 0.f, 0.f, 0.f};   // inter LayerNorm: d gamma, d beta of features 16 (c >> 1) + 4 q + 2 (c & 1) + {0, 1} (colsum8x2)
+  f32x4 dgg[2], dgb[2];
+  zero<2>(dgg); zero<2>(dgb);
+#else
   f32x4 dg1[8], db1[8], dgg[2], dgb[2];
   zero<8>(dg1); zero<8>(db1); zero<2>(dgg); zero<2>(dgb);
+#endif
 
 #pragma unroll 1
   for (int tile = blockIdx.x * BF_WAVES + wave; tile < ntiles; tile += nw) {
@@ -462,7 +573,11 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
       mm<8, 2, LDO>(g, wi2t, b2);
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) g[ft] = rh4(g[ft]);
+#if MDX_BF_LNP_DPP
+      ln_relu_bwd8_rs(g, xp, C + BwdLds::C_G1, C + BwdLds::C_BE1, q, c, ok, acc1);
+#else
       ln_relu_bwd<8>(g, xp, C + BwdLds::C_G1, C + BwdLds::C_BE1, q, ok, dg1, db1);
+#endif
       uint2 pg[8];
 #pragma unroll
       for (int ft = 0; ft < 8; ++ft) {
@@ -533,6 +648,13 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
   // partial row per workgroup; the caller's deferred reduction sums the gridDim.x rows
   __syncthreads();   // every wave is done with the weights: the LDS area is free
   float* R = reinterpret_cast<float*>(bf_smem);
+#if MDX_BF_LNP_DPP
+  {
+    const int f = 16 * (c >> 1) + 4 * q + 2 * (c & 1);
+    R[wave * BF_LNP + f] = acc1[0], R[wave * BF_LNP + f + 1] = acc1[1];
+    R[wave * BF_LNP + 128 + f] = acc1[2], R[wave * BF_LNP + 128 + f + 1] = acc1[3];
+  }
+#else
 #pragma unroll
   for (int ft = 0; ft < 8; ++ft)
 #pragma unroll
@@ -543,6 +665,7 @@ __global__ __launch_bounds__(BF_THREADS) void bondffn_bwd_kernel(const mdx_bondf
         R[wave * BF_LNP + 128 + 16 * ft + 4 * q + s] = v2;
       }
     }
+#endif
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -1479,21 +1602,6 @@ __device__ __forceinline__ void cs_sum(f32x4& acc, const float* T, int lane, int
 #ifndef MDX_NM_LNP_DPP
 #define MDX_NM_LNP_DPP 1
 #endif
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float v) {
-  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
-}
-// one butterfly step on a pair of tiles: keep the tile of this lane's side, add the partner lane's value of it
-template <int CTRL>
-__device__ __forceinline__ f32x4 rs_comb(f32x4 lo, f32x4 hi, bool bit) {
-  f32x4 out;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float send = bit ? lo[r] : hi[r], keep = bit ? hi[r] : lo[r];
-    out[r] = keep + dpp_row<CTRL>(send);
-  }
-  return out;
-}
 // depth first (a tile pair is folded as soon as both halves exist): at most ~6 tiles of temporaries alive instead of the 8 + 4 of a
 // step-by-step butterfly -- the kernel has no registers to spare
 template <class F>
