@@ -11,11 +11,11 @@ for tag in base $(ls $ROOT/tools/_ab | sed -n 's/^lib_\(.*\)\.so$/\1/p'); do
   rm -rf /tmp/p_$tag
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$tag -o p -- python $ROOT/bench.py --train --precision fp16 --no-cpu-baseline --steps 6 --warmup 2 > /tmp/line_$tag.json 2>/dev/null
   python - $tag <<'P'
-import sys, glob, csv, json
+import sys, glob, csv, json, os
 tag = sys.argv[1]
 f = glob.glob(f'/tmp/p_{tag}/**/*kernel_stats.csv', recursive=True)
 rows = list(csv.DictReader(open(f[0])))
-pick = {r['Name'][:40]: round(float(r['AverageNs']) / 1e3, 1) for r in rows if any(k in r['Name'] for k in ('nodemsg', 'bondffn', 'posffn'))}
+pick = {r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')[:34]: round(float(r['AverageNs']) / 1e3, 1) for r in rows if any(k in r['Name'] for k in os.environ.get('AB_KERNELS', 'nodemsg,bondffn,posffn').split(','))}
 try:
     ms = round(json.loads(open(f'/tmp/line_{tag}.json').read().strip().splitlines()[-1])['ms_per_step'], 2)
 except Exception as e:
