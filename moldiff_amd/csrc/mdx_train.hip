@@ -2719,8 +2719,8 @@ extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits
   if (splits < 1) splits = 1;
   int mper = (int)((std::max<int64_t>(M, 1) + splits - 1) / splits);
   mper = (mper + HW_MC - 1) / HW_MC * HW_MC;
-  const int64_t S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
-  const int64_t nc = (S + RED_CHUNK - 1) / RED_CHUNK;
+  int64_t S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
+  int64_t nc = (S + RED_CHUNK - 1) / RED_CHUNK;
   int kind = 4, tn = 64, tk = 64;
   if ((dt & 3) == 3 && N % 64 == 0 && K % 64 == 0 && ldg % 8 == 0 && ldx % 8 == 0 && aligned) {
     // MDX_WGRAD_TILE: 0 (default) 128-wide tiles where the layer allows; 1: n x k = 128 x 64; 2: 64 x 64 (A/B knob: the 128 x 128 class runs
@@ -2735,6 +2735,15 @@ extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits
   } else if ((N == 1 && K % 4 == 0 && K <= 256) || (K == 1 && N % 4 == 0 && N <= 256)) {
     tn = (int)N, tk = (int)K;   // one block per row range
     kind = 7;
+    // a scaled column sum has ONE block per row range and a partial of at most 256 floats: with the queue's 2,048 rows per block the six
+    // 154,666 x 256 jobs of a step were 456 blocks on 256 CUs (two blocks = 32 KB of loads in flight per CU, 1.6 TB/s); 256 rows per
+    // block give eight times the blocks for 0.6 MB of partials per job (MDX_WGRAD_COLSUM_ROWS)
+    static const int cs_rows = getenv("MDX_WGRAD_COLSUM_ROWS") ? std::max(HW_MC, atoi(getenv("MDX_WGRAD_COLSUM_ROWS")) / HW_MC * HW_MC) : 256;
+    if (mper > cs_rows) {
+      mper = cs_rows;
+      S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
+      nc = (S + RED_CHUNK - 1) / RED_CHUNK;
+    }
   }
   const int64_t gx = (K + tk - 1) / tk, gy = (N + tn - 1) / tn;
   out[0] = kind, out[1] = gx, out[2] = gy, out[3] = S, out[4] = mper;
