@@ -2713,6 +2713,15 @@ extern "C" int mdx_op_xgemm_tn_t(const void* Gv, int64_t ldg, const void* Xv, in
 // partial area (products, first reduction stage, bias partials and theirs: the layout of mdx_op_xgemm_tn_t), blocks.  `aligned` = both
 // operands start on 16 bytes.  mdx_op_wgrad_grouped: one launch over a device table of `n` records of one kind (16 x int64 each, layout
 // at the kernel), `total_blocks` = sum of their blocks; the partials are left for mdx_op_reduce_deferred.
+#ifndef MDX_KROWS_2
+// measured per class (us per step, 2,048 -> shipped): 64x128 170 -> 165, 64x64 171 -> 156, converting 64x64 318 -> 240, 32x64 133 -> 113,
+// 64x32 72 -> 81; the deferred reduction 214 -> 227 (profiles/HISTORY.md, round 6 third session)
+#define MDX_KROWS_2 1024
+#define MDX_KROWS_3 1024
+#define MDX_KROWS_4 512
+#define MDX_KROWS_5 1024
+#define MDX_KROWS_6 1024
+#endif
 extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits, int32_t dt, int64_t ldg, int64_t ldx, int32_t aligned,
                                  int64_t* out) {
   if (!out || N <= 0 || K <= 0) return bad("wgrad_plan: bad arguments");
@@ -2741,6 +2750,29 @@ extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits
     static const int cs_rows = getenv("MDX_WGRAD_COLSUM_ROWS") ? std::max(HW_MC, atoi(getenv("MDX_WGRAD_COLSUM_ROWS")) / HW_MC * HW_MC) : 256;
     if (mper > cs_rows) {
       mper = cs_rows;
+      S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
+      nc = (S + RED_CHUNK - 1) / RED_CHUNK;
+    }
+  }
+  if (kind != 7) {
+    // rows per block by tile class (MDX_WGRAD_KROWS = eight comma-separated values, 0 = the caller's): the classes with few, small tiles
+    // per row range do not fill the chip at the queue's 2,048 rows per block
+    static int krows[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
+    if (krows[0] < 0) {
+      static const int dflt[8] = {0, 0, MDX_KROWS_2, MDX_KROWS_3, MDX_KROWS_4, MDX_KROWS_5, MDX_KROWS_6, 0};
+      for (int i = 0; i < 8; ++i) krows[i] = dflt[i];
+      if (const char* e = getenv("MDX_WGRAD_KROWS")) {
+        int i = 0;
+        for (const char* p = e; *p && i < 8; ++i) {
+          krows[i] = atoi(p);
+          while (*p && *p != ',') ++p;
+          if (*p == ',') ++p;
+        }
+      }
+    }
+    const int kr = krows[kind] / HW_MC * HW_MC;
+    if (kr > 0 && mper > kr) {
+      mper = kr;
       S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
       nc = (S + RED_CHUNK - 1) / RED_CHUNK;
     }
