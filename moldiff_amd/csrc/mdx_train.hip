@@ -2757,20 +2757,20 @@ extern "C" int mdx_op_wgrad_plan(int64_t M, int64_t N, int64_t K, int32_t splits
   if (kind != 7) {
     // rows per block by tile class (MDX_WGRAD_KROWS = eight comma-separated values, 0 = the caller's): the classes with few, small tiles
     // per row range do not fill the chip at the queue's 2,048 rows per block
-    static int krows[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
-    if (krows[0] < 0) {
-      static const int dflt[8] = {0, 0, MDX_KROWS_2, MDX_KROWS_3, MDX_KROWS_4, MDX_KROWS_5, MDX_KROWS_6, 0};
-      for (int i = 0; i < 8; ++i) krows[i] = dflt[i];
+    struct KRows { int v[8]; };
+    static const KRows krows = [] {   // (a function-local static: initialised once, also when the first calls come from two threads)
+      KRows r{{0, 0, MDX_KROWS_2, MDX_KROWS_3, MDX_KROWS_4, MDX_KROWS_5, MDX_KROWS_6, 0}};
       if (const char* e = getenv("MDX_WGRAD_KROWS")) {
         int i = 0;
         for (const char* p = e; *p && i < 8; ++i) {
-          krows[i] = atoi(p);
+          r.v[i] = atoi(p);
           while (*p && *p != ',') ++p;
           if (*p == ',') ++p;
         }
       }
-    }
-    const int kr = krows[kind] / HW_MC * HW_MC;
+      return r;
+    }();
+    const int kr = krows.v[kind] / HW_MC * HW_MC;
     if (kr > 0 && mper > kr) {
       mper = kr;
       S = (std::max<int64_t>(M, 1) + mper - 1) / mper;
