@@ -1662,8 +1662,11 @@ __device__ __forceinline__ uint2 ts_get(const uint16_t* T, int ft, int c, int q)
   const tsu2_t v = *reinterpret_cast<const volatile tsu2_t*>(T + c * TS_LD + 16 * ft + 4 * q);
   return uint2{v.x, v.y};
 }
+// Measured (third session): with the running sums in LDS the kernel does not spill either way (228 VGPRs direct, 250 staged), and the
+// staged tile's LDS traffic and wave barriers cost more than its load pattern saves: 392.6 us direct against 418.7 us staged on the same
+// box.  The direct 8-byte loads are the default; 1 keeps the staged form.
 #ifndef MDX_NM_TSLOAD
-#define MDX_NM_TSLOAD 1
+#define MDX_NM_TSLOAD 0
 #endif
 static_assert(!MDX_NM_TSLOAD || MDX_NM_LNP_DPP, "the staged tile lives in the area the LDS column sums would use");
 
