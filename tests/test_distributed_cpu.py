@@ -195,3 +195,47 @@ def test_two_rank_deferred_class_check_raises_on_every_rank_in_the_same_step():
     assert res[0][0] == res[1][0] == 'ok'
     assert res[1][1] == 'Error: 9 >= 8'
     assert 'another rank' in res[0][1]
+
+
+# ---- the same check on a SUB-group: ranks outside the trainer's group never reach it ------------------------------
+def _defer_subgroup_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from moldiff_amd.diffusion import deferred_class_checks
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    grp = dist.new_group([0, 1])            # (every rank creates it; only 0 and 1 are members)
+    outcome = []
+    if rank in (0, 1):
+        for bad_rank in (None, 0):
+            with deferred_class_checks() as chk:
+                chk.items.append((torch.tensor(3 if rank != bad_rank else 8), 8))
+            verify = chk.finish(group=grp)  # the flag all-reduce pairs with the GROUP's ranks; on WORLD it would wait for rank 2 for ever
+            try:
+                verify()
+                outcome.append('ok')
+            except AssertionError as e:
+                outcome.append(str(e))
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_class_check_on_a_sub_group_does_not_wait_for_ranks_outside_it():
+    """Trainer(group=...) hands its group to deferred_class_checks.finish: with three ranks and a trainer group of two, the third rank
+    issues no collective at that point -- the check must complete on the two (a WORLD all-reduce would hang until the timeout below)
+    and a bad batch on rank 0 must still fail rank 1 in the same step."""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_defer_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[2] == []
+    assert res[0][0] == res[1][0] == 'ok'
+    assert res[0][1] == 'Error: 8 >= 8'
+    assert 'another rank' in res[1][1]
