@@ -84,3 +84,18 @@ def test_emit_result_writes_one_parseable_last_line(tmp_path, monkeypatch, capfd
     tree = json.load(open(tmp_path / 'bench_full.json'))
     assert tree['configs']['guided']['roofline']['frac'] == canned()['configs']['guided']['roofline']['frac']
     assert any(ln.startswith('BENCH_FULL ') for ln in err.splitlines())
+
+
+def test_round6_tree_keeps_the_training_probe_on_the_line():
+    """The round-6 tree (profiles/r6_bench_full_driver.json: the driver's command) carries config #5's fixed-probe loss pair; the line keeps it
+    as `configs.train.loss_fixed_probe` (two numbers, or a short message if the probe failed) and stays below the limit."""
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r6_bench_full_driver.json')))
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    tr = line['configs']['train']
+    assert tr['ms_per_step'] == pytest.approx(full['configs']['train']['ms_per_step'], rel=1e-5)
+    before, after = tr['loss_fixed_probe']
+    assert after < before
+    full['configs']['train']['loss_fixed_probe_before_after'] = ['RuntimeError(' + 'x' * 500 + ')'] * 2      # a failed probe: clipped text
+    line = bench.compact_line(full)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT and all(len(x) <= 40 for x in line['configs']['train']['loss_fixed_probe'])
